@@ -1,0 +1,191 @@
+/*
+ * sdfhip.h -- C ABI of libsdfhip.so: MI355X (gfx950) sphere tracing of
+ * adaptively sampled distance fields behind SdfBox's frame boundary.
+ *
+ * Plain C, cdecl, PODs and pointers only; every function returns an int
+ * status (SDFHIP_OK == 0) and never throws or aborts across the boundary;
+ * sdfhip_last_error() returns the calling thread's last message.
+ *
+ * Each entry point names the reference interface it replaces (paths are
+ * relative to the tau-dev/SdfBox checkout).  INTEGRATION.md shows the C#
+ * [DllImport] stub a maintainer would add.
+ */
+#ifndef SDFHIP_H
+#define SDFHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDFHIP_API __attribute__((visibility("default")))
+
+/* ---- status codes ------------------------------------------------------ */
+enum {
+    SDFHIP_OK = 0,
+    SDFHIP_ERR_ARG = 1,       /* null pointer, zero size, bad enum            */
+    SDFHIP_ERR_IO = 2,        /* file missing / short / not an .asdf          */
+    SDFHIP_ERR_BAD_TREE = 3,  /* parent/children index out of range           */
+    SDFHIP_ERR_DEVICE = 4,    /* HIP call failed or no gfx950 device          */
+    SDFHIP_ERR_NOMEM = 5
+};
+
+/* ---- data contract ----------------------------------------------------- */
+
+/* The `Info` cbuffer, passed verbatim (112 bytes).
+ * Replaces: struct Info, SdfBox/Logic.cs:407-420 == Compute.hlsl:70-81;
+ * heading rows are Float3x3, SdfBox/Logic.cs:427-463.
+ * buffer_size is ignored by the renderer (the scene handle knows its length);
+ * hidef is unused by the shader and by us. */
+typedef struct sdfhip_info {
+    float heading[3][4];   /*   0 */
+    float position[3];     /*  48 */
+    float margin;          /*  60 */
+    float screen_size[2];  /*  64 */
+    uint32_t buffer_size;  /*  72 */
+    float limit;           /*  76 */
+    float light[3];        /*  80 */
+    float strength;        /*  92 */
+    float fov;             /*  96 */
+    int32_t hidef;         /* 100 */
+    uint32_t pad_[2];      /* 104 -> 112 */
+} sdfhip_info;
+
+/* Flattened octree as the reference's native loader hands it over.
+ * Replaces: struct OctData {Length, Structs, Values}, SdfGen/dllmain.cpp:36-41
+ * == NativeOctData, SdfBox/Program.cs:579-583.  structs = N x {int32 parent,
+ * int32 children} (OctS, dllmain.cpp:18-29), values = N x 8 bytes, corner
+ * k = x + 2y + 4z, *before* the texture swizzle of Program.cs:514-538. */
+typedef struct sdfhip_octdata {
+    uint32_t length;
+    int32_t *structs;
+    uint8_t *values;
+} sdfhip_octdata;
+
+/* Opaque scene handle: the octree resident in one GPU's HBM. */
+typedef struct sdfhip_scene sdfhip_scene;
+
+/* Render flags. */
+enum {
+    SDFHIP_KERNEL_AUTO = 0,       /* cursor-stack kernel when the tree allows, else generic */
+    SDFHIP_KERNEL_GENERIC = 1,    /* one thread per pixel, loads as Compute.hlsl does      */
+    SDFHIP_KERNEL_STACK = 2,      /* ancestor stack in LDS, fused 16-B node records        */
+    SDFHIP_KERNEL_MASK = 0xF,
+    SDFHIP_FLAG_COMPACT = 0x10,   /* persistent waves, ballot/prefix refill of finished lanes */
+    SDFHIP_FLAG_COUNT = 0x20      /* also count algorithmic node/sample reads (slower)     */
+};
+
+/* Per-call statistics (all optional: pass NULL). */
+typedef struct sdfhip_stats {
+    float kernel_ms;        /* HIP-event time of the ray-march kernel(s)      */
+    float total_ms;         /* kernel + device->host copy, host clock         */
+    uint64_t n_nodes;       /* with SDFHIP_FLAG_COUNT: node records find()    */
+                            /* reads in the reference algorithm   */
+    uint64_t n_samples;     /* interpol_world calls                           */
+    uint64_t n_steps;       /* sum of the alpha channel (march steps)         */
+    uint32_t kernel_used;   /* SDFHIP_KERNEL_GENERIC or _STACK (| COMPACT)    */
+    uint32_t pad_;
+} sdfhip_stats;
+
+/* ---- errors ------------------------------------------------------------ */
+/* Replaces: CheckError -> throw across the FFI, SdfGen/pch.h:20-26. */
+SDFHIP_API const char *sdfhip_last_error(void);
+
+/* ---- scene data on the host (.asdf) ------------------------------------ */
+
+/* Replaces: LoadAsdf, SdfGen/dllmain.cpp:250-276 (P/Invoke Program.cs:658).
+ * Allocates out->structs / out->values; release with sdfhip_octdata_free. */
+SDFHIP_API int sdfhip_asdf_load(const char *path, sdfhip_octdata *out);
+
+/* Replaces: Save, SdfGen/dllmain.cpp:278-292 (P/Invoke Program.cs:661). */
+SDFHIP_API int sdfhip_asdf_save(const sdfhip_octdata *data, const char *path);
+
+/* Replaces: Free, SdfGen/dllmain.cpp:346-351 (P/Invoke Program.cs:666). */
+SDFHIP_API void sdfhip_octdata_free(sdfhip_octdata *data);
+
+/* Analytic scene builder: the split rule and quantiser of SdfGen's
+ * construct / FromFloat / WriteBytes (SdfGen/dllmain.cpp:163-207) applied to
+ * a closed-form distance function instead of a point cloud, same node order.
+ * Stands in for SdfGen (dllmain.cpp:295-319), which needs mesh files that do
+ * not ship.  shape: SDFHIP_SHAPE_*; params: see each shape. */
+enum {
+    SDFHIP_SHAPE_SPHERE = 0,   /* params: cx, cy, cz, r                        */
+    SDFHIP_SHAPE_TORUS = 1,    /* params: cx, cy, cz, R, r  (axis = y)         */
+    SDFHIP_SHAPE_GYROID = 2    /* params: cx, cy, cz, clip_r, freq, thickness  */
+};
+SDFHIP_API int sdfhip_generate(int shape, const float *params, int nparams,
+                               int max_depth, int nthreads, sdfhip_octdata *out);
+
+/* Structural check used by upload: 0 = ok.  depth_out = deepest level,
+ * consistent_out = 1 when every child's parent field points back at it. */
+SDFHIP_API int sdfhip_octdata_validate(const int32_t *structs, uint32_t n,
+                                       uint32_t *depth_out, int *consistent_out);
+
+/* ---- camera block ------------------------------------------------------ */
+
+/* Replaces: Logic.State initialiser, SdfBox/Logic.cs:30-38 + Program.cs:54
+ * (heading = identity via Logic.Heading = Zero) + limit via Logic.Position. */
+SDFHIP_API void sdfhip_info_default(sdfhip_info *info, float width, float height);
+
+/* Replaces: Logic.Heading setter, SdfBox/Logic.cs:46-55:
+ * heading = Float3x3(Matrix4x4.CreateFromYawPitchRoll(heading_y, heading_x, 0)). */
+SDFHIP_API void sdfhip_info_set_heading(sdfhip_info *info, float heading_x, float heading_y);
+
+/* Replaces: Logic.Position setter, SdfBox/Logic.cs:60-78 (position + limit). */
+SDFHIP_API void sdfhip_info_set_position(sdfhip_info *info, float x, float y, float z);
+
+/* ---- device ------------------------------------------------------------ */
+
+SDFHIP_API int sdfhip_device_count(int *count);
+
+/* Replaces: OctData.StructBuffer() + OctData.ValueTexture(),
+ * SdfBox/Program.cs:543-572, bound at Program.cs:147-152: copies the scene to
+ * device `device` once.  Host arrays may be freed after return. */
+SDFHIP_API int sdfhip_scene_upload(int device, const int32_t *structs, const uint8_t *values,
+                                   uint32_t n, sdfhip_scene **out);
+SDFHIP_API int sdfhip_scene_free(sdfhip_scene *scene);
+SDFHIP_API int sdfhip_scene_info(const sdfhip_scene *scene, uint32_t *n, uint32_t *depth,
+                                 int *stack_kernel_ok, int *device);
+
+/* Replaces: Program.Draw's UpdateBuffer(info) + DispatchSized(W, H, 1),
+ * SdfBox/Program.cs:81,94 (kernel: Compute.hlsl:180-231).  Renders the whole
+ * W x H frame and copies it to `rgba_out` (host, W*H*4 floats, row-major,
+ * top-left origin, tightly packed: no 12-pixel padding, unlike Program.cs:
+ * 311-314).  Synchronous. */
+SDFHIP_API int sdfhip_render(sdfhip_scene *scene, const sdfhip_info *info,
+                             uint32_t width, uint32_t height, uint32_t flags,
+                             float *rgba_out, sdfhip_stats *stats);
+
+/* Device-resident variant for callers that keep the frame in HBM (multi-GPU
+ * tile sharding, timing with inputs resident).  Renders the rows
+ *     y = band_first*band_rows + (k / band_rows)*band_stride*band_rows + k % band_rows,
+ * k = 0 .. nrows_out-1, i.e. every band_stride-th band of band_rows rows
+ * starting at band `band_first`, into d_rgba_out (device pointer, nrows_out x
+ * width x 4 floats, compact).  band_stride = 1, band_first = 0, nrows_out =
+ * height renders the whole frame.  Asynchronous on `stream` (a hipStream_t;
+ * NULL = the scene's own stream); no host synchronisation unless `stats` is
+ * given. */
+SDFHIP_API int sdfhip_render_device(sdfhip_scene *scene, const sdfhip_info *info,
+                                    uint32_t width, uint32_t height,
+                                    uint32_t band_rows, uint32_t band_first,
+                                    uint32_t band_stride, uint32_t nrows_out,
+                                    uint32_t flags, float *d_rgba_out, void *stream,
+                                    sdfhip_stats *stats);
+
+/* Rank-0 helper for the tile gather: scatter `world` compact band buffers
+ * (as all-gathered: rank r's rows at d_gathered + r*rows_per_rank*width*4)
+ * back into row order.  Asynchronous on `stream`. */
+SDFHIP_API int sdfhip_deinterleave_device(int device, const float *d_gathered, float *d_frame,
+                                          uint32_t width, uint32_t height,
+                                          uint32_t band_rows, uint32_t world,
+                                          uint32_t rows_per_rank, void *stream);
+
+/* Test hook: the kernel's R8_UNorm decode of bytes 0..255 (256 floats to the
+ * host), checked exhaustively against byte/255.0f. */
+SDFHIP_API int sdfhip_debug_unorm_table(int device, float *out256);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFHIP_H */

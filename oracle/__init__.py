@@ -1,0 +1,95 @@
+"""ctypes access to the CPU oracle (oracle/sdf_oracle.c).
+
+TEST INFRASTRUCTURE: importable only from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Nothing in sdfbox_amd/ imports this package.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "sdf_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u32, c = ctypes.c_void_p, ctypes.c_uint32, ctypes
+        L.oracle_render_rows.restype = c.c_int
+        L.oracle_render_rows.argtypes = [vp, vp, u32, vp, u32, u32, u32, vp, vp, vp, c.c_int]
+        L.oracle_pixel.restype = None
+        L.oracle_pixel.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp]
+        L.oracle_distance_at.restype = c.c_float
+        L.oracle_distance_at.argtypes = [vp, vp, u32, c.c_float, c.c_float, c.c_float,
+                                         c.POINTER(u32), c.POINTER(c.c_float)]
+        L.oracle_unorm_table.restype = None
+        L.oracle_unorm_table.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def _info_buf(info):
+    b = bytes(info)
+    assert len(b) == 112
+    return ctypes.create_string_buffer(b, 112)
+
+
+def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1, per_pixel_nodes=False):
+    """-> (rgba[nrows, W, 4] f32, counters[3] u64 (nodes, samples, steps)[, nodes per pixel])."""
+    structs = np.ascontiguousarray(structs, dtype=np.int32)
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    n = structs.size // 2
+    if nrows is None:
+        nrows = height - row0
+    out = np.zeros((nrows, width, 4), dtype=np.float32)
+    cnt = np.zeros(3, dtype=np.uint64)
+    pix = np.zeros((nrows, width), dtype=np.uint32) if per_pixel_nodes else None
+    ib = _info_buf(info)
+    rc = lib().oracle_render_rows(structs.ctypes.data, values.ctypes.data, n, ctypes.addressof(ib),
+                                  width, row0, nrows, out.ctypes.data, cnt.ctypes.data,
+                                  pix.ctypes.data if pix is not None else None, int(nthreads))
+    if rc != 0:
+        raise MemoryError("oracle_render_rows failed")
+    return (out, cnt, pix) if per_pixel_nodes else (out, cnt)
+
+
+def pixel(structs, values, info, x, y):
+    structs = np.ascontiguousarray(structs, dtype=np.int32)
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    out = np.zeros(4, dtype=np.float32)
+    cnt = np.zeros(3, dtype=np.uint64)
+    ib = _info_buf(info)
+    lib().oracle_pixel(structs.ctypes.data, values.ctypes.data, structs.size // 2,
+                       ctypes.addressof(ib), int(x), int(y), out.ctypes.data, cnt.ctypes.data)
+    return out, cnt
+
+
+def distance_at(structs, values, x, y, z):
+    structs = np.ascontiguousarray(structs, dtype=np.int32)
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    idx = ctypes.c_uint32()
+    sc = ctypes.c_float()
+    d = lib().oracle_distance_at(structs.ctypes.data, values.ctypes.data, structs.size // 2,
+                                 float(x), float(y), float(z), ctypes.byref(idx), ctypes.byref(sc))
+    return float(d), idx.value, sc.value
+
+
+def unorm_table():
+    out = np.zeros(256, dtype=np.float32)
+    lib().oracle_unorm_table(out.ctypes.data)
+    return out

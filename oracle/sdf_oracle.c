@@ -1,0 +1,386 @@
+/*
+ * sdf_oracle.c -- CPU restatement of SdfBox's ray-march compute pass.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under sdfbox_amd/ may include, link or
+ * call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and there only as the checker / the timed CPU
+ * baseline -- never as the thing shipped.
+ *
+ * PARITY UNPINNED BY THE REFERENCE: the reference has no CPU implementation
+ * of this path, no tests, no golden vectors, and its
+ * only implementation is HLSL run through D3D11 texture hardware.  This file
+ * is a scalar fp32 restatement of that HLSL, statement by statement, and is
+ * the specification the HIP kernels are held to bit-for-bit.  It is anchored
+ * by closed-form cases in tests/test_oracle_analytic.py, nothing more.
+ *
+ * Follows (all paths relative to the reference checkout):
+ *   SdfBox/Shaders/Compute.hlsl:15-29    sam / sample_at      -> o_sample_at
+ *   SdfBox/Shaders/Compute.hlsl:31-58    Cube                 -> o_cube, o_*
+ *   SdfBox/Shaders/Compute.hlsl:88-108   find                 -> o_find
+ *   SdfBox/Shaders/Compute.hlsl:112-130  gradient             -> o_gradient
+ *   SdfBox/Shaders/Compute.hlsl:163-168  ray                  -> o_ray
+ *   SdfBox/Shaders/Compute.hlsl:180-231  main                 -> o_pixel
+ *   SdfBox/Logic.cs:407-463              Info / Float3x3      -> o_info
+ *   SdfBox/Program.cs:514-538            value texture layout -> o_sample_at
+ *
+ * Arithmetic contract (shared with the HIP kernels, DESIGN.md "Numerics"):
+ *   - every operation is an individually rounded IEEE fp32 operation in the
+ *     order written here; build with -ffp-contract=off, no fast-math;
+ *   - saturate(x)   = fminf(fmaxf(x, 0), 1)           (NaN -> 0, as HLSL)
+ *   - lerp(a,b,t)   = a + t*(b - a)
+ *   - dot(a,b)      = (a.x*b.x + a.y*b.y) + a.z*b.z
+ *   - normalize(v)  = v / sqrtf(dot(v,v))             (component-wise divide)
+ *   - length(v)     = sqrtf(dot(v,v))
+ *   - R8_UNorm texel = (float)byte / 255.0f, bilinear = x-lerp then y-lerp
+ *   - exp2(strength) is evaluated once per frame on the host (exp2f).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- Info, 112 bytes, Logic.cs:407-420 / Compute.hlsl:70-81 ------------- */
+typedef struct {
+    float heading[3][4];   /* offset 0: three float4 rows, Logic.cs:427-463 */
+    float position[3];     /* 48 */
+    float margin;          /* 60 */
+    float screen_size[2];  /* 64 */
+    uint32_t buffer_size;  /* 72 (ignored: the scene's own length is used) */
+    float limit;           /* 76 */
+    float light[3];        /* 80 */
+    float strength;        /* 92 */
+    float fov;             /* 96 */
+    int32_t hidef;         /* 100 (unused by the shader) */
+    uint32_t pad[2];       /* -> 112 */
+} o_info;
+
+typedef struct {
+    const int32_t *structs;  /* N x {parent, children}, Program.cs:339-350 */
+    const uint8_t *values;   /* N x 8 corner bytes, k = x + 2y + 4z */
+    uint32_t n;
+} o_scene;
+
+/* Cube, Compute.hlsl:31-61 */
+typedef struct { float lx, ly, lz, scale; } o_cube;
+
+/* per-pixel state: the shader's static `index` and `box` (Compute.hlsl:12,61) */
+typedef struct {
+    const o_scene *sc;
+    uint32_t index;
+    o_cube box;
+    uint64_t n_nodes;    /* node records read by find(): SURVEY 8d */
+    uint64_t n_samples;  /* interpol_world calls */
+} o_ctx;
+
+static inline float o_sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+static inline float o_lerp(float a, float b, float t) { return a + t * (b - a); }
+static inline float o_dot(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx + ay * by) + az * bz;
+}
+
+/* Cube::scale_up, Compute.hlsl:36-40 */
+static inline void o_scale_up(o_cube *b)
+{
+    b->scale *= 2.0f;
+    b->lx = floorf(b->lx / b->scale) * b->scale;
+    b->ly = floorf(b->ly / b->scale) * b->scale;
+    b->lz = floorf(b->lz / b->scale) * b->scale;
+}
+/* Cube::scale_down, Compute.hlsl:41-45 */
+static inline void o_scale_down(o_cube *b, int dx, int dy, int dz)
+{
+    b->scale /= 2.0f;
+    b->lx += (float)dx * b->scale;
+    b->ly += (float)dy * b->scale;
+    b->lz += (float)dz * b->scale;
+}
+/* Cube::inside, Compute.hlsl:50-53 */
+static inline int o_inside(const o_cube *b, float px, float py, float pz)
+{
+    float hx = b->lx + b->scale, hy = b->ly + b->scale, hz = b->lz + b->scale;
+    return (b->lx <= px && b->ly <= py && b->lz <= pz) &&
+           (px <= hx && py <= hy && pz <= hz);
+}
+
+/* find, Compute.hlsl:88-108 */
+static void o_find(o_ctx *t, float px, float py, float pz)
+{
+    const int32_t *S = t->sc->structs;
+    int iterations = 0;
+    int32_t c_parent = S[2 * (size_t)t->index], c_children = S[2 * (size_t)t->index + 1];
+    t->n_nodes++;
+
+    while (!o_inside(&t->box, px, py, pz) && c_parent >= 0) {
+        t->index = (uint32_t)c_parent;
+        c_parent = S[2 * (size_t)t->index];
+        c_children = S[2 * (size_t)t->index + 1];
+        t->n_nodes++;
+        o_scale_up(&t->box);
+    }
+    while (t->index < t->sc->n && iterations < 12 && c_children >= 0) {
+        /* (int3) saturate((pos - box.lower) / box.scale * subdiv) */
+        int dx = (int)o_sat((px - t->box.lx) / t->box.scale * 2.0f);
+        int dy = (int)o_sat((py - t->box.ly) / t->box.scale * 2.0f);
+        int dz = (int)o_sat((pz - t->box.lz) / t->box.scale * 2.0f);
+        int p = dx + 2 * dy + 4 * dz;
+        t->index = (uint32_t)(c_children + p);
+        c_parent = S[2 * (size_t)t->index];
+        c_children = S[2 * (size_t)t->index + 1];
+        t->n_nodes++;
+        o_scale_down(&t->box, dx, dy, dz);
+        iterations++;
+    }
+}
+
+/* The 8 texels of the current node as R8_UNorm floats.  Texture layout
+ * (Program.cs:514-538): row0 = corners {0,1,4,5}, row1 = {2,3,6,7}; one
+ * bilinear tap at (d.xy + p) blends corners 0..3, the tap at +(2,0) blends
+ * corners 4..7 (Compute.hlsl:19-29). */
+static inline void o_texels(const o_ctx *t, float v[8])
+{
+    const uint8_t *b = t->sc->values + 8 * (size_t)t->index;
+    for (int k = 0; k < 8; k++) v[k] = (float)b[k] / 255.0f;
+}
+static inline float o_bilerp(float t00, float t10, float t01, float t11, float wx, float wy)
+{
+    float top = o_lerp(t00, t10, wx);
+    float bot = o_lerp(t01, t11, wx);
+    return o_lerp(top, bot, wy);
+}
+
+/* sample_at, Compute.hlsl:19-29 */
+static float o_sample_at(o_ctx *t, float dx, float dy, float dz, float scale)
+{
+    float v[8];
+    o_texels(t, v);
+    float loadL = o_bilerp(v[0], v[1], v[2], v[3], dx, dy);
+    float loadH = o_bilerp(v[4], v[5], v[6], v[7], dx, dy);
+    float result = (o_lerp(loadL, loadH, dz) - 0.25f) * scale * 2.0f;
+    return result;
+}
+/* Cube::interpol_world, Compute.hlsl:54-58 */
+static float o_interpol_world(o_ctx *t, float px, float py, float pz)
+{
+    float dx = o_sat((px - t->box.lx) / t->box.scale);
+    float dy = o_sat((py - t->box.ly) / t->box.scale);
+    float dz = o_sat((pz - t->box.lz) / t->box.scale);
+    t->n_samples++;
+    return o_sample_at(t, dx, dy, dz, t->box.scale);
+}
+
+/* gradient, Compute.hlsl:112-130.  A tap at integer x (or y) has bilinear
+ * weight 0 towards its neighbour, i.e. lerp(a, b, 0) = a exactly. */
+static void o_gradient(const o_ctx *t, float px, float py, float pz, float g[3])
+{
+    float dx = o_sat((px - t->box.lx) / t->box.scale);
+    float dy = o_sat((py - t->box.ly) / t->box.scale);
+    float dz = o_sat((pz - t->box.lz) / t->box.scale);
+    float v[8];
+    o_texels(t, v);
+
+    float xl = o_lerp(o_lerp(v[0], v[2], dy), o_lerp(v[4], v[6], dy), dz);
+    float xh = o_lerp(o_lerp(v[1], v[3], dy), o_lerp(v[5], v[7], dy), dz);
+
+    float yl = o_lerp(o_lerp(v[0], v[1], dx), o_lerp(v[4], v[5], dx), dz);
+    float yh = o_lerp(o_lerp(v[2], v[3], dx), o_lerp(v[6], v[7], dx), dz);
+
+    float zl = o_bilerp(v[0], v[1], v[2], v[3], dx, dy);
+    float zh = o_bilerp(v[4], v[5], v[6], v[7], dx, dy);
+
+    g[0] = xh - xl;
+    g[1] = yh - yl;
+    g[2] = zh - zl;
+}
+
+/* ray, Compute.hlsl:163-168 */
+static void o_ray(const o_info *inf, uint32_t cx, uint32_t cy, float dir[3])
+{
+    float sx = (float)cx / inf->screen_size[1] - inf->screen_size[0] / inf->screen_size[1] * 0.5f;
+    float sy = (float)cy / inf->screen_size[1] - 0.5f;
+    float vx = sx * inf->fov, vy = sy * inf->fov, vz = 0.5f;
+    /* mul(v, heading): component j = dot(v, j-th float4 row of Info) */
+    float d0 = o_dot(vx, vy, vz, inf->heading[0][0], inf->heading[0][1], inf->heading[0][2]);
+    float d1 = o_dot(vx, vy, vz, inf->heading[1][0], inf->heading[1][1], inf->heading[1][2]);
+    float d2 = o_dot(vx, vy, vz, inf->heading[2][0], inf->heading[2][1], inf->heading[2][2]);
+    float len = sqrtf(o_dot(d0, d1, d2, d0, d1, d2));
+    dir[0] = d0 / len;
+    dir[1] = d1 / len;
+    dir[2] = d2 / len;
+}
+
+/* main, Compute.hlsl:180-231.  out = rgba; counters accumulate in t. */
+static void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_m1,
+                    uint32_t cx, uint32_t cy, float out[4], uint64_t cnt[3])
+{
+    o_ctx t;
+    t.sc = sc;
+    t.index = 0;
+    t.box.lx = t.box.ly = t.box.lz = 0.0f;
+    t.box.scale = 1.0f;
+    t.n_nodes = t.n_samples = 0;
+
+    float px = inf->position[0], py = inf->position[1], pz = inf->position[2];
+    float dir[3];
+    o_ray(inf, cx, cy, dir);
+    float prox = 1.0f;
+    const float margin = inf->margin;
+
+    int i, j = 0;
+    for (i = 0; (prox > margin * 2.0f || prox < 0.0f) && i < 100; i++) {
+        if (o_dot(px, py, pz, px, py, pz) > inf->limit) {
+            out[0] = 0.005f; out[1] = 0.01f; out[2] = 0.2f; out[3] = (float)i;
+            goto done;
+        }
+        o_find(&t, px, py, pz);
+        prox = o_interpol_world(&t, px, py, pz);
+        px += dir[0] * prox;
+        py += dir[1] * prox;
+        pz += dir[2] * prox;
+    }
+    {
+        /* dir = normalize(inf.light - pos); pos += dir * inf.margin; */
+        float lx = inf->light[0] - px, ly = inf->light[1] - py, lz = inf->light[2] - pz;
+        float len = sqrtf(o_dot(lx, ly, lz, lx, ly, lz));
+        dir[0] = lx / len; dir[1] = ly / len; dir[2] = lz / len;
+        px += dir[0] * margin;
+        py += dir[1] * margin;
+        pz += dir[2] * margin;
+        /* angle = dot(dir, normalize(gradient(pos))) */
+        float g[3];
+        o_gradient(&t, px, py, pz, g);
+        float gl = sqrtf(o_dot(g[0], g[1], g[2], g[0], g[1], g[2]));
+        float angle = o_dot(dir[0], dir[1], dir[2], g[0] / gl, g[1] / gl, g[2] / gl);
+        if (angle < 0.0f) {
+            out[0] = out[1] = out[2] = 0.0f; out[3] = (float)i;
+            goto done;
+        }
+        /* dist = length(inf.light - pos) / 2 */
+        lx = inf->light[0] - px; ly = inf->light[1] - py; lz = inf->light[2] - pz;
+        float dist = sqrtf(o_dot(lx, ly, lz, lx, ly, lz)) / 2.0f;
+        for (j = 0; j < 40 && prox > -margin; j++) {
+            if (prox > dist || (px < 0.0f || py < 0.0f || pz < 0.0f) ||
+                (px > 1.0f || py > 1.0f || pz > 1.0f)) {
+                float attenuation = angle / (dist * dist) * exp2_strength_m1;
+                out[0] = out[1] = out[2] = attenuation; out[3] = (float)(i + j);
+                goto done;
+            }
+            if (prox < margin) {
+                o_gradient(&t, px, py, pz, g);
+                if (o_dot(g[0], g[1], g[2], dir[0], dir[1], dir[2]) < 0.0f)
+                    break;
+            }
+            o_find(&t, px, py, pz);
+            prox = o_interpol_world(&t, px, py, pz);
+            float step = prox + margin;
+            px += dir[0] * step;
+            py += dir[1] * step;
+            pz += dir[2] * step;
+        }
+        out[0] = out[1] = out[2] = 0.0f; out[3] = (float)(i + j);
+    }
+done:
+    cnt[0] += t.n_nodes;
+    cnt[1] += t.n_samples;
+    cnt[2] += (uint64_t)(i + j);
+}
+
+/* ---- exported entry points --------------------------------------------- */
+
+typedef struct {
+    o_scene sc;
+    o_info inf;
+    float k;
+    uint32_t W, row0, nrows;
+    int tid, nthreads;
+    float *rgba;          /* nrows x W x 4, row-major, row 0 = global row0 */
+    uint32_t *pix_nodes;  /* optional: nrows x W algorithmic node reads per pixel */
+    uint64_t cnt[3];
+} o_job;
+
+static void *o_worker(void *arg)
+{
+    o_job *jb = (o_job *)arg;
+    for (uint32_t r = (uint32_t)jb->tid; r < jb->nrows; r += (uint32_t)jb->nthreads) {
+        for (uint32_t x = 0; x < jb->W; x++) {
+            uint64_t before = jb->cnt[0];
+            o_pixel(&jb->sc, &jb->inf, jb->k, x, jb->row0 + r,
+                    jb->rgba + 4 * ((size_t)r * jb->W + x), jb->cnt);
+            if (jb->pix_nodes)
+                jb->pix_nodes[(size_t)r * jb->W + x] = (uint32_t)(jb->cnt[0] - before);
+        }
+    }
+    return NULL;
+}
+
+/* Render rows [row0, row0+nrows) of a W-wide frame.  Pixel (x, y) uses the
+ * dispatch-thread id (x, y) exactly as Compute.hlsl:180 does.  counters[0..2]
+ * receive node reads, samples, march steps summed over the rendered pixels
+ * (may be NULL).  Rows are interleaved over `nthreads` pthreads. */
+int oracle_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n,
+                       const void *info112, uint32_t W, uint32_t row0, uint32_t nrows,
+                       float *rgba, uint64_t *counters, uint32_t *pix_nodes, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    o_job *jobs = (o_job *)calloc((size_t)nthreads, sizeof(o_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    o_info inf;
+    memcpy(&inf, info112, sizeof inf);
+    float k = exp2f(inf.strength) - 1.0f;
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t].sc.structs = structs; jobs[t].sc.values = values; jobs[t].sc.n = n;
+        jobs[t].inf = inf; jobs[t].k = k;
+        jobs[t].W = W; jobs[t].row0 = row0; jobs[t].nrows = nrows;
+        jobs[t].tid = t; jobs[t].nthreads = nthreads;
+        jobs[t].rgba = rgba; jobs[t].pix_nodes = pix_nodes;
+    }
+    if (nthreads == 1) {
+        o_worker(&jobs[0]);
+    } else {
+        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, o_worker, &jobs[t]);
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    }
+    if (counters) {
+        counters[0] = counters[1] = counters[2] = 0;
+        for (int t = 0; t < nthreads; t++)
+            for (int c = 0; c < 3; c++) counters[c] += jobs[t].cnt[c];
+    }
+    free(jobs); free(th);
+    return 0;
+}
+
+/* One pixel, for unit tests.  out[4] = rgba, cnt[3] = nodes, samples, steps. */
+void oracle_pixel(const int32_t *structs, const uint8_t *values, uint32_t n,
+                  const void *info112, uint32_t x, uint32_t y, float *out, uint64_t *cnt)
+{
+    o_scene sc = { structs, values, n };
+    o_info inf;
+    memcpy(&inf, info112, sizeof inf);
+    cnt[0] = cnt[1] = cnt[2] = 0;
+    o_pixel(&sc, &inf, exp2f(inf.strength) - 1.0f, x, y, out, cnt);
+}
+
+/* Trilinear distance at a world position starting from the root cursor:
+ * find() + interpol_world().  For the analytic anchors in the tests. */
+float oracle_distance_at(const int32_t *structs, const uint8_t *values, uint32_t n,
+                         float x, float y, float z, uint32_t *leaf_index, float *leaf_scale)
+{
+    o_scene sc = { structs, values, n };
+    o_ctx t;
+    t.sc = &sc; t.index = 0; t.box.lx = t.box.ly = t.box.lz = 0.0f; t.box.scale = 1.0f;
+    t.n_nodes = t.n_samples = 0;
+    o_find(&t, x, y, z);
+    if (leaf_index) *leaf_index = t.index;
+    if (leaf_scale) *leaf_scale = t.box.scale;
+    return o_interpol_world(&t, x, y, z);
+}
+
+/* The 256 R8_UNorm decode values, so the GPU's reciprocal-and-fixup decode
+ * can be checked exhaustively against the division it stands for. */
+void oracle_unorm_table(float *out256)
+{
+    for (int b = 0; b < 256; b++) out256[b] = (float)b / 255.0f;
+}

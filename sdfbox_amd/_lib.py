@@ -1,0 +1,120 @@
+"""ctypes binding of libsdfhip.so (include/sdfhip.h).
+
+The library is the product; there is no Python or CPU fallback.  If it has not
+been built (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C sdfbox_amd/csrc``) importing this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdfhip.so")
+
+# PyTorch bundles its own libamdhip64.so; load it first so that libsdfhip.so
+# binds to the same HIP runtime instance torch uses (one runtime per process:
+# device pointers and streams are then interchangeable).
+try:  # pragma: no cover - depends on the environment
+    import torch  # noqa: F401
+except Exception:  # torch is plumbing, not a requirement of the C ABI
+    torch = None
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+        "(hipcc --offload-arch=gfx950). sdfbox_amd has no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+OK, ERR_ARG, ERR_IO, ERR_BAD_TREE, ERR_DEVICE, ERR_NOMEM = range(6)
+
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_STACK = 0, 1, 2
+FLAG_COMPACT, FLAG_COUNT = 0x10, 0x20
+SHAPE_SPHERE, SHAPE_TORUS, SHAPE_GYROID = 0, 1, 2
+
+
+class Info(ctypes.Structure):
+    """The 112-byte `Info` cbuffer (Logic.cs:407-420)."""
+    _fields_ = [
+        ("heading", (ctypes.c_float * 4) * 3),
+        ("position", ctypes.c_float * 3),
+        ("margin", ctypes.c_float),
+        ("screen_size", ctypes.c_float * 2),
+        ("buffer_size", ctypes.c_uint32),
+        ("limit", ctypes.c_float),
+        ("light", ctypes.c_float * 3),
+        ("strength", ctypes.c_float),
+        ("fov", ctypes.c_float),
+        ("hidef", ctypes.c_int32),
+        ("pad_", ctypes.c_uint32 * 2),
+    ]
+
+
+assert ctypes.sizeof(Info) == 112
+
+
+class COctData(ctypes.Structure):
+    _fields_ = [
+        ("length", ctypes.c_uint32),
+        ("structs", ctypes.POINTER(ctypes.c_int32)),
+        ("values", ctypes.POINTER(ctypes.c_uint8)),
+    ]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("kernel_ms", ctypes.c_float),
+        ("total_ms", ctypes.c_float),
+        ("n_nodes", ctypes.c_uint64),
+        ("n_samples", ctypes.c_uint64),
+        ("n_steps", ctypes.c_uint64),
+        ("kernel_used", ctypes.c_uint32),
+        ("pad_", ctypes.c_uint32),
+    ]
+
+
+class SdfHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"sdfhip error {code}: {message}")
+        self.code = code
+
+
+_c = ctypes
+_vp = ctypes.c_void_p
+_SIG = {
+    "sdfhip_last_error": (_c.c_char_p, []),
+    "sdfhip_asdf_load": (_c.c_int, [_c.c_char_p, _c.POINTER(COctData)]),
+    "sdfhip_asdf_save": (_c.c_int, [_c.POINTER(COctData), _c.c_char_p]),
+    "sdfhip_octdata_free": (None, [_c.POINTER(COctData)]),
+    "sdfhip_generate": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.c_int,
+                                   _c.POINTER(COctData)]),
+    "sdfhip_octdata_validate": (_c.c_int, [_vp, _c.c_uint32, _c.POINTER(_c.c_uint32),
+                                           _c.POINTER(_c.c_int)]),
+    "sdfhip_info_default": (None, [_c.POINTER(Info), _c.c_float, _c.c_float]),
+    "sdfhip_info_set_heading": (None, [_c.POINTER(Info), _c.c_float, _c.c_float]),
+    "sdfhip_info_set_position": (None, [_c.POINTER(Info), _c.c_float, _c.c_float, _c.c_float]),
+    "sdfhip_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
+    "sdfhip_scene_upload": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.POINTER(_vp)]),
+    "sdfhip_scene_free": (_c.c_int, [_vp]),
+    "sdfhip_scene_info": (_c.c_int, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint32),
+                                     _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "sdfhip_render": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp,
+                                 _c.POINTER(Stats)]),
+    "sdfhip_render_device": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32,
+                                        _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                        _c.c_uint32, _vp, _vp, _c.POINTER(Stats)]),
+    "sdfhip_deinterleave_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32,
+                                              _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+    "sdfhip_debug_unorm_table": (_c.c_int, [_c.c_int, _vp]),
+}
+# every symbol include/sdfhip.h declares must be exported: fail at import otherwise
+for _name, (_res, _args) in _SIG.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED_SYMBOLS = tuple(_SIG)
+
+
+def check(code):
+    if code != OK:
+        raise SdfHipError(code, lib.sdfhip_last_error().decode("utf-8", "replace"))

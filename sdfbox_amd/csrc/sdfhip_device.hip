@@ -1,0 +1,591 @@
+// libsdfhip.so, device half: the ray-march kernels for gfx950 and the C-ABI
+// entry points that own HBM (scene upload, render, band de-interleave).
+//
+// Replaces the reference's compute pass and its dispatch:
+//   SdfBox/Shaders/Compute.hlsl:180-231   main()            -> k_plain / k_compact
+//   SdfBox/Program.cs:81,94               UpdateBuffer(info) + DispatchSized
+//                                                            -> sdfhip_render*
+//   SdfBox/Program.cs:543-572,147-152     StructBuffer/ValueTexture + binding
+//                                                            -> sdfhip_scene_upload
+//
+// Kernel structure (DESIGN.md "Kernels"):
+//   * one lane per pixel, 8x8 pixels per 64-lane wavefront;
+//   * the primary march, the shading step and the shadow march of
+//     Compute.hlsl:194-230 run as ONE per-lane state machine around a single
+//     find + sample body, so lanes in different phases share the instruction
+//     stream instead of serialising two loops;
+//   * k_plain: 16x16-pixel workgroups, blockIdx remapped so that each XCD (own
+//     L2) renders one contiguous slab of the frame;
+//   * k_compact: persistent waves pull 8x8 tiles from a queue and refill
+//     finished lanes by ballot + prefix count (wavefront ray compaction).
+#include "raymarch_device.h"
+#include "sdfhip_internal.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+namespace sdfhip {
+
+constexpr int BLOCK = 256;       // 4 wavefronts
+constexpr int MAX_STACK = 12;    // the shader's own descent limit (Compute.hlsl:98)
+constexpr int REFILL_MIN = 16;   // compact kernels: refill once this many lanes are idle
+
+struct RayState {
+    float px, py, pz;    // pos
+    float dx, dy, dz;    // dir (primary direction, then direction to the light)
+    float prox, angle, dist;
+    int i, j, phase;     // phase 0 = primary march, 1 = shadow march
+};
+
+__device__ __forceinline__ uint32_t global_row(const RenderParams &P, uint32_t yl)
+{
+    uint32_t band = yl / P.band_rows;
+    return (P.band_first + band * P.band_stride) * P.band_rows + (yl - band * P.band_rows);
+}
+
+__device__ __forceinline__ void start_pixel(const RenderParams &P, const NodeRec &root, uint32_t x,
+                                            uint32_t y, RayState &r, Cursor &c)
+{
+    // Compute.hlsl:182-191
+    r.px = P.posx; r.py = P.posy; r.pz = P.posz;
+    ray(P, x, y, r.dx, r.dy, r.dz);
+    r.prox = 1.0f;
+    r.angle = 0.0f; r.dist = 0.0f;
+    r.i = 0; r.j = 0; r.phase = 0;
+    c.lx = c.ly = c.lz = 0.0f; c.scale = 1.0f; c.inv = 1.0f;
+    c.index = 0; c.level = 0;
+    set_record(c, root);
+}
+
+// Everything main() does between two find() calls.  Returns true when the
+// pixel is finished, with its colour in `out` (alpha = step count).
+__device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, const Cursor &c, float4 &out)
+{
+    if (r.phase == 0) {
+        // loop header of Compute.hlsl:194
+        if ((r.prox > P.margin * 2.0f || r.prox < 0.0f) && r.i < 100) {
+            if (dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > P.limit) {  // :195-199
+                out = make_float4(0.005f, 0.01f, 0.2f, (float)r.i);
+                return true;
+            }
+            return false;
+        }
+        // Compute.hlsl:205-213
+        float lx = P.lightx - r.px, ly = P.lighty - r.py, lz = P.lightz - r.pz;
+        float len = sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+        r.dx = lx / len; r.dy = ly / len; r.dz = lz / len;
+        r.px += r.dx * P.margin;
+        r.py += r.dy * P.margin;
+        r.pz += r.dz * P.margin;
+        float gx, gy, gz;
+        gradient(c, r.px, r.py, r.pz, gx, gy, gz);
+        float gl = sqrtf(dot3(gx, gy, gz, gx, gy, gz));
+        r.angle = dot3(r.dx, r.dy, r.dz, gx / gl, gy / gl, gz / gl);
+        if (r.angle < 0.0f) {
+            out = make_float4(0.0f, 0.0f, 0.0f, (float)r.i);
+            return true;
+        }
+        lx = P.lightx - r.px; ly = P.lighty - r.py; lz = P.lightz - r.pz;
+        r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+        r.phase = 1;
+        r.j = 0;
+    }
+    // loop header of Compute.hlsl:214
+    if (!(r.j < 40 && r.prox > -P.margin)) {
+        out = make_float4(0.0f, 0.0f, 0.0f, (float)(r.i + r.j));  // :229
+        return true;
+    }
+    if (r.prox > r.dist || (r.px < 0.0f || r.py < 0.0f || r.pz < 0.0f) ||
+        (r.px > 1.0f || r.py > 1.0f || r.pz > 1.0f)) {           // :215-219
+        float a = r.angle / (r.dist * r.dist) * P.k_strength;
+        out = make_float4(a, a, a, (float)(r.i + r.j));
+        return true;
+    }
+    if (r.prox < P.margin) {                                       // :221-223
+        float gx, gy, gz;
+        gradient(c, r.px, r.py, r.pz, gx, gy, gz);
+        if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) {
+            out = make_float4(0.0f, 0.0f, 0.0f, (float)(r.i + r.j));
+            return true;
+        }
+    }
+    return false;
+}
+
+// find + interpol_world + advance: Compute.hlsl:200-202 / :225-227
+template <bool STACK>
+__device__ __forceinline__ uint32_t march_step(const RenderParams &P, RayState &r, Cursor &c,
+                                               int32_t *stack)
+{
+    uint32_t reads;
+    if (STACK) reads = find_stack(c, P.nodes, stack, BLOCK, r.px, r.py, r.pz);
+    else       reads = find_generic(c, P.nodes, P.n_nodes, r.px, r.py, r.pz);
+    r.prox = interpol_world(c, r.px, r.py, r.pz);
+    float step = r.phase ? r.prox + P.margin : r.prox;
+    r.px += r.dx * step;
+    r.py += r.dy * step;
+    r.pz += r.dz * step;
+    if (r.phase) r.j++; else r.i++;
+    return reads;
+}
+
+__device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned long long nodes,
+                                               unsigned long long samples, unsigned long long steps)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        nodes += __shfl_down(nodes, off);
+        samples += __shfl_down(samples, off);
+        steps += __shfl_down(steps, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&P.counters[0], nodes);
+        atomicAdd(&P.counters[1], samples);
+        atomicAdd(&P.counters[2], steps);
+    }
+}
+
+// ---- one lane per pixel, one 16x16 tile per workgroup -----------------------
+template <bool STACK, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_plain(RenderParams P)
+{
+    __shared__ int32_t stack_lds[STACK ? MAX_STACK * BLOCK : 1];
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give
+    // each of the 8 residue classes one contiguous run of tiles (bijective for
+    // any grid size).
+    const uint32_t nb = gridDim.x, bid = blockIdx.x;
+    const uint32_t q = nb >> 3, rem = nb & 7u, xcd = bid & 7u;
+    const uint32_t tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t x = tx * 16 + (wave & 1u) * 8 + (lane & 7u);
+    const uint32_t yl = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    unsigned long long cn = 0, cs = 0, ct = 0;
+    bool live = x < P.width && yl < P.nrows_out;
+    uint32_t y = 0;
+    if (live) { y = global_row(P, yl); live = y < P.height; }
+    if (live) {
+        RayState r;
+        Cursor c;
+        const NodeRec root = P.nodes[0];
+        start_pixel(P, root, x, y, r, c);
+        float4 out;
+        while (!pre_step(P, r, c, out)) {
+            uint32_t reads = march_step<STACK>(P, r, c, stack_lds + tid);
+            if (COUNT) { cn += reads; cs += 1; }
+        }
+        P.out[(size_t)yl * P.width + x] = out;
+        if (COUNT) ct = (unsigned long long)out.w;
+    }
+    if (COUNT) flush_counters(P, cn, cs, ct);
+}
+
+// ---- persistent waves with lane refill (wavefront ray compaction) -----------
+// Pixels are numbered in 8x8-tile order: p = tile*64 + (y&7)*8 + (x&7).  Each
+// wave owns the range [cur, end) of one tile at a time and hands the next
+// pixels of it to its idle lanes: rank = number of idle lanes below me
+// (ballot + mbcnt), lane gets pixel cur + rank.  A pixel's result depends on
+// its coordinates only, so the image is the plain kernel's bit for bit.
+// Exit: every wave leaves once the queue is exhausted and its lanes are idle.
+template <bool STACK, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_compact(RenderParams P)
+{
+    __shared__ int32_t stack_lds[STACK ? MAX_STACK * BLOCK : 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const NodeRec root = P.nodes[0];
+    unsigned long long cn = 0, cs = 0, ct = 0;
+    RayState r;
+    Cursor c;
+    bool active = false;
+    uint32_t x = 0, yl = 0;
+    uint32_t cur = 0, end = 0;  // wave-uniform
+    bool more = true;           // wave-uniform
+    r.px = r.py = r.pz = r.dx = r.dy = r.dz = r.prox = r.angle = r.dist = 0.0f;
+    r.i = r.j = r.phase = 0;
+    c.lx = c.ly = c.lz = 0.0f; c.scale = c.inv = 1.0f; c.children = -1; c.v0 = c.v1 = 0;
+    c.index = 0; c.parent = -1; c.level = 0;
+
+    for (;;) {
+        unsigned long long idle = __ballot(!active);
+        int nidle = __popcll(idle);
+        if (more && (nidle >= REFILL_MIN || nidle == 64)) {
+            while (more && nidle > 0) {
+                if (cur == end) {
+                    uint32_t t = 0;
+                    if (lane == 0) t = atomicAdd(P.queue, 1u);
+                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                    if (t >= P.n_tiles) { more = false; break; }
+                    cur = t * 64u;
+                    end = cur + 64u;
+                }
+                uint32_t take = min((uint32_t)nidle, end - cur);
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (!active && rank < take) {
+                    uint32_t p = cur + rank, tile = p >> 6, qq = p & 63u;
+                    x = (tile % P.tiles_x) * 8 + (qq & 7u);
+                    yl = (tile / P.tiles_x) * 8 + (qq >> 3);
+                    if (x < P.width && yl < P.nrows_out) {
+                        uint32_t y = global_row(P, yl);
+                        if (y < P.height) {
+                            start_pixel(P, root, x, y, r, c);
+                            active = true;
+                        }
+                    }
+                }
+                cur += take;
+                idle = __ballot(!active);
+                nidle = __popcll(idle);
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (!more) break;
+            continue;
+        }
+        if (active) {
+            float4 out;
+            if (pre_step(P, r, c, out)) {
+                P.out[(size_t)yl * P.width + x] = out;
+                if (COUNT) ct += (unsigned long long)out.w;
+                active = false;
+            } else {
+                uint32_t reads = march_step<STACK>(P, r, c, stack_lds + tid);
+                if (COUNT) { cn += reads; cs += 1; }
+            }
+        }
+    }
+    if (COUNT) flush_counters(P, cn, cs, ct);
+}
+
+// ---- small helper kernels -----------------------------------------------------
+// {parent, children}[N] + bytes[N][8] -> fused 16-byte records (upload).
+__global__ void k_fuse(const int2 *__restrict__ structs, const uint2 *__restrict__ values,
+                       NodeRec *__restrict__ nodes, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int2 s = structs[i];
+        uint2 v = values[i];
+        nodes[i] = make_uint4((uint32_t)s.x, (uint32_t)s.y, v.x, v.y);
+    }
+}
+
+// Gathered compact band buffers -> frame rows (rank-0 side of the tile gather).
+__global__ void k_deinterleave(const float4 *__restrict__ gathered, float4 *__restrict__ frame,
+                               uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world,
+                               uint32_t rows_per_rank)
+{
+    size_t total = (size_t)width * height;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i - (size_t)y * width);
+        uint32_t band = y / band_rows, rank = band % world, lband = band / world;
+        uint32_t yl = lband * band_rows + (y - band * band_rows);
+        frame[i] = gathered[((size_t)rank * rows_per_rank + yl) * width + x];
+    }
+}
+
+__global__ void k_unorm_table(float *out)
+{
+    out[threadIdx.x] = unorm8((float)threadIdx.x);
+}
+
+}  // namespace sdfhip
+
+// ===============================================================================
+// Host side of the device half
+// ===============================================================================
+using namespace sdfhip;
+
+struct sdfhip_scene {
+    int device;
+    uint32_t n, depth;
+    int stack_ok;
+    void *alloc;            // hipMalloc'ed block holding the records
+    NodeRec *nodes;         // = alloc + 112: node 1 (first sibling block) starts a 128-B line
+    hipStream_t stream;
+    unsigned long long *d_counters;  // 3 x u64
+    uint32_t *d_queue;
+    float4 *d_frame;        // grown on demand by sdfhip_render
+    size_t frame_cap;
+    hipEvent_t ev0, ev1;
+    int cu_count;
+    std::mutex lock;        // render on one handle is single-caller; this makes misuse safe
+};
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(SDFHIP_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+namespace {
+// Keeps the caller's current device intact (the host process may be PyTorch).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
+extern "C" int sdfhip_device_count(int *count)
+{
+    if (!count) return fail(SDFHIP_ERR_ARG, "device_count: null argument");
+    *count = 0;
+    HIP_TRY(hipGetDeviceCount(count));
+    return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_scene_free(sdfhip_scene *s)
+{
+    if (!s) return SDFHIP_OK;
+    {
+        DeviceGuard g(s->device);
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        if (s->alloc) (void)hipFree(s->alloc);
+        if (s->d_counters) (void)hipFree(s->d_counters);
+        if (s->d_queue) (void)hipFree(s->d_queue);
+        if (s->d_frame) (void)hipFree(s->d_frame);
+        if (s->ev0) (void)hipEventDestroy(s->ev0);
+        if (s->ev1) (void)hipEventDestroy(s->ev1);
+        if (s->stream) (void)hipStreamDestroy(s->stream);
+    }
+    delete s;
+    return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uint8_t *values,
+                                   uint32_t n, sdfhip_scene **out)
+{
+    if (!structs || !values || !out || n == 0)
+        return fail(SDFHIP_ERR_ARG, "scene_upload: null argument or empty scene");
+    *out = nullptr;
+    uint32_t depth = 0;
+    int consistent = 0;
+    int rc = sdfhip_octdata_validate(structs, n, &depth, &consistent);
+    if (rc != SDFHIP_OK) return rc;
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(SDFHIP_ERR_DEVICE, "scene_upload: device %d of %d does not exist", device, ndev);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "scene_upload: hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SDFHIP_ERR_DEVICE, "scene_upload: device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+
+    sdfhip_scene *s = new (std::nothrow) sdfhip_scene();
+    if (!s) return fail(SDFHIP_ERR_NOMEM, "scene_upload: out of host memory");
+    s->device = device; s->n = n; s->depth = depth;
+    s->stack_ok = (consistent && depth <= (uint32_t)MAX_STACK) ? 1 : 0;
+    s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr;
+    s->d_queue = nullptr; s->d_frame = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
+    s->cu_count = prop.multiProcessorCount;
+
+    void *d_s = nullptr, *d_v = nullptr;
+    auto bail = [&](hipError_t e, const char *what) {
+        if (d_s) (void)hipFree(d_s);
+        if (d_v) (void)hipFree(d_v);
+        sdfhip_scene_free(s);
+        return fail(SDFHIP_ERR_DEVICE, "scene_upload: %s failed: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+    const size_t bytes = (size_t)n * 8;
+    if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipEventCreate(&s->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&s->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipMalloc(&s->alloc, (size_t)n * 16 + 128)) != hipSuccess) return bail(e, "hipMalloc(records)");
+    s->nodes = reinterpret_cast<NodeRec *>(static_cast<char *>(s->alloc) + 112);
+    if ((e = hipMalloc((void **)&s->d_counters, 3 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMalloc((void **)&s->d_queue, 256)) != hipSuccess) return bail(e, "hipMalloc(queue)");
+    if ((e = hipMalloc(&d_s, bytes)) != hipSuccess) return bail(e, "hipMalloc(structs)");
+    if ((e = hipMalloc(&d_v, bytes)) != hipSuccess) return bail(e, "hipMalloc(values)");
+    if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
+    if ((e = hipMemcpyAsync(d_v, values, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(values)");
+    uint32_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_fuse, dim3(blocks), dim3(256), 0, s->stream, (const int2 *)d_s,
+                       (const uint2 *)d_v, s->nodes, n);
+    if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_fuse launch");
+    if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail(e, "k_fuse");
+    (void)hipFree(d_s); d_s = nullptr;
+    (void)hipFree(d_v); d_v = nullptr;
+    *out = s;
+    return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_scene_info(const sdfhip_scene *s, uint32_t *n, uint32_t *depth,
+                                 int *stack_kernel_ok, int *device)
+{
+    if (!s) return fail(SDFHIP_ERR_ARG, "scene_info: null scene");
+    if (n) *n = s->n;
+    if (depth) *depth = s->depth;
+    if (stack_kernel_ok) *stack_kernel_ok = s->stack_ok;
+    if (device) *device = s->device;
+    return SDFHIP_OK;
+}
+
+namespace {
+
+template <bool STACK, bool COUNT>
+void launch_pair(bool compact, dim3 grid, hipStream_t st, const RenderParams &P)
+{
+    if (compact) hipLaunchKernelGGL((k_compact<STACK, COUNT>), grid, dim3(BLOCK), 0, st, P);
+    else         hipLaunchKernelGGL((k_plain<STACK, COUNT>), grid, dim3(BLOCK), 0, st, P);
+}
+
+int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32_t height,
+                uint32_t band_rows, uint32_t band_first, uint32_t band_stride, uint32_t nrows_out,
+                uint32_t flags, float *d_out, hipStream_t st, sdfhip_stats *stats)
+{
+    if (width == 0 || height == 0 || nrows_out == 0 || band_rows == 0 || band_stride == 0)
+        return fail(SDFHIP_ERR_ARG, "render: zero-sized frame or band");
+    if ((uint64_t)width * nrows_out > 0x7FFFFFFFull)
+        return fail(SDFHIP_ERR_ARG, "render: %u x %u pixels exceed the 31-bit pixel index", width, nrows_out);
+    uint32_t kind = flags & SDFHIP_KERNEL_MASK;
+    if (kind > SDFHIP_KERNEL_STACK) return fail(SDFHIP_ERR_ARG, "render: unknown kernel selector %u", kind);
+    if (kind == SDFHIP_KERNEL_STACK && !s->stack_ok)
+        return fail(SDFHIP_ERR_ARG, "render: the cursor-stack kernel needs a parent/child-consistent tree of depth <= %d (this scene: depth %u)", MAX_STACK, s->depth);
+    const bool use_stack = kind == SDFHIP_KERNEL_STACK || (kind == SDFHIP_KERNEL_AUTO && s->stack_ok);
+    const bool compact = (flags & SDFHIP_FLAG_COMPACT) != 0;
+    const bool count = (flags & SDFHIP_FLAG_COUNT) != 0;
+
+    RenderParams P;
+    P.nodes = s->nodes; P.n_nodes = s->n;
+    P.out = reinterpret_cast<float4 *>(d_out);
+    P.width = width; P.height = height;
+    P.band_rows = band_rows; P.band_first = band_first; P.band_stride = band_stride;
+    P.nrows_out = nrows_out;
+    const uint32_t tile = compact ? 8u : 16u;
+    P.tiles_x = (width + tile - 1) / tile;
+    P.tiles_y = (nrows_out + tile - 1) / tile;
+    P.n_tiles = P.tiles_x * P.tiles_y;
+    P.h0x = info->heading[0][0]; P.h0y = info->heading[0][1]; P.h0z = info->heading[0][2];
+    P.h1x = info->heading[1][0]; P.h1y = info->heading[1][1]; P.h1z = info->heading[1][2];
+    P.h2x = info->heading[2][0]; P.h2y = info->heading[2][1]; P.h2z = info->heading[2][2];
+    P.posx = info->position[0]; P.posy = info->position[1]; P.posz = info->position[2];
+    P.margin = info->margin;
+    P.screen_w = info->screen_size[0]; P.screen_h = info->screen_size[1];
+    P.limit = info->limit;
+    P.lightx = info->light[0]; P.lighty = info->light[1]; P.lightz = info->light[2];
+    P.fov = info->fov;
+    P.k_strength = exp2f(info->strength) - 1.0f;   // Compute.hlsl:216, once per frame
+    P.counters = s->d_counters;
+    P.queue = s->d_queue;
+
+    if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 3 * sizeof(unsigned long long), st));
+    if (compact) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(uint32_t), st));
+    dim3 grid;
+    if (compact) {
+        uint32_t waves = (P.n_tiles + 0u);            // never more waves than tiles
+        uint32_t blocks = (uint32_t)s->cu_count * 8u; // 8 x 256 threads per CU = full occupancy
+        uint32_t need = (waves + 3) / 4;
+        grid = dim3(blocks < need ? blocks : (need ? need : 1));
+    } else {
+        grid = dim3(P.n_tiles);
+    }
+    if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
+    if (use_stack) { if (count) launch_pair<true, true>(compact, grid, st, P); else launch_pair<true, false>(compact, grid, st, P); }
+    else           { if (count) launch_pair<false, true>(compact, grid, st, P); else launch_pair<false, false>(compact, grid, st, P); }
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        HIP_TRY(hipEventRecord(s->ev1, st));
+        HIP_TRY(hipEventSynchronize(s->ev1));
+        memset(stats, 0, sizeof *stats);
+        HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, s->ev0, s->ev1));
+        stats->kernel_used = (use_stack ? SDFHIP_KERNEL_STACK : SDFHIP_KERNEL_GENERIC) |
+                             (compact ? SDFHIP_FLAG_COMPACT : 0u);
+        if (count) {
+            unsigned long long h[3];
+            HIP_TRY(hipMemcpyAsync(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            stats->n_nodes = h[0]; stats->n_samples = h[1]; stats->n_steps = h[2];
+        }
+    }
+    return SDFHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int sdfhip_render_device(sdfhip_scene *s, const sdfhip_info *info, uint32_t width,
+                                    uint32_t height, uint32_t band_rows, uint32_t band_first,
+                                    uint32_t band_stride, uint32_t nrows_out, uint32_t flags,
+                                    float *d_rgba_out, void *stream, sdfhip_stats *stats)
+{
+    if (!s || !info || !d_rgba_out) return fail(SDFHIP_ERR_ARG, "render_device: null argument");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render_device: hipSetDevice(%d) failed", s->device);
+    hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+    return render_impl(s, info, width, height, band_rows, band_first, band_stride, nrows_out, flags,
+                       d_rgba_out, st, stats);
+}
+
+extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t width,
+                             uint32_t height, uint32_t flags, float *rgba_out, sdfhip_stats *stats)
+{
+    if (!s || !info || !rgba_out) return fail(SDFHIP_ERR_ARG, "render: null argument");
+    if (width == 0 || height == 0) return fail(SDFHIP_ERR_ARG, "render: zero-sized frame");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render: hipSetDevice(%d) failed", s->device);
+    auto t0 = std::chrono::steady_clock::now();
+    size_t need = (size_t)width * height;
+    if (need > s->frame_cap) {
+        if (s->d_frame) { (void)hipFree(s->d_frame); s->d_frame = nullptr; s->frame_cap = 0; }
+        HIP_TRY(hipMalloc((void **)&s->d_frame, need * sizeof(float4)));
+        s->frame_cap = need;
+    }
+    int rc = render_impl(s, info, width, height, height, 0, 1, height, flags,
+                         reinterpret_cast<float *>(s->d_frame), s->stream, stats);
+    if (rc != SDFHIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(rgba_out, s->d_frame, need * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (stats)
+        stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_deinterleave_device(int device, const float *d_gathered, float *d_frame,
+                                          uint32_t width, uint32_t height, uint32_t band_rows,
+                                          uint32_t world, uint32_t rows_per_rank, void *stream)
+{
+    if (!d_gathered || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
+        return fail(SDFHIP_ERR_ARG, "deinterleave: null or zero argument");
+    uint32_t nbands = (height + band_rows - 1) / band_rows;
+    uint32_t need_rows = ((nbands + world - 1) / world) * band_rows;
+    if (rows_per_rank < need_rows)
+        return fail(SDFHIP_ERR_ARG, "deinterleave: rows_per_rank %u < %u needed for %u bands over %u ranks", rows_per_rank, need_rows, nbands, world);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "deinterleave: hipSetDevice(%d) failed", device);
+    size_t total = (size_t)width * height;
+    uint32_t blocks = (uint32_t)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_deinterleave, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)d_gathered, (float4 *)d_frame, width, height, band_rows,
+                       world, rows_per_rank);
+    HIP_TRY(hipGetLastError());
+    return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_debug_unorm_table(int device, float *out256)
+{
+    if (!out256) return fail(SDFHIP_ERR_ARG, "debug_unorm_table: null argument");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "debug_unorm_table: hipSetDevice(%d) failed", device);
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 256 * sizeof(float)));
+    hipLaunchKernelGGL(k_unorm_table, dim3(1), dim3(256), 0, 0, d);
+    hipError_t e = hipMemcpy(out256, d, 256 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(SDFHIP_ERR_DEVICE, "debug_unorm_table: %s", hipGetErrorString(e));
+    return SDFHIP_OK;
+}

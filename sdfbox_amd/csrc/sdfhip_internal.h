@@ -1,0 +1,19 @@
+// Internal helpers shared by the host-side sources of libsdfhip.so.
+#pragma once
+#include "../../include/sdfhip.h"
+#include <cstdarg>
+#include <cstdio>
+
+namespace sdfhip {
+
+// Thread-local message behind sdfhip_last_error().  Returns `code` so call
+// sites can `return fail(SDFHIP_ERR_IO, "...")`.
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void clear_error();
+
+// Deterministic double-precision sin/cos (no libm): the same bytes come out of
+// the scene generator on every x86-64 host, whatever glibc's ifunc picks.
+double det_sin(double x);
+double det_cos(double x);
+
+}  // namespace sdfhip

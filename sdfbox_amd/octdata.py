@@ -1,0 +1,103 @@
+"""Scene data on the host: the flattened octree and the .asdf file.
+
+Mirrors `OctData` / `OctData.NativeOctData` of SdfBox/Program.cs:503-667: the
+arrays are produced by the native library (load or generate), copied into
+managed (numpy) arrays, and the native copy is freed -- the same ownership
+hand-off as Logic.MakeData (Logic.cs:87-105).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+
+class OctData:
+    """`Structs` (N x {parent, children} int32) and `Values` (N x 8 uint8, corner
+    k = x + 2y + 4z, not texture-swizzled).  Program.cs:503-511."""
+
+    def __init__(self, structs, values):
+        structs = np.ascontiguousarray(structs, dtype=np.int32).reshape(-1, 2)
+        values = np.ascontiguousarray(values, dtype=np.uint8).reshape(-1, 8)
+        if len(structs) != len(values) or len(structs) == 0:
+            raise ValueError("OctData: structs and values must describe the same, non-zero, node count")
+        self.Structs = structs
+        self.Values = values
+
+    @property
+    def Length(self):
+        return len(self.Structs)
+
+    @property
+    def nbytes(self):
+        return 16 * self.Length
+
+    # -- native hand-off ---------------------------------------------------
+    @classmethod
+    def _from_native(cls, raw):
+        n = raw.length
+        try:
+            s = np.ctypeslib.as_array(raw.structs, shape=(n, 2)).copy()
+            v = np.ctypeslib.as_array(raw.values, shape=(n, 8)).copy()
+        finally:
+            lib.sdfhip_octdata_free(ctypes.byref(raw))   # NativeOctData.Free, Logic.cs:99
+        return cls(s, v)
+
+    def _as_native(self):
+        raw = _lib.COctData()
+        raw.length = self.Length
+        raw.structs = self.Structs.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        raw.values = self.Values.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+        return raw
+
+    # -- .asdf ------------------------------------------------------------
+    @classmethod
+    def LoadAsdf(cls, path):
+        """NativeOctData.LoadAsdf, Program.cs:657-658 -> dllmain.cpp:250-276."""
+        raw = _lib.COctData()
+        check(lib.sdfhip_asdf_load(os.fsencode(path), ctypes.byref(raw)))
+        return cls._from_native(raw)
+
+    def Save(self, path):
+        """NativeOctData.Save, Program.cs:660-661 -> dllmain.cpp:278-292."""
+        raw = self._as_native()
+        check(lib.sdfhip_asdf_save(ctypes.byref(raw), os.fsencode(path)))
+
+    # -- analytic builder (stands in for SdfGen, which needs mesh files) ----
+    @classmethod
+    def Generate(cls, shape, params, max_depth, nthreads=None):
+        if nthreads is None:
+            nthreads = min(32, os.cpu_count() or 1)
+        p = (ctypes.c_float * len(params))(*[float(x) for x in params])
+        raw = _lib.COctData()
+        check(lib.sdfhip_generate(int(shape), p, len(params), int(max_depth), int(nthreads),
+                                  ctypes.byref(raw)))
+        return cls._from_native(raw)
+
+    def validate(self):
+        """(depth, consistent) or raises SdfHipError(ERR_BAD_TREE)."""
+        depth = ctypes.c_uint32()
+        cons = ctypes.c_int()
+        check(lib.sdfhip_octdata_validate(self.Structs.ctypes.data, self.Length,
+                                          ctypes.byref(depth), ctypes.byref(cons)))
+        return depth.value, bool(cons.value)
+
+
+# Named synthetic scenes.  All deterministic.
+def sphere_d4():
+    """cfg-1: SDF |p - 0.5| - 0.3, depth 4."""
+    return OctData.Generate(_lib.SHAPE_SPHERE, [0.5, 0.5, 0.5, 0.3], 4)
+
+
+def torus_d6():
+    return OctData.Generate(_lib.SHAPE_TORUS, [0.5, 0.5, 0.5, 0.25, 0.09], 6)
+
+
+def dragon_standin(depth=9, nthreads=None):
+    """cfg-2..4: gyroid shell (frequency 12*pi, half-thickness 0.004) clipped to
+    the ball r = 0.42 about the cube centre; stands in for the Stanford dragon,
+    which does not ship and cannot be fetched."""
+    return OctData.Generate(_lib.SHAPE_GYROID, [0.5, 0.5, 0.5, 0.42, 12.0 * np.pi, 0.004], depth,
+                            nthreads)

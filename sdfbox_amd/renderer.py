@@ -1,0 +1,80 @@
+"""Frame driver: what `Program.Draw` does for the compute pass
+(SdfBox/Program.cs:79-110: UpdateBuffer(info) + DispatchSized(W, H, 1)),
+on an MI355X through libsdfhip.so.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import Info, Stats, check, lib
+
+
+class Scene:
+    """A scene resident in one GPU's HBM (replaces the `data` / `values`
+    bindings of Program.cs:147-152)."""
+
+    def __init__(self, octdata, device=0):
+        self._h = ctypes.c_void_p()
+        self.device = int(device)
+        check(lib.sdfhip_scene_upload(self.device, octdata.Structs.ctypes.data,
+                                      octdata.Values.ctypes.data, octdata.Length,
+                                      ctypes.byref(self._h)))
+        n = ctypes.c_uint32(); d = ctypes.c_uint32(); ok = ctypes.c_int(); dev = ctypes.c_int()
+        check(lib.sdfhip_scene_info(self._h, ctypes.byref(n), ctypes.byref(d), ctypes.byref(ok),
+                                    ctypes.byref(dev)))
+        self.Length, self.depth, self.stack_kernel_ok = n.value, d.value, bool(ok.value)
+
+    def close(self):
+        if self._h:
+            lib.sdfhip_scene_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- Program.Draw ----------------------------------------------------
+    def Draw(self, state, width, height, flags=_lib.KERNEL_AUTO, want_stats=False):
+        """Render one frame to a host array (H, W, 4) float32; alpha = step count."""
+        out = np.empty((int(height), int(width), 4), dtype=np.float32)
+        st = Stats()
+        info = state if isinstance(state, Info) else state.State
+        check(lib.sdfhip_render(self._h, ctypes.byref(info), int(width), int(height), int(flags),
+                                out.ctypes.data, ctypes.byref(st) if want_stats else None))
+        return (out, st) if want_stats else out
+
+    def DrawDevice(self, state, width, height, out_ptr, nrows_out=None, band_rows=None,
+                   band_first=0, band_stride=1, flags=_lib.KERNEL_AUTO, stream=None, stats=None):
+        """Render into device memory at `out_ptr` (nrows_out x width x 4 floats),
+        asynchronously on `stream` (a raw hipStream_t value or None)."""
+        info = state if isinstance(state, Info) else state.State
+        if nrows_out is None:
+            nrows_out = height
+        if band_rows is None:
+            band_rows = height
+        check(lib.sdfhip_render_device(self._h, ctypes.byref(info), int(width), int(height),
+                                       int(band_rows), int(band_first), int(band_stride),
+                                       int(nrows_out), int(flags), ctypes.c_void_p(int(out_ptr)),
+                                       ctypes.c_void_p(int(stream)) if stream else None,
+                                       ctypes.byref(stats) if stats is not None else None))
+
+
+def device_count():
+    n = ctypes.c_int()
+    check(lib.sdfhip_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def unorm_table(device=0):
+    out = np.empty(256, dtype=np.float32)
+    check(lib.sdfhip_debug_unorm_table(int(device), out.ctypes.data))
+    return out
