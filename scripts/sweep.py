@@ -1,0 +1,41 @@
+"""Dev script: time every kernel variant on the bench workload in ONE process
+(interleaved rounds, same device), print per-variant kernel ms and roofline."""
+import argparse, sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import torch
+import sdfbox_amd as sb
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--depth", type=int, default=9)
+ap.add_argument("--sizes", default="1920x1080,3840x2160")
+ap.add_argument("--rounds", type=int, default=10)
+a = ap.parse_args()
+t0 = time.time(); od = sb.dragon_standin(a.depth); print(f"scene d{a.depth}: N={od.Length} ({od.nbytes/1e6:.1f} MB) built in {time.time()-t0:.1f}s", flush=True)
+sc = sb.Scene(od); print("depth", sc.depth, "stack ok", sc.stack_kernel_ok, flush=True)
+stream = torch.cuda.current_stream().cuda_stream
+variants = [("generic", sb.KERNEL_GENERIC), ("stack", sb.KERNEL_STACK),
+            ("generic+compact", sb.KERNEL_GENERIC | sb.FLAG_COMPACT), ("stack+compact", sb.KERNEL_STACK | sb.FLAG_COMPACT)]
+for size in a.sizes.split(","):
+    W, H = (int(v) for v in size.split("x"))
+    cam = sb.Logic(W, H); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
+    buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    st = sb.Stats()
+    sc.DrawDevice(cam, W, H, buf.data_ptr(), flags=sb.KERNEL_STACK | sb.FLAG_COUNT, stream=stream, stats=st)
+    alg = 8 * st.n_nodes + 8 * st.n_samples + 16 * W * H
+    print(f"{size}: nodes {st.n_nodes} samples {st.n_samples} steps {st.n_steps} -> {alg/1e9:.3f} GB algorithmic, "
+          f"{st.n_steps/(W*H):.1f} steps/px, {st.n_nodes/max(1,st.n_samples):.2f} nodes/step", flush=True)
+    ref = buf.clone()
+    times = {n: [] for n, _ in variants}
+    for r in range(a.rounds):
+        for n, fl in variants:
+            sc.DrawDevice(cam, W, H, buf.data_ptr(), flags=fl, stream=stream, stats=st)
+            times[n].append(st.kernel_ms)
+            if r == 0:
+                torch.cuda.synchronize()
+                print(f"   {n}: identical to stack image: {torch.equal(buf.view(torch.int32), ref.view(torch.int32))}", flush=True)
+    for n, _ in variants:
+        t = np.array(times[n][1:])
+        ms = np.median(t)
+        print(f"  {n:16s} median {ms:8.3f} ms  min {t.min():8.3f}  -> {W*H/ms/1e3:8.1f} Mray/s  {alg/ms/1e6:8.1f} GB/s algorithmic ({alg/ms/1e6/8000*100:.1f}% of 8 TB/s)", flush=True)
+sc.close()

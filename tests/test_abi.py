@@ -1,0 +1,89 @@
+"""The C-ABI library loads and exports every symbol include/sdfhip.h declares;
+struct layouts match the reference's; errors are status codes + messages."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "sdfhip.h")).read()
+    return sorted(set(re.findall(r"SDFHIP_API[^;]*?\b(sdfhip_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(sb):
+    names = declared_symbols()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(sb._lib.lib, n), f"{n} declared in include/sdfhip.h but not exported"
+    # and the Python binding covers exactly the declared set
+    assert sorted(sb._lib.EXPORTED_SYMBOLS) == names
+
+
+def test_info_layout_matches_logic_cs(sb):
+    # Logic.cs:407-420 (Pack 16, Size 112) / Compute.hlsl:70-81
+    I = sb.Info
+    assert ctypes.sizeof(I) == 112
+    off = {f: getattr(I, f).offset for f, _ in I._fields_}
+    assert off["heading"] == 0 and off["position"] == 48 and off["margin"] == 60
+    assert off["screen_size"] == 64 and off["buffer_size"] == 72 and off["limit"] == 76
+    assert off["light"] == 80 and off["strength"] == 92 and off["fov"] == 96 and off["hidef"] == 100
+
+
+def test_errors_are_codes_not_crashes(sb, tmp_path):
+    L = sb._lib
+    raw = L.COctData()
+    rc = L.lib.sdfhip_asdf_load(os.fsencode(str(tmp_path / "nope.asdf")), ctypes.byref(raw))
+    assert rc == L.ERR_IO and b"could not open" in L.lib.sdfhip_last_error()
+    assert L.lib.sdfhip_asdf_load(None, ctypes.byref(raw)) == L.ERR_ARG
+    with pytest.raises(sb.SdfHipError) as e:
+        sb.OctData.Generate(7, [0.0] * 4, 3)
+    assert e.value.code == L.ERR_ARG
+    with pytest.raises(sb.SdfHipError):
+        sb.OctData.Generate(L.SHAPE_SPHERE, [0.5, 0.5, 0.5], 3)       # wrong param count
+    with pytest.raises(sb.SdfHipError):
+        sb.OctData.Generate(L.SHAPE_SPHERE, [0.5, 0.5, 0.5, 0.3], 13)  # deeper than the shader can descend
+
+
+def test_validate_rejects_out_of_range_links(sb):
+    od = sb.sphere_d4()
+    s = od.Structs.copy()
+    s[5, 1] = od.Length - 3          # children block would run past the end
+    with pytest.raises(sb.SdfHipError) as e:
+        sb.OctData(s, od.Values).validate()
+    assert e.value.code == sb._lib.ERR_BAD_TREE
+    s = od.Structs.copy()
+    s[9, 0] = od.Length + 10         # parent out of range
+    with pytest.raises(sb.SdfHipError):
+        sb.OctData(s, od.Values).validate()
+    # in range but inconsistent: legal for the generic kernel, not for the stack kernel
+    s = od.Structs.copy()
+    s[9, 0] = 3
+    depth, consistent = sb.OctData(s, od.Values).validate()
+    assert not consistent
+    assert od.validate() == (4, True)
+
+
+def test_product_fails_loudly_without_a_gpu(sb):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(sb.SdfHipError) as e:
+        sb.Scene(sb.sphere_d4())
+    assert e.value.code == sb._lib.ERR_DEVICE
+
+
+def test_product_never_imports_the_oracle():
+    # the oracle is test infrastructure: no file of the package may import, include,
+    # link or load it (comments may cite it)
+    pkg = os.path.join(REPO, "sdfbox_amd")
+    pat = re.compile(r"^\s*(import\s+oracle|from\s+oracle\b)|#\s*include\s*[<\"][^>\"]*oracle|liboracle|-loracle", re.M)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert not pat.search(text), os.path.join(root, f)
