@@ -263,35 +263,31 @@ def load_traffic(W, H, scene_name, flags):
 def cpu_baseline(od, cam, W, H, target_seconds):
     """The CPU oracle (the build's C restatement of Compute.hlsl: the reference has
     no CPU path) timed on this host over a bounded sample of the
-    same frame: every `stride`-th 8-row band."""
+    same frame: every `step`-th row, rows interleaved over all hardware threads."""
     import oracle
     oracle.build()
-    ncpu = os.cpu_count() or 1
-    nthreads = min(ncpu, 64)
-    # calibrate on 8 rows spread over the frame
-    rows = list(range(4, H, max(1, H // 8)))[:8]
+    nthreads = min(os.cpu_count() or 1, 64)
+    # calibrate on 2*nthreads rows spread over the frame, then size the sample
+    ncal = min(H, 2 * nthreads)
     t0 = time.perf_counter()
-    for y in rows:
-        oracle.render(od.Structs, od.Values, cam.State, W, H, row0=y, nrows=1, nthreads=1)
-    per_row_1t = (time.perf_counter() - t0) / len(rows)
-    budget_rows = max(8, int(target_seconds * nthreads / max(per_row_1t, 1e-6)))
-    nbands = max(1, min(H // 8, budget_rows // 8))
-    stride = max(1, (H // 8) // nbands)
-    bands = list(range(0, H // 8, stride))
+    oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=ncal, row_step=max(1, H // ncal),
+                  nthreads=nthreads)
+    per_row = (time.perf_counter() - t0) / ncal
+    rows = int(min(H, max(nthreads, target_seconds / max(per_row, 1e-9))))
+    step = max(1, H // rows)
+    nrows = (H + step - 1) // step
     t0 = time.perf_counter()
-    pix = 0
-    # one multi-threaded call per band keeps every thread busy within a band
-    for b in bands:
-        oracle.render(od.Structs, od.Values, cam.State, W, H, row0=b * 8, nrows=8, nthreads=nthreads)
-        pix += 8 * W
+    oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=nrows, row_step=step, nthreads=nthreads)
     dt = time.perf_counter() - t0
+    pix = nrows * W
     return {
         "value": round(pix / dt / 1e6, 3),
         "unit": "Mray/s",
         "cores": nthreads,
         "kind": "port",
-        "sample": f"{len(bands)} bands of 8 rows (every {stride}th band) of the same {W}x{H} frame = {pix} pixels in {dt:.1f} s; "
-                  f"oracle/sdf_oracle.c, gcc -O2 -ffp-contract=off, {nthreads} pthreads",
+        "sample": f"every {step}th row of the same {W}x{H} frame = {pix} pixels in {dt:.2f} s wall "
+                  f"({dt * nthreads:.0f} core-seconds); oracle/sdf_oracle.c, gcc -O2 -ffp-contract=off, "
+                  f"{nthreads} pthreads, rows interleaved",
     }
 
 

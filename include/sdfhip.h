@@ -159,13 +159,13 @@ SDFHIP_API int sdfhip_render(sdfhip_scene *scene, const sdfhip_info *info,
 
 /* Device-resident variant for callers that keep the frame in HBM (multi-GPU
  * tile sharding, timing with inputs resident).  Renders the rows
- *     y = band_first*band_rows + (k / band_rows)*band_stride*band_rows + k % band_rows,
+ *     y = (band_first + (k / band_rows)*band_stride)*band_rows + k % band_rows,
  * k = 0 .. nrows_out-1, i.e. every band_stride-th band of band_rows rows
  * starting at band `band_first`, into d_rgba_out (device pointer, nrows_out x
  * width x 4 floats, compact).  band_stride = 1, band_first = 0, nrows_out =
  * height renders the whole frame.  Asynchronous on `stream` (a hipStream_t;
- * NULL = the scene's own stream); no host synchronisation unless `stats` is
- * given. */
+ * NULL = the HIP default stream, as for any HIP call); no host
+ * synchronisation unless `stats` is given. */
 SDFHIP_API int sdfhip_render_device(sdfhip_scene *scene, const sdfhip_info *info,
                                     uint32_t width, uint32_t height,
                                     uint32_t band_rows, uint32_t band_first,

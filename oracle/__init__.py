@@ -31,7 +31,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         vp, u32, c = ctypes.c_void_p, ctypes.c_uint32, ctypes
         L.oracle_render_rows.restype = c.c_int
-        L.oracle_render_rows.argtypes = [vp, vp, u32, vp, u32, u32, u32, vp, vp, vp, c.c_int]
+        L.oracle_render_rows.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, vp, vp, vp, c.c_int]
         L.oracle_pixel.restype = None
         L.oracle_pixel.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp]
         L.oracle_distance_at.restype = c.c_float
@@ -49,19 +49,20 @@ def _info_buf(info):
     return ctypes.create_string_buffer(b, 112)
 
 
-def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1, per_pixel_nodes=False):
+def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1, per_pixel_nodes=False,
+           row_step=1):
     """-> (rgba[nrows, W, 4] f32, counters[3] u64 (nodes, samples, steps)[, nodes per pixel])."""
     structs = np.ascontiguousarray(structs, dtype=np.int32)
     values = np.ascontiguousarray(values, dtype=np.uint8)
     n = structs.size // 2
     if nrows is None:
-        nrows = height - row0
+        nrows = (height - row0 + row_step - 1) // row_step
     out = np.zeros((nrows, width, 4), dtype=np.float32)
     cnt = np.zeros(3, dtype=np.uint64)
     pix = np.zeros((nrows, width), dtype=np.uint32) if per_pixel_nodes else None
     ib = _info_buf(info)
     rc = lib().oracle_render_rows(structs.ctypes.data, values.ctypes.data, n, ctypes.addressof(ib),
-                                  width, row0, nrows, out.ctypes.data, cnt.ctypes.data,
+                                  width, row0, nrows, row_step, out.ctypes.data, cnt.ctypes.data,
                                   pix.ctypes.data if pix is not None else None, int(nthreads))
     if rc != 0:
         raise MemoryError("oracle_render_rows failed")

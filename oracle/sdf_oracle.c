@@ -11,7 +11,7 @@
  * only implementation is HLSL run through D3D11 texture hardware.  This file
  * is a scalar fp32 restatement of that HLSL, statement by statement, and is
  * the specification the HIP kernels are held to bit-for-bit.  It is anchored
- * by closed-form cases in tests/test_oracle_analytic.py, nothing more.
+ * by closed-form cases in tests/test_oracle.py, nothing more.
  *
  * Follows (all paths relative to the reference checkout):
  *   SdfBox/Shaders/Compute.hlsl:15-29    sam / sample_at      -> o_sample_at
@@ -292,7 +292,7 @@ typedef struct {
     o_scene sc;
     o_info inf;
     float k;
-    uint32_t W, row0, nrows;
+    uint32_t W, row0, nrows, row_step;
     int tid, nthreads;
     float *rgba;          /* nrows x W x 4, row-major, row 0 = global row0 */
     uint32_t *pix_nodes;  /* optional: nrows x W algorithmic node reads per pixel */
@@ -305,7 +305,7 @@ static void *o_worker(void *arg)
     for (uint32_t r = (uint32_t)jb->tid; r < jb->nrows; r += (uint32_t)jb->nthreads) {
         for (uint32_t x = 0; x < jb->W; x++) {
             uint64_t before = jb->cnt[0];
-            o_pixel(&jb->sc, &jb->inf, jb->k, x, jb->row0 + r,
+            o_pixel(&jb->sc, &jb->inf, jb->k, x, jb->row0 + r * jb->row_step,
                     jb->rgba + 4 * ((size_t)r * jb->W + x), jb->cnt);
             if (jb->pix_nodes)
                 jb->pix_nodes[(size_t)r * jb->W + x] = (uint32_t)(jb->cnt[0] - before);
@@ -314,13 +314,14 @@ static void *o_worker(void *arg)
     return NULL;
 }
 
-/* Render rows [row0, row0+nrows) of a W-wide frame.  Pixel (x, y) uses the
- * dispatch-thread id (x, y) exactly as Compute.hlsl:180 does.  counters[0..2]
+/* Render the nrows rows y = row0 + r*row_step (r = 0..nrows-1) of a W-wide
+ * frame into compact rows of `rgba`.  Pixel (x, y) uses the dispatch-thread id
+ * (x, y) exactly as Compute.hlsl:180 does.  counters[0..2]
  * receive node reads, samples, march steps summed over the rendered pixels
  * (may be NULL).  Rows are interleaved over `nthreads` pthreads. */
 int oracle_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n,
                        const void *info112, uint32_t W, uint32_t row0, uint32_t nrows,
-                       float *rgba, uint64_t *counters, uint32_t *pix_nodes, int nthreads)
+                       uint32_t row_step, float *rgba, uint64_t *counters, uint32_t *pix_nodes, int nthreads)
 {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
@@ -333,7 +334,7 @@ int oracle_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n
     for (int t = 0; t < nthreads; t++) {
         jobs[t].sc.structs = structs; jobs[t].sc.values = values; jobs[t].sc.n = n;
         jobs[t].inf = inf; jobs[t].k = k;
-        jobs[t].W = W; jobs[t].row0 = row0; jobs[t].nrows = nrows;
+        jobs[t].W = W; jobs[t].row0 = row0; jobs[t].nrows = nrows; jobs[t].row_step = row_step ? row_step : 1;
         jobs[t].tid = t; jobs[t].nthreads = nthreads;
         jobs[t].rgba = rgba; jobs[t].pix_nodes = pix_nodes;
     }

@@ -525,7 +525,7 @@ extern "C" int sdfhip_render_device(sdfhip_scene *s, const sdfhip_info *info, ui
     std::lock_guard<std::mutex> lk(s->lock);
     DeviceGuard g(s->device);
     if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render_device: hipSetDevice(%d) failed", s->device);
-    hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = the HIP default stream, as everywhere in HIP
     return render_impl(s, info, width, height, band_rows, band_first, band_stride, nrows_out, flags,
                        d_rgba_out, st, stats);
 }
