@@ -25,11 +25,15 @@
  *
  * Arithmetic contract (shared with the HIP kernels, DESIGN.md "Numerics"):
  *   - every operation is an individually rounded IEEE fp32 operation in the
- *     order written here; build with -ffp-contract=off, no fast-math;
+ *     order written here; build with -ffp-contract=off, no fast-math: the
+ *     compiler fuses nothing on its own;
+ *   - the multiply-adds that HLSL compiles to `mad` / `dp3` are written as
+ *     explicit fused fmaf (D3D11 leaves mad's fusing to the implementation):
+ *       lerp(a,b,t)   = fmaf(t, b - a, a)
+ *       dot(a,b)      = fmaf(a.z, b.z, fmaf(a.y, b.y, a.x*b.x))
+ *       pos += dir*s  = fmaf(dir, s, pos)
  *   - saturate(x)   = fminf(fmaxf(x, 0), 1)           (NaN -> 0, as HLSL)
- *   - lerp(a,b,t)   = a + t*(b - a)
- *   - dot(a,b)      = (a.x*b.x + a.y*b.y) + a.z*b.z
- *   - normalize(v)  = v / sqrtf(dot(v,v))             (component-wise divide)
+ *   - normalize(v)  = v * (1.0f / sqrtf(dot(v,v)))    (HLSL: v * rsqrt(dot(v,v)))
  *   - length(v)     = sqrtf(dot(v,v))
  *   - R8_UNorm texel = (float)byte / 255.0f, bilinear = x-lerp then y-lerp
  *   - exp2(strength) is evaluated once per frame on the host (exp2f).
@@ -73,15 +77,21 @@ typedef struct {
     uint64_t n_samples;  /* interpol_world calls */
 } o_ctx;
 
-static inline float o_sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
-static inline float o_lerp(float a, float b, float t) { return a + t * (b - a); }
-static inline float o_dot(float ax, float ay, float az, float bx, float by, float bz)
+/* Every helper is forced inline so that the two clones of the exported entry
+ * points (plain x86-64 and +fma, where fmaf is one vfmadd instruction;
+ * elsewhere it is libm's correctly rounded fmaf: same bits) carry their own copy. */
+#define O_INLINE static inline __attribute__((always_inline))
+#define O_CLONES __attribute__((target_clones("default", "fma")))
+
+O_INLINE float o_sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+O_INLINE float o_lerp(float a, float b, float t) { return fmaf(t, b - a, a); }
+O_INLINE float o_dot(float ax, float ay, float az, float bx, float by, float bz)
 {
-    return (ax * bx + ay * by) + az * bz;
+    return fmaf(az, bz, fmaf(ay, by, ax * bx));
 }
 
 /* Cube::scale_up, Compute.hlsl:36-40 */
-static inline void o_scale_up(o_cube *b)
+O_INLINE void o_scale_up(o_cube *b)
 {
     b->scale *= 2.0f;
     b->lx = floorf(b->lx / b->scale) * b->scale;
@@ -89,7 +99,7 @@ static inline void o_scale_up(o_cube *b)
     b->lz = floorf(b->lz / b->scale) * b->scale;
 }
 /* Cube::scale_down, Compute.hlsl:41-45 */
-static inline void o_scale_down(o_cube *b, int dx, int dy, int dz)
+O_INLINE void o_scale_down(o_cube *b, int dx, int dy, int dz)
 {
     b->scale /= 2.0f;
     b->lx += (float)dx * b->scale;
@@ -97,7 +107,7 @@ static inline void o_scale_down(o_cube *b, int dx, int dy, int dz)
     b->lz += (float)dz * b->scale;
 }
 /* Cube::inside, Compute.hlsl:50-53 */
-static inline int o_inside(const o_cube *b, float px, float py, float pz)
+O_INLINE int o_inside(const o_cube *b, float px, float py, float pz)
 {
     float hx = b->lx + b->scale, hy = b->ly + b->scale, hz = b->lz + b->scale;
     return (b->lx <= px && b->ly <= py && b->lz <= pz) &&
@@ -105,7 +115,7 @@ static inline int o_inside(const o_cube *b, float px, float py, float pz)
 }
 
 /* find, Compute.hlsl:88-108 */
-static void o_find(o_ctx *t, float px, float py, float pz)
+O_INLINE void o_find(o_ctx *t, float px, float py, float pz)
 {
     const int32_t *S = t->sc->structs;
     int iterations = 0;
@@ -138,12 +148,12 @@ static void o_find(o_ctx *t, float px, float py, float pz)
  * (Program.cs:514-538): row0 = corners {0,1,4,5}, row1 = {2,3,6,7}; one
  * bilinear tap at (d.xy + p) blends corners 0..3, the tap at +(2,0) blends
  * corners 4..7 (Compute.hlsl:19-29). */
-static inline void o_texels(const o_ctx *t, float v[8])
+O_INLINE void o_texels(const o_ctx *t, float v[8])
 {
     const uint8_t *b = t->sc->values + 8 * (size_t)t->index;
     for (int k = 0; k < 8; k++) v[k] = (float)b[k] / 255.0f;
 }
-static inline float o_bilerp(float t00, float t10, float t01, float t11, float wx, float wy)
+O_INLINE float o_bilerp(float t00, float t10, float t01, float t11, float wx, float wy)
 {
     float top = o_lerp(t00, t10, wx);
     float bot = o_lerp(t01, t11, wx);
@@ -151,7 +161,7 @@ static inline float o_bilerp(float t00, float t10, float t01, float t11, float w
 }
 
 /* sample_at, Compute.hlsl:19-29 */
-static float o_sample_at(o_ctx *t, float dx, float dy, float dz, float scale)
+O_INLINE float o_sample_at(o_ctx *t, float dx, float dy, float dz, float scale)
 {
     float v[8];
     o_texels(t, v);
@@ -161,7 +171,7 @@ static float o_sample_at(o_ctx *t, float dx, float dy, float dz, float scale)
     return result;
 }
 /* Cube::interpol_world, Compute.hlsl:54-58 */
-static float o_interpol_world(o_ctx *t, float px, float py, float pz)
+O_INLINE float o_interpol_world(o_ctx *t, float px, float py, float pz)
 {
     float dx = o_sat((px - t->box.lx) / t->box.scale);
     float dy = o_sat((py - t->box.ly) / t->box.scale);
@@ -172,7 +182,7 @@ static float o_interpol_world(o_ctx *t, float px, float py, float pz)
 
 /* gradient, Compute.hlsl:112-130.  A tap at integer x (or y) has bilinear
  * weight 0 towards its neighbour, i.e. lerp(a, b, 0) = a exactly. */
-static void o_gradient(const o_ctx *t, float px, float py, float pz, float g[3])
+O_INLINE void o_gradient(const o_ctx *t, float px, float py, float pz, float g[3])
 {
     float dx = o_sat((px - t->box.lx) / t->box.scale);
     float dy = o_sat((py - t->box.ly) / t->box.scale);
@@ -195,7 +205,7 @@ static void o_gradient(const o_ctx *t, float px, float py, float pz, float g[3])
 }
 
 /* ray, Compute.hlsl:163-168 */
-static void o_ray(const o_info *inf, uint32_t cx, uint32_t cy, float dir[3])
+O_INLINE void o_ray(const o_info *inf, uint32_t cx, uint32_t cy, float dir[3])
 {
     float sx = (float)cx / inf->screen_size[1] - inf->screen_size[0] / inf->screen_size[1] * 0.5f;
     float sy = (float)cy / inf->screen_size[1] - 0.5f;
@@ -204,14 +214,15 @@ static void o_ray(const o_info *inf, uint32_t cx, uint32_t cy, float dir[3])
     float d0 = o_dot(vx, vy, vz, inf->heading[0][0], inf->heading[0][1], inf->heading[0][2]);
     float d1 = o_dot(vx, vy, vz, inf->heading[1][0], inf->heading[1][1], inf->heading[1][2]);
     float d2 = o_dot(vx, vy, vz, inf->heading[2][0], inf->heading[2][1], inf->heading[2][2]);
-    float len = sqrtf(o_dot(d0, d1, d2, d0, d1, d2));
-    dir[0] = d0 / len;
-    dir[1] = d1 / len;
-    dir[2] = d2 / len;
+    /* normalize(v) = v * rsqrt(dot(v, v)) in HLSL; here rsqrt(x) = 1 / sqrtf(x) */
+    float rl = 1.0f / sqrtf(o_dot(d0, d1, d2, d0, d1, d2));
+    dir[0] = d0 * rl;
+    dir[1] = d1 * rl;
+    dir[2] = d2 * rl;
 }
 
 /* main, Compute.hlsl:180-231.  out = rgba; counters accumulate in t. */
-static void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_m1,
+O_INLINE void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_m1,
                     uint32_t cx, uint32_t cy, float out[4], uint64_t cnt[3])
 {
     o_ctx t;
@@ -235,23 +246,23 @@ static void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_m1
         }
         o_find(&t, px, py, pz);
         prox = o_interpol_world(&t, px, py, pz);
-        px += dir[0] * prox;
-        py += dir[1] * prox;
-        pz += dir[2] * prox;
+        px = fmaf(dir[0], prox, px);
+        py = fmaf(dir[1], prox, py);
+        pz = fmaf(dir[2], prox, pz);
     }
     {
         /* dir = normalize(inf.light - pos); pos += dir * inf.margin; */
         float lx = inf->light[0] - px, ly = inf->light[1] - py, lz = inf->light[2] - pz;
-        float len = sqrtf(o_dot(lx, ly, lz, lx, ly, lz));
-        dir[0] = lx / len; dir[1] = ly / len; dir[2] = lz / len;
-        px += dir[0] * margin;
-        py += dir[1] * margin;
-        pz += dir[2] * margin;
+        float rl = 1.0f / sqrtf(o_dot(lx, ly, lz, lx, ly, lz));
+        dir[0] = lx * rl; dir[1] = ly * rl; dir[2] = lz * rl;
+        px = fmaf(dir[0], margin, px);
+        py = fmaf(dir[1], margin, py);
+        pz = fmaf(dir[2], margin, pz);
         /* angle = dot(dir, normalize(gradient(pos))) */
         float g[3];
         o_gradient(&t, px, py, pz, g);
-        float gl = sqrtf(o_dot(g[0], g[1], g[2], g[0], g[1], g[2]));
-        float angle = o_dot(dir[0], dir[1], dir[2], g[0] / gl, g[1] / gl, g[2] / gl);
+        float rg = 1.0f / sqrtf(o_dot(g[0], g[1], g[2], g[0], g[1], g[2]));
+        float angle = o_dot(dir[0], dir[1], dir[2], g[0] * rg, g[1] * rg, g[2] * rg);
         if (angle < 0.0f) {
             out[0] = out[1] = out[2] = 0.0f; out[3] = (float)i;
             goto done;
@@ -274,9 +285,9 @@ static void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_m1
             o_find(&t, px, py, pz);
             prox = o_interpol_world(&t, px, py, pz);
             float step = prox + margin;
-            px += dir[0] * step;
-            py += dir[1] * step;
-            pz += dir[2] * step;
+            px = fmaf(dir[0], step, px);
+            py = fmaf(dir[1], step, py);
+            pz = fmaf(dir[2], step, pz);
         }
         out[0] = out[1] = out[2] = 0.0f; out[3] = (float)(i + j);
     }
@@ -299,7 +310,7 @@ typedef struct {
     uint64_t cnt[3];
 } o_job;
 
-static void *o_worker(void *arg)
+O_CLONES static void *o_worker_impl(void *arg)
 {
     o_job *jb = (o_job *)arg;
     for (uint32_t r = (uint32_t)jb->tid; r < jb->nrows; r += (uint32_t)jb->nthreads) {
@@ -319,6 +330,8 @@ static void *o_worker(void *arg)
  * (x, y) exactly as Compute.hlsl:180 does.  counters[0..2]
  * receive node reads, samples, march steps summed over the rendered pixels
  * (may be NULL).  Rows are interleaved over `nthreads` pthreads. */
+static void *o_worker(void *arg) { return o_worker_impl(arg); }
+
 int oracle_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n,
                        const void *info112, uint32_t W, uint32_t row0, uint32_t nrows,
                        uint32_t row_step, float *rgba, uint64_t *counters, uint32_t *pix_nodes, int nthreads)
@@ -354,7 +367,7 @@ int oracle_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n
 }
 
 /* One pixel, for unit tests.  out[4] = rgba, cnt[3] = nodes, samples, steps. */
-void oracle_pixel(const int32_t *structs, const uint8_t *values, uint32_t n,
+O_CLONES void oracle_pixel(const int32_t *structs, const uint8_t *values, uint32_t n,
                   const void *info112, uint32_t x, uint32_t y, float *out, uint64_t *cnt)
 {
     o_scene sc = { structs, values, n };
@@ -366,7 +379,7 @@ void oracle_pixel(const int32_t *structs, const uint8_t *values, uint32_t n,
 
 /* Trilinear distance at a world position starting from the root cursor:
  * find() + interpol_world().  For the analytic anchors in the tests. */
-float oracle_distance_at(const int32_t *structs, const uint8_t *values, uint32_t n,
+O_CLONES float oracle_distance_at(const int32_t *structs, const uint8_t *values, uint32_t n,
                          float x, float y, float z, uint32_t *leaf_index, float *leaf_scale)
 {
     o_scene sc = { structs, values, n };

@@ -2,16 +2,21 @@
 //
 // Arithmetic contract (DESIGN.md "Numerics"; identical to oracle/sdf_oracle.c):
 // every fp32 operation is individually rounded in the order written (the
-// translation unit is built with -ffp-contract=off; the only fused operations
-// are the explicit __builtin_fmaf calls in unorm8(), which reproduce the
-// correctly rounded byte/255.0f), IEEE divide and sqrt.
+// translation unit is built with -ffp-contract=off: the compiler fuses nothing
+// on its own), IEEE divide and sqrt.  The multiply-adds HLSL compiles to
+// mad / dp3 are explicit fused __builtin_fmaf on both sides:
+//     lerp(a,b,t) = fma(t, b - a, a)      dot = fma(az,bz, fma(ay,by, ax*bx))
+//     pos += dir*s = fma(dir, s, pos)     normalize(v) = v * (1 / sqrt(dot(v,v)))
 //
-// Two exact rewrites relative to the HLSL text, both bit-identical:
-//   * x / box.scale  ->  x * box.inv   (scale is a power of two, inv = 1/scale
-//     is tracked alongside it; multiplying by an exact power of two rounds
-//     exactly like dividing by it);
+// Exact rewrites relative to the HLSL text, all bit-identical:
+//   * x / box.scale  ->  x * box.inv   (scale is a power of two, inv = 1/scale:
+//     multiplying by an exact power of two rounds exactly like dividing by it);
 //   * (int) saturate(v * 2)  ->  v >= 0.5f   (v*2 is exact; saturate maps NaN
-//     to 0, and NaN >= 0.5f is false).
+//     to 0, and NaN >= 0.5f is false);
+//   * (float)b / 255.0f  ->  one Newton fix-up of b * fl(1/255) (unorm8 below,
+//     checked for all 256 bytes);
+//   * the cursor-stack kernel walks the tree on integer cell coordinates
+//     (find_stack below states why that visits the same cells).
 //
 // Reference: SdfBox/Shaders/Compute.hlsl (line numbers cited per function).
 #pragma once
@@ -24,6 +29,8 @@ namespace sdfhip {
 // OctS (SdfGen/dllmain.cpp:18-29) + its 8 value bytes, so one global_load_dwordx4
 // brings topology and corner distances together.
 typedef uint4 NodeRec;
+
+constexpr int BLOCK_THREADS = 256;   // workgroup size of the ray-march kernels (LDS stack stride)
 
 // Kernel parameters: the Info block unpacked (Logic.cs:407-420) + frame geometry.
 struct RenderParams {
@@ -43,10 +50,10 @@ struct RenderParams {
 };
 
 __device__ __forceinline__ float sat(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
-__device__ __forceinline__ float lerp(float a, float b, float t) { return a + t * (b - a); }
+__device__ __forceinline__ float lerp(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
-    return (ax * bx + ay * by) + az * bz;
+    return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
 }
 
 // R8_UNorm decode, bit-identical to (float)b / 255.0f for b = 0..255 (checked
@@ -81,27 +88,38 @@ __device__ __forceinline__ float bilerp(float t00, float t10, float t01, float t
     return lerp(top, bot, wy);
 }
 
-// The per-pixel cursor: the shader's static `index` + `box` (Compute.hlsl:12,61)
-// plus the record of the node it sits on, kept in registers.
-struct Cursor {
-    float lx, ly, lz, scale, inv;  // Cube (Compute.hlsl:31-58); inv == 1/scale exactly
-    int32_t children;              // Oct.children of the current node
-    uint32_t v0, v1;               // its 8 value bytes
-    // generic traversal only
+// A cell as the sampling code sees it: Cube (Compute.hlsl:31-58) plus the 8 value
+// bytes of the node the cursor sits on.  inv == 1/scale exactly.
+struct Cell {
+    float lx, ly, lz, scale, inv;
+    uint32_t v0, v1;
+};
+
+// ---- generic cursor: float box, links followed through memory ----------------
+// The shader's static `index` + `box` (Compute.hlsl:12,61) plus the record of the
+// node it sits on, kept in registers.
+struct CursorG {
+    float lx, ly, lz, scale, inv;
+    int32_t parent, children;
+    uint32_t v0, v1;
     uint32_t index;
-    int32_t parent;
-    // stack traversal only
-    int32_t level;
+
+    __device__ __forceinline__ void reset(const NodeRec &root)
+    {
+        lx = ly = lz = 0.0f; scale = 1.0f; inv = 1.0f; index = 0;
+        parent = (int32_t)root.x; children = (int32_t)root.y; v0 = root.z; v1 = root.w;
+    }
+    __device__ __forceinline__ Cell cell() const { return Cell{lx, ly, lz, scale, inv, v0, v1}; }
 };
 
 // Cube::inside, Compute.hlsl:50-53
-__device__ __forceinline__ bool inside(const Cursor &c, float px, float py, float pz)
+__device__ __forceinline__ bool inside(const CursorG &c, float px, float py, float pz)
 {
     float hx = c.lx + c.scale, hy = c.ly + c.scale, hz = c.lz + c.scale;
     return (c.lx <= px && c.ly <= py && c.lz <= pz) && (px <= hx && py <= hy && pz <= hz);
 }
 // Cube::scale_up, Compute.hlsl:36-40
-__device__ __forceinline__ void scale_up(Cursor &c)
+__device__ __forceinline__ void scale_up(CursorG &c)
 {
     c.scale *= 2.0f;
     c.inv *= 0.5f;
@@ -111,7 +129,7 @@ __device__ __forceinline__ void scale_up(Cursor &c)
 }
 // child octant of pos in the current cell: (int3) saturate((pos - lower) / scale * 2),
 // Compute.hlsl:100, then Cube::scale_down, Compute.hlsl:41-45.  Returns p = x + 2y + 4z.
-__device__ __forceinline__ int descend_box(Cursor &c, float px, float py, float pz)
+__device__ __forceinline__ int descend_box(CursorG &c, float px, float py, float pz)
 {
     bool bx = (px - c.lx) * c.inv >= 0.5f;
     bool by = (py - c.ly) * c.inv >= 0.5f;
@@ -124,25 +142,18 @@ __device__ __forceinline__ int descend_box(Cursor &c, float px, float py, float 
     return (bx ? 1 : 0) + (by ? 2 : 0) + (bz ? 4 : 0);
 }
 
-__device__ __forceinline__ void set_record(Cursor &c, const NodeRec &r)
-{
-    c.parent = (int32_t)r.x;
-    c.children = (int32_t)r.y;
-    c.v0 = r.z;
-    c.v1 = r.w;
-}
-
-// find, Compute.hlsl:88-108 -- generic form: follows parent and children
-// links through memory exactly as the shader does (the entry read of
-// data[index] is served from the registers that already hold that record).
-// Returns the number of node records the *reference* reads in this call.
-__device__ __forceinline__ uint32_t find_generic(Cursor &c, const NodeRec *__restrict__ nodes,
-                                                 uint32_t n_nodes, float px, float py, float pz)
+// find, Compute.hlsl:88-108 -- generic form: follows parent and children links
+// through memory exactly as the shader does (the entry read of data[index] is
+// served from the registers that already hold that record).  Returns the number
+// of node records the *reference* reads in this call.
+__device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__ nodes,
+                                         uint32_t n_nodes, int32_t *, float px, float py, float pz)
 {
     uint32_t reads = 1;
     while (!inside(c, px, py, pz) && c.parent >= 0) {
         c.index = (uint32_t)c.parent;
-        set_record(c, nodes[c.index]);
+        NodeRec r = nodes[c.index];
+        c.parent = (int32_t)r.x; c.children = (int32_t)r.y; c.v0 = r.z; c.v1 = r.w;
         scale_up(c);
         reads++;
     }
@@ -150,49 +161,130 @@ __device__ __forceinline__ uint32_t find_generic(Cursor &c, const NodeRec *__res
     while (c.index < n_nodes && iterations < 12 && c.children >= 0) {
         int p = descend_box(c, px, py, pz);
         c.index = (uint32_t)(c.children + p);
-        set_record(c, nodes[c.index]);
+        NodeRec r = nodes[c.index];
+        c.parent = (int32_t)r.x; c.children = (int32_t)r.y; c.v0 = r.z; c.v1 = r.w;
         iterations++;
         reads++;
     }
     return reads;
 }
 
-// find -- cursor-stack form, for consistent trees of depth <= 12 (checked at
-// upload).  Ascending needs no memory: a node's parent is the level above on
-// the descent path, and the only thing the descent loop needs from an
-// ancestor is its `children` field, which was pushed to an LDS stack
-// (stack[level * blockDim + tid]: conflict-free for any mix of levels) when
-// the path went through it.  For such trees `index < buffer_size` always
-// holds and `iterations < 12` never binds (a call descends at most `depth`
-// levels), so the visited cells, and hence every result, are the shader's.
-__device__ __forceinline__ uint32_t find_stack(Cursor &c, const NodeRec *__restrict__ nodes,
-                                               int32_t *__restrict__ stack, uint32_t stride,
-                                               float px, float py, float pz)
-{
-    uint32_t reads = 1;
-    if (!inside(c, px, py, pz) && c.level > 0) {
-        do {
-            c.level--;
-            scale_up(c);
-            reads++;
-        } while (!inside(c, px, py, pz) && c.level > 0);
-        c.children = stack[(uint32_t)c.level * stride];
+// ---- cursor-stack form: integer cell coordinates, ancestors in LDS -----------
+// For parent/child-consistent trees of depth <= LM = 12 (checked at upload).
+//
+// Why it visits the shader's cells.  Every box the shader can hold is a dyadic
+// cell: lower = a * 2^-LM with integer a, scale = 2^-level.  All of Cube's float
+// arithmetic on such boxes is exact (scale_up's floor(lower/scale)*scale, and
+// scale_down's lower += p*scale), so a cell is fully described by (level, a).
+//   * inside(pos), per axis lower <= pos <= lower + scale, with u = pos * 2^LM
+//     (exact) is  a <= u <= a + 2^s,  s = LM - level.  With A = floor(u) and
+//     B = ceil(u) - 1 (B = A unless u is an integer, then B = A - 1) this is
+//     (B >> t) <= (a >> t) <= (A >> t) at t = s; the ancestor k levels up has
+//     the same test at t = s + k.  Since A - B <= 1, the test holds exactly when
+//     a >> t equals A >> t or B >> t, i.e. t >= min(bitlen(a^A), bitlen(a^B)).
+//     So the ascend loop of Compute.hlsl:93-97 stops after
+//         k = min(level, max(0, max_axes(min(bitlen(a^A), bitlen(a^B))) - s))
+//     steps: no loop, no memory.  (A is clamped to [-1, 2^LM+1]; NaN gives -1:
+//     then nothing matches and the cursor goes to the root, as in the shader,
+//     where every comparison with NaN is false.)
+//   * descent, per axis (int) saturate((pos - lower)/scale*2): pos - lower is
+//     exact in fp32 here (both are multiples of ulp(pos), the difference is not
+//     larger than the operands), so the bit is [pos >= cell midpoint].  Inside
+//     the cell that is the next lower bit of A -- or of B when the cell matched
+//     through B only (pos exactly on its upper face: the shader's saturate
+//     gives 1 on every level below, and B's low bits are all ones).  Outside
+//     the root cube saturate clamps: all zeros below 0, all ones above 1, which
+//     is what clamping A/B to [0, 2^LM - 1] yields.
+//   * `index < buffer_size` always holds for a validated tree and `iterations <
+//     12` never binds, because one call descends at most depth <= 12 levels.
+// The only thing the descent needs from an ancestor is its `children` field,
+// which was pushed to an LDS stack (stack[level * blockDim + tid]: conflict-free
+// for any mix of levels) when the path went down through it.
+constexpr int LM = 12;
+
+struct CursorS {
+    int32_t ax, ay, az;      // lower * 2^LM
+    int32_t level;
+    int32_t children;
+    uint32_t v0, v1;
+
+    __device__ __forceinline__ void reset(const NodeRec &root)
+    {
+        ax = ay = az = 0; level = 0;
+        children = (int32_t)root.y; v0 = root.z; v1 = root.w;
     }
-    while (c.children >= 0) {
-        stack[(uint32_t)c.level * stride] = c.children;
-        int p = descend_box(c, px, py, pz);
-        NodeRec r = nodes[(uint32_t)(c.children + p)];
-        c.children = (int32_t)r.y;
-        c.v0 = r.z;
-        c.v1 = r.w;
-        c.level++;
-        reads++;
+    __device__ __forceinline__ Cell cell() const
+    {
+        Cell k;
+        const float q = 1.0f / 4096.0f;
+        k.lx = (float)ax * q; k.ly = (float)ay * q; k.lz = (float)az * q;   // exact
+        k.scale = __int_as_float((127 - level) << 23);                      // 2^-level
+        k.inv = __int_as_float((127 + level) << 23);                        // 2^level
+        k.v0 = v0; k.v1 = v1;
+        return k;
+    }
+};
+
+// per axis: A, B as above (clamped) from one coordinate
+__device__ __forceinline__ void axis_ab(float p, int32_t &A, int32_t &B)
+{
+    float u = p * 4096.0f;
+    float f = floorf(u);
+    int32_t a = (int32_t)__builtin_fmaxf(__builtin_fminf(f, 4097.0f), -2.0f);   // NaN -> 4097 here, fixed next line
+    A = (u >= -1.0f) ? a : -1;                             // below the cube, or NaN: -1
+    B = A - ((u == f) ? 1 : 0);
+}
+__device__ __forceinline__ int bitlen(uint32_t x) { return 32 - __clz((int)x); }   // bitlen(0) = 0
+
+__device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, uint32_t,
+                                         int32_t *__restrict__ stack, float px, float py, float pz)
+{
+    int32_t Ax, Bx, Ay, By, Az, Bz;
+    axis_ab(px, Ax, Bx);
+    axis_ab(py, Ay, By);
+    axis_ab(pz, Az, Bz);
+    const int s = LM - c.level;
+    int tx = min(bitlen((uint32_t)(c.ax ^ Ax)), bitlen((uint32_t)(c.ax ^ Bx)));
+    int ty = min(bitlen((uint32_t)(c.ay ^ Ay)), bitlen((uint32_t)(c.ay ^ By)));
+    int tz = min(bitlen((uint32_t)(c.az ^ Az)), bitlen((uint32_t)(c.az ^ Bz)));
+    int t = max(max(tx, ty), max(tz, s));
+    int k = min(t - s, c.level);                 // ascents (Compute.hlsl:93-97)
+    uint32_t reads = 1u + (uint32_t)k;
+    if (k > 0) {
+        c.level -= k;
+        c.children = stack[(uint32_t)c.level * BLOCK_THREADS];
+    }
+    if (c.children >= 0) {
+        // where the descent reads its octant bits from (see above), clamped into the cube
+        const int tt = LM - c.level;             // <= LM
+        int32_t Dx = (((uint32_t)(c.ax ^ Ax) >> tt) == 0u) ? Ax : Bx;
+        int32_t Dy = (((uint32_t)(c.ay ^ Ay) >> tt) == 0u) ? Ay : By;
+        int32_t Dz = (((uint32_t)(c.az ^ Az) >> tt) == 0u) ? Az : Bz;
+        Dx = min(max(Dx, 0), 4095); Dy = min(max(Dy, 0), 4095); Dz = min(max(Dz, 0), 4095);
+        do {
+            stack[(uint32_t)c.level * BLOCK_THREADS] = c.children;
+            const int sb = LM - 1 - c.level;
+            uint32_t p = ((uint32_t)Dx >> sb & 1u) | (((uint32_t)Dy >> sb & 1u) << 1) | (((uint32_t)Dz >> sb & 1u) << 2);
+            NodeRec r = nodes[(uint32_t)c.children + p];
+            c.children = (int32_t)r.y;
+            c.v0 = r.z;
+            c.v1 = r.w;
+            c.level++;
+            reads++;
+        } while (c.children >= 0);
+        const int32_t keep = ~((1 << (LM - c.level)) - 1);
+        c.ax = Dx & keep; c.ay = Dy & keep; c.az = Dz & keep;
+    } else if (k > 0) {
+        // unreachable for a consistent tree (an ancestor always has children); keep the
+        // anchor coherent anyway
+        const int32_t keep = ~((1 << (LM - c.level)) - 1);
+        c.ax &= keep; c.ay &= keep; c.az &= keep;
     }
     return reads;
 }
 
 // Cube::interpol_world -> sample_at, Compute.hlsl:54-58,19-29
-__device__ __forceinline__ float interpol_world(const Cursor &c, float px, float py, float pz)
+__device__ __forceinline__ float interpol_world(const Cell &c, float px, float py, float pz)
 {
     float dx = sat((px - c.lx) * c.inv);
     float dy = sat((py - c.ly) * c.inv);
@@ -205,7 +297,7 @@ __device__ __forceinline__ float interpol_world(const Cursor &c, float px, float
 
 // gradient, Compute.hlsl:112-130 (taps at integer x / y have bilinear weight 0
 // towards the neighbouring texel: lerp(a, b, 0) == a)
-__device__ __forceinline__ void gradient(const Cursor &c, float px, float py, float pz,
+__device__ __forceinline__ void gradient(const Cell &c, float px, float py, float pz,
                                          float &gx, float &gy, float &gz)
 {
     float dx = sat((px - c.lx) * c.inv);
@@ -233,10 +325,10 @@ __device__ __forceinline__ void ray(const RenderParams &P, uint32_t cx, uint32_t
     float d0 = dot3(vx, vy, vz, P.h0x, P.h0y, P.h0z);
     float d1 = dot3(vx, vy, vz, P.h1x, P.h1y, P.h1z);
     float d2 = dot3(vx, vy, vz, P.h2x, P.h2y, P.h2z);
-    float len = sqrtf(dot3(d0, d1, d2, d0, d1, d2));
-    dx = d0 / len;
-    dy = d1 / len;
-    dz = d2 / len;
+    float rl = 1.0f / sqrtf(dot3(d0, d1, d2, d0, d1, d2));
+    dx = d0 * rl;
+    dy = d1 * rl;
+    dz = d2 * rl;
 }
 
 }  // namespace sdfhip

@@ -29,9 +29,12 @@
 
 namespace sdfhip {
 
-constexpr int BLOCK = 256;       // 4 wavefronts
-constexpr int MAX_STACK = 12;    // the shader's own descent limit (Compute.hlsl:98)
+constexpr int BLOCK = BLOCK_THREADS;   // 4 wavefronts
+constexpr int MAX_STACK = LM;          // the shader's own descent limit (Compute.hlsl:98)
 constexpr int REFILL_MIN = 16;   // compact kernels: refill once this many lanes are idle
+
+template <bool STACK> struct CursorOf { typedef CursorG type; };
+template <> struct CursorOf<true> { typedef CursorS type; };
 
 struct RayState {
     float px, py, pz;    // pos
@@ -46,8 +49,9 @@ __device__ __forceinline__ uint32_t global_row(const RenderParams &P, uint32_t y
     return (P.band_first + band * P.band_stride) * P.band_rows + (yl - band * P.band_rows);
 }
 
+template <class CursorT>
 __device__ __forceinline__ void start_pixel(const RenderParams &P, const NodeRec &root, uint32_t x,
-                                            uint32_t y, RayState &r, Cursor &c)
+                                            uint32_t y, RayState &r, CursorT &c)
 {
     // Compute.hlsl:182-191
     r.px = P.posx; r.py = P.posy; r.pz = P.posz;
@@ -55,14 +59,12 @@ __device__ __forceinline__ void start_pixel(const RenderParams &P, const NodeRec
     r.prox = 1.0f;
     r.angle = 0.0f; r.dist = 0.0f;
     r.i = 0; r.j = 0; r.phase = 0;
-    c.lx = c.ly = c.lz = 0.0f; c.scale = 1.0f; c.inv = 1.0f;
-    c.index = 0; c.level = 0;
-    set_record(c, root);
+    c.reset(root);
 }
 
 // Everything main() does between two find() calls.  Returns true when the
 // pixel is finished, with its colour in `out` (alpha = step count).
-__device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, const Cursor &c, float4 &out)
+__device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, const Cell &c, float4 &out)
 {
     if (r.phase == 0) {
         // loop header of Compute.hlsl:194
@@ -75,15 +77,15 @@ __device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, con
         }
         // Compute.hlsl:205-213
         float lx = P.lightx - r.px, ly = P.lighty - r.py, lz = P.lightz - r.pz;
-        float len = sqrtf(dot3(lx, ly, lz, lx, ly, lz));
-        r.dx = lx / len; r.dy = ly / len; r.dz = lz / len;
-        r.px += r.dx * P.margin;
-        r.py += r.dy * P.margin;
-        r.pz += r.dz * P.margin;
+        float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+        r.dx = lx * rl; r.dy = ly * rl; r.dz = lz * rl;
+        r.px = __builtin_fmaf(r.dx, P.margin, r.px);
+        r.py = __builtin_fmaf(r.dy, P.margin, r.py);
+        r.pz = __builtin_fmaf(r.dz, P.margin, r.pz);
         float gx, gy, gz;
         gradient(c, r.px, r.py, r.pz, gx, gy, gz);
-        float gl = sqrtf(dot3(gx, gy, gz, gx, gy, gz));
-        r.angle = dot3(r.dx, r.dy, r.dz, gx / gl, gy / gl, gz / gl);
+        float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
+        r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
         if (r.angle < 0.0f) {
             out = make_float4(0.0f, 0.0f, 0.0f, (float)r.i);
             return true;
@@ -116,18 +118,16 @@ __device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, con
 }
 
 // find + interpol_world + advance: Compute.hlsl:200-202 / :225-227
-template <bool STACK>
-__device__ __forceinline__ uint32_t march_step(const RenderParams &P, RayState &r, Cursor &c,
+template <class CursorT>
+__device__ __forceinline__ uint32_t march_step(const RenderParams &P, RayState &r, CursorT &c,
                                                int32_t *stack)
 {
-    uint32_t reads;
-    if (STACK) reads = find_stack(c, P.nodes, stack, BLOCK, r.px, r.py, r.pz);
-    else       reads = find_generic(c, P.nodes, P.n_nodes, r.px, r.py, r.pz);
-    r.prox = interpol_world(c, r.px, r.py, r.pz);
+    uint32_t reads = find(c, P.nodes, P.n_nodes, stack, r.px, r.py, r.pz);
+    r.prox = interpol_world(c.cell(), r.px, r.py, r.pz);
     float step = r.phase ? r.prox + P.margin : r.prox;
-    r.px += r.dx * step;
-    r.py += r.dy * step;
-    r.pz += r.dz * step;
+    r.px = __builtin_fmaf(r.dx, step, r.px);
+    r.py = __builtin_fmaf(r.dy, step, r.py);
+    r.pz = __builtin_fmaf(r.dz, step, r.pz);
     if (r.phase) r.j++; else r.i++;
     return reads;
 }
@@ -168,12 +168,12 @@ __global__ __launch_bounds__(BLOCK) void k_plain(RenderParams P)
     if (live) { y = global_row(P, yl); live = y < P.height; }
     if (live) {
         RayState r;
-        Cursor c;
+        typename CursorOf<STACK>::type c;
         const NodeRec root = P.nodes[0];
         start_pixel(P, root, x, y, r, c);
         float4 out;
-        while (!pre_step(P, r, c, out)) {
-            uint32_t reads = march_step<STACK>(P, r, c, stack_lds + tid);
+        while (!pre_step(P, r, c.cell(), out)) {
+            uint32_t reads = march_step(P, r, c, stack_lds + tid);
             if (COUNT) { cn += reads; cs += 1; }
         }
         P.out[(size_t)yl * P.width + x] = out;
@@ -197,15 +197,14 @@ __global__ __launch_bounds__(BLOCK) void k_compact(RenderParams P)
     const NodeRec root = P.nodes[0];
     unsigned long long cn = 0, cs = 0, ct = 0;
     RayState r;
-    Cursor c;
+    typename CursorOf<STACK>::type c;
     bool active = false;
     uint32_t x = 0, yl = 0;
     uint32_t cur = 0, end = 0;  // wave-uniform
     bool more = true;           // wave-uniform
     r.px = r.py = r.pz = r.dx = r.dy = r.dz = r.prox = r.angle = r.dist = 0.0f;
     r.i = r.j = r.phase = 0;
-    c.lx = c.ly = c.lz = 0.0f; c.scale = c.inv = 1.0f; c.children = -1; c.v0 = c.v1 = 0;
-    c.index = 0; c.parent = -1; c.level = 0;
+    c.reset(root);
 
     for (;;) {
         unsigned long long idle = __ballot(!active);
@@ -246,12 +245,12 @@ __global__ __launch_bounds__(BLOCK) void k_compact(RenderParams P)
         }
         if (active) {
             float4 out;
-            if (pre_step(P, r, c, out)) {
+            if (pre_step(P, r, c.cell(), out)) {
                 P.out[(size_t)yl * P.width + x] = out;
                 if (COUNT) ct += (unsigned long long)out.w;
                 active = false;
             } else {
-                uint32_t reads = march_step<STACK>(P, r, c, stack_lds + tid);
+                uint32_t reads = march_step(P, r, c, stack_lds + tid);
                 if (COUNT) { cn += reads; cs += 1; }
             }
         }

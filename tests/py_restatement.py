@@ -1,7 +1,10 @@
 """Second, independent restatement of SdfBox/Shaders/Compute.hlsl in numpy
-float32 scalars (every operation individually rounded), written from the HLSL
+float32 scalars (every operation individually rounded; the mads of lerp, dot
+and pos += dir*s fused, computed exactly with rationals), written from the HLSL
 text, not from oracle/sdf_oracle.c.  Slow; used on a handful of pixels to
 cross-check the C oracle bit for bit (tests/test_oracle.py)."""
+from fractions import Fraction
+
 import numpy as np
 
 f32 = np.float32
@@ -15,17 +18,46 @@ def sat(x):
     return f32(min(max(x, f32(0)), f32(1)))
 
 
+def fma(a, b, c):
+    """Correctly rounded float32 a*b + c (one rounding), by exact rational arithmetic."""
+    a, b, c = f32(a), f32(b), f32(c)
+    if not (np.isfinite(a) and np.isfinite(b) and np.isfinite(c)):
+        return f32(f32(a * b) + c)                      # inf/nan propagate the same way
+    v = Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))
+    if v == 0:
+        # sign of an exact zero sum: +0 unless both addends are -0
+        prod_neg = (np.signbit(a) != np.signbit(b))
+        return f32(-0.0) if (prod_neg and np.signbit(c)) else f32(0.0)
+    sign = -1 if v < 0 else 1
+    m = abs(v)
+    e = m.numerator.bit_length() - m.denominator.bit_length()   # 2^e <= m < 2^(e+2) roughly
+    while Fraction(2) ** e > m:
+        e -= 1
+    while Fraction(2) ** (e + 1) <= m:
+        e += 1
+    q = max(e - 23, -149)                                # ulp exponent (subnormals: 2^-149)
+    scaled = m / (Fraction(2) ** q)
+    n = scaled.numerator // scaled.denominator
+    rem = scaled - n
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (n & 1)):
+        n += 1
+    return f32(sign * float(n) * 2.0 ** q)               # n < 2^25 and 2^q are exact in double
+
+
 def lerp(a, b, t):
-    return f32(a + f32(t * f32(b - a)))
+    # HLSL lerp compiles to add + mad; the contract fuses the mad (DESIGN.md "Numerics")
+    return fma(t, f32(b - a), a)
 
 
 def dot(a, b):
-    return f32(f32(f32(a[0] * b[0]) + f32(a[1] * b[1])) + f32(a[2] * b[2]))
+    # dp3 as a chain of mads
+    return fma(a[2], b[2], fma(a[1], b[1], f32(a[0] * b[0])))
 
 
 def normalize(v):
-    n = np.sqrt(dot(v, v))
-    return [f32(v[0] / n), f32(v[1] / n), f32(v[2] / n)]
+    # HLSL normalize(v) = v * rsqrt(dot(v, v)); rsqrt(x) = 1 / sqrt(x), each correctly rounded
+    r = f32(f32(1) / np.sqrt(dot(v, v)))
+    return [f32(v[0] * r), f32(v[1] * r), f32(v[2] * r)]
 
 
 class Texture:
@@ -153,10 +185,10 @@ class Shader:
                 return [f32(0.005), f32(0.01), f32(0.2), f32(i)]
             self.find(pos)
             prox = self.interpol_world(pos)
-            pos = [f32(p + f32(di * prox)) for p, di in zip(pos, d)]
+            pos = [fma(di, prox, p) for p, di in zip(pos, d)]
             i += 1
         d = normalize([f32(l - p) for l, p in zip(self.light, pos)])
-        pos = [f32(p + f32(di * m)) for p, di in zip(pos, d)]
+        pos = [fma(di, m, p) for p, di in zip(pos, d)]
         angle = dot(d, normalize(self.gradient(pos)))
         if angle < 0:
             return [f32(0), f32(0), f32(0), f32(i)]
@@ -173,6 +205,6 @@ class Shader:
                     break
             self.find(pos)
             prox = self.interpol_world(pos)
-            pos = [f32(p + f32(di * f32(prox + m))) for p, di in zip(pos, d)]
+            pos = [fma(di, f32(prox + m), p) for p, di in zip(pos, d)]
             j += 1
         return [f32(0), f32(0), f32(0), f32(i + j)]
