@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "stack"])
     ap.add_argument("--compact", type=int, default=-1, help="wavefront ray compaction: 1 on, 0 off, -1 default")
     ap.add_argument("--band-rows", type=int, default=16)
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="consecutive frames are rendered on this many HIP streams (double buffering): the "
+                         "long tail of one frame (a few 100-140-step pixels) overlaps the body of the next")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 path through host buffers (not a perf mode)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
@@ -90,22 +93,29 @@ def main():
     flags = kflag | (sb.FLAG_COMPACT if compact else 0)
 
     layout = BandLayout(H, world, args.band_rows)
-    stream = torch.cuda.current_stream().cuda_stream
-    nbuf = 2 if world > 1 else 1
+    # default: 2 frames in flight on one GPU; with the frame sharded over `world` GPUs each
+    # rank's share is mostly tail, so keep more frames in flight
+    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else min(8, 2 * world))
+    if world > 1:
+        nbuf = max(2, nbuf)
+    streams = [torch.cuda.Stream() for _ in range(nbuf)]     # one per frame in flight
+    main_stream = torch.cuda.current_stream()
+    stream = main_stream.cuda_stream
     local = [torch.zeros((layout.rows_per_rank if world > 1 else H, W, 4), dtype=torch.float32, device="cuda")
              for _ in range(nbuf)]
     gathered = frame = None
     if world > 1 and rank == 0:
         gathered = [torch.zeros((world, layout.rows_per_rank, W, 4), dtype=torch.float32, device="cuda")
                     for _ in range(nbuf)]
-        frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        frame = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
 
-    def render(buf, stats=None, fl=None):
+    def render(buf, stats=None, fl=None, st=None):
+        st = stream if st is None else st
         if world == 1:
-            scene.DrawDevice(cam, W, H, buf.data_ptr(), flags=flags if fl is None else fl, stream=stream, stats=stats)
+            scene.DrawDevice(cam, W, H, buf.data_ptr(), flags=flags if fl is None else fl, stream=st, stats=stats)
         else:
             render_bands(scene, cam, W, layout, rank, buf.data_ptr(), flags=flags if fl is None else fl,
-                         stream=stream, stats=stats)
+                         stream=st, stats=stats)
 
     pending = [None] * nbuf
 
@@ -116,29 +126,34 @@ def main():
             return
         pending[slot] = None
         if args.backend == "nccl":
-            w.wait()                                  # compute stream waits for the gather
-            if rank == 0:
-                deinterleave(device, gathered[slot].data_ptr(), frame.data_ptr(), W, layout, stream=stream)
+            with torch.cuda.stream(streams[slot]):
+                w.wait()                              # this slot's stream waits for its gather
+                if rank == 0:
+                    deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout,
+                                 stream=streams[slot].cuda_stream)
         else:                                         # gloo rehearsal: host buffers
             if rank == 0:
                 g = torch.stack(w).cuda()
                 gathered[slot].copy_(g)
-                deinterleave(device, gathered[slot].data_ptr(), frame.data_ptr(), W, layout, stream=stream)
+                deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=stream)
 
     def step(k):
         slot = k % nbuf
         finish(slot)                                   # buffer reuse: its previous gather must be done
-        render(local[slot])
+        render(local[slot], st=streams[slot].cuda_stream)
         if world > 1:
             if args.backend == "nccl":
                 glist = list(gathered[slot].unbind(0)) if rank == 0 else None
-                pending[slot] = dist.gather(local[slot], glist, dst=0, async_op=True)
+                with torch.cuda.stream(streams[slot]):  # the collective orders itself after this stream's render
+                    pending[slot] = dist.gather(local[slot], glist, dst=0, async_op=True)
             else:
+                streams[slot].synchronize()
                 host = local[slot].cpu()
                 glist = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, glist, dst=0)
                 pending[slot] = glist if rank == 0 else True
-            finish((k + 1) % nbuf)                     # overlap: assemble frame k-1 behind render k
+            if args.backend != "nccl":
+                finish(slot)
 
     def drain():
         for s in range(nbuf):
@@ -190,8 +205,7 @@ def main():
             ref = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
             scene.DrawDevice(cam, W, H, ref.data_ptr(), flags=flags, stream=stream)
             torch.cuda.synchronize()
-            a, b = frame.view(torch.int32), ref.view(torch.int32)
-            check_ok = bool(torch.equal(a, b))
+            check_ok = all(bool(torch.equal(f.view(torch.int32), ref.view(torch.int32))) for f in frame)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -217,6 +231,7 @@ def main():
                             f"(N={od.Length} nodes, {od.nbytes / 1e6:.1f} MB), camera (0.5,0.5,-0.35) yaw 0.35 pitch -0.2",
                 "kernel": ("stack" if (st.kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else ""),
                 "parallelism": "1 GPU" if world == 1 else f"{world} GPUs, {args.band_rows}-row bands round-robin + gather to rank 0 ({args.backend})",
+                "frames_in_flight": nbuf,
                 "gstep_per_s": round(float(counters[2]) / (elapsed / args.steps) / 1e9, 3),
                 "scene_build_s": round(t_gen, 2),
             },

@@ -73,7 +73,12 @@ enum {
     SDFHIP_KERNEL_STACK = 2,      /* ancestor stack in LDS, fused 16-B node records        */
     SDFHIP_KERNEL_MASK = 0xF,
     SDFHIP_FLAG_COMPACT = 0x10,   /* persistent waves, ballot/prefix refill of finished lanes */
-    SDFHIP_FLAG_COUNT = 0x20      /* also count algorithmic node/sample reads (slower)     */
+    SDFHIP_FLAG_COUNT = 0x20,     /* also count algorithmic node/sample reads (slower)     */
+    /* tuning knobs for A/B measurements (0 = the default): bits 8..11 blockIdx -> tile
+     * order of the plain kernel (1 row-major, 2 one slab per XCD), bits 12..15 workgroup
+     * size (1 = 64, 2 = 128, 3 = 256 threads).  Results never depend on them. */
+    SDFHIP_TUNE_ORDER_SHIFT = 8,
+    SDFHIP_TUNE_BLOCK_SHIFT = 12
 };
 
 /* Per-call statistics (all optional: pass NULL). */

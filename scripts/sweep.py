@@ -14,8 +14,9 @@ a = ap.parse_args()
 t0 = time.time(); od = sb.dragon_standin(a.depth); print(f"scene d{a.depth}: N={od.Length} ({od.nbytes/1e6:.1f} MB) built in {time.time()-t0:.1f}s", flush=True)
 sc = sb.Scene(od); print("depth", sc.depth, "stack ok", sc.stack_kernel_ok, flush=True)
 stream = torch.cuda.current_stream().cuda_stream
-variants = [("generic", sb.KERNEL_GENERIC), ("stack", sb.KERNEL_STACK),
-            ("generic+compact", sb.KERNEL_GENERIC | sb.FLAG_COMPACT), ("stack+compact", sb.KERNEL_STACK | sb.FLAG_COMPACT)]
+variants = [("generic", sb.KERNEL_GENERIC), ("stack", sb.KERNEL_STACK), ("stack o1", sb.KERNEL_STACK | 0x100), ("stack slabs", sb.KERNEL_STACK | 0x200),
+            ("stack b128", sb.KERNEL_STACK | 0x2000), ("stack b256", sb.KERNEL_STACK | 0x3000),
+            ("stack+compact", sb.KERNEL_STACK | sb.FLAG_COMPACT)]
 for size in a.sizes.split(","):
     W, H = (int(v) for v in size.split("x"))
     cam = sb.Logic(W, H); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
@@ -34,6 +35,20 @@ for size in a.sizes.split(","):
             if r == 0:
                 torch.cuda.synchronize()
                 print(f"   {n}: identical to stack image: {torch.equal(buf.view(torch.int32), ref.view(torch.int32))}", flush=True)
+    # throughput with 2 frames in flight (two streams, two buffers)
+    s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = [buf, torch.zeros_like(buf)]
+    thr = {}
+    for n, fl in variants:
+        best = 1e9
+        for rep in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for k in range(40):
+                sc.DrawDevice(cam, W, H, bufs[k % 2].data_ptr(), flags=fl, stream=s2[k % 2].cuda_stream)
+            torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 40 * 1e3)
+        thr[n] = best
+    for n, _ in variants:
+        print(f"  {n:16s} 2-in-flight {thr[n]:8.3f} ms/frame -> {W*H/thr[n]/1e3:8.1f} Mray/s", flush=True)
     for n, _ in variants:
         t = np.array(times[n][1:])
         ms = np.median(t)

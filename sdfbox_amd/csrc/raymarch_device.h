@@ -30,7 +30,6 @@ namespace sdfhip {
 // brings topology and corner distances together.
 typedef uint4 NodeRec;
 
-constexpr int BLOCK_THREADS = 256;   // workgroup size of the ray-march kernels (LDS stack stride)
 
 // Kernel parameters: the Info block unpacked (Logic.cs:407-420) + frame geometry.
 struct RenderParams {
@@ -47,6 +46,7 @@ struct RenderParams {
     float fov, k_strength;     // k_strength = exp2f(strength) - 1, evaluated on the host
     unsigned long long *counters;  // [0] nodes [1] samples [2] steps (COUNT builds)
     uint32_t *queue;           // tile queue head (compact kernels)
+    uint32_t tile_order;       // k_plain: blockIdx -> tile mapping (tuning knob, flags bits 8..11)
 };
 
 __device__ __forceinline__ float sat(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
@@ -147,7 +147,7 @@ __device__ __forceinline__ int descend_box(CursorG &c, float px, float py, float
 // served from the registers that already hold that record).  Returns the number
 // of node records the *reference* reads in this call.
 __device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__ nodes,
-                                         uint32_t n_nodes, int32_t *, float px, float py, float pz)
+                                         uint32_t n_nodes, int32_t *, uint32_t, float px, float py, float pz)
 {
     uint32_t reads = 1;
     while (!inside(c, px, py, pz) && c.parent >= 0) {
@@ -198,7 +198,7 @@ __device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__
 //   * `index < buffer_size` always holds for a validated tree and `iterations <
 //     12` never binds, because one call descends at most depth <= 12 levels.
 // The only thing the descent needs from an ancestor is its `children` field,
-// which was pushed to an LDS stack (stack[level * blockDim + tid]: conflict-free
+// which was pushed to an LDS stack (stack[level * stride + tid]: conflict-free
 // for any mix of levels) when the path went down through it.
 constexpr int LM = 12;
 
@@ -237,7 +237,7 @@ __device__ __forceinline__ void axis_ab(float p, int32_t &A, int32_t &B)
 __device__ __forceinline__ int bitlen(uint32_t x) { return 32 - __clz((int)x); }   // bitlen(0) = 0
 
 __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, uint32_t,
-                                         int32_t *__restrict__ stack, float px, float py, float pz)
+                                         int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz)
 {
     int32_t Ax, Bx, Ay, By, Az, Bz;
     axis_ab(px, Ax, Bx);
@@ -252,7 +252,7 @@ __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__
     uint32_t reads = 1u + (uint32_t)k;
     if (k > 0) {
         c.level -= k;
-        c.children = stack[(uint32_t)c.level * BLOCK_THREADS];
+        c.children = stack[(uint32_t)c.level * stride];
     }
     if (c.children >= 0) {
         // where the descent reads its octant bits from (see above), clamped into the cube
@@ -262,13 +262,17 @@ __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__
         int32_t Dz = (((uint32_t)(c.az ^ Az) >> tt) == 0u) ? Az : Bz;
         Dx = min(max(Dx, 0), 4095); Dy = min(max(Dy, 0), 4095); Dz = min(max(Dz, 0), 4095);
         do {
-            stack[(uint32_t)c.level * BLOCK_THREADS] = c.children;
+            stack[(uint32_t)c.level * stride] = c.children;
             const int sb = LM - 1 - c.level;
             uint32_t p = ((uint32_t)Dx >> sb & 1u) | (((uint32_t)Dy >> sb & 1u) << 1) | (((uint32_t)Dz >> sb & 1u) << 2);
             NodeRec r = nodes[(uint32_t)c.children + p];
             c.children = (int32_t)r.y;
             c.v0 = r.z;
             c.v1 = r.w;
+            // keep the value bytes live in every iteration: otherwise the compiler loads only
+            // `children` in the loop and fetches the leaf's values in a second, dependent
+            // round trip after it (one more L1 latency on every march step)
+            asm volatile("" : "+v"(c.v0), "+v"(c.v1));
             c.level++;
             reads++;
         } while (c.children >= 0);

@@ -14,8 +14,9 @@
 //     Compute.hlsl:194-230 run as ONE per-lane state machine around a single
 //     find + sample body, so lanes in different phases share the instruction
 //     stream instead of serialising two loops;
-//   * k_plain: 16x16-pixel workgroups, blockIdx remapped so that each XCD (own
-//     L2) renders one contiguous slab of the frame;
+//   * k_plain: one 8x8 wave tile per workgroup; blockIdx is remapped so that XCD k
+//     (own L2) renders tile rows k, k+8, ...: every XCD sees the same mix of sky
+//     and object rows (balance) while whole rows of neighbouring tiles share an L2;
 //   * k_compact: persistent waves pull 8x8 tiles from a queue and refill
 //     finished lanes by ballot + prefix count (wavefront ray compaction).
 #include "raymarch_device.h"
@@ -29,8 +30,11 @@
 
 namespace sdfhip {
 
-constexpr int BLOCK = BLOCK_THREADS;   // 4 wavefronts
+constexpr int BLOCK = 256;             // k_compact: 4 wavefronts
 constexpr int MAX_STACK = LM;          // the shader's own descent limit (Compute.hlsl:98)
+#ifndef PLAIN_WAVES_PER_SIMD
+#define PLAIN_WAVES_PER_SIMD 8          // <= 64 VGPRs: 8 waves per SIMD (2nd launch-bound = waves per SIMD)
+#endif
 constexpr int REFILL_MIN = 16;   // compact kernels: refill once this many lanes are idle
 
 template <bool STACK> struct CursorOf { typedef CursorG type; };
@@ -120,9 +124,9 @@ __device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, con
 // find + interpol_world + advance: Compute.hlsl:200-202 / :225-227
 template <class CursorT>
 __device__ __forceinline__ uint32_t march_step(const RenderParams &P, RayState &r, CursorT &c,
-                                               int32_t *stack)
+                                               int32_t *stack, uint32_t stride)
 {
-    uint32_t reads = find(c, P.nodes, P.n_nodes, stack, r.px, r.py, r.pz);
+    uint32_t reads = find(c, P.nodes, P.n_nodes, stack, stride, r.px, r.py, r.pz);
     r.prox = interpol_world(c.cell(), r.px, r.py, r.pz);
     float step = r.phase ? r.prox + P.margin : r.prox;
     r.px = __builtin_fmaf(r.dx, step, r.px);
@@ -147,21 +151,35 @@ __device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned l
     }
 }
 
-// ---- one lane per pixel, one 16x16 tile per workgroup -----------------------
-template <bool STACK, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_plain(RenderParams P)
+// ---- one lane per pixel; a workgroup of BT threads renders a 16 x (BT/16) tile (BT >= 128)
+// or one 8x8 wave tile (BT = 64) ------------------------------------------------
+template <bool STACK, bool COUNT, int BT>
+__global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams P)
 {
-    __shared__ int32_t stack_lds[STACK ? MAX_STACK * BLOCK : 1];
+    __shared__ int32_t stack_lds[STACK ? MAX_STACK * BT : 1];
+    constexpr uint32_t TW = BT >= 128 ? 16 : 8, TH = BT / 8 / (TW / 8);   // tile = TW x TH pixels
     // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give
     // each of the 8 residue classes one contiguous run of tiles (bijective for
     // any grid size).
     const uint32_t nb = gridDim.x, bid = blockIdx.x;
-    const uint32_t q = nb >> 3, rem = nb & 7u, xcd = bid & 7u;
-    const uint32_t tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    uint32_t tile;
+    if (P.tile_order == 2) {          // one contiguous slab of tiles per XCD (load-imbalanced: kept for A/B runs)
+        const uint32_t q = nb >> 3, rem = nb & 7u, xcd = bid & 7u;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    } else if (P.tile_order == 1) {   // dispatch order = row-major tile order
+        tile = bid;
+    } else {                          // default: XCD k renders tile rows k, k+8, ... (grid padded to 8*ceil(tiles_y/8) rows)
+        const uint32_t xcd = bid & 7u, j = bid >> 3;           // j-th block of this XCD
+        const uint32_t r = j / P.tiles_x, cx = j - r * P.tiles_x;
+        const uint32_t row = r * 8 + xcd;
+        tile = row < P.tiles_y ? row * P.tiles_x + cx : 0xFFFFFFFFu;
+    }
+    if (tile >= P.n_tiles) return;
     const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t x = tx * 16 + (wave & 1u) * 8 + (lane & 7u);
-    const uint32_t yl = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+    constexpr uint32_t WX = TW / 8;                        // waves side by side in a tile
+    const uint32_t x = tx * TW + (wave % WX) * 8 + (lane & 7u);
+    const uint32_t yl = ty * TH + (wave / WX) * 8 + (lane >> 3);
     unsigned long long cn = 0, cs = 0, ct = 0;
     bool live = x < P.width && yl < P.nrows_out;
     uint32_t y = 0;
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(BLOCK) void k_plain(RenderParams P)
         start_pixel(P, root, x, y, r, c);
         float4 out;
         while (!pre_step(P, r, c.cell(), out)) {
-            uint32_t reads = march_step(P, r, c, stack_lds + tid);
+            uint32_t reads = march_step(P, r, c, stack_lds + tid, BT);
             if (COUNT) { cn += reads; cs += 1; }
         }
         P.out[(size_t)yl * P.width + x] = out;
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(BLOCK) void k_compact(RenderParams P)
                 if (COUNT) ct += (unsigned long long)out.w;
                 active = false;
             } else {
-                uint32_t reads = march_step(P, r, c, stack_lds + tid);
+                uint32_t reads = march_step(P, r, c, stack_lds + tid, BLOCK);
                 if (COUNT) { cn += reads; cs += 1; }
             }
         }
@@ -436,10 +454,12 @@ extern "C" int sdfhip_scene_info(const sdfhip_scene *s, uint32_t *n, uint32_t *d
 namespace {
 
 template <bool STACK, bool COUNT>
-void launch_pair(bool compact, dim3 grid, hipStream_t st, const RenderParams &P)
+void launch_pair(bool compact, int bt, dim3 grid, hipStream_t st, const RenderParams &P)
 {
-    if (compact) hipLaunchKernelGGL((k_compact<STACK, COUNT>), grid, dim3(BLOCK), 0, st, P);
-    else         hipLaunchKernelGGL((k_plain<STACK, COUNT>), grid, dim3(BLOCK), 0, st, P);
+    if (compact)        hipLaunchKernelGGL((k_compact<STACK, COUNT>), grid, dim3(BLOCK), 0, st, P);
+    else if (bt == 64)  hipLaunchKernelGGL((k_plain<STACK, COUNT, 64>), grid, dim3(64), 0, st, P);
+    else if (bt == 128) hipLaunchKernelGGL((k_plain<STACK, COUNT, 128>), grid, dim3(128), 0, st, P);
+    else                hipLaunchKernelGGL((k_plain<STACK, COUNT, 256>), grid, dim3(256), 0, st, P);
 }
 
 int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32_t height,
@@ -464,9 +484,13 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     P.width = width; P.height = height;
     P.band_rows = band_rows; P.band_first = band_first; P.band_stride = band_stride;
     P.nrows_out = nrows_out;
-    const uint32_t tile = compact ? 8u : 16u;
-    P.tiles_x = (width + tile - 1) / tile;
-    P.tiles_y = (nrows_out + tile - 1) / tile;
+    P.tile_order = (flags >> 8) & 0xF;
+    const uint32_t btsel = (flags >> 12) & 0xF;                       // tuning knob: 0 = default
+    const int bt = btsel == 3 ? 256 : (btsel == 2 ? 128 : 64);
+    const uint32_t tile_w = compact ? 8u : (bt >= 128 ? 16u : 8u);
+    const uint32_t tile_h = compact ? 8u : (uint32_t)bt / 8u / (tile_w / 8u);
+    P.tiles_x = (width + tile_w - 1) / tile_w;
+    P.tiles_y = (nrows_out + tile_h - 1) / tile_h;
     P.n_tiles = P.tiles_x * P.tiles_y;
     P.h0x = info->heading[0][0]; P.h0y = info->heading[0][1]; P.h0z = info->heading[0][2];
     P.h1x = info->heading[1][0]; P.h1y = info->heading[1][1]; P.h1z = info->heading[1][2];
@@ -490,11 +514,11 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         uint32_t need = (waves + 3) / 4;
         grid = dim3(blocks < need ? blocks : (need ? need : 1));
     } else {
-        grid = dim3(P.n_tiles);
+        grid = dim3(P.tile_order == 0 ? 8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x : P.n_tiles);
     }
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
-    if (use_stack) { if (count) launch_pair<true, true>(compact, grid, st, P); else launch_pair<true, false>(compact, grid, st, P); }
-    else           { if (count) launch_pair<false, true>(compact, grid, st, P); else launch_pair<false, false>(compact, grid, st, P); }
+    if (use_stack) { if (count) launch_pair<true, true>(compact, bt, grid, st, P); else launch_pair<true, false>(compact, bt, grid, st, P); }
+    else           { if (count) launch_pair<false, true>(compact, bt, grid, st, P); else launch_pair<false, false>(compact, bt, grid, st, P); }
     HIP_TRY(hipGetLastError());
     if (stats) {
         HIP_TRY(hipEventRecord(s->ev1, st));

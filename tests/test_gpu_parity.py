@@ -68,6 +68,18 @@ def test_against_oracle_cfg1_and_ragged_sizes(sb, oracle_mod, scenes, gpu_scenes
         assert (st.n_nodes, st.n_samples, st.n_steps) == tuple(int(c) for c in cnt)
 
 
+def test_tuning_knobs_never_change_results(sb, gpu_scenes):
+    # blockIdx -> tile order (bits 8..11) and workgroup size (bits 12..15) are pure speed knobs
+    scene = gpu_scenes["torus_d6"]
+    cam = make_camera("rotated", 333, 211)
+    base = scene.Draw(cam, 333, 211, sb.KERNEL_STACK)
+    for kern in (sb.KERNEL_STACK, sb.KERNEL_GENERIC):
+        for order in (0, 1, 2):
+            for block in (0, 1, 2, 3):
+                img = scene.Draw(cam, 333, 211, kern | (order << 8) | (block << 12))
+                assert_frames_identical(img, base, f"kernel {kern} order {order} block {block}")
+
+
 def test_camera_edge_cases(sb, oracle_mod, scenes, gpu_scenes):
     W, H = 96, 64
     od, scene = scenes["torus_d6"], gpu_scenes["torus_d6"]
