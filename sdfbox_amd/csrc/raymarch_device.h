@@ -57,14 +57,13 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 }
 
 // R8_UNorm decode, bit-identical to (float)b / 255.0f for b = 0..255 (checked
-// exhaustively by tests/test_gpu_parity.py::test_unorm_table): one Newton
-// fix-up of b * fl(1/255).
+// exhaustively by tests/test_gpu_parity.py::test_unorm_table): 1/255 split into
+// fl(1/255) + a correction term, summed by one fma -- one rounding, like the division.
 __device__ __forceinline__ float unorm8(float b)
 {
-    const float r = 0x1.010102p-8f;  // fl(1/255)
-    float q = b * r;
-    float e = __builtin_fmaf(-255.0f, q, b);
-    return __builtin_fmaf(e, r, q);
+    const float r_hi = 0x1.010102p-8f;                   // fl(1/255)
+    const float r_lo = __uint_as_float(0xaf7efeffu);     // fl(1/255 - r_hi) = -2.3191758e-10
+    return __builtin_fmaf(b, r_hi, b * r_lo);
 }
 
 struct Texels { float v[8]; };
@@ -225,28 +224,34 @@ struct CursorS {
     }
 };
 
-// per axis: A, B as above (clamped) from one coordinate
-__device__ __forceinline__ void axis_ab(float p, int32_t &A, int32_t &B)
+// per axis: u = pos * 2^LM, its floor, and A = floor clamped to [-1, 2^LM + 1] (NaN -> -1)
+__device__ __forceinline__ int32_t axis_a(float p, float &u, float &f)
 {
-    float u = p * 4096.0f;
-    float f = floorf(u);
+    u = p * 4096.0f;
+    f = floorf(u);
     int32_t a = (int32_t)__builtin_fmaxf(__builtin_fminf(f, 4097.0f), -2.0f);   // NaN -> 4097 here, fixed next line
-    A = (u >= -1.0f) ? a : -1;                             // below the cube, or NaN: -1
-    B = A - ((u == f) ? 1 : 0);
+    return (u >= -1.0f) ? a : -1;                          // below the cube, or NaN: -1
 }
 __device__ __forceinline__ int bitlen(uint32_t x) { return 32 - __clz((int)x); }   // bitlen(0) = 0
 
-__device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, uint32_t,
-                                         int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz)
+// ON_GRID = false: no lane of the wave has a coordinate exactly on the 2^-LM grid, so
+// B == A on every axis and the B terms drop out (the common case; the wave-uniform
+// branch in find() picks it).
+template <bool ON_GRID>
+__device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict__ nodes,
+                                           int32_t *__restrict__ stack, uint32_t stride,
+                                           int32_t Ax, int32_t Ay, int32_t Az, bool gx, bool gy, bool gz)
 {
-    int32_t Ax, Bx, Ay, By, Az, Bz;
-    axis_ab(px, Ax, Bx);
-    axis_ab(py, Ay, By);
-    axis_ab(pz, Az, Bz);
+    const int32_t Bx = Ax - ((ON_GRID && gx) ? 1 : 0);
+    const int32_t By = Ay - ((ON_GRID && gy) ? 1 : 0);
+    const int32_t Bz = Az - ((ON_GRID && gz) ? 1 : 0);
     const int s = LM - c.level;
-    int tx = min(bitlen((uint32_t)(c.ax ^ Ax)), bitlen((uint32_t)(c.ax ^ Bx)));
-    int ty = min(bitlen((uint32_t)(c.ay ^ Ay)), bitlen((uint32_t)(c.ay ^ By)));
-    int tz = min(bitlen((uint32_t)(c.az ^ Az)), bitlen((uint32_t)(c.az ^ Bz)));
+    int tx = bitlen((uint32_t)(c.ax ^ Ax)), ty = bitlen((uint32_t)(c.ay ^ Ay)), tz = bitlen((uint32_t)(c.az ^ Az));
+    if (ON_GRID) {
+        tx = min(tx, bitlen((uint32_t)(c.ax ^ Bx)));
+        ty = min(ty, bitlen((uint32_t)(c.ay ^ By)));
+        tz = min(tz, bitlen((uint32_t)(c.az ^ Bz)));
+    }
     int t = max(max(tx, ty), max(tz, s));
     int k = min(t - s, c.level);                 // ascents (Compute.hlsl:93-97)
     uint32_t reads = 1u + (uint32_t)k;
@@ -256,10 +261,13 @@ __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__
     }
     if (c.children >= 0) {
         // where the descent reads its octant bits from (see above), clamped into the cube
-        const int tt = LM - c.level;             // <= LM
-        int32_t Dx = (((uint32_t)(c.ax ^ Ax) >> tt) == 0u) ? Ax : Bx;
-        int32_t Dy = (((uint32_t)(c.ay ^ Ay) >> tt) == 0u) ? Ay : By;
-        int32_t Dz = (((uint32_t)(c.az ^ Az) >> tt) == 0u) ? Az : Bz;
+        int32_t Dx = Ax, Dy = Ay, Dz = Az;
+        if (ON_GRID) {
+            const int tt = LM - c.level;         // <= LM
+            Dx = (((uint32_t)(c.ax ^ Ax) >> tt) == 0u) ? Ax : Bx;
+            Dy = (((uint32_t)(c.ay ^ Ay) >> tt) == 0u) ? Ay : By;
+            Dz = (((uint32_t)(c.az ^ Az) >> tt) == 0u) ? Az : Bz;
+        }
         Dx = min(max(Dx, 0), 4095); Dy = min(max(Dy, 0), 4095); Dz = min(max(Dz, 0), 4095);
         do {
             stack[(uint32_t)c.level * stride] = c.children;
@@ -271,7 +279,7 @@ __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__
             c.v1 = r.w;
             // keep the value bytes live in every iteration: otherwise the compiler loads only
             // `children` in the loop and fetches the leaf's values in a second, dependent
-            // round trip after it (one more L1 latency on every march step)
+            // round trip after it
             asm volatile("" : "+v"(c.v0), "+v"(c.v1));
             c.level++;
             reads++;
@@ -285,6 +293,17 @@ __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__
         c.ax &= keep; c.ay &= keep; c.az &= keep;
     }
     return reads;
+}
+
+__device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, uint32_t,
+                                         int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz)
+{
+    float ux, uy, uz, fx, fy, fz;
+    const int32_t Ax = axis_a(px, ux, fx), Ay = axis_a(py, uy, fy), Az = axis_a(pz, uz, fz);
+    const bool gx = ux == fx, gy = uy == fy, gz = uz == fz;    // on the 2^-LM grid (false for NaN)
+    if (__ballot(gx || gy || gz) == 0ull)
+        return find_s<false>(c, nodes, stack, stride, Ax, Ay, Az, false, false, false);
+    return find_s<true>(c, nodes, stack, stride, Ax, Ay, Az, gx, gy, gz);
 }
 
 // Cube::interpol_world -> sample_at, Compute.hlsl:54-58,19-29

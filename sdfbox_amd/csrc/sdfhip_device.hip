@@ -68,7 +68,8 @@ __device__ __forceinline__ void start_pixel(const RenderParams &P, const NodeRec
 
 // Everything main() does between two find() calls.  Returns true when the
 // pixel is finished, with its colour in `out` (alpha = step count).
-__device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, const Cell &c, float4 &out)
+template <class CursorT>
+__device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, const CursorT &c, float4 &out)
 {
     if (r.phase == 0) {
         // loop header of Compute.hlsl:194
@@ -87,7 +88,7 @@ __device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, con
         r.py = __builtin_fmaf(r.dy, P.margin, r.py);
         r.pz = __builtin_fmaf(r.dz, P.margin, r.pz);
         float gx, gy, gz;
-        gradient(c, r.px, r.py, r.pz, gx, gy, gz);
+        gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
         float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
         r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
         if (r.angle < 0.0f) {
@@ -112,7 +113,7 @@ __device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, con
     }
     if (r.prox < P.margin) {                                       // :221-223
         float gx, gy, gz;
-        gradient(c, r.px, r.py, r.pz, gx, gy, gz);
+        gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
         if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) {
             out = make_float4(0.0f, 0.0f, 0.0f, (float)(r.i + r.j));
             return true;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
         const NodeRec root = P.nodes[0];
         start_pixel(P, root, x, y, r, c);
         float4 out;
-        while (!pre_step(P, r, c.cell(), out)) {
+        while (!pre_step(P, r, c, out)) {
             uint32_t reads = march_step(P, r, c, stack_lds + tid, BT);
             if (COUNT) { cn += reads; cs += 1; }
         }
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(BLOCK) void k_compact(RenderParams P)
         }
         if (active) {
             float4 out;
-            if (pre_step(P, r, c.cell(), out)) {
+            if (pre_step(P, r, c, out)) {
                 P.out[(size_t)yl * P.width + x] = out;
                 if (COUNT) ct += (unsigned long long)out.w;
                 active = false;
