@@ -4,7 +4,10 @@
 A "step" is one frame of the workload: every rank ray-marches its row bands of
 the frame (scene and camera already resident in HBM), the band buffers are
 gathered to rank 0 over RCCL and put back in row order.  At N=1 a step is the
-ray-march kernel alone.  Prints ONE JSON line on rank 0.
+ray-march kernel alone.  Consecutive frames are double-buffered on separate HIP
+streams (frames in flight), as a renderer would: the long tail of one frame (a
+few 100-140-step pixels) overlaps the body of the next.  Prints ONE JSON line
+on rank 0.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -21,6 +24,10 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+# Wavefront ray compaction is measured slower than the plain kernel on this workload
+# (DESIGN.md section 6), so it is off unless asked for.
+DEFAULT_COMPACT = False
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -34,13 +41,15 @@ def parse():
     ap.add_argument("--compact", type=int, default=-1, help="wavefront ray compaction: 1 on, 0 off, -1 default")
     ap.add_argument("--band-rows", type=int, default=16)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="consecutive frames are rendered on this many HIP streams (double buffering): the "
-                         "long tail of one frame (a few 100-140-step pixels) overlaps the body of the next")
+                    help="frames rendered concurrently on separate HIP streams (0 = default: 2 on one GPU, "
+                         "min(8, 2N) when the frame is sharded over N GPUs, whose shares are mostly tail)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 path through host buffers (not a perf mode)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--exercise-gather", action="store_true",
+                    help="run the sharded path (bands + gather + de-interleave) even with one rank")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time target of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", action="store_true", help="verify the assembled frame against a 1-GPU render")
+    ap.add_argument("--check", action="store_true", help="verify the assembled frame against a whole-frame render")
     return ap.parse_args()
 
 
@@ -58,20 +67,25 @@ def main():
     import torch.distributed as dist
 
     import sdfbox_amd as sb
-    from sdfbox_amd import _lib
     from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     ndev = torch.cuda.device_count()
-    device = local_rank % ndev            # gloo rehearsal may put several ranks on one GPU
+    device = local_rank % ndev            # the gloo rehearsal may put several ranks on one GPU
     torch.cuda.set_device(device)
-    if world > 1:
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+    sharded = world > 1 or args.exercise_gather
+    if sharded:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        kw = {"device_id": torch.device("cuda", device)} if args.backend == "nccl" else {}
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
+    nccl = args.backend == "nccl"
 
     W, H = (int(v) for v in args.size.lower().split("x"))
 
-    # ---- scene (host build, then resident in HBM before anything is timed) ----
+    # ---- scene: built on the host, resident in HBM before anything is timed ----------
     t0 = time.time()
     ncpu = os.cpu_count() or 1
     if args.asdf:
@@ -83,7 +97,7 @@ def main():
     t_gen = time.time() - t0
     scene = sb.Scene(od, device=device)
 
-    # ---- camera: SURVEY.md 8d cfg-2 --------------------------------------------
+    # ---- camera: SURVEY.md 8d cfg-2 ---------------------------------------------------
     cam = sb.Logic(W, H)
     cam.Position = (0.5, 0.5, -0.35)
     cam.Heading = (-0.2, 0.35)            # (X = pitch, Y = yaw), Logic.cs:53
@@ -93,67 +107,66 @@ def main():
     flags = kflag | (sb.FLAG_COMPACT if compact else 0)
 
     layout = BandLayout(H, world, args.band_rows)
-    # default: 2 frames in flight on one GPU; with the frame sharded over `world` GPUs each
-    # rank's share is mostly tail, so keep more frames in flight
     nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else min(8, 2 * world))
-    if world > 1:
-        nbuf = max(2, nbuf)
     streams = [torch.cuda.Stream() for _ in range(nbuf)]     # one per frame in flight
-    main_stream = torch.cuda.current_stream()
-    stream = main_stream.cuda_stream
-    local = [torch.zeros((layout.rows_per_rank if world > 1 else H, W, 4), dtype=torch.float32, device="cuda")
-             for _ in range(nbuf)]
+    main = torch.cuda.current_stream().cuda_stream
+    rows_local = layout.rows_per_rank if sharded else H
+    local = [torch.zeros((rows_local, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
     gathered = frame = None
-    if world > 1 and rank == 0:
+    if sharded and rank == 0:
         gathered = [torch.zeros((world, layout.rows_per_rank, W, 4), dtype=torch.float32, device="cuda")
                     for _ in range(nbuf)]
         frame = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
 
-    def render(buf, stats=None, fl=None, st=None):
-        st = stream if st is None else st
-        if world == 1:
-            scene.DrawDevice(cam, W, H, buf.data_ptr(), flags=flags if fl is None else fl, stream=st, stats=stats)
+    def render(buf, st, stats=None, fl=None):
+        f = flags if fl is None else fl
+        if sharded:
+            render_bands(scene, cam, W, layout, rank, buf.data_ptr(), flags=f, stream=st, stats=stats)
         else:
-            render_bands(scene, cam, W, layout, rank, buf.data_ptr(), flags=flags if fl is None else fl,
-                         stream=st, stats=stats)
+            scene.DrawDevice(cam, W, H, buf.data_ptr(), flags=f, stream=st, stats=stats)
 
     pending = [None] * nbuf
+    ev = []                               # (start, end) HIP events around each timed launch
 
     def finish(slot):
-        """Complete the gather issued from buffer `slot` and, on rank 0, assemble the frame."""
-        w = pending[slot]
+        """Complete the gather issued from buffer `slot`; rank 0 puts the rows back in order."""
+        w, pending[slot] = pending[slot], None
         if w is None:
             return
-        pending[slot] = None
-        if args.backend == "nccl":
+        if nccl:
             with torch.cuda.stream(streams[slot]):
                 w.wait()                              # this slot's stream waits for its gather
                 if rank == 0:
                     deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout,
                                  stream=streams[slot].cuda_stream)
-        else:                                         # gloo rehearsal: host buffers
-            if rank == 0:
-                g = torch.stack(w).cuda()
-                gathered[slot].copy_(g)
-                deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=stream)
+        elif rank == 0:                               # gloo rehearsal: through host buffers
+            gathered[slot].copy_(torch.stack(w).cuda())
+            deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=main)
 
-    def step(k):
+    def step(k, timed=False):
         slot = k % nbuf
-        finish(slot)                                   # buffer reuse: its previous gather must be done
-        render(local[slot], st=streams[slot].cuda_stream)
-        if world > 1:
-            if args.backend == "nccl":
-                glist = list(gathered[slot].unbind(0)) if rank == 0 else None
-                with torch.cuda.stream(streams[slot]):  # the collective orders itself after this stream's render
-                    pending[slot] = dist.gather(local[slot], glist, dst=0, async_op=True)
-            else:
-                streams[slot].synchronize()
-                host = local[slot].cpu()
-                glist = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                dist.gather(host, glist, dst=0)
-                pending[slot] = glist if rank == 0 else True
-            if args.backend != "nccl":
-                finish(slot)
+        finish(slot)                                  # the slot's previous frame must be complete
+        s = streams[slot]
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+        render(local[slot], s.cuda_stream)
+        if timed:
+            e1.record(s)
+            ev.append((e0, e1))
+        if not sharded:
+            return
+        if nccl:
+            glist = list(gathered[slot].unbind(0)) if rank == 0 else None
+            with torch.cuda.stream(s):                # the collective orders itself behind this stream's render
+                pending[slot] = dist.gather(local[slot], glist, dst=0, async_op=True)
+        else:
+            s.synchronize()
+            host = local[slot].cpu()
+            glist = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, glist, dst=0)
+            pending[slot] = glist if rank == 0 else True
+            finish(slot)
 
     def drain():
         for s in range(nbuf):
@@ -164,63 +177,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- algorithmic work of one frame (counting launch, untimed) ---------------
+    # ---- algorithmic work of one frame: counting build of the same kernel, untimed ------
     st = sb.Stats()
-    render(local[0], stats=st, fl=flags | sb.FLAG_COUNT)
+    render(local[0], main, stats=st, fl=flags | sb.FLAG_COUNT)
     torch.cuda.synchronize()
-    my_pixels = W * H if world == 1 else len(layout.rows_of(rank)) * W
+    my_pixels = len(layout.rows_of(rank)) * W if sharded else W * H
     alg_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + 16 * my_pixels
-    counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps, alg_bytes_rank], dtype=torch.float64)
+    counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps], dtype=torch.float64)
+    kernel_used = st.kernel_used
 
-    # ---- warm-up, then the timed region -------------------------------------------
+    # ---- warm-up, then the timed region ---------------------------------------------------
     for k in range(args.warmup):
         step(k)
     drain()
     barrier()
     t_start = time.perf_counter()
     for k in range(args.steps):
-        step(k)
+        step(k, timed=True)
     drain()
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = counters.cuda() if args.backend == "nccl" else counters
+        c = counters.cuda() if nccl else counters
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         counters = c.cpu()
-
-    # ---- per-launch kernel time, HIP events on the launch stream -----------------
-    kms = []
-    for _ in range(min(args.steps, 20)):
-        render(local[0], stats=st)
-        kms.append(st.kernel_ms)
-    kernel_ms = float(np.mean(kms))
-    torch.cuda.synchronize()
+    # average duration of the ray-march launch over the timed region (HIP events on the
+    # stream each launch went to; with frames in flight the launches overlap each other)
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     check_ok = None
-    if args.check and world > 1:
-        if rank == 0:
-            ref = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-            scene.DrawDevice(cam, W, H, ref.data_ptr(), flags=flags, stream=stream)
-            torch.cuda.synchronize()
-            check_ok = all(bool(torch.equal(f.view(torch.int32), ref.view(torch.int32))) for f in frame)
+    if args.check and sharded and rank == 0:
+        ref = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        scene.DrawDevice(cam, W, H, ref.data_ptr(), flags=flags, stream=main)
+        torch.cuda.synchronize()
+        check_ok = all(bool(torch.equal(f.view(torch.int32), ref.view(torch.int32))) for f in frame[:min(nbuf, args.steps)])
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        mrays = W * H / (elapsed / args.steps) / 1e6
+        sec_per_step = elapsed / args.steps
         peak = 8000.0                                  # GB/s, HBM3E spec (MI355X_MICROARCH.md)
         achieved = alg_bytes_rank / (kernel_ms * 1e-3) / 1e9
-        traffic = load_traffic(W, H, scene_name, flags)
         out = {
             "metric": "Mray/s (primary rays; frame W*H / time per frame)",
-            "value": round(mrays, 2),
+            "value": round(W * H / sec_per_step / 1e6, 2),
             "unit": "Mray/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step": round(sec_per_step * 1e3, 4),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -229,10 +235,11 @@ def main():
             "config": {
                 "workload": f"{W}x{H} primary-ray sphere trace + shadow march, {scene_name} "
                             f"(N={od.Length} nodes, {od.nbytes / 1e6:.1f} MB), camera (0.5,0.5,-0.35) yaw 0.35 pitch -0.2",
-                "kernel": ("stack" if (st.kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else ""),
-                "parallelism": "1 GPU" if world == 1 else f"{world} GPUs, {args.band_rows}-row bands round-robin + gather to rank 0 ({args.backend})",
+                "kernel": ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else ""),
+                "parallelism": "1 GPU" if not sharded else
+                               f"{world} GPU(s), {args.band_rows}-row bands round-robin + gather to rank 0 ({args.backend})",
                 "frames_in_flight": nbuf,
-                "gstep_per_s": round(float(counters[2]) / (elapsed / args.steps) / 1e9, 3),
+                "gstep_per_s": round(float(counters[2]) / sec_per_step / 1e9, 3),
                 "scene_build_s": round(t_gen, 2),
             },
             "roofline": {
@@ -241,36 +248,32 @@ def main():
                 "peak": peak,
                 "unit": "GB/s",
                 "frac": round(achieved / peak, 4),
-                "traffic": traffic,
+                "traffic": load_traffic(W, H, scene_name, world),
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes_rank),
             },
         }
         if check_ok is not None:
-            out["config"]["assembled_frame_equals_1gpu"] = check_ok
+            out["config"]["assembled_frame_equals_whole_frame_render"] = check_ok
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(od, cam, W, H, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     scene.close()
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 
 
-# Compaction is the default only where it measured faster (DESIGN.md "Measurements").
-DEFAULT_COMPACT = False
-
-
-def load_traffic(W, H, scene_name, flags):
-    """HBM bytes per launch from the committed PMC passes (profiles/), or None.
-    bench.py cannot run rocprofv3 on itself; the passes are collected with
-    scripts/profile_pmc.sh and summarised in profiles/hbm_traffic.json."""
-    p = os.path.join(REPO, "profiles", "hbm_traffic.json")
+def load_traffic(W, H, scene_name, world):
+    """HBM bytes per launch from the committed PMC passes, or None.  bench.py cannot run
+    rocprofv3 on itself; scripts/profile.sh collects the separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this command and scripts/summarise_profile.py writes
+    profiles/hbm_traffic.json (method and gfx950 corrections: DESIGN.md section 6)."""
+    if world != 1:
+        return None
     try:
-        with open(p) as f:
-            t = json.load(f)
-        key = f"{W}x{H}:{scene_name}:{flags}"
-        return t.get(key)
+        with open(os.path.join(REPO, "profiles", "hbm_traffic.json")) as f:
+            return json.load(f).get(f"{W}x{H}:{scene_name}")
     except (OSError, ValueError):
         return None
 

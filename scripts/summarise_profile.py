@@ -42,7 +42,7 @@ if bench:
 json.dump(pmc, open(f"profiles/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v for k, v in pmc.items() if k != "bench_line"}, indent=1, sort_keys=True))
 if bench and "hbm_bytes_per_launch" in pmc and len(sys.argv) > 2:
-    key = sys.argv[2]            # e.g. "1920x1080:dragon_standin_d9:0"
+    key = sys.argv[2]            # e.g. "1920x1080:dragon_standin_d9"
     p = "profiles/hbm_traffic.json"
     t = json.load(open(p)) if os.path.exists(p) else {}
     t[key] = int(pmc["hbm_bytes_per_launch"])

@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--depth", type=int, default=9)
 ap.add_argument("--sizes", default="1920x1080,3840x2160")
 ap.add_argument("--rounds", type=int, default=10)
+ap.add_argument("--camera", default="bench")
 a = ap.parse_args()
 t0 = time.time(); od = sb.dragon_standin(a.depth); print(f"scene d{a.depth}: N={od.Length} ({od.nbytes/1e6:.1f} MB) built in {time.time()-t0:.1f}s", flush=True)
 sc = sb.Scene(od); print("depth", sc.depth, "stack ok", sc.stack_kernel_ok, flush=True)
@@ -19,7 +20,11 @@ variants = [("generic", sb.KERNEL_GENERIC), ("stack", sb.KERNEL_STACK), ("stack 
             ("stack+compact", sb.KERNEL_STACK | sb.FLAG_COMPACT)]
 for size in a.sizes.split(","):
     W, H = (int(v) for v in size.split("x"))
-    cam = sb.Logic(W, H); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
+    cam = sb.Logic(W, H)
+    if a.camera == 'bench':
+        cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
+    else:
+        cam.Position = (0.5, 0.5, 0.02)      # close-up: the object fills the frame
     buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     st = sb.Stats()
     sc.DrawDevice(cam, W, H, buf.data_ptr(), flags=sb.KERNEL_STACK | sb.FLAG_COUNT, stream=stream, stats=st)

@@ -30,21 +30,22 @@
 
 namespace sdfhip {
 
-constexpr int BLOCK = 256;             // k_compact: 4 wavefronts
 constexpr int MAX_STACK = LM;          // the shader's own descent limit (Compute.hlsl:98)
 #ifndef PLAIN_WAVES_PER_SIMD
 #define PLAIN_WAVES_PER_SIMD 8          // <= 64 VGPRs: 8 waves per SIMD (2nd launch-bound = waves per SIMD)
 #endif
-constexpr int REFILL_MIN = 16;   // compact kernels: refill once this many lanes are idle
 
 template <bool STACK> struct CursorOf { typedef CursorG type; };
 template <> struct CursorOf<true> { typedef CursorS type; };
+
+// lane states: marching (primary / shadow), march over and shading pending, no pixel
+enum { PH_PRIMARY = 0, PH_SHADOW = 1, PH_SHADE = 2, PH_IDLE = 3, PH_DONE = 4 };   // DONE: idle, colour waiting in LDS
 
 struct RayState {
     float px, py, pz;    // pos
     float dx, dy, dz;    // dir (primary direction, then direction to the light)
     float prox, angle, dist;
-    int i, j, phase;     // phase 0 = primary march, 1 = shadow march
+    int i, j, phase;     // PH_*
 };
 
 __device__ __forceinline__ uint32_t global_row(const RenderParams &P, uint32_t yl)
@@ -62,64 +63,106 @@ __device__ __forceinline__ void start_pixel(const RenderParams &P, const NodeRec
     ray(P, x, y, r.dx, r.dy, r.dz);
     r.prox = 1.0f;
     r.angle = 0.0f; r.dist = 0.0f;
-    r.i = 0; r.j = 0; r.phase = 0;
+    r.i = 0; r.j = 0; r.phase = PH_PRIMARY;
     c.reset(root);
 }
 
-// Everything main() does between two find() calls.  Returns true when the
-// pixel is finished, with its colour in `out` (alpha = step count).
-template <class CursorT>
-__device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, const CursorT &c, float4 &out)
+// ---- main() between two find() calls, in three pieces -------------------------
+// A finished pixel's colour (alpha = step count = r.i + r.j) is stored to *dst by the
+// piece that finishes it.  (Storing there instead of returning the colour keeps four
+// values out of the march loop's phi nodes.)
+
+// Where a finished pixel's colour goes: straight to the frame (plain kernel), or to the
+// lane's LDS slot, to be flushed at the next refill (compact kernel: on gfx950 a store
+// counts on vmcnt like a load, so a global store per finished pixel would stall the very
+// next node load of the whole wave behind the store's completion).
+struct FrameSink {
+    float4 *p;
+    __device__ __forceinline__ void operator()(float r, float g, float b, float a) const { *p = make_float4(r, g, b, a); }
+};
+struct LdsSink {
+    float4 *slot;      // points into a __shared__ array (address space known after inlining)
+    __device__ __forceinline__ void operator()(float r, float g, float b, float a) const { *slot = make_float4(r, g, b, a); }
+};
+
+// Loop header + escape test of the primary march, Compute.hlsl:194-199.
+// 0: take a march step; 1: the march is over, shade next; 2: pixel finished (sky).
+template <class Sink>
+__device__ __forceinline__ int check_primary(const RenderParams &P, const RayState &r, const Sink &dst)
 {
-    if (r.phase == 0) {
-        // loop header of Compute.hlsl:194
-        if ((r.prox > P.margin * 2.0f || r.prox < 0.0f) && r.i < 100) {
-            if (dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > P.limit) {  // :195-199
-                out = make_float4(0.005f, 0.01f, 0.2f, (float)r.i);
-                return true;
-            }
-            return false;
+    if ((r.prox > P.margin * 2.0f || r.prox < 0.0f) && r.i < 100) {
+        if (dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > P.limit) {
+            dst(0.005f, 0.01f, 0.2f, (float)r.i);
+            return 2;
         }
-        // Compute.hlsl:205-213
-        float lx = P.lightx - r.px, ly = P.lighty - r.py, lz = P.lightz - r.pz;
-        float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
-        r.dx = lx * rl; r.dy = ly * rl; r.dz = lz * rl;
-        r.px = __builtin_fmaf(r.dx, P.margin, r.px);
-        r.py = __builtin_fmaf(r.dy, P.margin, r.py);
-        r.pz = __builtin_fmaf(r.dz, P.margin, r.pz);
-        float gx, gy, gz;
-        gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
-        float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
-        r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
-        if (r.angle < 0.0f) {
-            out = make_float4(0.0f, 0.0f, 0.0f, (float)r.i);
-            return true;
-        }
-        lx = P.lightx - r.px; ly = P.lighty - r.py; lz = P.lightz - r.pz;
-        r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
-        r.phase = 1;
-        r.j = 0;
+        return 0;
     }
-    // loop header of Compute.hlsl:214
+    return 1;
+}
+
+// Compute.hlsl:205-213: turn towards the light, Lambert term from the gradient.
+// true: pixel finished (faces away).  Otherwise the lane enters the shadow march.
+template <class CursorT, class Sink>
+__device__ __forceinline__ bool shade(const RenderParams &P, RayState &r, const CursorT &c, const Sink &dst)
+{
+    float lx = P.lightx - r.px, ly = P.lighty - r.py, lz = P.lightz - r.pz;
+    float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+    r.dx = lx * rl; r.dy = ly * rl; r.dz = lz * rl;
+    r.px = __builtin_fmaf(r.dx, P.margin, r.px);
+    r.py = __builtin_fmaf(r.dy, P.margin, r.py);
+    r.pz = __builtin_fmaf(r.dz, P.margin, r.pz);
+    float gx, gy, gz;
+    gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
+    float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
+    r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
+    if (r.angle < 0.0f) {
+        dst(0.0f, 0.0f, 0.0f, (float)r.i);
+        return true;
+    }
+    lx = P.lightx - r.px; ly = P.lighty - r.py; lz = P.lightz - r.pz;
+    r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+    r.phase = PH_SHADOW;
+    r.j = 0;
+    return false;
+}
+
+// Loop header and the three exits of the shadow march, Compute.hlsl:214-223,229.
+// true: pixel finished.
+template <class CursorT, class Sink>
+__device__ __forceinline__ bool check_shadow(const RenderParams &P, const RayState &r, const CursorT &c, const Sink &dst)
+{
     if (!(r.j < 40 && r.prox > -P.margin)) {
-        out = make_float4(0.0f, 0.0f, 0.0f, (float)(r.i + r.j));  // :229
+        dst(0.0f, 0.0f, 0.0f, (float)(r.i + r.j));  // :229
         return true;
     }
     if (r.prox > r.dist || (r.px < 0.0f || r.py < 0.0f || r.pz < 0.0f) ||
         (r.px > 1.0f || r.py > 1.0f || r.pz > 1.0f)) {           // :215-219
         float a = r.angle / (r.dist * r.dist) * P.k_strength;
-        out = make_float4(a, a, a, (float)(r.i + r.j));
+        dst(a, a, a, (float)(r.i + r.j));
         return true;
     }
     if (r.prox < P.margin) {                                       // :221-223
         float gx, gy, gz;
         gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
         if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) {
-            out = make_float4(0.0f, 0.0f, 0.0f, (float)(r.i + r.j));
+            dst(0.0f, 0.0f, 0.0f, (float)(r.i + r.j));
             return true;
         }
     }
     return false;
+}
+
+// The three pieces in program order: what one lane does between two march steps.
+template <class CursorT, class Sink>
+__device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, const CursorT &c, const Sink &dst)
+{
+    if (r.phase == PH_PRIMARY) {
+        int s = check_primary(P, r, dst);
+        if (s == 0) return false;
+        if (s == 2) return true;
+        if (shade(P, r, c, dst)) return true;
+    }
+    return check_shadow(P, r, c, dst);
 }
 
 // find + interpol_world + advance: Compute.hlsl:200-202 / :225-227
@@ -190,86 +233,135 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
         typename CursorOf<STACK>::type c;
         const NodeRec root = P.nodes[0];
         start_pixel(P, root, x, y, r, c);
-        float4 out;
-        while (!pre_step(P, r, c, out)) {
+        const FrameSink dst{P.out + ((size_t)yl * P.width + x)};
+        while (!pre_step(P, r, c, dst)) {
             uint32_t reads = march_step(P, r, c, stack_lds + tid, BT);
             if (COUNT) { cn += reads; cs += 1; }
         }
-        P.out[(size_t)yl * P.width + x] = out;
-        if (COUNT) ct = (unsigned long long)out.w;
+        if (COUNT) ct = (unsigned long long)(r.i + r.j);
     }
     if (COUNT) flush_counters(P, cn, cs, ct);
 }
 
-// ---- persistent waves with lane refill (wavefront ray compaction) -----------
-// Pixels are numbered in 8x8-tile order: p = tile*64 + (y&7)*8 + (x&7).  Each
-// wave owns the range [cur, end) of one tile at a time and hands the next
-// pixels of it to its idle lanes: rank = number of idle lanes below me
-// (ballot + mbcnt), lane gets pixel cur + rank.  A pixel's result depends on
-// its coordinates only, so the image is the plain kernel's bit for bit.
-// Exit: every wave leaves once the queue is exhausted and its lanes are idle.
+// ---- persistent waves with lane refill and state batching (wavefront ray compaction) --
+// One wave per workgroup, as many workgroups as the chip holds.  Lane states:
+// PRIMARY / SHADOW (marching), SHADE (march over, shading pending), IDLE (no pixel).
+//   * refill: pixels are numbered in 8x8-tile order, p = tile*64 + (y&7)*8 + (x&7).  A wave
+//     owns the range [cur, end) of one tile at a time and hands the next pixels of it to its
+//     idle lanes: rank = number of idle lanes below me (ballot + mbcnt), lane gets pixel
+//     cur + rank.  Tiles come from 8 atomic queues, one per XCD label (blockIdx & 7): queue q
+//     holds tile rows q, q+8, ... (the plain kernel's mapping), and a wave whose queue is
+//     empty steals from the next ones.
+//   * batching: refill runs only once REFILL_MIN lanes are idle, shading only once SHADE_MIN
+//     lanes wait for it (or nothing else can run), so those long divergent blocks execute
+//     for many lanes at a time instead of once per straggler.
+// A pixel's result depends on its coordinates only, so the image is the plain kernel's
+// bit for bit.  Exit: every wave leaves once all queues are exhausted and its lanes idle.
+constexpr int REFILL_MIN = 12;
+constexpr int SHADE_MIN = 8;
+
 template <bool STACK, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_compact(RenderParams P)
+__global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_compact(RenderParams P)
 {
-    __shared__ int32_t stack_lds[STACK ? MAX_STACK * BLOCK : 1];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    __shared__ int32_t stack_lds[STACK ? MAX_STACK * 64 : 1];
+    __shared__ float4 out_lds[64];
+    const uint32_t lane = threadIdx.x;
     const NodeRec root = P.nodes[0];
+    const LdsSink dst{&out_lds[lane]};
     unsigned long long cn = 0, cs = 0, ct = 0;
     RayState r;
     typename CursorOf<STACK>::type c;
-    bool active = false;
-    uint32_t x = 0, yl = 0;
-    uint32_t cur = 0, end = 0;  // wave-uniform
-    bool more = true;           // wave-uniform
+    uint32_t pix = 0;           // x | yl << 16
+    uint32_t cur = 0, end = 0;  // wave-uniform: pixel range of the current tile
+    uint32_t q = blockIdx.x & 7u, tried = 0;   // wave-uniform: queue in use, queues found empty
+    bool more = true, first = true;   // wave-uniform
     r.px = r.py = r.pz = r.dx = r.dy = r.dz = r.prox = r.angle = r.dist = 0.0f;
-    r.i = r.j = r.phase = 0;
+    r.i = r.j = 0;
+    r.phase = PH_IDLE;
     c.reset(root);
+    const uint32_t rows_q = (P.tiles_y + 7u) >> 3;         // tile rows per queue (upper bound)
 
     for (;;) {
-        unsigned long long idle = __ballot(!active);
-        int nidle = __popcll(idle);
-        if (more && (nidle >= REFILL_MIN || nidle == 64)) {
-            while (more && nidle > 0) {
+        unsigned long long m_idle = __ballot(r.phase >= PH_IDLE);
+        int n_idle = __popcll(m_idle);
+        int n_shade = __popcll(__ballot(r.phase == PH_SHADE));
+        int n_march = 64 - n_idle - n_shade;
+        if (n_idle >= REFILL_MIN || (n_march == 0 && n_shade == 0)) {
+            // flush the colours of the pixels finished since the last refill: one batch of
+            // stores, whose completion the wave waits for once (behind start_pixel's work)
+            if (r.phase == PH_DONE) {
+                P.out[(size_t)(pix >> 16) * P.width + (pix & 0xFFFFu)] = out_lds[lane];
+                r.phase = PH_IDLE;
+            }
+            while (more && n_idle > 0) {
                 if (cur == end) {
-                    uint32_t t = 0;
-                    if (lane == 0) t = atomicAdd(P.queue, 1u);
-                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                    if (t >= P.n_tiles) { more = false; break; }
-                    cur = t * 64u;
+                    // first tile of a wave: its own index within its queue, no atomic (all
+                    // waves start together; thousands of simultaneous adds on one word
+                    // serialise at ~90 per microsecond).  Later tiles: the queue head, one
+                    // 128-byte line per queue, counts on from where the static ones end.
+                    uint32_t t = blockIdx.x >> 3;
+                    if (!first) {
+                        if (lane == 0) t = atomicAdd(P.queue + q * 32u, 1u);
+                        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + ((gridDim.x + 7u - q) >> 3);
+                    }
+                    first = false;
+                    const uint32_t trow = (t / P.tiles_x) * 8u + q;
+                    if (t >= rows_q * P.tiles_x || trow >= P.tiles_y) {   // this queue is empty: steal
+                        q = (q + 1u) & 7u;
+                        if (++tried >= 8u) more = false;
+                        continue;
+                    }
+                    cur = (trow * P.tiles_x + (t % P.tiles_x)) * 64u;
                     end = cur + 64u;
                 }
-                uint32_t take = min((uint32_t)nidle, end - cur);
-                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32),
-                                    __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                if (!active && rank < take) {
+                uint32_t take = min((uint32_t)n_idle, end - cur);
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+                if (r.phase >= PH_IDLE && rank < take) {
                     uint32_t p = cur + rank, tile = p >> 6, qq = p & 63u;
-                    x = (tile % P.tiles_x) * 8 + (qq & 7u);
-                    yl = (tile / P.tiles_x) * 8 + (qq >> 3);
+                    uint32_t x = (tile % P.tiles_x) * 8 + (qq & 7u);
+                    uint32_t yl = (tile / P.tiles_x) * 8 + (qq >> 3);
                     if (x < P.width && yl < P.nrows_out) {
                         uint32_t y = global_row(P, yl);
                         if (y < P.height) {
                             start_pixel(P, root, x, y, r, c);
-                            active = true;
+                            pix = x | (yl << 16);
                         }
                     }
                 }
                 cur += take;
-                idle = __ballot(!active);
-                nidle = __popcll(idle);
+                m_idle = __ballot(r.phase >= PH_IDLE);
+                n_idle = __popcll(m_idle);
             }
+            n_march = 64 - n_idle - n_shade;
         }
-        if (__ballot(active) == 0ull) {
+        if (n_march == 0 && n_shade == 0) {
             if (!more) break;
             continue;
         }
-        if (active) {
-            float4 out;
-            if (pre_step(P, r, c, out)) {
-                P.out[(size_t)yl * P.width + x] = out;
-                if (COUNT) ct += (unsigned long long)out.w;
-                active = false;
+        if (n_shade >= SHADE_MIN || n_march == 0) {
+            if (r.phase == PH_SHADE) {
+                r.phase = PH_PRIMARY;
+                if (shade(P, r, c, dst)) {
+                    if (COUNT) ct += (unsigned long long)(r.i + r.j);
+                    r.phase = PH_DONE;
+                }
+            }
+        }
+        if (r.phase <= PH_SHADOW) {
+            bool done = false;
+            if (r.phase == PH_PRIMARY) {
+                int s = check_primary(P, r, dst);
+                if (s == 1) r.phase = PH_SHADE;
+                done = s == 2;
             } else {
-                uint32_t reads = march_step(P, r, c, stack_lds + tid, BLOCK);
+                done = check_shadow(P, r, c, dst);
+            }
+            if (done) {
+                if (COUNT) ct += (unsigned long long)(r.i + r.j);
+                r.phase = PH_DONE;
+            } else if (r.phase <= PH_SHADOW) {
+                uint32_t reads = march_step(P, r, c, stack_lds + lane, 64);
                 if (COUNT) { cn += reads; cs += 1; }
             }
         }
@@ -424,7 +516,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if ((e = hipMalloc(&s->alloc, (size_t)n * 16 + 128)) != hipSuccess) return bail(e, "hipMalloc(records)");
     s->nodes = reinterpret_cast<NodeRec *>(static_cast<char *>(s->alloc) + 112);
     if ((e = hipMalloc((void **)&s->d_counters, 3 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
-    if ((e = hipMalloc((void **)&s->d_queue, 256)) != hipSuccess) return bail(e, "hipMalloc(queue)");
+    if ((e = hipMalloc((void **)&s->d_queue, 8 * 32 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(queue)");
     if ((e = hipMalloc(&d_s, bytes)) != hipSuccess) return bail(e, "hipMalloc(structs)");
     if ((e = hipMalloc(&d_v, bytes)) != hipSuccess) return bail(e, "hipMalloc(values)");
     if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
@@ -457,7 +549,7 @@ namespace {
 template <bool STACK, bool COUNT>
 void launch_pair(bool compact, int bt, dim3 grid, hipStream_t st, const RenderParams &P)
 {
-    if (compact)        hipLaunchKernelGGL((k_compact<STACK, COUNT>), grid, dim3(BLOCK), 0, st, P);
+    if (compact)        hipLaunchKernelGGL((k_compact<STACK, COUNT>), grid, dim3(64), 0, st, P);
     else if (bt == 64)  hipLaunchKernelGGL((k_plain<STACK, COUNT, 64>), grid, dim3(64), 0, st, P);
     else if (bt == 128) hipLaunchKernelGGL((k_plain<STACK, COUNT, 128>), grid, dim3(128), 0, st, P);
     else                hipLaunchKernelGGL((k_plain<STACK, COUNT, 256>), grid, dim3(256), 0, st, P);
@@ -507,13 +599,11 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     P.queue = s->d_queue;
 
     if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 3 * sizeof(unsigned long long), st));
-    if (compact) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(uint32_t), st));
+    if (compact) HIP_TRY(hipMemsetAsync(s->d_queue, 0, 8 * 32 * sizeof(uint32_t), st));
     dim3 grid;
     if (compact) {
-        uint32_t waves = (P.n_tiles + 0u);            // never more waves than tiles
-        uint32_t blocks = (uint32_t)s->cu_count * 8u; // 8 x 256 threads per CU = full occupancy
-        uint32_t need = (waves + 3) / 4;
-        grid = dim3(blocks < need ? blocks : (need ? need : 1));
+        uint32_t blocks = (uint32_t)s->cu_count * 32u;   // one wave per workgroup, 32 waves per CU
+        grid = dim3(blocks < P.n_tiles ? blocks : (P.n_tiles ? P.n_tiles : 1));
     } else {
         grid = dim3(P.tile_order == 0 ? 8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x : P.n_tiles);
     }
