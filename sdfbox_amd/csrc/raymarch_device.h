@@ -309,6 +309,14 @@ __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__
 // Cube::interpol_world -> sample_at, Compute.hlsl:54-58,19-29
 __device__ __forceinline__ float interpol_world(const Cell &c, float px, float py, float pz)
 {
+    // Cells far from the surface hold 8 equal bytes (the quantiser clamps at 1.5 s and
+    // -0.5 s).  Every lerp of equal operands returns the operand exactly
+    // (fma(t, a - a, a) = a for finite t; d is saturated, hence finite), so the
+    // trilinear blend of such a cell is unorm8(byte) bit for bit.  When that holds for
+    // every active lane of the wave -- whole wavefronts of sky rays -- skip the blend.
+    const bool flat = c.v0 == c.v1 && c.v0 == (c.v0 & 0xFFu) * 0x01010101u;
+    if (__ballot(!flat) == 0ull)
+        return (unorm8((float)(c.v0 & 0xFFu)) - 0.25f) * c.scale * 2.0f;
     float dx = sat((px - c.lx) * c.inv);
     float dy = sat((py - c.ly) * c.inv);
     float dz = sat((pz - c.lz) * c.inv);
