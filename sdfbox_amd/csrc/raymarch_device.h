@@ -13,7 +13,7 @@
 //     multiplying by an exact power of two rounds exactly like dividing by it);
 //   * (int) saturate(v * 2)  ->  v >= 0.5f   (v*2 is exact; saturate maps NaN
 //     to 0, and NaN >= 0.5f is false);
-//   * (float)b / 255.0f  ->  one Newton fix-up of b * fl(1/255) (unorm8 below,
+//   * (float)b / 255.0f  ->  fma(b, fl(1/255), b * fl(1/255 - fl(1/255))) (unorm8 below,
 //     checked for all 256 bytes);
 //   * the cursor-stack kernel walks the tree on integer cell coordinates
 //     (find_stack below states why that visits the same cells).
