@@ -55,6 +55,11 @@ def parse():
 
 def main():
     args = parse()
+    # Exactly one line may reach stdout: the JSON.  Libraries loaded below print banners there
+    # (RCCL's version block, for one), so fd 1 points at stderr until the line is written.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -257,7 +262,8 @@ def main():
             out["config"]["assembled_frame_equals_whole_frame_render"] = check_ok
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(od, cam, W, H, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     scene.close()
     if sharded:
         dist.barrier()

@@ -224,13 +224,16 @@ struct CursorS {
     }
 };
 
-// per axis: u = pos * 2^LM, its floor, and A = floor clamped to [-1, 2^LM + 1] (NaN -> -1)
+// per axis: u = pos * 2^LM, its floor, and A = floor clamped to [-2, 2^LM + 1].  Every
+// negative A means "below the cube" (it matches no cell and clamps to octant bits 0).
+// v_med3_f32 returns the minimum of its non-NaN operands when one is NaN, so NaN gives
+// -2: nothing matches, the cursor goes to the root and descends with octant bits 0 --
+// what the shader does when every comparison with NaN is false and saturate(NaN) is 0.
 __device__ __forceinline__ int32_t axis_a(float p, float &u, float &f)
 {
     u = p * 4096.0f;
     f = floorf(u);
-    int32_t a = (int32_t)__builtin_fmaxf(__builtin_fminf(f, 4097.0f), -2.0f);   // NaN -> 4097 here, fixed next line
-    return (u >= -1.0f) ? a : -1;                          // below the cube, or NaN: -1
+    return (int32_t)__builtin_amdgcn_fmed3f(f, -2.0f, 4097.0f);
 }
 __device__ __forceinline__ int bitlen(uint32_t x) { return 32 - __clz((int)x); }   // bitlen(0) = 0
 
