@@ -49,6 +49,9 @@ def parse():
                     help="run the sharded path (bands + gather + de-interleave) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time target of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--display", action="store_true",
+                    help="fuse SdfBox's display pass (DisplayFrag.hlsl) into the epilogue: RGBA8 frames, 4x fewer "
+                         "bytes stored and gathered (SURVEY 8f N2); the headline metric is measured without it")
     ap.add_argument("--check", action="store_true", help="verify the assembled frame against a whole-frame render")
     return ap.parse_args()
 
@@ -109,19 +112,20 @@ def main():
 
     kflag = {"auto": sb.KERNEL_AUTO, "generic": sb.KERNEL_GENERIC, "stack": sb.KERNEL_STACK}[args.kernel]
     compact = (args.compact == 1) if args.compact >= 0 else DEFAULT_COMPACT
-    flags = kflag | (sb.FLAG_COMPACT if compact else 0)
+    flags = kflag | (sb.FLAG_COMPACT if compact else 0) | (sb.FLAG_DISPLAY if args.display else 0)
+    px_shape, px_dtype, px_bytes = ((), torch.int32, 4) if args.display else ((4,), torch.float32, 16)
 
     layout = BandLayout(H, world, args.band_rows)
     nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else min(8, 2 * world))
     streams = [torch.cuda.Stream() for _ in range(nbuf)]     # one per frame in flight
     main = torch.cuda.current_stream().cuda_stream
     rows_local = layout.rows_per_rank if sharded else H
-    local = [torch.zeros((rows_local, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+    local = [torch.zeros((rows_local, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
     gathered = frame = None
     if sharded and rank == 0:
-        gathered = [torch.zeros((world, layout.rows_per_rank, W, 4), dtype=torch.float32, device="cuda")
+        gathered = [torch.zeros((world, layout.rows_per_rank, W) + px_shape, dtype=px_dtype, device="cuda")
                     for _ in range(nbuf)]
-        frame = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+        frame = [torch.zeros((H, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
 
     def render(buf, st, stats=None, fl=None):
         f = flags if fl is None else fl
@@ -143,10 +147,11 @@ def main():
                 w.wait()                              # this slot's stream waits for its gather
                 if rank == 0:
                     deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout,
-                                 stream=streams[slot].cuda_stream)
+                                 stream=streams[slot].cuda_stream, pixel_bytes=px_bytes)
         elif rank == 0:                               # gloo rehearsal: through host buffers
             gathered[slot].copy_(torch.stack(w).cuda())
-            deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=main)
+            deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=main,
+                         pixel_bytes=px_bytes)
 
     def step(k, timed=False):
         slot = k % nbuf
@@ -187,7 +192,7 @@ def main():
     render(local[0], main, stats=st, fl=flags | sb.FLAG_COUNT)
     torch.cuda.synchronize()
     my_pixels = len(layout.rows_of(rank)) * W if sharded else W * H
-    alg_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + 16 * my_pixels
+    alg_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + px_bytes * my_pixels
     counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps], dtype=torch.float64)
     kernel_used = st.kernel_used
 
@@ -215,7 +220,7 @@ def main():
 
     check_ok = None
     if args.check and sharded and rank == 0:
-        ref = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        ref = torch.zeros((H, W) + px_shape, dtype=px_dtype, device="cuda")
         scene.DrawDevice(cam, W, H, ref.data_ptr(), flags=flags, stream=main)
         torch.cuda.synchronize()
         check_ok = all(bool(torch.equal(f.view(torch.int32), ref.view(torch.int32))) for f in frame[:min(nbuf, args.steps)])
@@ -244,6 +249,7 @@ def main():
                 "parallelism": "1 GPU" if not sharded else
                                f"{world} GPU(s), {args.band_rows}-row bands round-robin + gather to rank 0 ({args.backend})",
                 "frames_in_flight": nbuf,
+                "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
                 "gstep_per_s": round(float(counters[2]) / sec_per_step / 1e9, 3),
                 "scene_build_s": round(t_gen, 2),
             },
@@ -253,7 +259,7 @@ def main():
                 "peak": peak,
                 "unit": "GB/s",
                 "frac": round(achieved / peak, 4),
-                "traffic": load_traffic(W, H, scene_name, world),
+                "traffic": None if args.display else load_traffic(W, H, scene_name, world),
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes_rank),
             },

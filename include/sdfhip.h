@@ -74,6 +74,8 @@ enum {
     SDFHIP_KERNEL_MASK = 0xF,
     SDFHIP_FLAG_COMPACT = 0x10,   /* persistent waves, ballot/prefix refill of finished lanes */
     SDFHIP_FLAG_COUNT = 0x20,     /* also count algorithmic node/sample reads (slower)     */
+    SDFHIP_FLAG_DISPLAY = 0x40,   /* fused display pass: output is RGBA8, gamma 1/2.2 (DisplayFrag.hlsl:24) */
+    SDFHIP_FLAG_DISPLAY_DEBUG = 0x80, /* fused display pass, debug heat map w/140 (DisplayFrag.hlsl:21-22) */
     /* tuning knobs for A/B measurements (0 = the default): bits 8..11 blockIdx -> tile
      * order of the plain kernel (1 row-major, 2 one slab per XCD), bits 12..15 workgroup
      * size (1 = 64, 2 = 128, 3 = 256 threads).  Results never depend on them. */
@@ -178,13 +180,26 @@ SDFHIP_API int sdfhip_render_device(sdfhip_scene *scene, const sdfhip_info *info
                                     uint32_t flags, float *d_rgba_out, void *stream,
                                     sdfhip_stats *stats);
 
+/* Replaces: the display pass, SdfBox/Shaders/DisplayFrag.hlsl:16-24 drawn by
+ * Program.cs:96-99, fused into the ray-march epilogue: the frame comes back as
+ * R8G8B8A8_UNorm bytes (W*H*4, row-major), `pow(val, 1/2.2)` per channel, or with
+ * debug != 0 the step-count heat map `(1,1,1,0) * val.w / 140`.  4x fewer bytes to
+ * store, gather and copy to the host.  (The same output is selected on the
+ * sdfhip_render / sdfhip_render_device calls by SDFHIP_FLAG_DISPLAY[_DEBUG]; their
+ * output pointer then addresses W*H uint32 pixels.) */
+SDFHIP_API int sdfhip_render_display(sdfhip_scene *scene, const sdfhip_info *info,
+                                     uint32_t width, uint32_t height, uint32_t flags, int debug,
+                                     uint8_t *rgba8_out, sdfhip_stats *stats);
+
 /* Rank-0 helper for the tile gather: scatter `world` compact band buffers
- * (as all-gathered: rank r's rows at d_gathered + r*rows_per_rank*width*4)
- * back into row order.  Asynchronous on `stream`. */
-SDFHIP_API int sdfhip_deinterleave_device(int device, const float *d_gathered, float *d_frame,
+ * (as gathered: rank r's rows at d_gathered + r*rows_per_rank*width pixels)
+ * back into row order.  pixel_bytes = 16 (RGBA32F) or 4 (RGBA8).  Asynchronous
+ * on `stream`. */
+SDFHIP_API int sdfhip_deinterleave_device(int device, const void *d_gathered, void *d_frame,
                                           uint32_t width, uint32_t height,
                                           uint32_t band_rows, uint32_t world,
-                                          uint32_t rows_per_rank, void *stream);
+                                          uint32_t rows_per_rank, uint32_t pixel_bytes,
+                                          void *stream);
 
 /* Test hook: the kernel's R8_UNorm decode of bytes 0..255 (256 floats to the
  * host), checked exhaustively against byte/255.0f. */

@@ -39,6 +39,8 @@ def lib():
                                          c.POINTER(u32), c.POINTER(c.c_float)]
         L.oracle_unorm_table.restype = None
         L.oracle_unorm_table.argtypes = [vp]
+        L.oracle_display.restype = None
+        L.oracle_display.argtypes = [vp, c.c_uint64, c.c_int, vp]
         _lib = L
     return _lib
 
@@ -93,4 +95,12 @@ def distance_at(structs, values, x, y, z):
 def unorm_table():
     out = np.zeros(256, dtype=np.float32)
     lib().oracle_unorm_table(out.ctypes.data)
+    return out
+
+
+def display(rgba, debug=False):
+    """DisplayFrag.hlsl on a float frame (H, W, 4) -> uint8 (H, W, 4), R,G,B,A."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    out = np.zeros(rgba.shape, dtype=np.uint8)
+    lib().oracle_display(rgba.ctypes.data, rgba.size // 4, 1 if debug else 0, out.ctypes.data)
     return out

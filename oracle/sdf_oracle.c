@@ -22,6 +22,7 @@
  *   SdfBox/Shaders/Compute.hlsl:180-231  main                 -> o_pixel
  *   SdfBox/Logic.cs:407-463              Info / Float3x3      -> o_info
  *   SdfBox/Program.cs:514-538            value texture layout -> o_sample_at
+ *   SdfBox/Shaders/DisplayFrag.hlsl:16-24 display pass         -> oracle_display
  *
  * Arithmetic contract (shared with the HIP kernels, DESIGN.md "Numerics"):
  *   - every operation is an individually rounded IEEE fp32 operation in the
@@ -397,4 +398,29 @@ O_CLONES float oracle_distance_at(const int32_t *structs, const uint8_t *values,
 void oracle_unorm_table(float *out256)
 {
     for (int b = 0; b < 256; b++) out256[b] = (float)b / 255.0f;
+}
+
+/* ---- display pass: SdfBox/Shaders/DisplayFrag.hlsl:16-24 ------------------------
+ * The fragment shader samples the result texture at the fragment's own texel and
+ * returns pow(val, 1/2.2) (all four channels), or with `debug` the heat map
+ * float4(1,1,1,0) * val.w / 140; the swap chain is R8G8B8A8_UNorm, so the output is
+ * converted as D3D11 converts render-target output: NaN -> 0, clamp to [0,1], scale by
+ * 255, round to nearest.  out = 4 bytes per pixel, R,G,B,A. */
+static uint8_t o_unorm8(float c)
+{
+    return (uint8_t)(fminf(fmaxf(c, 0.0f), 1.0f) * 255.0f + 0.5f);
+}
+void oracle_display(const float *rgba, uint64_t npix, int debug, uint8_t *out)
+{
+    for (uint64_t i = 0; i < npix; i++) {
+        const float *v = rgba + 4 * i;
+        uint8_t *o = out + 4 * i;
+        if (debug) {
+            float h = 1.0f * v[3] / 140.0f;
+            o[0] = o[1] = o[2] = o_unorm8(h);
+            o[3] = o_unorm8(0.0f * v[3] / 140.0f);
+        } else {
+            for (int c = 0; c < 4; c++) o[c] = o_unorm8(powf(v[c], 1.0f / 2.2f));
+        }
+    }
 }

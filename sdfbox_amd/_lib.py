@@ -28,7 +28,7 @@ lib = ctypes.CDLL(LIB_PATH)
 OK, ERR_ARG, ERR_IO, ERR_BAD_TREE, ERR_DEVICE, ERR_NOMEM = range(6)
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_STACK = 0, 1, 2
-FLAG_COMPACT, FLAG_COUNT = 0x10, 0x20
+FLAG_COMPACT, FLAG_COUNT, FLAG_DISPLAY, FLAG_DISPLAY_DEBUG = 0x10, 0x20, 0x40, 0x80
 SHAPE_SPHERE, SHAPE_TORUS, SHAPE_GYROID = 0, 1, 2
 
 
@@ -102,8 +102,10 @@ _SIG = {
     "sdfhip_render_device": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32,
                                         _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                         _c.c_uint32, _vp, _vp, _c.POINTER(Stats)]),
+    "sdfhip_render_display": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                         _c.c_int, _vp, _c.POINTER(Stats)]),
     "sdfhip_deinterleave_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32,
-                                              _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+                                              _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "sdfhip_debug_unorm_table": (_c.c_int, [_c.c_int, _vp]),
 }
 # every symbol include/sdfhip.h declares must be exported: fail at import otherwise

@@ -47,6 +47,10 @@ struct RenderParams {
     unsigned long long *counters;  // [0] nodes [1] samples [2] steps (COUNT builds)
     uint32_t *queue;           // tile queue head (compact kernels)
     uint32_t tile_order;       // k_plain: blockIdx -> tile mapping (tuning knob, flags bits 8..11)
+    // fused display pass (DisplayFrag.hlsl): out_mode 0 = RGBA32F frame, 1 = gamma RGBA8,
+    // 2 = step-count heat map RGBA8; out8 aliases `out` as one uint32 per pixel
+    uint32_t out_mode;
+    uint32_t sky8;             // the sky constant through the display pass (host-computed, alpha excluded)
 };
 
 __device__ __forceinline__ float sat(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }

@@ -72,17 +72,60 @@ __device__ __forceinline__ void start_pixel(const RenderParams &P, const NodeRec
 // piece that finishes it.  (Storing there instead of returning the colour keeps four
 // values out of the march loop's phi nodes.)
 
-// Where a finished pixel's colour goes: straight to the frame (plain kernel), or to the
-// lane's LDS slot, to be flushed at the next refill (compact kernel: on gfx950 a store
-// counts on vmcnt like a load, so a global store per finished pixel would stall the very
-// next node load of the whole wave behind the store's completion).
+// ---- fused display pass: SdfBox/Shaders/DisplayFrag.hlsl:16-24 --------------------------
+// float -> R8G8B8A8_UNorm as D3D11 converts render-target output: NaN -> 0, clamp to
+// [0, 1], scale by 255, round to nearest.
+__device__ __forceinline__ uint32_t to_unorm8(float c) { return (uint32_t)(sat(c) * 255.0f + 0.5f); }
+// `return pow(val, 1 / 2.2)` on one channel
+__device__ __forceinline__ uint32_t gamma8(float c) { return to_unorm8(powf(c, 1.0f / 2.2f)); }
+// alpha = step count: pow(n, 1/2.2) >= 1 for n >= 1, and pow(0, .) = 0
+__device__ __forceinline__ uint32_t alpha8(float steps) { return steps >= 1.0f ? 0xFF000000u : 0u; }
+// `return float4(1, 1, 1, 0) * val.w / 140` (debug heat map)
+__device__ __forceinline__ uint32_t heat8(float steps)
+{
+    uint32_t q = to_unorm8(steps / 140.0f);
+    return q | (q << 8) | (q << 16);
+}
+// any colour (used where colours come back from LDS in the compact kernel)
+__device__ __forceinline__ uint32_t display8(const float4 &v, uint32_t mode)
+{
+    if (mode == 2u) return heat8(v.w);
+    return gamma8(v.x) | (gamma8(v.y) << 8) | (gamma8(v.z) << 16) | alpha8(v.w);
+}
+
+// Where a finished pixel's colour goes: straight to the frame (plain kernel) -- as
+// RGBA32F, or through the display pass as RGBA8 -- or to the lane's LDS slot, to be
+// flushed at the next refill (compact kernel: on gfx950 a store counts on vmcnt like a
+// load, so a global store per finished pixel would stall the very next node load of
+// the whole wave behind the store's completion).  Every finished pixel is the sky
+// constant, black, or a grey level, which keeps the display pass to one pow.
 struct FrameSink {
-    float4 *p;
-    __device__ __forceinline__ void operator()(float r, float g, float b, float a) const { *p = make_float4(r, g, b, a); }
+    float4 *p;            // RGBA32F pixel, or (as uint32_t *) the RGBA8 pixel
+    uint32_t mode, sky8;
+    __device__ __forceinline__ void sky(float steps) const
+    {
+        if (mode == 0u) *p = make_float4(0.005f, 0.01f, 0.2f, steps);
+        else *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : (sky8 | alpha8(steps));
+    }
+    __device__ __forceinline__ void grey(float a, float steps) const
+    {
+        if (mode == 0u) *p = make_float4(a, a, a, steps);
+        else {
+            uint32_t q = gamma8(a);
+            *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : (q | (q << 8) | (q << 16) | alpha8(steps));
+        }
+    }
+    __device__ __forceinline__ void black(float steps) const
+    {
+        if (mode == 0u) *p = make_float4(0.0f, 0.0f, 0.0f, steps);
+        else *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : alpha8(steps);
+    }
 };
 struct LdsSink {
     float4 *slot;      // points into a __shared__ array (address space known after inlining)
-    __device__ __forceinline__ void operator()(float r, float g, float b, float a) const { *slot = make_float4(r, g, b, a); }
+    __device__ __forceinline__ void sky(float steps) const { *slot = make_float4(0.005f, 0.01f, 0.2f, steps); }
+    __device__ __forceinline__ void grey(float a, float steps) const { *slot = make_float4(a, a, a, steps); }
+    __device__ __forceinline__ void black(float steps) const { *slot = make_float4(0.0f, 0.0f, 0.0f, steps); }
 };
 
 // Loop header + escape test of the primary march, Compute.hlsl:194-199.
@@ -92,7 +135,7 @@ __device__ __forceinline__ int check_primary(const RenderParams &P, const RaySta
 {
     if ((r.prox > P.margin * 2.0f || r.prox < 0.0f) && r.i < 100) {
         if (dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > P.limit) {
-            dst(0.005f, 0.01f, 0.2f, (float)r.i);
+            dst.sky((float)r.i);
             return 2;
         }
         return 0;
@@ -116,7 +159,7 @@ __device__ __forceinline__ bool shade(const RenderParams &P, RayState &r, const 
     float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
     r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
     if (r.angle < 0.0f) {
-        dst(0.0f, 0.0f, 0.0f, (float)r.i);
+        dst.black((float)r.i);
         return true;
     }
     lx = P.lightx - r.px; ly = P.lighty - r.py; lz = P.lightz - r.pz;
@@ -132,20 +175,20 @@ template <class CursorT, class Sink>
 __device__ __forceinline__ bool check_shadow(const RenderParams &P, const RayState &r, const CursorT &c, const Sink &dst)
 {
     if (!(r.j < 40 && r.prox > -P.margin)) {
-        dst(0.0f, 0.0f, 0.0f, (float)(r.i + r.j));  // :229
+        dst.black((float)(r.i + r.j));  // :229
         return true;
     }
     if (r.prox > r.dist || (r.px < 0.0f || r.py < 0.0f || r.pz < 0.0f) ||
         (r.px > 1.0f || r.py > 1.0f || r.pz > 1.0f)) {           // :215-219
         float a = r.angle / (r.dist * r.dist) * P.k_strength;
-        dst(a, a, a, (float)(r.i + r.j));
+        dst.grey(a, (float)(r.i + r.j));
         return true;
     }
     if (r.prox < P.margin) {                                       // :221-223
         float gx, gy, gz;
         gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
         if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) {
-            dst(0.0f, 0.0f, 0.0f, (float)(r.i + r.j));
+            dst.black((float)(r.i + r.j));
             return true;
         }
     }
@@ -233,7 +276,9 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
         typename CursorOf<STACK>::type c;
         const NodeRec root = P.nodes[0];
         start_pixel(P, root, x, y, r, c);
-        const FrameSink dst{P.out + ((size_t)yl * P.width + x)};
+        const size_t pidx = (size_t)yl * P.width + x;
+        const FrameSink dst{P.out_mode == 0u ? P.out + pidx : reinterpret_cast<float4 *>(reinterpret_cast<uint32_t *>(P.out) + pidx),
+                            P.out_mode, P.sky8};
         while (!pre_step(P, r, c, dst)) {
             uint32_t reads = march_step(P, r, c, stack_lds + tid, BT);
             if (COUNT) { cn += reads; cs += 1; }
@@ -290,7 +335,9 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_compact(RenderPara
             // flush the colours of the pixels finished since the last refill: one batch of
             // stores, whose completion the wave waits for once (behind start_pixel's work)
             if (r.phase == PH_DONE) {
-                P.out[(size_t)(pix >> 16) * P.width + (pix & 0xFFFFu)] = out_lds[lane];
+                const size_t pidx = (size_t)(pix >> 16) * P.width + (pix & 0xFFFFu);
+                if (P.out_mode == 0u) P.out[pidx] = out_lds[lane];
+                else reinterpret_cast<uint32_t *>(P.out)[pidx] = display8(out_lds[lane], P.out_mode);
                 r.phase = PH_IDLE;
             }
             while (more && n_idle > 0) {
@@ -382,7 +429,8 @@ __global__ void k_fuse(const int2 *__restrict__ structs, const uint2 *__restrict
 }
 
 // Gathered compact band buffers -> frame rows (rank-0 side of the tile gather).
-__global__ void k_deinterleave(const float4 *__restrict__ gathered, float4 *__restrict__ frame,
+template <class Pixel>
+__global__ void k_deinterleave(const Pixel *__restrict__ gathered, Pixel *__restrict__ frame,
                                uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world,
                                uint32_t rows_per_rank)
 {
@@ -570,6 +618,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     const bool use_stack = kind == SDFHIP_KERNEL_STACK || (kind == SDFHIP_KERNEL_AUTO && s->stack_ok);
     const bool compact = (flags & SDFHIP_FLAG_COMPACT) != 0;
     const bool count = (flags & SDFHIP_FLAG_COUNT) != 0;
+    const uint32_t out_mode = (flags & SDFHIP_FLAG_DISPLAY_DEBUG) ? 2u : ((flags & SDFHIP_FLAG_DISPLAY) ? 1u : 0u);
 
     RenderParams P;
     P.nodes = s->nodes; P.n_nodes = s->n;
@@ -595,6 +644,11 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     P.lightx = info->light[0]; P.lighty = info->light[1]; P.lightz = info->light[2];
     P.fov = info->fov;
     P.k_strength = exp2f(info->strength) - 1.0f;   // Compute.hlsl:216, once per frame
+    P.out_mode = out_mode;
+    {   // the sky constant of Compute.hlsl:196 through DisplayFrag.hlsl:24, alpha excluded
+        auto q = [](float c) { float v = powf(c, 1.0f / 2.2f); v = v > 1.0f ? 1.0f : (v > 0.0f ? v : 0.0f); return (uint32_t)(v * 255.0f + 0.5f); };
+        P.sky8 = q(0.005f) | (q(0.01f) << 8) | (q(0.2f) << 16);
+    }
     P.counters = s->d_counters;
     P.queue = s->d_queue;
 
@@ -662,19 +716,32 @@ extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t 
     int rc = render_impl(s, info, width, height, height, 0, 1, height, flags,
                          reinterpret_cast<float *>(s->d_frame), s->stream, stats);
     if (rc != SDFHIP_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(rgba_out, s->d_frame, need * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    const size_t px_bytes = (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG)) ? 4 : sizeof(float4);
+    HIP_TRY(hipMemcpyAsync(rgba_out, s->d_frame, need * px_bytes, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (stats)
         stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SDFHIP_OK;
 }
 
-extern "C" int sdfhip_deinterleave_device(int device, const float *d_gathered, float *d_frame,
+extern "C" int sdfhip_render_display(sdfhip_scene *s, const sdfhip_info *info, uint32_t width,
+                                     uint32_t height, uint32_t flags, int debug, uint8_t *rgba8_out,
+                                     sdfhip_stats *stats)
+{
+    flags = (flags & ~(uint32_t)(SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG)) |
+            (debug ? SDFHIP_FLAG_DISPLAY_DEBUG : SDFHIP_FLAG_DISPLAY);
+    return sdfhip_render(s, info, width, height, flags, reinterpret_cast<float *>(rgba8_out), stats);
+}
+
+extern "C" int sdfhip_deinterleave_device(int device, const void *d_gathered, void *d_frame,
                                           uint32_t width, uint32_t height, uint32_t band_rows,
-                                          uint32_t world, uint32_t rows_per_rank, void *stream)
+                                          uint32_t world, uint32_t rows_per_rank, uint32_t pixel_bytes,
+                                          void *stream)
 {
     if (!d_gathered || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
         return fail(SDFHIP_ERR_ARG, "deinterleave: null or zero argument");
+    if (pixel_bytes != 16 && pixel_bytes != 4)
+        return fail(SDFHIP_ERR_ARG, "deinterleave: pixel_bytes must be 16 (RGBA32F) or 4 (RGBA8), got %u", pixel_bytes);
     uint32_t nbands = (height + band_rows - 1) / band_rows;
     uint32_t need_rows = ((nbands + world - 1) / world) * band_rows;
     if (rows_per_rank < need_rows)
@@ -683,9 +750,14 @@ extern "C" int sdfhip_deinterleave_device(int device, const float *d_gathered, f
     if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "deinterleave: hipSetDevice(%d) failed", device);
     size_t total = (size_t)width * height;
     uint32_t blocks = (uint32_t)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_deinterleave, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float4 *)d_gathered, (float4 *)d_frame, width, height, band_rows,
-                       world, rows_per_rank);
+    if (pixel_bytes == 16)
+        hipLaunchKernelGGL((k_deinterleave<float4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)d_gathered, (float4 *)d_frame, width, height, band_rows,
+                           world, rows_per_rank);
+    else
+        hipLaunchKernelGGL((k_deinterleave<uint32_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const uint32_t *)d_gathered, (uint32_t *)d_frame, width, height, band_rows,
+                           world, rows_per_rank);
     HIP_TRY(hipGetLastError());
     return SDFHIP_OK;
 }

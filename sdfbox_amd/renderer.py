@@ -52,6 +52,17 @@ class Scene:
                                 out.ctypes.data, ctypes.byref(st) if want_stats else None))
         return (out, st) if want_stats else out
 
+    def DrawDisplay(self, state, width, height, debug=False, flags=_lib.KERNEL_AUTO, want_stats=False):
+        """Render + display pass (DisplayFrag.hlsl) fused: host array (H, W, 4) uint8, R,G,B,A.
+        debug=True gives the step-count heat map of DisplayFrag.hlsl:21-22."""
+        out = np.empty((int(height), int(width), 4), dtype=np.uint8)
+        st = Stats()
+        info = state if isinstance(state, Info) else state.State
+        check(lib.sdfhip_render_display(self._h, ctypes.byref(info), int(width), int(height), int(flags),
+                                        1 if debug else 0, out.ctypes.data,
+                                        ctypes.byref(st) if want_stats else None))
+        return (out, st) if want_stats else out
+
     def DrawDevice(self, state, width, height, out_ptr, nrows_out=None, band_rows=None,
                    band_first=0, band_stride=1, flags=_lib.KERNEL_AUTO, stream=None, stats=None):
         """Render into device memory at `out_ptr` (nrows_out x width x 4 floats),

@@ -53,10 +53,11 @@ def render_bands(scene, state, width, layout, rank, out_ptr, flags=0, stream=Non
                      flags=flags, stream=stream, stats=stats)
 
 
-def deinterleave(device, gathered_ptr, frame_ptr, width, layout, stream=None):
-    """Rank 0: gathered compact buffers (world x rows_per_rank x width x 4) -> frame."""
+def deinterleave(device, gathered_ptr, frame_ptr, width, layout, stream=None, pixel_bytes=16):
+    """Rank 0: gathered compact buffers (world x rows_per_rank x width pixels) -> frame.
+    pixel_bytes: 16 for RGBA32F frames, 4 for RGBA8 frames of the fused display pass."""
     check(lib.sdfhip_deinterleave_device(int(device), ctypes.c_void_p(int(gathered_ptr)),
                                          ctypes.c_void_p(int(frame_ptr)), int(width),
                                          layout.height, layout.band_rows, layout.world,
-                                         layout.rows_per_rank,
+                                         layout.rows_per_rank, int(pixel_bytes),
                                          ctypes.c_void_p(int(stream)) if stream else None))

@@ -194,6 +194,51 @@ def test_band_rendering_reassembles_the_frame(sb, gpu_scenes):
         assert torch.equal(frame.view(torch.int32), full.view(torch.int32)), (W, H, world, band_rows, variant)
 
 
+def assert_display_close(got, ref, what):
+    # pow() is the one operation the GPU and the host libm do not share bit for bit; after the
+    # 8-bit quantiser a 1-ulp difference shows only on a rounding boundary.  Tolerance: no byte
+    # off by more than 1 LSB, at least 99.9 % of the bytes equal.
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1, f"{what}: max byte difference {d.max()}"
+    assert (d == 0).mean() >= 0.999, f"{what}: only {(d == 0).mean():.5f} of the bytes equal"
+
+
+@pytest.mark.parametrize("variant", ALL_VARIANTS)
+def test_fused_display_pass(sb, oracle_mod, scenes, gpu_scenes, variant):
+    # N2: DisplayFrag.hlsl fused into the epilogue -- gamma RGBA8 and the debug heat map
+    for sname in ("sphere_d4", "torus_d6"):
+        for cname, (W, H) in (("default", (200, 120)), ("rotated", (97, 61)), ("closeup", (64, 64))):
+            cam = make_camera(cname, W, H)
+            frame, _ = oracle_mod.render(scenes[sname].Structs, scenes[sname].Values, cam.State, W, H, nthreads=8)
+            got = gpu_scenes[sname].DrawDisplay(cam, W, H, flags=flags_of(sb, variant))
+            assert_display_close(got, oracle_mod.display(frame), f"{variant} {sname}/{cname} gamma")
+            heat = gpu_scenes[sname].DrawDisplay(cam, W, H, debug=True, flags=flags_of(sb, variant))
+            assert (heat == oracle_mod.display(frame, debug=True)).all(), f"{variant} {sname}/{cname} heat map"
+    # NaN colours (zero gradient) and step count 0 (limit 0) go through the UNORM rules
+    cam = sb.Logic(64, 48); cam.State.limit = 0.0
+    got = gpu_scenes["torus_d6"].DrawDisplay(cam, 64, 48, flags=flags_of(sb, variant))
+    frame, _ = oracle_mod.render(scenes["torus_d6"].Structs, scenes["torus_d6"].Values, cam.State, 64, 48)
+    assert (got == oracle_mod.display(frame)).all() and (got[..., 3] == 0).all()
+
+
+def test_display_bands_reassemble(sb, gpu_scenes):
+    import torch
+    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands
+    scene = gpu_scenes["torus_d6"]
+    W, H, world = 150, 90, 3
+    cam = make_camera("rotated", W, H)
+    full = torch.from_numpy(scene.DrawDisplay(cam, W, H).view(np.uint32).reshape(H, W).astype(np.int64)).cuda()
+    lay = BandLayout(H, world, 16)
+    gathered = torch.zeros((world, lay.rows_per_rank, W), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for r in range(world):
+        render_bands(scene, cam, W, lay, r, gathered[r].data_ptr(), flags=sb.FLAG_DISPLAY, stream=stream)
+    frame = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    deinterleave(0, gathered.data_ptr(), frame.data_ptr(), W, lay, stream=stream, pixel_bytes=4)
+    torch.cuda.synchronize()
+    assert torch.equal(frame.to(torch.int64) & 0xFFFFFFFF, full)
+
+
 def test_two_handles_render_concurrently(sb, oracle_mod, scenes):
     # upload / render are callable from several threads on different handles
     cam = make_camera("default", 128, 128)

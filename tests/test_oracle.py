@@ -160,3 +160,17 @@ def test_unorm_table_is_byte_over_255(oracle_mod):
     t = oracle_mod.unorm_table()
     assert t[0] == 0 and t[255] == 1
     assert (t == (np.arange(256, dtype=np.float32) / np.float32(255))).all()
+
+
+def test_display_pass_rules(oracle_mod):
+    # DisplayFrag.hlsl: pow(val, 1/2.2) then R8G8B8A8_UNorm; debug: (1,1,1,0) * w / 140
+    px = np.array([[[0.0, 1.0, 0.2, 26.0], [0.005, 0.01, 0.2, 0.0], [np.nan, -1.0, 2.0, 140.0],
+                    [0.5, 0.5, 0.5, 70.0]]], dtype=np.float32)
+    out = oracle_mod.display(px)
+    assert out[0, 0].tolist() == [0, 255, round(0.2 ** (1 / 2.2) * 255), 255]
+    assert out[0, 1].tolist() == [round(0.005 ** (1 / 2.2) * 255), round(0.01 ** (1 / 2.2) * 255), 123, 0]
+    assert out[0, 2].tolist() == [0, 0, 255, 255]            # NaN -> 0, negative -> NaN -> 0, > 1 clamps
+    assert out[0, 3].tolist() == [186, 186, 186, 255]
+    heat = oracle_mod.display(px, debug=True)
+    assert heat[0, 0].tolist() == [round(26 / 140 * 255)] * 3 + [0]
+    assert heat[0, 2].tolist() == [255, 255, 255, 0] and heat[0, 1].tolist() == [0, 0, 0, 0]
