@@ -1,0 +1,44 @@
+"""The ABI from plain C (no Python, no PyTorch in the process): compile tests/c_harness.c
+against include/sdfhip.h + libsdfhip.so and run it."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO, assert_frames_identical
+
+
+def build(tmp_path):
+    exe = str(tmp_path / "c_harness")
+    libdir = os.path.join(REPO, "sdfbox_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-I", os.path.join(REPO, "include"),
+                           os.path.join(REPO, "tests", "c_harness.c"), "-o", exe, "-L", libdir, "-lsdfhip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_c_caller_links_and_reports_missing_gpu(tmp_path):
+    import torch
+    exe = build(tmp_path)
+    out = subprocess.run([exe, os.path.join(GOLDEN, "sphere_d4.asdf"), "64", "64", str(tmp_path / "f.raw")],
+                         capture_output=True, text=True, timeout=120)
+    assert "nodes 3465 depth 4 consistent 1" in out.stdout
+    if not torch.cuda.is_available():
+        assert out.returncode == 3 and "upload:" in out.stderr       # loud, no fallback
+    else:
+        assert out.returncode == 0, out.stderr
+
+
+@pytest.mark.gpu
+def test_c_caller_renders_the_oracle_frame(tmp_path, sb, oracle_mod, scenes):
+    exe = build(tmp_path)
+    raw = tmp_path / "f.raw"
+    out = subprocess.run([exe, os.path.join(GOLDEN, "sphere_d4.asdf"), "200", "120", str(raw)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    frame = np.fromfile(raw, dtype=np.float32).reshape(120, 200, 4)
+    cam = sb.Logic(200, 120)
+    ref, cnt = oracle_mod.render(scenes["sphere_d4"].Structs, scenes["sphere_d4"].Values, cam.State, 200, 120)
+    assert_frames_identical(frame, ref, "C harness")
+    assert f"{int(cnt[0])} node reads, {int(cnt[1])} samples, {int(cnt[2])} steps" in out.stdout
