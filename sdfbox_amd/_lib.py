@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdfhip.so")
+LIB_PATH = os.path.abspath(os.environ.get("SDFHIP_LIB") or os.path.join(_HERE, "libsdfhip.so"))   # SDFHIP_LIB: A/B builds
 
 # PyTorch bundles its own libamdhip64.so; load it first so that libsdfhip.so
 # binds to the same HIP runtime instance torch uses (one runtime per process:

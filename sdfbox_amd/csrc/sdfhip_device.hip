@@ -31,6 +31,9 @@
 namespace sdfhip {
 
 constexpr int MAX_STACK = LM;          // the shader's own descent limit (Compute.hlsl:98)
+#ifndef COMPACT_WAVES_PER_SIMD
+#define COMPACT_WAVES_PER_SIMD 8
+#endif
 #ifndef PLAIN_WAVES_PER_SIMD
 #define PLAIN_WAVES_PER_SIMD 8          // <= 64 VGPRs: 8 waves per SIMD (2nd launch-bound = waves per SIMD)
 #endif
@@ -306,7 +309,7 @@ constexpr int REFILL_MIN = 12;
 constexpr int SHADE_MIN = 8;
 
 template <bool STACK, bool COUNT>
-__global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_compact(RenderParams P)
+__global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderParams P)
 {
     __shared__ int32_t stack_lds[STACK ? MAX_STACK * 64 : 1];
     __shared__ float4 out_lds[64];

@@ -304,3 +304,71 @@ def test_full_size_properties(sb, oracle_mod, dragon, size):
     for y0 in list(range(0, H - 8, H // 6)) + [H - 8]:
         ref, _ = oracle_mod.render(od.Structs, od.Values, cam.State, W, H, row0=y0, nrows=8, nthreads=16)
         assert_frames_identical(base[y0:y0 + 8], ref, f"rows {y0}..{y0 + 7} of {W}x{H}")
+
+
+# ---- fuzz: random trees, on-grid cameras, axis-aligned rays ---------------------------------
+def _random_tree(rng, max_depth, p_split, max_nodes=60000):
+    """A consistent octree with random splits (DFS pre-order, like SdfGen) and random bytes."""
+    structs = [[-1, -1]]
+
+    def grow(node, depth):
+        if depth >= max_depth or len(structs) + 8 > max_nodes or rng.random() > p_split:
+            return
+        c = len(structs)
+        structs[node][1] = c
+        for _ in range(8):
+            structs.append([node, -1])
+        for k in range(8):
+            grow(c + k, depth + 1)
+
+    grow(0, 0)
+    s = np.array(structs, dtype=np.int32)
+    mode = rng.integers(3)
+    if mode == 0:
+        v = rng.integers(0, 256, size=(len(s), 8), dtype=np.uint8)
+    elif mode == 1:      # mostly flat cells (exercises the flat fast path next to non-flat lanes)
+        v = np.repeat(rng.integers(0, 256, size=(len(s), 1), dtype=np.uint8), 8, axis=1)
+        noisy = rng.random(len(s)) < 0.2
+        v[noisy] = rng.integers(0, 256, size=(int(noisy.sum()), 8), dtype=np.uint8)
+    else:                # a crude distance-like field: larger values near the cube faces
+        v = rng.integers(60, 200, size=(len(s), 8), dtype=np.uint8)
+    return s, v
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_random_trees_and_on_grid_cameras(sb, oracle_mod, seed):
+    rng = np.random.default_rng(1000 + seed)
+    depth = [3, 5, 7, 9, 11, 12][seed]
+    s, v = _random_tree(rng, depth, p_split=[0.9, 0.7, 0.55, 0.45, 0.42, 0.4][seed])
+    od = sb.OctData(s, v)
+    W, H = 72, 56
+    cams = []
+    for _ in range(5):
+        cam = sb.Logic(W, H)
+        kind = rng.integers(4)
+        if kind == 0:      # position exactly on the 2^-k grid (cell faces / corners), generic heading
+            k = int(rng.integers(1, 13))
+            cam.Position = tuple(float(rng.integers(0, 2 ** k + 1)) / 2 ** k for _ in range(3))
+            cam.Heading = (float(rng.uniform(-1, 1)), float(rng.uniform(-3, 3)))
+        elif kind == 1:    # axis-aligned centre ray from a grid point: positions stay on grid lines
+            k = int(rng.integers(1, 8))
+            cam.Position = (float(rng.integers(0, 2 ** k + 1)) / 2 ** k, float(rng.integers(0, 2 ** k + 1)) / 2 ** k, -0.25)
+            cam.State.fov = 0.0                     # every pixel shoots the same axis ray (0, 0, 1)
+        elif kind == 2:    # outside the cube, looking in
+            cam.Position = tuple(float(x) for x in rng.uniform(-0.6, 1.6, 3))
+            cam.Heading = (float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-3, 3)))
+        else:              # inside, light moved, margins changed
+            cam.Position = tuple(float(x) for x in rng.uniform(0.05, 0.95, 3))
+            cam.Heading = (float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-3, 3)))
+            for i in range(3):
+                cam.State.light[i] = float(rng.uniform(-0.5, 1.5))
+            cam.State.margin = float(rng.choice([1e-5, 4e-4, 3e-3]))
+        cams.append(cam)
+    with sb.Scene(od) as sc:
+        assert sc.stack_kernel_ok
+        for ci, cam in enumerate(cams):
+            ref, cnt = oracle_mod.render(s, v, cam.State, W, H, nthreads=8)
+            for variant in ALL_VARIANTS:
+                img, st = sc.Draw(cam, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
+                assert_frames_identical(img, ref, f"seed {seed} cam {ci} {variant}")
+                assert (st.n_nodes, st.n_samples, st.n_steps) == tuple(int(c) for c in cnt), (seed, ci, variant)
