@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--display", action="store_true",
                     help="fuse SdfBox's display pass (DisplayFrag.hlsl) into the epilogue: RGBA8 frames, 4x fewer "
                          "bytes stored and gathered (SURVEY 8f N2); the headline metric is measured without it")
+    ap.add_argument("--spp", type=int, default=0,
+                    help="path-traced mode (BASELINE config 5: --size 3840x2160 --spp 16): spp jittered camera "
+                         "rays per pixel + 3 diffuse bounces; Mray/s then counts W*H*spp camera rays")
     ap.add_argument("--check", action="store_true", help="verify the assembled frame against a whole-frame render")
     return ap.parse_args()
 
@@ -114,6 +117,9 @@ def main():
     compact = (args.compact == 1) if args.compact >= 0 else DEFAULT_COMPACT
     flags = kflag | (sb.FLAG_COMPACT if compact else 0) | (sb.FLAG_DISPLAY if args.display else 0)
     px_shape, px_dtype, px_bytes = ((), torch.int32, 4) if args.display else ((4,), torch.float32, 16)
+    pt = sb.PathTrace(spp=args.spp) if args.spp > 0 else None
+    if pt is not None and (args.display or compact):
+        raise SystemExit("--spp excludes --display and --compact")
 
     layout = BandLayout(H, world, args.band_rows)
     nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else min(8, 2 * world))
@@ -130,7 +136,9 @@ def main():
     def render(buf, st, stats=None, fl=None):
         f = flags if fl is None else fl
         if sharded:
-            render_bands(scene, cam, W, layout, rank, buf.data_ptr(), flags=f, stream=st, stats=stats)
+            render_bands(scene, cam, W, layout, rank, buf.data_ptr(), flags=f, stream=st, stats=stats, pt=pt)
+        elif pt is not None:
+            scene.DrawPathDevice(cam, W, H, buf.data_ptr(), pt=pt, flags=f, stream=st, stats=stats)
         else:
             scene.DrawDevice(cam, W, H, buf.data_ptr(), flags=f, stream=st, stats=stats)
 
@@ -221,7 +229,10 @@ def main():
     check_ok = None
     if args.check and sharded and rank == 0:
         ref = torch.zeros((H, W) + px_shape, dtype=px_dtype, device="cuda")
-        scene.DrawDevice(cam, W, H, ref.data_ptr(), flags=flags, stream=main)
+        if pt is not None:
+            scene.DrawPathDevice(cam, W, H, ref.data_ptr(), pt=pt, flags=flags, stream=main)
+        else:
+            scene.DrawDevice(cam, W, H, ref.data_ptr(), flags=flags, stream=main)
         torch.cuda.synchronize()
         check_ok = all(bool(torch.equal(f.view(torch.int32), ref.view(torch.int32))) for f in frame[:min(nbuf, args.steps)])
 
@@ -231,7 +242,7 @@ def main():
         achieved = alg_bytes_rank / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "Mray/s (primary rays; frame W*H / time per frame)",
-            "value": round(W * H / sec_per_step / 1e6, 2),
+            "value": round(W * H * max(1, args.spp) / sec_per_step / 1e6, 2),
             "unit": "Mray/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -243,9 +254,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{W}x{H} primary-ray sphere trace + shadow march, {scene_name} "
+                "workload": (f"{W}x{H} path trace, {args.spp} spp, 3 diffuse bounces, seed 0x5DFB0C5, " if pt is not None else
+                             f"{W}x{H} primary-ray sphere trace + shadow march, ") + f"{scene_name} "
                             f"(N={od.Length} nodes, {od.nbytes / 1e6:.1f} MB), camera (0.5,0.5,-0.35) yaw 0.35 pitch -0.2",
-                "kernel": ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else ""),
+                "kernel": ("path/" if pt is not None else "") +
+                          ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else ""),
                 "parallelism": "1 GPU" if not sharded else
                                f"{world} GPU(s), {args.band_rows}-row bands round-robin + gather to rank 0 ({args.backend})",
                 "frames_in_flight": nbuf,
@@ -259,7 +272,7 @@ def main():
                 "peak": peak,
                 "unit": "GB/s",
                 "frac": round(achieved / peak, 4),
-                "traffic": None if args.display else load_traffic(W, H, scene_name, world),
+                "traffic": None if (args.display or pt is not None) else load_traffic(W, H, scene_name, world),
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes_rank),
             },

@@ -180,6 +180,29 @@ SDFHIP_API int sdfhip_render_device(sdfhip_scene *scene, const sdfhip_info *info
                                     uint32_t flags, float *d_rgba_out, void *stream,
                                     sdfhip_stats *stats);
 
+/* Path-traced mode (BASELINE config 5: 16 spp diffuse path trace).  NOT in the
+ * reference -- its README lists path tracing under "plans" only -- so there is no
+ * interface to replace; the mode is defined by o_pixel_pt in oracle/sdf_oracle.c
+ * (DESIGN.md section 8): per pixel `spp` jittered camera rays, each followed by up to
+ * `max_bounces` cosine-weighted diffuse bounces, every segment marched, shaded and
+ * shadow-tested with the reference's own rules (Compute.hlsl:194-230); RNG = PCG hash
+ * of (seed + pixel, sample, bounce, draw).  Output RGBA32F: mean radiance, alpha =
+ * march steps of all segments.  Same buffer conventions as sdfhip_render[_device]. */
+typedef struct sdfhip_pathtrace {
+    uint32_t spp;           /* samples per pixel, 1..4096 (config 5: 16)            */
+    uint32_t max_bounces;   /* diffuse bounces after the camera ray (config 5: 3)   */
+    uint32_t seed;          /* config 5: 0x5DFB0C5                                  */
+    float albedo;           /* diffuse reflectance of the surface (0.8)             */
+} sdfhip_pathtrace;
+SDFHIP_API int sdfhip_render_path(sdfhip_scene *scene, const sdfhip_info *info,
+                                  const sdfhip_pathtrace *pt, uint32_t width, uint32_t height,
+                                  uint32_t flags, float *rgba_out, sdfhip_stats *stats);
+SDFHIP_API int sdfhip_render_path_device(sdfhip_scene *scene, const sdfhip_info *info,
+                                         const sdfhip_pathtrace *pt, uint32_t width, uint32_t height,
+                                         uint32_t band_rows, uint32_t band_first,
+                                         uint32_t band_stride, uint32_t nrows_out, uint32_t flags,
+                                         float *d_rgba_out, void *stream, sdfhip_stats *stats);
+
 /* Replaces: the display pass, SdfBox/Shaders/DisplayFrag.hlsl:16-24 drawn by
  * Program.cs:96-99, fused into the ray-march epilogue: the frame comes back as
  * R8G8B8A8_UNorm bytes (W*H*4, row-major), `pow(val, 1/2.2)` per channel, or with

@@ -32,6 +32,8 @@ def lib():
         vp, u32, c = ctypes.c_void_p, ctypes.c_uint32, ctypes
         L.oracle_render_rows.restype = c.c_int
         L.oracle_render_rows.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, vp, vp, vp, c.c_int]
+        L.oracle_render_rows_pt.restype = c.c_int
+        L.oracle_render_rows_pt.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, u32, u32, u32, c.c_float, vp, vp, c.c_int]
         L.oracle_pixel.restype = None
         L.oracle_pixel.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp]
         L.oracle_distance_at.restype = c.c_float
@@ -69,6 +71,25 @@ def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1,
     if rc != 0:
         raise MemoryError("oracle_render_rows failed")
     return (out, cnt, pix) if per_pixel_nodes else (out, cnt)
+
+
+def render_pt(structs, values, info, width, height, spp=16, max_bounces=3, seed=0x5DFB0C5, albedo=0.8,
+              row0=0, nrows=None, nthreads=1, row_step=1):
+    """Path-traced mode (BASELINE config 5): -> (rgba[nrows, W, 4] f32, counters[3] u64)."""
+    structs = np.ascontiguousarray(structs, dtype=np.int32)
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    if nrows is None:
+        nrows = (height - row0 + row_step - 1) // row_step
+    out = np.zeros((nrows, width, 4), dtype=np.float32)
+    cnt = np.zeros(3, dtype=np.uint64)
+    ib = _info_buf(info)
+    rc = lib().oracle_render_rows_pt(structs.ctypes.data, values.ctypes.data, structs.size // 2,
+                                     ctypes.addressof(ib), width, row0, nrows, row_step, int(spp),
+                                     int(max_bounces), int(seed), float(albedo), out.ctypes.data,
+                                     cnt.ctypes.data, int(nthreads))
+    if rc != 0:
+        raise ValueError("oracle_render_rows_pt failed")
+    return out, cnt
 
 
 def pixel(structs, values, info, x, y):

@@ -298,6 +298,148 @@ done:
     cnt[2] += (uint64_t)(i + j);
 }
 
+/* ---- path-traced mode (BASELINE config 5) ---------------
+ * NOT in the reference: its README lists "path tracing" under plans only.  This
+ * function DEFINES the mode; the HIP kernel k_path is held to it bit for bit.  It is
+ * built from the reference's own pieces -- the primary march (Compute.hlsl:194-203),
+ * the shading step and the shadow march towards the point light (:205-230) -- chained
+ * by cosine-weighted diffuse bounces:
+ *   per pixel, spp samples; per sample a jittered camera ray, then up to
+ *   1 + max_bounces segments.  A segment marches like the primary march; on escape it
+ *   adds throughput * sky (0.005, 0.01, 0.2) and the sample ends; on a hit it shades
+ *   exactly like main() (offset towards the light, gradient normal, shadow march) and
+ *   adds throughput * albedo * angle / dist^2 * (exp2(strength) - 1) when lit; then it
+ *   bounces: dir = normalize(n' + u), n' = the normal facing the incoming ray, u uniform
+ *   on the unit sphere (rejection in the cube, at most 8 tries), pos += n' * 4 * margin,
+ *   throughput *= albedo.  The cursor (index, box) carries over between segments, as it
+ *   does between the primary and the shadow march in the shader.
+ * RNG: PCG hash chained over (seed + pixel, sample, bounce, draw); uniform = top 24 bits
+ * * 2^-24.  No transcendental function anywhere, so parity stays bit-exact.
+ * out = mean radiance (r, g, b), alpha = march steps of all segments and samples. */
+O_INLINE uint32_t o_pcg(uint32_t v)
+{
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+O_INLINE float o_rnd(uint32_t seed, uint32_t p, uint32_t s, uint32_t b, uint32_t d)
+{
+    uint32_t h = o_pcg(o_pcg(o_pcg(o_pcg(seed + p) + s) + b) + d);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+/* ray() of Compute.hlsl:163-168 through a fractional pixel coordinate */
+O_INLINE void o_ray_f(const o_info *inf, float fx, float fy, float dir[3])
+{
+    float sx = fx / inf->screen_size[1] - inf->screen_size[0] / inf->screen_size[1] * 0.5f;
+    float sy = fy / inf->screen_size[1] - 0.5f;
+    float vx = sx * inf->fov, vy = sy * inf->fov, vz = 0.5f;
+    float d0 = o_dot(vx, vy, vz, inf->heading[0][0], inf->heading[0][1], inf->heading[0][2]);
+    float d1 = o_dot(vx, vy, vz, inf->heading[1][0], inf->heading[1][1], inf->heading[1][2]);
+    float d2 = o_dot(vx, vy, vz, inf->heading[2][0], inf->heading[2][1], inf->heading[2][2]);
+    float rl = 1.0f / sqrtf(o_dot(d0, d1, d2, d0, d1, d2));
+    dir[0] = d0 * rl; dir[1] = d1 * rl; dir[2] = d2 * rl;
+}
+
+O_INLINE void o_pixel_pt(const o_scene *sc, const o_info *inf, float k, uint32_t spp,
+                         uint32_t max_bounces, uint32_t seed, float albedo, uint32_t frame_w,
+                         uint32_t cx, uint32_t cy, float out[4], uint64_t cnt[3])
+{
+    o_ctx t;
+    t.sc = sc;
+    t.n_nodes = t.n_samples = 0;
+    const float margin = inf->margin;
+    const uint32_t p = cy * frame_w + cx;
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+    uint64_t steps = 0;
+    for (uint32_t s = 0; s < spp; s++) {
+        t.index = 0;
+        t.box.lx = t.box.ly = t.box.lz = 0.0f;
+        t.box.scale = 1.0f;
+        float px = inf->position[0], py = inf->position[1], pz = inf->position[2];
+        float dir[3];
+        o_ray_f(inf, (float)cx + o_rnd(seed, p, s, 0, 0), (float)cy + o_rnd(seed, p, s, 0, 1), dir);
+        float T = 1.0f;
+        for (uint32_t b = 0;; b++) {
+            float prox = 1.0f;
+            int i, escaped = 0;
+            for (i = 0; (prox > margin * 2.0f || prox < 0.0f) && i < 100; i++) {
+                if (o_dot(px, py, pz, px, py, pz) > inf->limit) { escaped = 1; break; }
+                o_find(&t, px, py, pz);
+                prox = o_interpol_world(&t, px, py, pz);
+                px = fmaf(dir[0], prox, px);
+                py = fmaf(dir[1], prox, py);
+                pz = fmaf(dir[2], prox, pz);
+            }
+            steps += (uint64_t)i;
+            if (escaped) {
+                acc0 = fmaf(T, 0.005f, acc0); acc1 = fmaf(T, 0.01f, acc1); acc2 = fmaf(T, 0.2f, acc2);
+                break;
+            }
+            /* shade, Compute.hlsl:205-213 */
+            float lx = inf->light[0] - px, ly = inf->light[1] - py, lz = inf->light[2] - pz;
+            float rl = 1.0f / sqrtf(o_dot(lx, ly, lz, lx, ly, lz));
+            float L0 = lx * rl, L1 = ly * rl, L2 = lz * rl;
+            px = fmaf(L0, margin, px); py = fmaf(L1, margin, py); pz = fmaf(L2, margin, pz);
+            float g[3];
+            o_gradient(&t, px, py, pz, g);
+            float rg = 1.0f / sqrtf(o_dot(g[0], g[1], g[2], g[0], g[1], g[2]));
+            float n0 = g[0] * rg, n1 = g[1] * rg, n2 = g[2] * rg;
+            float angle = o_dot(L0, L1, L2, n0, n1, n2);
+            if (!(angle < 0.0f)) {
+                /* shadow march, Compute.hlsl:213-230, on a copy of pos */
+                float sx = px, sy = py, sz = pz, sprox = prox;
+                lx = inf->light[0] - px; ly = inf->light[1] - py; lz = inf->light[2] - pz;
+                float dist = sqrtf(o_dot(lx, ly, lz, lx, ly, lz)) / 2.0f;
+                int j, lit = 0;
+                for (j = 0; j < 40 && sprox > -margin; j++) {
+                    if (sprox > dist || (sx < 0.0f || sy < 0.0f || sz < 0.0f) ||
+                        (sx > 1.0f || sy > 1.0f || sz > 1.0f)) { lit = 1; break; }
+                    if (sprox < margin) {
+                        float gg[3];
+                        o_gradient(&t, sx, sy, sz, gg);
+                        if (o_dot(gg[0], gg[1], gg[2], L0, L1, L2) < 0.0f) break;
+                    }
+                    o_find(&t, sx, sy, sz);
+                    sprox = o_interpol_world(&t, sx, sy, sz);
+                    float st = sprox + margin;
+                    sx = fmaf(L0, st, sx); sy = fmaf(L1, st, sy); sz = fmaf(L2, st, sz);
+                }
+                steps += (uint64_t)j;
+                if (lit) {
+                    float e = T * (albedo * (angle / (dist * dist) * k));
+                    acc0 += e; acc1 += e; acc2 += e;
+                }
+            }
+            if (b == max_bounces) break;
+            /* diffuse bounce */
+            if (o_dot(n0, n1, n2, dir[0], dir[1], dir[2]) > 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
+            float u0 = n0, u1 = n1, u2 = n2, q = 1.0f;
+            for (uint32_t a = 0; a < 8; a++) {
+                float c0 = o_rnd(seed, p, s, b + 1, 3 * a) * 2.0f - 1.0f;
+                float c1 = o_rnd(seed, p, s, b + 1, 3 * a + 1) * 2.0f - 1.0f;
+                float c2 = o_rnd(seed, p, s, b + 1, 3 * a + 2) * 2.0f - 1.0f;
+                float qq = o_dot(c0, c1, c2, c0, c1, c2);
+                if (qq <= 1.0f && qq > 1e-12f) { u0 = c0; u1 = c1; u2 = c2; q = qq; break; }
+            }
+            float ru = 1.0f / sqrtf(q);
+            float d0 = fmaf(u0, ru, n0), d1 = fmaf(u1, ru, n1), d2 = fmaf(u2, ru, n2);
+            float qd = o_dot(d0, d1, d2, d0, d1, d2);
+            if (!(qd > 1e-12f)) { d0 = n0; d1 = n1; d2 = n2; qd = o_dot(n0, n1, n2, n0, n1, n2); }
+            float rd = 1.0f / sqrtf(qd);
+            dir[0] = d0 * rd; dir[1] = d1 * rd; dir[2] = d2 * rd;
+            float off = margin * 4.0f;
+            px = fmaf(n0, off, px); py = fmaf(n1, off, py); pz = fmaf(n2, off, pz);
+            T *= albedo;
+        }
+    }
+    float inv = (float)spp;
+    out[0] = acc0 / inv; out[1] = acc1 / inv; out[2] = acc2 / inv;
+    out[3] = (float)steps;
+    cnt[0] += t.n_nodes;
+    cnt[1] += t.n_samples;
+    cnt[2] += steps;
+}
+
 /* ---- exported entry points --------------------------------------------- */
 
 typedef struct {
@@ -309,6 +451,8 @@ typedef struct {
     float *rgba;          /* nrows x W x 4, row-major, row 0 = global row0 */
     uint32_t *pix_nodes;  /* optional: nrows x W algorithmic node reads per pixel */
     uint64_t cnt[3];
+    uint32_t pt_spp, pt_bounces, pt_seed, frame_w;   /* path-traced mode when pt_spp > 0 */
+    float pt_albedo;
 } o_job;
 
 O_CLONES static void *o_worker_impl(void *arg)
@@ -317,8 +461,13 @@ O_CLONES static void *o_worker_impl(void *arg)
     for (uint32_t r = (uint32_t)jb->tid; r < jb->nrows; r += (uint32_t)jb->nthreads) {
         for (uint32_t x = 0; x < jb->W; x++) {
             uint64_t before = jb->cnt[0];
-            o_pixel(&jb->sc, &jb->inf, jb->k, x, jb->row0 + r * jb->row_step,
-                    jb->rgba + 4 * ((size_t)r * jb->W + x), jb->cnt);
+            if (jb->pt_spp)
+                o_pixel_pt(&jb->sc, &jb->inf, jb->k, jb->pt_spp, jb->pt_bounces, jb->pt_seed, jb->pt_albedo,
+                           jb->frame_w, x, jb->row0 + r * jb->row_step,
+                           jb->rgba + 4 * ((size_t)r * jb->W + x), jb->cnt);
+            else
+                o_pixel(&jb->sc, &jb->inf, jb->k, x, jb->row0 + r * jb->row_step,
+                        jb->rgba + 4 * ((size_t)r * jb->W + x), jb->cnt);
             if (jb->pix_nodes)
                 jb->pix_nodes[(size_t)r * jb->W + x] = (uint32_t)(jb->cnt[0] - before);
         }
@@ -333,9 +482,10 @@ O_CLONES static void *o_worker_impl(void *arg)
  * (may be NULL).  Rows are interleaved over `nthreads` pthreads. */
 static void *o_worker(void *arg) { return o_worker_impl(arg); }
 
-int oracle_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n,
-                       const void *info112, uint32_t W, uint32_t row0, uint32_t nrows,
-                       uint32_t row_step, float *rgba, uint64_t *counters, uint32_t *pix_nodes, int nthreads)
+static int o_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n,
+                         const void *info112, uint32_t W, uint32_t row0, uint32_t nrows,
+                         uint32_t row_step, float *rgba, uint64_t *counters, uint32_t *pix_nodes, int nthreads,
+                         uint32_t pt_spp, uint32_t pt_bounces, uint32_t pt_seed, float pt_albedo)
 {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
@@ -351,6 +501,8 @@ int oracle_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n
         jobs[t].W = W; jobs[t].row0 = row0; jobs[t].nrows = nrows; jobs[t].row_step = row_step ? row_step : 1;
         jobs[t].tid = t; jobs[t].nthreads = nthreads;
         jobs[t].rgba = rgba; jobs[t].pix_nodes = pix_nodes;
+        jobs[t].pt_spp = pt_spp; jobs[t].pt_bounces = pt_bounces; jobs[t].pt_seed = pt_seed;
+        jobs[t].pt_albedo = pt_albedo; jobs[t].frame_w = W;
     }
     if (nthreads == 1) {
         o_worker(&jobs[0]);
@@ -365,6 +517,25 @@ int oracle_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n
     }
     free(jobs); free(th);
     return 0;
+}
+
+int oracle_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n,
+                       const void *info112, uint32_t W, uint32_t row0, uint32_t nrows,
+                       uint32_t row_step, float *rgba, uint64_t *counters, uint32_t *pix_nodes, int nthreads)
+{
+    return o_render_rows(structs, values, n, info112, W, row0, nrows, row_step, rgba, counters, pix_nodes,
+                         nthreads, 0, 0, 0, 0.0f);
+}
+
+/* Path-traced mode (see o_pixel_pt).  The pixel index that seeds the RNG is y * W + x. */
+int oracle_render_rows_pt(const int32_t *structs, const uint8_t *values, uint32_t n,
+                          const void *info112, uint32_t W, uint32_t row0, uint32_t nrows,
+                          uint32_t row_step, uint32_t spp, uint32_t max_bounces, uint32_t seed,
+                          float albedo, float *rgba, uint64_t *counters, int nthreads)
+{
+    if (spp == 0) return -1;
+    return o_render_rows(structs, values, n, info112, W, row0, nrows, row_step, rgba, counters, NULL,
+                         nthreads, spp, max_bounces, seed, albedo);
 }
 
 /* One pixel, for unit tests.  out[4] = rgba, cnt[3] = nodes, samples, steps. */

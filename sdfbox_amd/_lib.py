@@ -72,6 +72,19 @@ class Stats(ctypes.Structure):
     ]
 
 
+class PathTrace(ctypes.Structure):
+    """sdfhip_pathtrace: parameters of the path-traced mode (BASELINE config 5 defaults)."""
+    _fields_ = [
+        ("spp", ctypes.c_uint32),
+        ("max_bounces", ctypes.c_uint32),
+        ("seed", ctypes.c_uint32),
+        ("albedo", ctypes.c_float),
+    ]
+
+    def __init__(self, spp=16, max_bounces=3, seed=0x5DFB0C5, albedo=0.8):
+        super().__init__(int(spp), int(max_bounces), int(seed), float(albedo))
+
+
 class SdfHipError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"sdfhip error {code}: {message}")
@@ -102,6 +115,11 @@ _SIG = {
     "sdfhip_render_device": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32,
                                         _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                         _c.c_uint32, _vp, _vp, _c.POINTER(Stats)]),
+    "sdfhip_render_path": (_c.c_int, [_vp, _c.POINTER(Info), _c.POINTER(PathTrace), _c.c_uint32, _c.c_uint32,
+                                      _c.c_uint32, _vp, _c.POINTER(Stats)]),
+    "sdfhip_render_path_device": (_c.c_int, [_vp, _c.POINTER(Info), _c.POINTER(PathTrace), _c.c_uint32,
+                                             _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                             _c.c_uint32, _c.c_uint32, _vp, _vp, _c.POINTER(Stats)]),
     "sdfhip_render_display": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                          _c.c_int, _vp, _c.POINTER(Stats)]),
     "sdfhip_deinterleave_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32,

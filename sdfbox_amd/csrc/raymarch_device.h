@@ -51,6 +51,9 @@ struct RenderParams {
     // 2 = step-count heat map RGBA8; out8 aliases `out` as one uint32 per pixel
     uint32_t out_mode;
     uint32_t sky8;             // the sky constant through the display pass (host-computed, alpha excluded)
+    // path-traced mode (k_path): samples per pixel, diffuse bounces, RNG seed, albedo
+    uint32_t pt_spp, pt_bounces, pt_seed;
+    float pt_albedo;
 };
 
 __device__ __forceinline__ float sat(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
@@ -359,6 +362,34 @@ __device__ __forceinline__ void ray(const RenderParams &P, uint32_t cx, uint32_t
 {
     float sx = (float)cx / P.screen_h - P.screen_w / P.screen_h * 0.5f;
     float sy = (float)cy / P.screen_h - 0.5f;
+    float vx = sx * P.fov, vy = sy * P.fov, vz = 0.5f;
+    float d0 = dot3(vx, vy, vz, P.h0x, P.h0y, P.h0z);
+    float d1 = dot3(vx, vy, vz, P.h1x, P.h1y, P.h1z);
+    float d2 = dot3(vx, vy, vz, P.h2x, P.h2y, P.h2z);
+    float rl = 1.0f / sqrtf(dot3(d0, d1, d2, d0, d1, d2));
+    dx = d0 * rl;
+    dy = d1 * rl;
+    dz = d2 * rl;
+}
+
+// ---- path-traced mode helpers (oracle/sdf_oracle.c o_pcg / o_rnd / o_ray_f) ------------
+__device__ __forceinline__ uint32_t pcg(uint32_t v)
+{
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+// uniform in [0, 1): top 24 bits of the hash chained over (seed + pixel, sample, bounce, draw)
+__device__ __forceinline__ float rnd(uint32_t seed, uint32_t p, uint32_t s, uint32_t b, uint32_t d)
+{
+    uint32_t h = pcg(pcg(pcg(pcg(seed + p) + s) + b) + d);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+// ray() through a fractional pixel coordinate
+__device__ __forceinline__ void ray_f(const RenderParams &P, float fx, float fy, float &dx, float &dy, float &dz)
+{
+    float sx = fx / P.screen_h - P.screen_w / P.screen_h * 0.5f;
+    float sy = fy / P.screen_h - 0.5f;
     float vx = sx * P.fov, vy = sy * P.fov, vz = 0.5f;
     float d0 = dot3(vx, vy, vz, P.h0x, P.h0y, P.h0z);
     float d1 = dot3(vx, vy, vz, P.h1x, P.h1y, P.h1z);

@@ -419,6 +419,122 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
     if (COUNT) flush_counters(P, cn, cs, ct);
 }
 
+// ---- path-traced mode (BASELINE config 5) -----------------------------------------------
+// Not in the reference (README "plans" only); defined by o_pixel_pt in oracle/sdf_oracle.c,
+// which this kernel follows operation for operation: per pixel spp samples, each a jittered
+// camera ray followed by up to 1 + max_bounces segments built from the reference's own
+// pieces (primary march, shading, shadow march) chained by cosine-weighted diffuse
+// bounces; PCG-hash RNG; no transcendental function.  One lane per pixel, one 8x8 tile per
+// wave, the plain kernel's XCD-interleaved tile rows; the secondary rays of neighbouring
+// pixels diverge at the first bounce -- the incoherent-traversal stress the config asks for.
+template <bool STACK, bool COUNT>
+__global__ __launch_bounds__(64) void k_path(RenderParams P)
+{
+    __shared__ int32_t stack_lds[STACK ? MAX_STACK * 64 : 1];
+    const uint32_t bid = blockIdx.x, xcd = bid & 7u, jb = bid >> 3;
+    const uint32_t rr = jb / P.tiles_x, cxx = jb - rr * P.tiles_x, row = rr * 8 + xcd;
+    if (row >= P.tiles_y) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t x = cxx * 8 + (lane & 7u), yl = row * 8 + (lane >> 3);
+    unsigned long long cn = 0, cs = 0, ct = 0;
+    bool live = x < P.width && yl < P.nrows_out;
+    uint32_t y = 0;
+    if (live) { y = global_row(P, yl); live = y < P.height; }
+    if (live) {
+        typedef typename CursorOf<STACK>::type CursorT;
+        const NodeRec root = P.nodes[0];
+        const uint32_t p = y * P.width + x;
+        const float margin = P.margin;
+        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+        uint32_t steps = 0;
+        int32_t *stack = stack_lds + lane;
+        for (uint32_t s = 0; s < P.pt_spp; s++) {
+            CursorT c;
+            c.reset(root);
+            float px = P.posx, py = P.posy, pz = P.posz, dx, dy, dz;
+            ray_f(P, (float)x + rnd(P.pt_seed, p, s, 0, 0), (float)y + rnd(P.pt_seed, p, s, 0, 1), dx, dy, dz);
+            float T = 1.0f;
+            for (uint32_t b = 0;; b++) {
+                float prox = 1.0f;
+                int i;
+                bool escaped = false;
+                for (i = 0; (prox > margin * 2.0f || prox < 0.0f) && i < 100; i++) {
+                    if (dot3(px, py, pz, px, py, pz) > P.limit) { escaped = true; break; }
+                    uint32_t reads = find(c, P.nodes, P.n_nodes, stack, 64, px, py, pz);
+                    prox = interpol_world(c.cell(), px, py, pz);
+                    if (COUNT) { cn += reads; cs += 1; }
+                    px = __builtin_fmaf(dx, prox, px);
+                    py = __builtin_fmaf(dy, prox, py);
+                    pz = __builtin_fmaf(dz, prox, pz);
+                }
+                steps += (uint32_t)i;
+                if (escaped) {
+                    acc0 = __builtin_fmaf(T, 0.005f, acc0); acc1 = __builtin_fmaf(T, 0.01f, acc1); acc2 = __builtin_fmaf(T, 0.2f, acc2);
+                    break;
+                }
+                float lx = P.lightx - px, ly = P.lighty - py, lz = P.lightz - pz;
+                float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+                const float L0 = lx * rl, L1 = ly * rl, L2 = lz * rl;
+                px = __builtin_fmaf(L0, margin, px); py = __builtin_fmaf(L1, margin, py); pz = __builtin_fmaf(L2, margin, pz);
+                float g0, g1, g2;
+                gradient(c.cell(), px, py, pz, g0, g1, g2);
+                float rg = 1.0f / sqrtf(dot3(g0, g1, g2, g0, g1, g2));
+                float n0 = g0 * rg, n1 = g1 * rg, n2 = g2 * rg;
+                const float angle = dot3(L0, L1, L2, n0, n1, n2);
+                if (!(angle < 0.0f)) {
+                    float sx = px, sy = py, sz = pz, sprox = prox;
+                    lx = P.lightx - px; ly = P.lighty - py; lz = P.lightz - pz;
+                    const float dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+                    int j;
+                    bool lit = false;
+                    for (j = 0; j < 40 && sprox > -margin; j++) {
+                        if (sprox > dist || (sx < 0.0f || sy < 0.0f || sz < 0.0f) ||
+                            (sx > 1.0f || sy > 1.0f || sz > 1.0f)) { lit = true; break; }
+                        if (sprox < margin) {
+                            float q0, q1, q2;
+                            gradient(c.cell(), sx, sy, sz, q0, q1, q2);
+                            if (dot3(q0, q1, q2, L0, L1, L2) < 0.0f) break;
+                        }
+                        uint32_t reads = find(c, P.nodes, P.n_nodes, stack, 64, sx, sy, sz);
+                        sprox = interpol_world(c.cell(), sx, sy, sz);
+                        if (COUNT) { cn += reads; cs += 1; }
+                        const float st = sprox + margin;
+                        sx = __builtin_fmaf(L0, st, sx); sy = __builtin_fmaf(L1, st, sy); sz = __builtin_fmaf(L2, st, sz);
+                    }
+                    steps += (uint32_t)j;
+                    if (lit) {
+                        const float e = T * (P.pt_albedo * (angle / (dist * dist) * P.k_strength));
+                        acc0 += e; acc1 += e; acc2 += e;
+                    }
+                }
+                if (b == P.pt_bounces) break;
+                if (dot3(n0, n1, n2, dx, dy, dz) > 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
+                float u0 = n0, u1 = n1, u2 = n2, q = 1.0f;
+                for (uint32_t a = 0; a < 8; a++) {
+                    const float c0 = rnd(P.pt_seed, p, s, b + 1, 3 * a) * 2.0f - 1.0f;
+                    const float c1 = rnd(P.pt_seed, p, s, b + 1, 3 * a + 1) * 2.0f - 1.0f;
+                    const float c2 = rnd(P.pt_seed, p, s, b + 1, 3 * a + 2) * 2.0f - 1.0f;
+                    const float qq = dot3(c0, c1, c2, c0, c1, c2);
+                    if (qq <= 1.0f && qq > 1e-12f) { u0 = c0; u1 = c1; u2 = c2; q = qq; break; }
+                }
+                const float ru = 1.0f / sqrtf(q);
+                float d0 = __builtin_fmaf(u0, ru, n0), d1 = __builtin_fmaf(u1, ru, n1), d2 = __builtin_fmaf(u2, ru, n2);
+                float qd = dot3(d0, d1, d2, d0, d1, d2);
+                if (!(qd > 1e-12f)) { d0 = n0; d1 = n1; d2 = n2; qd = dot3(n0, n1, n2, n0, n1, n2); }
+                const float rd = 1.0f / sqrtf(qd);
+                dx = d0 * rd; dy = d1 * rd; dz = d2 * rd;
+                const float off = margin * 4.0f;
+                px = __builtin_fmaf(n0, off, px); py = __builtin_fmaf(n1, off, py); pz = __builtin_fmaf(n2, off, pz);
+                T *= P.pt_albedo;
+            }
+        }
+        const float inv = (float)P.pt_spp;
+        P.out[(size_t)yl * P.width + x] = make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps);
+        if (COUNT) ct = steps;
+    }
+    if (COUNT) flush_counters(P, cn, cs, ct);
+}
+
 // ---- small helper kernels -----------------------------------------------------
 // {parent, children}[N] + bytes[N][8] -> fused 16-byte records (upload).
 __global__ void k_fuse(const int2 *__restrict__ structs, const uint2 *__restrict__ values,
@@ -608,7 +724,8 @@ void launch_pair(bool compact, int bt, dim3 grid, hipStream_t st, const RenderPa
 
 int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32_t height,
                 uint32_t band_rows, uint32_t band_first, uint32_t band_stride, uint32_t nrows_out,
-                uint32_t flags, float *d_out, hipStream_t st, sdfhip_stats *stats)
+                uint32_t flags, float *d_out, hipStream_t st, sdfhip_stats *stats,
+                const sdfhip_pathtrace *pt = nullptr)
 {
     if (width == 0 || height == 0 || nrows_out == 0 || band_rows == 0 || band_stride == 0)
         return fail(SDFHIP_ERR_ARG, "render: zero-sized frame or band");
@@ -622,6 +739,12 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     const bool compact = (flags & SDFHIP_FLAG_COMPACT) != 0;
     const bool count = (flags & SDFHIP_FLAG_COUNT) != 0;
     const uint32_t out_mode = (flags & SDFHIP_FLAG_DISPLAY_DEBUG) ? 2u : ((flags & SDFHIP_FLAG_DISPLAY) ? 1u : 0u);
+    if (pt) {
+        if (pt->spp == 0 || pt->spp > 4096 || pt->max_bounces > 64)
+            return fail(SDFHIP_ERR_ARG, "render_path: spp %u (1..4096) or max_bounces %u (0..64) out of range", pt->spp, pt->max_bounces);
+        if (out_mode != 0 || compact)
+            return fail(SDFHIP_ERR_ARG, "render_path: the display pass and compaction are not available in path-traced mode");
+    }
 
     RenderParams P;
     P.nodes = s->nodes; P.n_nodes = s->n;
@@ -632,8 +755,8 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     P.tile_order = (flags >> 8) & 0xF;
     const uint32_t btsel = (flags >> 12) & 0xF;                       // tuning knob: 0 = default
     const int bt = btsel == 3 ? 256 : (btsel == 2 ? 128 : 64);
-    const uint32_t tile_w = compact ? 8u : (bt >= 128 ? 16u : 8u);
-    const uint32_t tile_h = compact ? 8u : (uint32_t)bt / 8u / (tile_w / 8u);
+    const uint32_t tile_w = (compact || pt) ? 8u : (bt >= 128 ? 16u : 8u);
+    const uint32_t tile_h = (compact || pt) ? 8u : (uint32_t)bt / 8u / (tile_w / 8u);
     P.tiles_x = (width + tile_w - 1) / tile_w;
     P.tiles_y = (nrows_out + tile_h - 1) / tile_h;
     P.n_tiles = P.tiles_x * P.tiles_y;
@@ -652,6 +775,8 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         auto q = [](float c) { float v = powf(c, 1.0f / 2.2f); v = v > 1.0f ? 1.0f : (v > 0.0f ? v : 0.0f); return (uint32_t)(v * 255.0f + 0.5f); };
         P.sky8 = q(0.005f) | (q(0.01f) << 8) | (q(0.2f) << 16);
     }
+    P.pt_spp = pt ? pt->spp : 0; P.pt_bounces = pt ? pt->max_bounces : 0; P.pt_seed = pt ? pt->seed : 0;
+    P.pt_albedo = pt ? pt->albedo : 0.0f;
     P.counters = s->d_counters;
     P.queue = s->d_queue;
 
@@ -665,8 +790,13 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         grid = dim3(P.tile_order == 0 ? 8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x : P.n_tiles);
     }
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
-    if (use_stack) { if (count) launch_pair<true, true>(compact, bt, grid, st, P); else launch_pair<true, false>(compact, bt, grid, st, P); }
-    else           { if (count) launch_pair<false, true>(compact, bt, grid, st, P); else launch_pair<false, false>(compact, bt, grid, st, P); }
+    if (pt) {
+        grid = dim3(8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x);
+        if (use_stack) { if (count) hipLaunchKernelGGL((k_path<true, true>), grid, dim3(64), 0, st, P); else hipLaunchKernelGGL((k_path<true, false>), grid, dim3(64), 0, st, P); }
+        else           { if (count) hipLaunchKernelGGL((k_path<false, true>), grid, dim3(64), 0, st, P); else hipLaunchKernelGGL((k_path<false, false>), grid, dim3(64), 0, st, P); }
+    }
+    else if (use_stack) { if (count) launch_pair<true, true>(compact, bt, grid, st, P); else launch_pair<true, false>(compact, bt, grid, st, P); }
+    else                { if (count) launch_pair<false, true>(compact, bt, grid, st, P); else launch_pair<false, false>(compact, bt, grid, st, P); }
     HIP_TRY(hipGetLastError());
     if (stats) {
         HIP_TRY(hipEventRecord(s->ev1, st));
@@ -721,6 +851,45 @@ extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t 
     if (rc != SDFHIP_OK) return rc;
     const size_t px_bytes = (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG)) ? 4 : sizeof(float4);
     HIP_TRY(hipMemcpyAsync(rgba_out, s->d_frame, need * px_bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (stats)
+        stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_render_path_device(sdfhip_scene *s, const sdfhip_info *info, const sdfhip_pathtrace *pt,
+                                         uint32_t width, uint32_t height, uint32_t band_rows,
+                                         uint32_t band_first, uint32_t band_stride, uint32_t nrows_out,
+                                         uint32_t flags, float *d_rgba_out, void *stream, sdfhip_stats *stats)
+{
+    if (!s || !info || !pt || !d_rgba_out) return fail(SDFHIP_ERR_ARG, "render_path_device: null argument");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render_path_device: hipSetDevice(%d) failed", s->device);
+    return render_impl(s, info, width, height, band_rows, band_first, band_stride, nrows_out, flags,
+                       d_rgba_out, (hipStream_t)stream, stats, pt);
+}
+
+extern "C" int sdfhip_render_path(sdfhip_scene *s, const sdfhip_info *info, const sdfhip_pathtrace *pt,
+                                  uint32_t width, uint32_t height, uint32_t flags, float *rgba_out,
+                                  sdfhip_stats *stats)
+{
+    if (!s || !info || !pt || !rgba_out) return fail(SDFHIP_ERR_ARG, "render_path: null argument");
+    if (width == 0 || height == 0) return fail(SDFHIP_ERR_ARG, "render_path: zero-sized frame");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render_path: hipSetDevice(%d) failed", s->device);
+    auto t0 = std::chrono::steady_clock::now();
+    size_t need = (size_t)width * height;
+    if (need > s->frame_cap) {
+        if (s->d_frame) { (void)hipFree(s->d_frame); s->d_frame = nullptr; s->frame_cap = 0; }
+        HIP_TRY(hipMalloc((void **)&s->d_frame, need * sizeof(float4)));
+        s->frame_cap = need;
+    }
+    int rc = render_impl(s, info, width, height, height, 0, 1, height, flags,
+                         reinterpret_cast<float *>(s->d_frame), s->stream, stats, pt);
+    if (rc != SDFHIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(rgba_out, s->d_frame, need * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (stats)
         stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

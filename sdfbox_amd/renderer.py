@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import Info, Stats, check, lib
+from ._lib import Info, PathTrace, Stats, check, lib
 
 
 class Scene:
@@ -51,6 +51,31 @@ class Scene:
         check(lib.sdfhip_render(self._h, ctypes.byref(info), int(width), int(height), int(flags),
                                 out.ctypes.data, ctypes.byref(st) if want_stats else None))
         return (out, st) if want_stats else out
+
+    def DrawPath(self, state, width, height, pt=None, flags=_lib.KERNEL_AUTO, want_stats=False):
+        """Path-traced frame (BASELINE config 5; defined by the oracle's o_pixel_pt): host array
+        (H, W, 4) float32, mean radiance + step count."""
+        pt = pt if pt is not None else PathTrace()
+        out = np.empty((int(height), int(width), 4), dtype=np.float32)
+        st = Stats()
+        info = state if isinstance(state, Info) else state.State
+        check(lib.sdfhip_render_path(self._h, ctypes.byref(info), ctypes.byref(pt), int(width), int(height),
+                                     int(flags), out.ctypes.data, ctypes.byref(st) if want_stats else None))
+        return (out, st) if want_stats else out
+
+    def DrawPathDevice(self, state, width, height, out_ptr, pt=None, nrows_out=None, band_rows=None,
+                       band_first=0, band_stride=1, flags=_lib.KERNEL_AUTO, stream=None, stats=None):
+        pt = pt if pt is not None else PathTrace()
+        info = state if isinstance(state, Info) else state.State
+        if nrows_out is None:
+            nrows_out = height
+        if band_rows is None:
+            band_rows = height
+        check(lib.sdfhip_render_path_device(self._h, ctypes.byref(info), ctypes.byref(pt), int(width),
+                                            int(height), int(band_rows), int(band_first), int(band_stride),
+                                            int(nrows_out), int(flags), ctypes.c_void_p(int(out_ptr)),
+                                            ctypes.c_void_p(int(stream)) if stream else None,
+                                            ctypes.byref(stats) if stats is not None else None))
 
     def DrawDisplay(self, state, width, height, debug=False, flags=_lib.KERNEL_AUTO, want_stats=False):
         """Render + display pass (DisplayFrag.hlsl) fused: host array (H, W, 4) uint8, R,G,B,A.

@@ -46,11 +46,14 @@ class BandLayout:
         return b % self.world, (b // self.world) * self.band_rows + y % self.band_rows
 
 
-def render_bands(scene, state, width, layout, rank, out_ptr, flags=0, stream=None, stats=None):
-    """Render `rank`'s bands of the frame into its compact device buffer."""
-    scene.DrawDevice(state, width, layout.height, out_ptr, nrows_out=layout.rows_per_rank,
-                     band_rows=layout.band_rows, band_first=rank, band_stride=layout.world,
-                     flags=flags, stream=stream, stats=stats)
+def render_bands(scene, state, width, layout, rank, out_ptr, flags=0, stream=None, stats=None, pt=None):
+    """Render `rank`'s bands of the frame into its compact device buffer (pt: path-traced mode)."""
+    kw = dict(nrows_out=layout.rows_per_rank, band_rows=layout.band_rows, band_first=rank,
+              band_stride=layout.world, flags=flags, stream=stream, stats=stats)
+    if pt is None:
+        scene.DrawDevice(state, width, layout.height, out_ptr, **kw)
+    else:
+        scene.DrawPathDevice(state, width, layout.height, out_ptr, pt=pt, **kw)
 
 
 def deinterleave(device, gathered_ptr, frame_ptr, width, layout, stream=None, pixel_bytes=16):

@@ -194,6 +194,51 @@ def test_band_rendering_reassembles_the_frame(sb, gpu_scenes):
         assert torch.equal(frame.view(torch.int32), full.view(torch.int32)), (W, H, world, band_rows, variant)
 
 
+@pytest.mark.parametrize("kernel", ["generic", "stack"])
+def test_path_traced_mode(sb, oracle_mod, scenes, gpu_scenes, kernel):
+    # BASELINE config 5 in small: the mode is defined by the oracle (no reference semantics);
+    # no transcendental function in it, so parity is bit-exact, counters included
+    g = np.load(os.path.join(GOLDEN, "frames.npz"))
+    fl = flags_of(sb, kernel)
+    for sname in ("sphere_d4", "torus_d6"):
+        cam = make_camera("default", 48, 32)
+        img, st = gpu_scenes[sname].DrawPath(cam, 48, 32, sb.PathTrace(spp=4), flags=fl | sb.FLAG_COUNT, want_stats=True)
+        assert_frames_identical(img, g[f"{sname}/path4/rgba"], f"{kernel} {sname} golden path4")
+        assert [st.n_nodes, st.n_samples, st.n_steps] == g[f"{sname}/path4/counters"].tolist()
+        for cname, (W, H), pt in (("rotated", (61, 37), sb.PathTrace(spp=16, max_bounces=3)),
+                                  ("closeup", (40, 40), sb.PathTrace(spp=3, max_bounces=5, seed=7, albedo=0.5)),
+                                  ("default", (33, 20), sb.PathTrace(spp=2, max_bounces=0))):
+            cam = make_camera(cname, W, H)
+            ref, cnt = oracle_mod.render_pt(scenes[sname].Structs, scenes[sname].Values, cam.State, W, H, spp=pt.spp,
+                                            max_bounces=pt.max_bounces, seed=pt.seed, albedo=pt.albedo, nthreads=8)
+            img, st = gpu_scenes[sname].DrawPath(cam, W, H, pt, flags=fl | sb.FLAG_COUNT, want_stats=True)
+            assert_frames_identical(img, ref, f"{kernel} {sname}/{cname} path")
+            assert (st.n_nodes, st.n_samples, st.n_steps) == tuple(int(c) for c in cnt)
+            assert_frames_identical(gpu_scenes[sname].DrawPath(cam, W, H, pt, flags=fl), img, "count vs no-count")
+    with pytest.raises(sb.SdfHipError):
+        gpu_scenes["sphere_d4"].DrawPath(make_camera("default", 8, 8), 8, 8, sb.PathTrace(spp=0))
+    with pytest.raises(sb.SdfHipError):
+        gpu_scenes["sphere_d4"].DrawPath(make_camera("default", 8, 8), 8, 8, flags=sb.FLAG_COMPACT)
+
+
+def test_path_traced_config5_full_size(sb, oracle_mod, dragon):
+    # BASELINE config 5: 3840x2160, 16 spp, 3 bounces, seed 0x5DFB0C5 on the dragon stand-in.
+    # Size-independent properties + the oracle on sampled rows.
+    od, sc = dragon
+    W, H = 3840, 2160
+    cam = sb.Logic(W, H); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
+    img, st = sc.DrawPath(cam, W, H, sb.PathTrace(), flags=sb.FLAG_COUNT, want_stats=True)
+    a = img[..., 3].astype(np.float64)
+    assert (a == np.floor(a)).all() and a.min() >= 16 * 1 and a.max() <= 16 * 4 * 140
+    assert int(a.sum()) == st.n_steps == st.n_samples
+    assert np.isfinite(img[..., :3]).mean() > 0.99 and np.nanmin(img[..., :3]) >= 0
+    gen = sc.DrawPath(cam, W, H, sb.PathTrace(), flags=sb.KERNEL_GENERIC)
+    assert_frames_identical(gen, img, "generic vs stack, config 5")
+    for y0 in (300, 700, 1100, H - 4):
+        ref, _ = oracle_mod.render_pt(od.Structs, od.Values, cam.State, W, H, row0=y0, nrows=4, nthreads=16)
+        assert_frames_identical(img[y0:y0 + 4], ref, f"config 5 rows {y0}..{y0 + 3}")
+
+
 def assert_display_close(got, ref, what):
     # pow() is the one operation the GPU and the host libm do not share bit for bit; after the
     # 8-bit quantiser a 1-ulp difference shows only on a rounding boundary.  Tolerance: no byte

@@ -37,6 +37,38 @@ def test_oracle_reproduces_golden_frames(oracle_mod, scenes):
             assert int(img[..., 3].sum()) == int(cnt[2])
 
 
+def test_oracle_reproduces_golden_path_traced_frames(oracle_mod, scenes):
+    g = np.load(os.path.join(GOLDEN, "frames.npz"))
+    for sname, od in scenes.items():
+        cam = make_camera("default", 48, 32)
+        img, cnt = oracle_mod.render_pt(od.Structs, od.Values, cam.State, 48, 32, spp=4, max_bounces=3, nthreads=4)
+        assert_frames_identical(img, g[f"{sname}/path4/rgba"], f"{sname}/path4")
+        assert cnt.tolist() == g[f"{sname}/path4/counters"].tolist()
+        assert int(img[..., 3].astype(np.float64).sum()) == int(cnt[2])
+
+
+def test_path_traced_mode_sanity(oracle_mod, scenes):
+    od = scenes["sphere_d4"]
+    cam = make_camera("default", 40, 30)
+    direct, _ = oracle_mod.render(od.Structs, od.Values, cam.State, 40, 30)
+    # 0 bounces, albedo 1: every sample is the direct-lighting result of its jittered ray, so the
+    # mean stays close to main()'s image wherever that is smooth
+    pt0, _ = oracle_mod.render_pt(od.Structs, od.Values, cam.State, 40, 30, spp=8, max_bounces=0, albedo=1.0)
+    lit = (direct[..., 0] > 0.05) & (direct[..., 2] != np.float32(0.2))
+    assert lit.sum() > 200
+    rel = np.abs(pt0[..., 0][lit] - direct[..., 0][lit]) / direct[..., 0][lit]
+    assert np.median(rel) < 0.1
+    # bounces only add light (sky + indirect); the seed changes the noise, not the mean much
+    pt3, _ = oracle_mod.render_pt(od.Structs, od.Values, cam.State, 40, 30, spp=8, max_bounces=3, albedo=1.0)
+    assert np.nanmean(pt3[..., 2]) >= np.nanmean(pt0[..., 2])
+    a, _ = oracle_mod.render_pt(od.Structs, od.Values, cam.State, 40, 30, spp=8, seed=1)
+    b, _ = oracle_mod.render_pt(od.Structs, od.Values, cam.State, 40, 30, spp=8, seed=2)
+    assert not np.array_equal(a, b) and abs(np.nanmean(a[..., :3]) - np.nanmean(b[..., :3])) < 0.02
+    # rows and threads do not change pixels (the RNG is keyed by the pixel, not by the visit order)
+    part, _ = oracle_mod.render_pt(od.Structs, od.Values, cam.State, 40, 30, spp=8, seed=1, row0=7, nrows=5, nthreads=3)
+    assert_frames_identical(part, a[7:12], "path rows")
+
+
 def test_threads_and_row_windows_do_not_change_pixels(oracle_mod, scenes):
     od = scenes["torus_d6"]
     cam = make_camera("rotated", 96, 40)
