@@ -124,7 +124,9 @@ enum {
 SDFHIP_API int sdfhip_generate(int shape, const float *params, int nparams,
                                int max_depth, int nthreads, sdfhip_octdata *out);
 
-/* Structural check used by upload: 0 = ok.  depth_out = deepest level,
+/* Structural check used by upload: 0 = ok; SDFHIP_ERR_BAD_TREE for an index out of
+ * range, a cycle in the parent links or a parent chain of more than 64 links (either
+ * would keep the shader's ascend loop from terminating).  depth_out = deepest level,
  * consistent_out = 1 when every child's parent field points back at it. */
 SDFHIP_API int sdfhip_octdata_validate(const int32_t *structs, uint32_t n,
                                        uint32_t *depth_out, int *consistent_out);

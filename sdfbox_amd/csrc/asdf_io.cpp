@@ -79,6 +79,42 @@ extern "C" int sdfhip_octdata_validate(const int32_t *structs, uint32_t n, uint3
                 if (structs[2 * ((size_t)c + k)] != (int32_t)i) consistent = false;
         }
     }
+    // Parent chains must end at a node without parent after a bounded number of links.
+    // The shader's ascend loop (Compute.hlsl:93-97) follows `parent` until the box contains
+    // the position or parent < 0; for a position outside the root cube it walks the whole
+    // chain, so a cycle would never terminate (a GPU hang) and a chain of millions of links
+    // would take seconds per march step.  No octree the shader can descend (12 levels) needs
+    // more than a few links: chains longer than MAX_CHAIN are rejected.
+    {
+        const uint32_t MAX_CHAIN = 64;
+        std::vector<uint8_t> links;             // links to the chain's end, 0xFF = unknown
+        try { links.assign(n, 0xFF); } catch (const std::bad_alloc &) {
+            return fail(SDFHIP_ERR_NOMEM, "validate: out of memory");
+        }
+        std::vector<uint32_t> path;
+        for (uint32_t i = 0; i < n; i++) {
+            if (links[i] != 0xFF) continue;
+            path.clear();
+            uint32_t j = i;
+            uint32_t base = 0;
+            for (;;) {
+                if (links[j] != 0xFF) { base = links[j]; break; }
+                int32_t p = structs[2 * (size_t)j];
+                path.push_back(j);
+                if (p < 0) { base = 0; path.pop_back(); links[j] = 0; break; }
+                if (path.size() > MAX_CHAIN + 1)
+                    return fail(SDFHIP_ERR_BAD_TREE, "node %u: parent chain longer than %u links or cyclic", i, MAX_CHAIN);
+                j = (uint32_t)p;
+            }
+            // path holds i .. (node before j), nearest-to-end last
+            for (size_t k = path.size(); k-- > 0;) {
+                base += 1;
+                if (base > MAX_CHAIN)
+                    return fail(SDFHIP_ERR_BAD_TREE, "node %u: parent chain longer than %u links", path[k], MAX_CHAIN);
+                links[path[k]] = (uint8_t)base;
+            }
+        }
+    }
     // Depth by following parent links needs a consistent tree; for an
     // inconsistent one report "unknown" as 0xFFFFFFFF.
     uint32_t depth = 0xFFFFFFFFu;

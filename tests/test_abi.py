@@ -60,6 +60,20 @@ def test_validate_rejects_out_of_range_links(sb):
     s[9, 0] = od.Length + 10         # parent out of range
     with pytest.raises(sb.SdfHipError):
         sb.OctData(s, od.Values).validate()
+    # parent cycles and endless parent chains would hang the shader's ascend loop: rejected
+    s = od.Structs.copy()
+    s[9, 0] = 17; s[17, 0] = 9
+    with pytest.raises(sb.SdfHipError) as e:
+        sb.OctData(s, od.Values).validate()
+    assert e.value.code == sb._lib.ERR_BAD_TREE and "chain" in str(e.value)
+    s = od.Structs.copy()
+    s[1:200, 0] = np.arange(0, 199)            # node i's parent is node i-1: a 199-link chain
+    with pytest.raises(sb.SdfHipError):
+        sb.OctData(s, od.Values).validate()
+    s = od.Structs.copy()
+    s[0, 0] = 0                                # the root is its own parent
+    with pytest.raises(sb.SdfHipError):
+        sb.OctData(s, od.Values).validate()
     # in range but inconsistent: legal for the generic kernel, not for the stack kernel
     s = od.Structs.copy()
     s[9, 0] = 3
