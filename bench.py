@@ -41,8 +41,11 @@ def parse():
     ap.add_argument("--compact", type=int, default=-1, help="wavefront ray compaction: 1 on, 0 off, -1 default")
     ap.add_argument("--band-rows", type=int, default=16)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames rendered concurrently on separate HIP streams (0 = default: 2 on one GPU, "
-                         "min(8, 2N) when the frame is sharded over N GPUs, whose shares are mostly tail)")
+                    help="HIP streams / buffers used round-robin (0 = default: 2).  Unsharded: frames in flight.  "
+                         "Sharded: groups of --gather-every frames in flight")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="sharded runs: frames per gather (fewer, larger messages; one collective launch per "
+                         "group instead of per frame).  0 = default: 4")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 path through host buffers (not a perf mode)")
     ap.add_argument("--exercise-gather", action="store_true",
@@ -122,16 +125,18 @@ def main():
         raise SystemExit("--spp excludes --display and --compact")
 
     layout = BandLayout(H, world, args.band_rows)
-    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else min(8, 2 * world))
-    streams = [torch.cuda.Stream() for _ in range(nbuf)]     # one per frame in flight
+    # sharded: G frames share one gather; nbuf groups are in flight (so G*nbuf frames)
+    G = (args.gather_every if args.gather_every > 0 else 4) if sharded else 1
+    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else 2
+    streams = [[torch.cuda.Stream() for _ in range(G)] for _ in range(nbuf)]   # one per frame in flight
     main = torch.cuda.current_stream().cuda_stream
     rows_local = layout.rows_per_rank if sharded else H
-    local = [torch.zeros((rows_local, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
+    local = [torch.zeros((G, rows_local, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
     gathered = frame = None
     if sharded and rank == 0:
-        gathered = [torch.zeros((world, layout.rows_per_rank, W) + px_shape, dtype=px_dtype, device="cuda")
+        gathered = [torch.zeros((world, G, layout.rows_per_rank, W) + px_shape, dtype=px_dtype, device="cuda")
                     for _ in range(nbuf)]
-        frame = [torch.zeros((H, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
+        frame = [torch.zeros((G, H, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
 
     def render(buf, st, stats=None, fl=None):
         f = flags if fl is None else fl
@@ -146,40 +151,51 @@ def main():
     ev = []                               # (start, end) HIP events around each timed launch
 
     def finish(slot):
-        """Complete the gather issued from buffer `slot`; rank 0 puts the rows back in order."""
+        """Complete the gather issued from group buffer `slot`; rank 0 puts the rows of its G frames
+        back in order."""
         w, pending[slot] = pending[slot], None
         if w is None:
             return
         if nccl:
-            with torch.cuda.stream(streams[slot]):
-                w.wait()                              # this slot's stream waits for its gather
+            last = streams[slot][G - 1]
+            with torch.cuda.stream(last):
+                w.wait()                              # the group's last stream waits for its gather
                 if rank == 0:
                     deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout,
-                                 stream=streams[slot].cuda_stream, pixel_bytes=px_bytes)
+                                 stream=last.cuda_stream, pixel_bytes=px_bytes, frames=G)
+            for s in streams[slot][:G - 1]:           # the group buffer is free again for all its streams
+                s.wait_stream(last)
         elif rank == 0:                               # gloo rehearsal: through host buffers
             gathered[slot].copy_(torch.stack(w).cuda())
             deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=main,
-                         pixel_bytes=px_bytes)
+                         pixel_bytes=px_bytes, frames=G)
 
-    def step(k, timed=False):
-        slot = k % nbuf
-        finish(slot)                                  # the slot's previous frame must be complete
-        s = streams[slot]
+    def step(k, timed=False, last=False):
+        group, within = divmod(k, G)
+        slot = group % nbuf
+        if within == 0:
+            finish(slot)                              # the slot's previous group must be complete
+        s = streams[slot][within]                     # every frame of the group on its own stream
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
-        render(local[slot], s.cuda_stream)
+        render(local[slot][within], s.cuda_stream)
         if timed:
             e1.record(s)
             ev.append((e0, e1))
-        if not sharded:
+        if not sharded or not (within == G - 1 or last):
             return
+        # one collective for the whole group (a partial last group is gathered whole, too),
+        # ordered behind all of the group's renders
+        tail = streams[slot][G - 1]
+        for o in streams[slot][:G - 1]:
+            tail.wait_stream(o)
         if nccl:
             glist = list(gathered[slot].unbind(0)) if rank == 0 else None
-            with torch.cuda.stream(s):                # the collective orders itself behind this stream's render
+            with torch.cuda.stream(tail):
                 pending[slot] = dist.gather(local[slot], glist, dst=0, async_op=True)
         else:
-            s.synchronize()
+            tail.synchronize()
             host = local[slot].cpu()
             glist = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
             dist.gather(host, glist, dst=0)
@@ -206,12 +222,12 @@ def main():
 
     # ---- warm-up, then the timed region ---------------------------------------------------
     for k in range(args.warmup):
-        step(k)
+        step(k, last=(k == args.warmup - 1))
     drain()
     barrier()
     t_start = time.perf_counter()
     for k in range(args.steps):
-        step(k, timed=True)
+        step(k, timed=True, last=(k == args.steps - 1))
     drain()
     barrier()
     elapsed = time.perf_counter() - t_start
@@ -234,7 +250,10 @@ def main():
         else:
             scene.DrawDevice(cam, W, H, ref.data_ptr(), flags=flags, stream=main)
         torch.cuda.synchronize()
-        check_ok = all(bool(torch.equal(f.view(torch.int32), ref.view(torch.int32))) for f in frame[:min(nbuf, args.steps)])
+        # every frame of every group buffer that the timed steps filled
+        filled = [(g % nbuf, w) for g in range(max(0, (args.steps - 1) // G + 1 - nbuf), (args.steps - 1) // G + 1)
+                  for w in range(G) if g * G + w < args.steps]
+        check_ok = all(bool(torch.equal(frame[sl][w].view(torch.int32), ref.view(torch.int32))) for sl, w in filled)
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
@@ -261,7 +280,8 @@ def main():
                           ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else ""),
                 "parallelism": "1 GPU" if not sharded else
                                f"{world} GPU(s), {args.band_rows}-row bands round-robin + gather to rank 0 ({args.backend})",
-                "frames_in_flight": nbuf,
+                "frames_in_flight": nbuf * G,
+                "frames_per_gather": G if sharded else None,
                 "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
                 "gstep_per_s": round(float(counters[2]) / sec_per_step / 1e9, 3),
                 "scene_build_s": round(t_gen, 2),

@@ -216,15 +216,16 @@ SDFHIP_API int sdfhip_render_display(sdfhip_scene *scene, const sdfhip_info *inf
                                      uint32_t width, uint32_t height, uint32_t flags, int debug,
                                      uint8_t *rgba8_out, sdfhip_stats *stats);
 
-/* Rank-0 helper for the tile gather: scatter `world` compact band buffers
- * (as gathered: rank r's rows at d_gathered + r*rows_per_rank*width pixels)
- * back into row order.  pixel_bytes = 16 (RGBA32F) or 4 (RGBA8).  Asynchronous
+/* Rank-0 helper for the tile gather: scatter `world` compact band buffers back into
+ * row order.  One gather may carry several frames (fewer, larger messages):
+ * d_gathered is [world][frames][rows_per_rank][width] pixels, d_frame is
+ * [frames][height][width].  pixel_bytes = 16 (RGBA32F) or 4 (RGBA8).  Asynchronous
  * on `stream`. */
 SDFHIP_API int sdfhip_deinterleave_device(int device, const void *d_gathered, void *d_frame,
                                           uint32_t width, uint32_t height,
                                           uint32_t band_rows, uint32_t world,
                                           uint32_t rows_per_rank, uint32_t pixel_bytes,
-                                          void *stream);
+                                          uint32_t frames, void *stream);
 
 /* Test hook: the kernel's R8_UNorm decode of bytes 0..255 (256 floats to the
  * host), checked exhaustively against byte/255.0f. */

@@ -123,7 +123,7 @@ _SIG = {
     "sdfhip_render_display": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                          _c.c_int, _vp, _c.POINTER(Stats)]),
     "sdfhip_deinterleave_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32,
-                                              _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+                                              _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "sdfhip_debug_unorm_table": (_c.c_int, [_c.c_int, _vp]),
 }
 # every symbol include/sdfhip.h declares must be exported: fail at import otherwise

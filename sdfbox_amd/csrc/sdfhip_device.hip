@@ -551,15 +551,18 @@ __global__ void k_fuse(const int2 *__restrict__ structs, const uint2 *__restrict
 template <class Pixel>
 __global__ void k_deinterleave(const Pixel *__restrict__ gathered, Pixel *__restrict__ frame,
                                uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world,
-                               uint32_t rows_per_rank)
+                               uint32_t rows_per_rank, uint32_t frames)
 {
-    size_t total = (size_t)width * height;
+    // gathered: [world][frames][rows_per_rank][width]  ->  frame: [frames][height][width]
+    size_t per_frame = (size_t)width * height, total = per_frame * frames;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
-        uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i - (size_t)y * width);
+        uint32_t f = (uint32_t)(i / per_frame);
+        size_t r = i - (size_t)f * per_frame;
+        uint32_t y = (uint32_t)(r / width), x = (uint32_t)(r - (size_t)y * width);
         uint32_t band = y / band_rows, rank = band % world, lband = band / world;
         uint32_t yl = lband * band_rows + (y - band * band_rows);
-        frame[i] = gathered[((size_t)rank * rows_per_rank + yl) * width + x];
+        frame[i] = gathered[(((size_t)rank * frames + f) * rows_per_rank + yl) * width + x];
     }
 }
 
@@ -908,8 +911,9 @@ extern "C" int sdfhip_render_display(sdfhip_scene *s, const sdfhip_info *info, u
 extern "C" int sdfhip_deinterleave_device(int device, const void *d_gathered, void *d_frame,
                                           uint32_t width, uint32_t height, uint32_t band_rows,
                                           uint32_t world, uint32_t rows_per_rank, uint32_t pixel_bytes,
-                                          void *stream)
+                                          uint32_t frames, void *stream)
 {
+    if (frames == 0) return fail(SDFHIP_ERR_ARG, "deinterleave: frames must be >= 1");
     if (!d_gathered || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
         return fail(SDFHIP_ERR_ARG, "deinterleave: null or zero argument");
     if (pixel_bytes != 16 && pixel_bytes != 4)
@@ -920,16 +924,16 @@ extern "C" int sdfhip_deinterleave_device(int device, const void *d_gathered, vo
         return fail(SDFHIP_ERR_ARG, "deinterleave: rows_per_rank %u < %u needed for %u bands over %u ranks", rows_per_rank, need_rows, nbands, world);
     DeviceGuard g(device);
     if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "deinterleave: hipSetDevice(%d) failed", device);
-    size_t total = (size_t)width * height;
-    uint32_t blocks = (uint32_t)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    size_t total = (size_t)width * height * frames;
+    uint32_t blocks = (uint32_t)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (pixel_bytes == 16)
         hipLaunchKernelGGL((k_deinterleave<float4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const float4 *)d_gathered, (float4 *)d_frame, width, height, band_rows,
-                           world, rows_per_rank);
+                           world, rows_per_rank, frames);
     else
         hipLaunchKernelGGL((k_deinterleave<uint32_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const uint32_t *)d_gathered, (uint32_t *)d_frame, width, height, band_rows,
-                           world, rows_per_rank);
+                           world, rows_per_rank, frames);
     HIP_TRY(hipGetLastError());
     return SDFHIP_OK;
 }

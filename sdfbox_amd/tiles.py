@@ -56,11 +56,12 @@ def render_bands(scene, state, width, layout, rank, out_ptr, flags=0, stream=Non
         scene.DrawPathDevice(state, width, layout.height, out_ptr, pt=pt, **kw)
 
 
-def deinterleave(device, gathered_ptr, frame_ptr, width, layout, stream=None, pixel_bytes=16):
-    """Rank 0: gathered compact buffers (world x rows_per_rank x width pixels) -> frame.
-    pixel_bytes: 16 for RGBA32F frames, 4 for RGBA8 frames of the fused display pass."""
+def deinterleave(device, gathered_ptr, frame_ptr, width, layout, stream=None, pixel_bytes=16, frames=1):
+    """Rank 0: gathered compact buffers (world x frames x rows_per_rank x width pixels) ->
+    frames x height x width.  pixel_bytes: 16 for RGBA32F frames, 4 for RGBA8 frames of the
+    fused display pass.  frames > 1: one gather carried several frames."""
     check(lib.sdfhip_deinterleave_device(int(device), ctypes.c_void_p(int(gathered_ptr)),
                                          ctypes.c_void_p(int(frame_ptr)), int(width),
                                          layout.height, layout.band_rows, layout.world,
-                                         layout.rows_per_rank, int(pixel_bytes),
+                                         layout.rows_per_rank, int(pixel_bytes), int(frames),
                                          ctypes.c_void_p(int(stream)) if stream else None))

@@ -284,6 +284,27 @@ def test_display_bands_reassemble(sb, gpu_scenes):
     assert torch.equal(frame.to(torch.int64) & 0xFFFFFFFF, full)
 
 
+def test_grouped_gather_deinterleave(sb, gpu_scenes):
+    # one gather may carry several frames: gathered [world][frames][rows][W] -> [frames][H][W]
+    import torch
+    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands
+    scene = gpu_scenes["sphere_d4"]
+    W, H, world, G = 120, 70, 3, 3
+    lay = BandLayout(H, world, 16)
+    cams = [make_camera(n, W, H) for n in ("default", "rotated", "closeup")]
+    full = [torch.from_numpy(scene.Draw(c, W, H)).cuda() for c in cams]
+    gathered = torch.zeros((world, G, lay.rows_per_rank, W, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for r in range(world):
+        for f, c in enumerate(cams):
+            render_bands(scene, c, W, lay, r, gathered[r, f].data_ptr(), stream=stream)
+    frames = torch.zeros((G, H, W, 4), dtype=torch.float32, device="cuda")
+    deinterleave(0, gathered.data_ptr(), frames.data_ptr(), W, lay, stream=stream, frames=G)
+    torch.cuda.synchronize()
+    for f in range(G):
+        assert torch.equal(frames[f].view(torch.int32), full[f].view(torch.int32)), f
+
+
 def test_two_handles_render_concurrently(sb, oracle_mod, scenes):
     # upload / render are callable from several threads on different handles
     cam = make_camera("default", 128, 128)
