@@ -124,6 +124,40 @@ enum {
 SDFHIP_API int sdfhip_generate(int shape, const float *params, int nparams,
                                int max_depth, int nthreads, sdfhip_octdata *out);
 
+/* ---- point cloud -> ASDF --------------------------------------------- */
+
+/* A point cloud with normals: count x {position xyz, normal xyz} floats.
+ * Replaces: gsl::span<Vertex>* / struct Vertex, SdfGen/math.h:47-51. */
+typedef struct sdfhip_points {
+    uint32_t count;
+    float *data;
+} sdfhip_points;
+
+/* Replaces: LoadPly, SdfGen/dllmain.cpp:244-248 -> ply_reader.cpp:35-71 (binary
+ * little-endian, vertex element first, 6 floats per vertex). */
+SDFHIP_API int sdfhip_load_ply(const char *path, sdfhip_points *out);
+/* Replaces: LoadObj, SdfGen/dllmain.cpp:237-242 -> obj_reader.cpp:45-96. */
+SDFHIP_API int sdfhip_load_obj(const char *path, sdfhip_points *out);
+SDFHIP_API void sdfhip_points_free(sdfhip_points *points);
+
+typedef struct sdfhip_sdfgen_stats {
+    uint32_t nodes, levels;
+    uint64_t candidate_entries;   /* sum of all candidate-list lengths: the work measure */
+    float global_scale;           /* GlobalScale / GlobalOffset of dllmain.cpp:67-80 */
+    float global_offset[3];
+    float total_ms;
+} sdfhip_sdfgen_stats;
+
+/* Replaces: SdfGen(vertices, depth), SdfGen/dllmain.cpp:295-319 (P/Invoke Program.cs:
+ * 662-663): builds the flattened octree of a point cloud on GPU `device`, level by
+ * level, one wavefront per node -- the same nodes, order and bytes as the reference's
+ * recursive construct (:163-207), including its lossy candidate pruning, corner
+ * inheritance and first-point tie-breaking.  out: release with sdfhip_octdata_free.
+ * SDFHIP_ERR_ARG when no point can be the nearest one (NaN input: the reference throws
+ * "Did not find" / "NaN distance"). */
+SDFHIP_API int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_t depth,
+                             sdfhip_octdata *out, sdfhip_sdfgen_stats *stats);
+
 /* Structural check used by upload: 0 = ok; SDFHIP_ERR_BAD_TREE for an index out of
  * range, a cycle in the parent links or a parent chain of more than 64 links (either
  * would keep the shader's ascend loop from terminating).  depth_out = deepest level,

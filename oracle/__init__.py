@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "sdf_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("sdf_oracle.c", "sdfgen_oracle.c")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return LIB_PATH
 
@@ -41,6 +41,11 @@ def lib():
                                          c.POINTER(u32), c.POINTER(c.c_float)]
         L.oracle_unorm_table.restype = None
         L.oracle_unorm_table.argtypes = [vp]
+        L.oracle_sdfgen.restype = c.c_int
+        L.oracle_sdfgen.argtypes = [vp, u32, c.c_int32, c.POINTER(vp), c.POINTER(vp), c.POINTER(vp), c.POINTER(u32),
+                                    c.POINTER(c.c_float), c.POINTER(c.c_float * 3)]
+        L.oracle_sdfgen_free.restype = None
+        L.oracle_sdfgen_free.argtypes = [vp]
         L.oracle_display.restype = None
         L.oracle_display.argtypes = [vp, c.c_uint64, c.c_int, vp]
         _lib = L
@@ -124,4 +129,28 @@ def display(rgba, debug=False):
     rgba = np.ascontiguousarray(rgba, dtype=np.float32)
     out = np.zeros(rgba.shape, dtype=np.uint8)
     lib().oracle_display(rgba.ctypes.data, rgba.size // 4, 1 if debug else 0, out.ctypes.data)
+    return out
+
+
+def sdfgen(verts6, depth):
+    """SdfGen (dllmain.cpp:295-319) on a point cloud: verts6 = (n, 6) float32 {position, normal}.
+    -> dict(structs (N,2) int32, values (N,8) uint8, float_values (N,8) float32, scale, offset)."""
+    v = np.ascontiguousarray(verts6, dtype=np.float32).reshape(-1, 6)
+    s, b, f = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    n = ctypes.c_uint32()
+    gs = ctypes.c_float()
+    go = (ctypes.c_float * 3)()
+    rc = lib().oracle_sdfgen(v.ctypes.data, len(v), int(depth), ctypes.byref(s), ctypes.byref(b), ctypes.byref(f),
+                             ctypes.byref(n), ctypes.byref(gs), ctypes.byref(go))
+    if rc != 0:
+        raise RuntimeError(f"oracle_sdfgen failed with code {rc} (2 = empty candidate list: the reference throws)")
+    N = n.value
+    out = {
+        "structs": np.ctypeslib.as_array(ctypes.cast(s, ctypes.POINTER(ctypes.c_int32)), (N, 2)).copy(),
+        "values": np.ctypeslib.as_array(ctypes.cast(b, ctypes.POINTER(ctypes.c_uint8)), (N, 8)).copy(),
+        "float_values": np.ctypeslib.as_array(ctypes.cast(f, ctypes.POINTER(ctypes.c_float)), (N, 8)).copy(),
+        "scale": gs.value, "offset": tuple(go),
+    }
+    for p in (s, b, f):
+        lib().oracle_sdfgen_free(p)
     return out

@@ -85,6 +85,19 @@ class PathTrace(ctypes.Structure):
         super().__init__(int(spp), int(max_bounces), int(seed), float(albedo))
 
 
+class CPoints(ctypes.Structure):
+    _fields_ = [("count", ctypes.c_uint32), ("data", ctypes.POINTER(ctypes.c_float))]
+
+
+class SdfGenStats(ctypes.Structure):
+    _fields_ = [
+        ("nodes", ctypes.c_uint32), ("levels", ctypes.c_uint32),
+        ("candidate_entries", ctypes.c_uint64),
+        ("global_scale", ctypes.c_float), ("global_offset", ctypes.c_float * 3),
+        ("total_ms", ctypes.c_float),
+    ]
+
+
 class SdfHipError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"sdfhip error {code}: {message}")
@@ -100,6 +113,11 @@ _SIG = {
     "sdfhip_octdata_free": (None, [_c.POINTER(COctData)]),
     "sdfhip_generate": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_float), _c.c_int, _c.c_int, _c.c_int,
                                    _c.POINTER(COctData)]),
+    "sdfhip_load_ply": (_c.c_int, [_c.c_char_p, _c.POINTER(CPoints)]),
+    "sdfhip_load_obj": (_c.c_int, [_c.c_char_p, _c.POINTER(CPoints)]),
+    "sdfhip_points_free": (None, [_c.POINTER(CPoints)]),
+    "sdfhip_sdfgen": (_c.c_int, [_c.c_int, _vp, _c.c_uint32, _c.c_int32, _c.POINTER(COctData),
+                                 _c.POINTER(SdfGenStats)]),
     "sdfhip_octdata_validate": (_c.c_int, [_vp, _c.c_uint32, _c.POINTER(_c.c_uint32),
                                            _c.POINTER(_c.c_int)]),
     "sdfhip_info_default": (None, [_c.POINTER(Info), _c.c_float, _c.c_float]),

@@ -76,6 +76,39 @@ class OctData:
                                   ctypes.byref(raw)))
         return cls._from_native(raw)
 
+    # -- SdfGen: point cloud -> ASDF on the GPU ---------------------------------------
+    @staticmethod
+    def LoadPly(path):
+        """NativeOctData.LoadPly, Program.cs:654-655 -> ply_reader.cpp: (n, 6) float32 {pos, normal}."""
+        raw = _lib.CPoints()
+        check(lib.sdfhip_load_ply(os.fsencode(path), ctypes.byref(raw)))
+        return OctData._points(raw)
+
+    @staticmethod
+    def LoadObj(path):
+        """NativeOctData.LoadObj, Program.cs:652-653 -> obj_reader.cpp."""
+        raw = _lib.CPoints()
+        check(lib.sdfhip_load_obj(os.fsencode(path), ctypes.byref(raw)))
+        return OctData._points(raw)
+
+    @staticmethod
+    def _points(raw):
+        try:
+            return np.ctypeslib.as_array(raw.data, shape=(raw.count, 6)).copy() if raw.count else np.zeros((0, 6), np.float32)
+        finally:
+            lib.sdfhip_points_free(ctypes.byref(raw))
+
+    @classmethod
+    def SdfGen(cls, vertices, depth, device=0, want_stats=False):
+        """NativeOctData.SdfGen(vertices, Model.MaxDepth), Program.cs:662-663 -> dllmain.cpp:295-319,
+        built on the GPU.  vertices: (n, 6) float32 {position, normal}."""
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 6)
+        raw = _lib.COctData()
+        st = _lib.SdfGenStats()
+        check(lib.sdfhip_sdfgen(int(device), v.ctypes.data, len(v), int(depth), ctypes.byref(raw), ctypes.byref(st)))
+        od = cls._from_native(raw)
+        return (od, st) if want_stats else od
+
     def validate(self):
         """(depth, consistent) or raises SdfHipError(ERR_BAD_TREE)."""
         depth = ctypes.c_uint32()

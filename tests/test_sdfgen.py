@@ -1,0 +1,147 @@
+"""N1: point cloud -> ASDF.  CPU: the readers and the SdfGen oracle (the restatement of
+SdfGen/dllmain.cpp) against the facts SURVEY.md recorded from a real SdfGen run.
+GPU: the level-synchronous HIP builder against the oracle, byte for byte."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+
+def fib_sphere(n, r=0.5, centre=(0.0, 0.0, 0.0)):
+    i = np.arange(n) + 0.5
+    phi = np.arccos(1 - 2 * i / n)
+    th = np.pi * (1 + 5 ** 0.5) * i
+    p = np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], 1)
+    return np.concatenate([p * r + np.asarray(centre), p], 1).astype(np.float32)
+
+
+def torus_cloud(n, R=0.6, r=0.2, seed=0):
+    rng = np.random.default_rng(seed)
+    u, v = rng.uniform(0, 2 * np.pi, n), rng.uniform(0, 2 * np.pi, n)
+    nrm = np.stack([np.cos(u) * np.cos(v), np.sin(v), np.sin(u) * np.cos(v)], 1)
+    pos = np.stack([np.cos(u) * R, np.zeros(n), np.sin(u) * R], 1) + nrm * r
+    return np.concatenate([pos, nrm], 1).astype(np.float32)
+
+
+def write_ply(path, verts, fmt="binary_little_endian"):
+    with open(path, "wb") as f:
+        f.write((f"ply\nformat {fmt} 1.0\ncomment made by tests\nelement vertex {len(verts)}\n"
+                 "property float x\nproperty float y\nproperty float z\n"
+                 "property float nx\nproperty float ny\nproperty float nz\nend_header\n").encode())
+        f.write(np.ascontiguousarray(verts, dtype="<f4").tobytes())
+
+
+def levels_of(structs):
+    lvl = np.zeros(len(structs), dtype=np.int32)
+    for i in range(len(structs)):
+        c = structs[i, 1]
+        if c >= 0:
+            lvl[c:c + 8] = lvl[i] + 1
+    return lvl
+
+
+# ---- readers ------------------------------------------------------------------------------
+def test_ply_reader(sb, tmp_path):
+    v = fib_sphere(1234)
+    p = tmp_path / "s.ply"
+    write_ply(p, v)
+    got = sb.OctData.LoadPly(str(p))
+    assert got.shape == (1234, 6) and (got == v).all()
+    for fmt in ("ascii", "binary_big_endian"):                     # refused, as in ply_reader.cpp:47-54
+        write_ply(p, v, fmt)
+        with pytest.raises(sb.SdfHipError):
+            sb.OctData.LoadPly(str(p))
+    p.write_bytes(b"plx\n")
+    with pytest.raises(sb.SdfHipError):
+        sb.OctData.LoadPly(str(p))
+    write_ply(p, v)
+    p.write_bytes(p.read_bytes()[:-100])                           # truncated payload
+    with pytest.raises(sb.SdfHipError):
+        sb.OctData.LoadPly(str(p))
+    with pytest.raises(sb.SdfHipError):
+        sb.OctData.LoadPly(str(tmp_path / "missing.ply"))
+
+
+def test_obj_reader(sb, tmp_path):
+    p = tmp_path / "m.obj"
+    p.write_text("# a comment\no thing\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0.5 0.5 1\nvt 0 0\nvn 0 0 1\nvn 1 0 0\ns off\n"
+                 "f 1/1/1 2/1/1 3/1/1\nf 2//2 3//2\n")
+    got = sb.OctData.LoadObj(str(p))
+    assert got.shape == (4, 6)
+    assert got[:, :3].tolist() == [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0.5, 0.5, 1]]
+    # a face assigns its normals to its vertices (later faces win); unmentioned vertices keep (0,0,0)
+    assert got[:, 3:].tolist() == [[0, 0, 1], [1, 0, 0], [1, 0, 0], [0, 0, 0]]
+    p.write_text("v 0 0 0\nvn 0 0 1\nf 1/1/2\n")                   # normal index out of range
+    with pytest.raises(sb.SdfHipError):
+        sb.OctData.LoadObj(str(p))
+    p.write_text("v 0 0 0\nq nonsense\n")
+    with pytest.raises(sb.SdfHipError):
+        sb.OctData.LoadObj(str(p))
+
+
+# ---- the SdfGen oracle against the reference's recorded run -----------------------------------
+def test_oracle_reproduces_the_survey_run(oracle_mod):
+    # SURVEY.md / BASELINE.md: sphere point cloud r = 0.5 with normals, 20 000 points, depth 4,
+    # real SdfGen: 4 529 nodes, 72 472-byte file, level histogram 1/8/64/512/3944
+    o = oracle_mod.sdfgen(fib_sphere(20000), 4)
+    assert len(o["structs"]) == 4529 and 8 + 16 * len(o["structs"]) == 72472
+    assert np.bincount(levels_of(o["structs"])).tolist() == [1, 8, 64, 512, 3944]
+    assert abs(o["scale"] - 1.1) < 1e-3 and all(abs(c - 0.003) < 1e-4 for c in o["offset"])
+    # corner values are distances to the sphere in unit-cube units: check the root's
+    s = o["scale"]
+    for k in range(8):
+        corner_model = (np.array([k % 2, 1 - (k // 2 % 2), k // 4 % 2]) - 0.5) * s + np.array(o["offset"])
+        assert abs(o["float_values"][0, k] - (np.linalg.norm(corner_model) - 0.5) / s) < 0.02
+
+
+def test_oracle_structure_and_inheritance(oracle_mod):
+    o = oracle_mod.sdfgen(torus_cloud(6000), 5)
+    s, fv = o["structs"], o["float_values"]
+    assert s[0].tolist()[0] == -1
+    internal = np.nonzero(s[:, 1] >= 0)[0]
+    for i in internal[:300]:
+        c = s[i, 1]
+        assert (s[c:c + 8, 0] == i).all()
+        for k in range(8):                      # child k inherits corner k (dllmain.cpp:181)
+            assert fv[c + k, k] == fv[i, k]
+    # the reference throws "Did not find" / "NaN distance" when no point can be the nearest one
+    # (the pruning radius always keeps the nearest point, so that takes NaN input); the oracle
+    # reports it as an error
+    with pytest.raises(RuntimeError):
+        oracle_mod.sdfgen(np.full((10, 6), np.nan, dtype=np.float32), 3)
+
+
+# ---- the HIP builder -----------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cloud,depth", [("sphere20k", 4), ("sphere20k", 6), ("torus", 5), ("torus", 7), ("two", 5)])
+def test_gpu_builder_equals_oracle(sb, oracle_mod, cloud, depth):
+    v = {"sphere20k": fib_sphere(20000), "torus": torus_cloud(30000),
+         "two": np.concatenate([fib_sphere(4000, 0.3, (-0.2, 0.1, 0.0)), fib_sphere(3000, 0.25, (0.35, -0.1, 0.2))])}[cloud]
+    o = oracle_mod.sdfgen(v, depth)
+    od, st = sb.OctData.SdfGen(v, depth, want_stats=True)
+    assert od.Length == len(o["structs"]) == st.nodes
+    assert (od.Structs == o["structs"]).all()
+    assert (od.Values == o["values"]).all()
+    assert st.global_scale == np.float32(o["scale"]) and tuple(st.global_offset) == tuple(np.float32(c) for c in o["offset"])
+    assert od.validate() == (int(levels_of(od.Structs).max()), True)
+
+
+@pytest.mark.gpu
+def test_gpu_builder_end_to_end(sb, oracle_mod, tmp_path):
+    # .ply -> SdfGen on the GPU -> .asdf -> render: the whole of Logic.MakeData + Program.Draw
+    v = fib_sphere(20000)
+    ply = tmp_path / "sphere.ply"
+    write_ply(ply, v)
+    od = sb.OctData.SdfGen(sb.OctData.LoadPly(str(ply)), 5)
+    od.Save(str(tmp_path / "sphere.asdf"))
+    back = sb.OctData.LoadAsdf(str(tmp_path / "sphere.asdf"))
+    cam = sb.Logic(96, 96)
+    ref, _ = oracle_mod.render(back.Structs, back.Values, cam.State, 96, 96, nthreads=8)
+    with sb.Scene(back) as sc:
+        img = sc.Draw(cam, 96, 96)
+    same = (img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))
+    assert same.all()
+    assert (img[..., 0] > 0.0051).sum() > 500                 # the sphere is there and lit
+    with pytest.raises(sb.SdfHipError):                      # no usable point: an error code, not a crash
+        sb.OctData.SdfGen(np.full((10, 6), np.nan, dtype=np.float32), 3)
