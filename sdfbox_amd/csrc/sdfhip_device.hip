@@ -420,13 +420,17 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
 }
 
 // ---- path-traced mode (BASELINE config 5) -----------------------------------------------
-// Not in the reference (README "plans" only); defined by o_pixel_pt in oracle/sdf_oracle.c,
-// which this kernel follows operation for operation: per pixel spp samples, each a jittered
-// camera ray followed by up to 1 + max_bounces segments built from the reference's own
-// pieces (primary march, shading, shadow march) chained by cosine-weighted diffuse
-// bounces; PCG-hash RNG; no transcendental function.  One lane per pixel, one 8x8 tile per
-// wave, the plain kernel's XCD-interleaved tile rows; the secondary rays of neighbouring
-// pixels diverge at the first bounce -- the incoherent-traversal stress the config asks for.
+// Not in the reference (README "plans" only); defined by o_pixel_pt in oracle/sdf_oracle.c:
+// per pixel spp samples, each a jittered camera ray followed by up to 1 + max_bounces
+// segments built from the reference's own pieces (primary march, shading, shadow march)
+// chained by cosine-weighted diffuse bounces; PCG-hash RNG; no transcendental function.
+// The oracle writes that as four nested loops.  After the first bounce every lane of a wave
+// is somewhere else in them, and nested loops would run one lane group at a time; here, as
+// in k_plain, a lane is a state machine -- MARCH (a segment's march) or SHADOW (its shadow
+// march) -- around ONE find + sample + advance body, so whatever phase the 64 lanes are in,
+// they share the instruction stream of the expensive part.  The arithmetic and its order per
+// pixel are the oracle's; only the control flow differs.  One lane per pixel, one 8x8 tile
+// per wave, the plain kernel's XCD-interleaved tile rows.
 template <bool STACK, bool COUNT>
 __global__ __launch_bounds__(64) void k_path(RenderParams P)
 {
@@ -445,88 +449,128 @@ __global__ __launch_bounds__(64) void k_path(RenderParams P)
         const NodeRec root = P.nodes[0];
         const uint32_t p = y * P.width + x;
         const float margin = P.margin;
+        int32_t *stack = stack_lds + lane;
         float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
         uint32_t steps = 0;
-        int32_t *stack = stack_lds + lane;
-        for (uint32_t s = 0; s < P.pt_spp; s++) {
-            CursorT c;
-            c.reset(root);
-            float px = P.posx, py = P.posy, pz = P.posz, dx, dy, dz;
-            ray_f(P, (float)x + rnd(P.pt_seed, p, s, 0, 0), (float)y + rnd(P.pt_seed, p, s, 0, 1), dx, dy, dz);
-            float T = 1.0f;
-            for (uint32_t b = 0;; b++) {
-                float prox = 1.0f;
-                int i;
-                bool escaped = false;
-                for (i = 0; (prox > margin * 2.0f || prox < 0.0f) && i < 100; i++) {
-                    if (dot3(px, py, pz, px, py, pz) > P.limit) { escaped = true; break; }
-                    uint32_t reads = find(c, P.nodes, P.n_nodes, stack, 64, px, py, pz);
-                    prox = interpol_world(c.cell(), px, py, pz);
-                    if (COUNT) { cn += reads; cs += 1; }
-                    px = __builtin_fmaf(dx, prox, px);
-                    py = __builtin_fmaf(dy, prox, py);
-                    pz = __builtin_fmaf(dz, prox, pz);
-                }
-                steps += (uint32_t)i;
-                if (escaped) {
-                    acc0 = __builtin_fmaf(T, 0.005f, acc0); acc1 = __builtin_fmaf(T, 0.01f, acc1); acc2 = __builtin_fmaf(T, 0.2f, acc2);
-                    break;
-                }
-                float lx = P.lightx - px, ly = P.lighty - py, lz = P.lightz - pz;
-                float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
-                const float L0 = lx * rl, L1 = ly * rl, L2 = lz * rl;
-                px = __builtin_fmaf(L0, margin, px); py = __builtin_fmaf(L1, margin, py); pz = __builtin_fmaf(L2, margin, pz);
-                float g0, g1, g2;
-                gradient(c.cell(), px, py, pz, g0, g1, g2);
-                float rg = 1.0f / sqrtf(dot3(g0, g1, g2, g0, g1, g2));
-                float n0 = g0 * rg, n1 = g1 * rg, n2 = g2 * rg;
-                const float angle = dot3(L0, L1, L2, n0, n1, n2);
-                if (!(angle < 0.0f)) {
-                    float sx = px, sy = py, sz = pz, sprox = prox;
-                    lx = P.lightx - px; ly = P.lighty - py; lz = P.lightz - pz;
-                    const float dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
-                    int j;
-                    bool lit = false;
-                    for (j = 0; j < 40 && sprox > -margin; j++) {
-                        if (sprox > dist || (sx < 0.0f || sy < 0.0f || sz < 0.0f) ||
-                            (sx > 1.0f || sy > 1.0f || sz > 1.0f)) { lit = true; break; }
-                        if (sprox < margin) {
-                            float q0, q1, q2;
-                            gradient(c.cell(), sx, sy, sz, q0, q1, q2);
-                            if (dot3(q0, q1, q2, L0, L1, L2) < 0.0f) break;
-                        }
-                        uint32_t reads = find(c, P.nodes, P.n_nodes, stack, 64, sx, sy, sz);
-                        sprox = interpol_world(c.cell(), sx, sy, sz);
-                        if (COUNT) { cn += reads; cs += 1; }
-                        const float st = sprox + margin;
-                        sx = __builtin_fmaf(L0, st, sx); sy = __builtin_fmaf(L1, st, sy); sz = __builtin_fmaf(L2, st, sz);
+        // lane state
+        CursorT c;
+        float mx, my, mz;        // the position being marched (segment, then shadow ray)
+        float ux, uy, uz;        // its direction (segment direction, then direction to the light)
+        float hx = 0, hy = 0, hz = 0;   // the hit point, kept while the shadow ray marches
+        float n0 = 0, n1 = 0, n2 = 0;   // the hit normal, facing the incoming ray
+        float T = 1.0f, prox = 1.0f, angle = 0.0f, dist = 0.0f;
+        uint32_t s = 0, b = 0;
+        int it = 0;              // i of the segment march, or j of the shadow march
+        bool shadow = false;
+
+        // start of sample s: reset cursor, jittered camera ray (o_pixel_pt's sample loop head)
+        c.reset(root);
+        mx = P.posx; my = P.posy; mz = P.posz;
+        ray_f(P, (float)x + rnd(P.pt_seed, p, 0, 0, 0), (float)y + rnd(P.pt_seed, p, 0, 0, 1), ux, uy, uz);
+
+        for (;;) {
+            // ---- everything between two march steps --------------------------------------
+            bool bounce = false, end_sample = false;
+            if (!shadow) {
+                if ((prox > margin * 2.0f || prox < 0.0f) && it < 100) {
+                    if (dot3(mx, my, mz, mx, my, mz) > P.limit) {            // escaped: sky
+                        steps += (uint32_t)it;
+                        acc0 = __builtin_fmaf(T, 0.005f, acc0); acc1 = __builtin_fmaf(T, 0.01f, acc1); acc2 = __builtin_fmaf(T, 0.2f, acc2);
+                        end_sample = true;
                     }
-                    steps += (uint32_t)j;
-                    if (lit) {
-                        const float e = T * (P.pt_albedo * (angle / (dist * dist) * P.k_strength));
-                        acc0 += e; acc1 += e; acc2 += e;
+                } else {                                                     // hit: shade (Compute.hlsl:205-213)
+                    steps += (uint32_t)it;
+                    float lx = P.lightx - mx, ly = P.lighty - my, lz = P.lightz - mz;
+                    const float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+                    const float L0 = lx * rl, L1 = ly * rl, L2 = lz * rl;
+                    mx = __builtin_fmaf(L0, margin, mx); my = __builtin_fmaf(L1, margin, my); mz = __builtin_fmaf(L2, margin, mz);
+                    float g0, g1, g2;
+                    gradient(c.cell(), mx, my, mz, g0, g1, g2);
+                    const float rg = 1.0f / sqrtf(dot3(g0, g1, g2, g0, g1, g2));
+                    n0 = g0 * rg; n1 = g1 * rg; n2 = g2 * rg;
+                    angle = dot3(L0, L1, L2, n0, n1, n2);
+                    // the bounce needs the normal facing the incoming ray; decide now, while
+                    // the incoming direction is still in (ux, uy, uz)
+                    const bool flip = dot3(n0, n1, n2, ux, uy, uz) > 0.0f;
+                    hx = mx; hy = my; hz = mz;
+                    if (!(angle < 0.0f)) {
+                        lx = P.lightx - mx; ly = P.lighty - my; lz = P.lightz - mz;
+                        dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+                        ux = L0; uy = L1; uz = L2;
+                        shadow = true;
+                        it = 0;
+                    } else {
+                        bounce = true;
                     }
+                    if (flip) { n0 = -n0; n1 = -n1; n2 = -n2; }
                 }
-                if (b == P.pt_bounces) break;
-                if (dot3(n0, n1, n2, dx, dy, dz) > 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
-                float u0 = n0, u1 = n1, u2 = n2, q = 1.0f;
-                for (uint32_t a = 0; a < 8; a++) {
-                    const float c0 = rnd(P.pt_seed, p, s, b + 1, 3 * a) * 2.0f - 1.0f;
-                    const float c1 = rnd(P.pt_seed, p, s, b + 1, 3 * a + 1) * 2.0f - 1.0f;
-                    const float c2 = rnd(P.pt_seed, p, s, b + 1, 3 * a + 2) * 2.0f - 1.0f;
-                    const float qq = dot3(c0, c1, c2, c0, c1, c2);
-                    if (qq <= 1.0f && qq > 1e-12f) { u0 = c0; u1 = c1; u2 = c2; q = qq; break; }
-                }
-                const float ru = 1.0f / sqrtf(q);
-                float d0 = __builtin_fmaf(u0, ru, n0), d1 = __builtin_fmaf(u1, ru, n1), d2 = __builtin_fmaf(u2, ru, n2);
-                float qd = dot3(d0, d1, d2, d0, d1, d2);
-                if (!(qd > 1e-12f)) { d0 = n0; d1 = n1; d2 = n2; qd = dot3(n0, n1, n2, n0, n1, n2); }
-                const float rd = 1.0f / sqrtf(qd);
-                dx = d0 * rd; dy = d1 * rd; dz = d2 * rd;
-                const float off = margin * 4.0f;
-                px = __builtin_fmaf(n0, off, px); py = __builtin_fmaf(n1, off, py); pz = __builtin_fmaf(n2, off, pz);
-                T *= P.pt_albedo;
             }
+            if (shadow) {                                                    // Compute.hlsl:214-223
+                bool over = false;
+                if (!(it < 40 && prox > -margin)) {
+                    over = true;
+                } else if (prox > dist || (mx < 0.0f || my < 0.0f || mz < 0.0f) ||
+                           (mx > 1.0f || my > 1.0f || mz > 1.0f)) {
+                    // angle was computed with the unflipped normal; n is stored flipped
+                    const float e = T * (P.pt_albedo * (angle / (dist * dist) * P.k_strength));
+                    acc0 += e; acc1 += e; acc2 += e;
+                    over = true;
+                } else if (prox < margin) {
+                    float q0, q1, q2;
+                    gradient(c.cell(), mx, my, mz, q0, q1, q2);
+                    if (dot3(q0, q1, q2, ux, uy, uz) < 0.0f) over = true;
+                }
+                if (over) {
+                    steps += (uint32_t)it;
+                    shadow = false;
+                    bounce = true;
+                }
+            }
+            if (bounce) {
+                if (b == P.pt_bounces) {
+                    end_sample = true;
+                } else {                                                     // o_pixel_pt "diffuse bounce"
+                    float u0 = n0, u1 = n1, u2 = n2, q = 1.0f;
+                    for (uint32_t a = 0; a < 8; a++) {
+                        const float c0 = rnd(P.pt_seed, p, s, b + 1, 3 * a) * 2.0f - 1.0f;
+                        const float c1 = rnd(P.pt_seed, p, s, b + 1, 3 * a + 1) * 2.0f - 1.0f;
+                        const float c2 = rnd(P.pt_seed, p, s, b + 1, 3 * a + 2) * 2.0f - 1.0f;
+                        const float qq = dot3(c0, c1, c2, c0, c1, c2);
+                        if (qq <= 1.0f && qq > 1e-12f) { u0 = c0; u1 = c1; u2 = c2; q = qq; break; }
+                    }
+                    const float ru = 1.0f / sqrtf(q);
+                    float d0 = __builtin_fmaf(u0, ru, n0), d1 = __builtin_fmaf(u1, ru, n1), d2 = __builtin_fmaf(u2, ru, n2);
+                    float qd = dot3(d0, d1, d2, d0, d1, d2);
+                    if (!(qd > 1e-12f)) { d0 = n0; d1 = n1; d2 = n2; qd = dot3(n0, n1, n2, n0, n1, n2); }
+                    const float rd = 1.0f / sqrtf(qd);
+                    ux = d0 * rd; uy = d1 * rd; uz = d2 * rd;
+                    const float off = margin * 4.0f;
+                    mx = __builtin_fmaf(n0, off, hx); my = __builtin_fmaf(n1, off, hy); mz = __builtin_fmaf(n2, off, hz);
+                    T *= P.pt_albedo;
+                    b++;
+                    prox = 1.0f;
+                    it = 0;
+                    continue;                   // the new segment starts with its loop-header checks
+                }
+            }
+            if (end_sample) {
+                s++;
+                if (s == P.pt_spp) break;
+                c.reset(root);
+                mx = P.posx; my = P.posy; mz = P.posz;
+                ray_f(P, (float)x + rnd(P.pt_seed, p, s, 0, 0), (float)y + rnd(P.pt_seed, p, s, 0, 1), ux, uy, uz);
+                T = 1.0f; b = 0; prox = 1.0f; it = 0;
+                continue;
+            }
+            // ---- one march step of the segment or of the shadow ray -----------------------
+            uint32_t reads = find(c, P.nodes, P.n_nodes, stack, 64, mx, my, mz);
+            prox = interpol_world(c.cell(), mx, my, mz);
+            if (COUNT) { cn += reads; cs += 1; }
+            const float st = shadow ? prox + margin : prox;
+            mx = __builtin_fmaf(ux, st, mx);
+            my = __builtin_fmaf(uy, st, my);
+            mz = __builtin_fmaf(uz, st, mz);
+            it++;
         }
         const float inv = (float)P.pt_spp;
         P.out[(size_t)yl * P.width + x] = make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps);
