@@ -1,0 +1,574 @@
+// The ray-march kernels of libsdfhip.so (gfx950): k_plain, k_compact, k_path and the pieces
+// of Compute.hlsl's main() they are built from.  Device building blocks (cursors, find,
+// sampling): raymarch_device.h.  Host side (launches, C ABI): sdfhip_device.hip.
+//
+// Replaces: SdfBox/Shaders/Compute.hlsl:180-231 main() and, fused into the epilogue,
+// SdfBox/Shaders/DisplayFrag.hlsl:16-24.
+//
+// Kernel structure:
+//   * one lane per pixel, 8x8 pixels per 64-lane wavefront;
+//   * the primary march, the shading step and the shadow march of Compute.hlsl:194-230 run
+//     as ONE per-lane state machine around a single find + sample body, so lanes in
+//     different phases share the instruction stream instead of serialising two loops;
+//   * k_plain: one 8x8 wave tile per workgroup; blockIdx is remapped so that XCD k (own L2)
+//     renders tile rows k, k+8, ...: every XCD sees the same mix of sky and object rows
+//     (balance) while whole rows of neighbouring tiles share an L2;
+//   * k_compact: persistent waves pull 8x8 tiles from per-XCD queues and refill finished
+//     lanes by ballot + prefix count (wavefront ray compaction), with refill and shading
+//     batched;
+//   * k_path: the path-traced mode of BASELINE config 5 (defined by the oracle).
+#pragma once
+#include "raymarch_device.h"
+
+namespace sdfhip {
+
+constexpr int MAX_STACK = LM;          // the shader's own descent limit (Compute.hlsl:98)
+#ifndef COMPACT_WAVES_PER_SIMD
+#define COMPACT_WAVES_PER_SIMD 8
+#endif
+#ifndef PLAIN_WAVES_PER_SIMD
+#define PLAIN_WAVES_PER_SIMD 8          // <= 64 VGPRs: 8 waves per SIMD (2nd launch-bound = waves per SIMD)
+#endif
+
+template <bool STACK> struct CursorOf { typedef CursorG type; };
+template <> struct CursorOf<true> { typedef CursorS type; };
+
+// lane states: marching (primary / shadow), march over and shading pending, no pixel
+enum { PH_PRIMARY = 0, PH_SHADOW = 1, PH_SHADE = 2, PH_IDLE = 3, PH_DONE = 4 };   // DONE: idle, colour waiting in LDS
+
+struct RayState {
+    float px, py, pz;    // pos
+    float dx, dy, dz;    // dir (primary direction, then direction to the light)
+    float prox, angle, dist;
+    int i, j, phase;     // PH_*
+};
+
+__device__ __forceinline__ uint32_t global_row(const RenderParams &P, uint32_t yl)
+{
+    uint32_t band = yl / P.band_rows;
+    return (P.band_first + band * P.band_stride) * P.band_rows + (yl - band * P.band_rows);
+}
+
+template <class CursorT>
+__device__ __forceinline__ void start_pixel(const RenderParams &P, const NodeRec &root, uint32_t x,
+                                            uint32_t y, RayState &r, CursorT &c)
+{
+    // Compute.hlsl:182-191
+    r.px = P.posx; r.py = P.posy; r.pz = P.posz;
+    ray(P, x, y, r.dx, r.dy, r.dz);
+    r.prox = 1.0f;
+    r.angle = 0.0f; r.dist = 0.0f;
+    r.i = 0; r.j = 0; r.phase = PH_PRIMARY;
+    c.reset(root);
+}
+
+// ---- main() between two find() calls, in three pieces -------------------------
+// A finished pixel's colour (alpha = step count = r.i + r.j) is stored to *dst by the
+// piece that finishes it.  (Storing there instead of returning the colour keeps four
+// values out of the march loop's phi nodes.)
+
+// ---- fused display pass: SdfBox/Shaders/DisplayFrag.hlsl:16-24 --------------------------
+// float -> R8G8B8A8_UNorm as D3D11 converts render-target output: NaN -> 0, clamp to
+// [0, 1], scale by 255, round to nearest.
+__device__ __forceinline__ uint32_t to_unorm8(float c) { return (uint32_t)(sat(c) * 255.0f + 0.5f); }
+// `return pow(val, 1 / 2.2)` on one channel
+__device__ __forceinline__ uint32_t gamma8(float c) { return to_unorm8(powf(c, 1.0f / 2.2f)); }
+// alpha = step count: pow(n, 1/2.2) >= 1 for n >= 1, and pow(0, .) = 0
+__device__ __forceinline__ uint32_t alpha8(float steps) { return steps >= 1.0f ? 0xFF000000u : 0u; }
+// `return float4(1, 1, 1, 0) * val.w / 140` (debug heat map)
+__device__ __forceinline__ uint32_t heat8(float steps)
+{
+    uint32_t q = to_unorm8(steps / 140.0f);
+    return q | (q << 8) | (q << 16);
+}
+// any colour (used where colours come back from LDS in the compact kernel)
+__device__ __forceinline__ uint32_t display8(const float4 &v, uint32_t mode)
+{
+    if (mode == 2u) return heat8(v.w);
+    return gamma8(v.x) | (gamma8(v.y) << 8) | (gamma8(v.z) << 16) | alpha8(v.w);
+}
+
+// Where a finished pixel's colour goes: straight to the frame (plain kernel) -- as
+// RGBA32F, or through the display pass as RGBA8 -- or to the lane's LDS slot, to be
+// flushed at the next refill (compact kernel: on gfx950 a store counts on vmcnt like a
+// load, so a global store per finished pixel would stall the very next node load of
+// the whole wave behind the store's completion).  Every finished pixel is the sky
+// constant, black, or a grey level, which keeps the display pass to one pow.
+struct FrameSink {
+    float4 *p;            // RGBA32F pixel, or (as uint32_t *) the RGBA8 pixel
+    uint32_t mode, sky8;
+    __device__ __forceinline__ void sky(float steps) const
+    {
+        if (mode == 0u) *p = make_float4(0.005f, 0.01f, 0.2f, steps);
+        else *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : (sky8 | alpha8(steps));
+    }
+    __device__ __forceinline__ void grey(float a, float steps) const
+    {
+        if (mode == 0u) *p = make_float4(a, a, a, steps);
+        else {
+            uint32_t q = gamma8(a);
+            *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : (q | (q << 8) | (q << 16) | alpha8(steps));
+        }
+    }
+    __device__ __forceinline__ void black(float steps) const
+    {
+        if (mode == 0u) *p = make_float4(0.0f, 0.0f, 0.0f, steps);
+        else *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : alpha8(steps);
+    }
+};
+struct LdsSink {
+    float4 *slot;      // points into a __shared__ array (address space known after inlining)
+    __device__ __forceinline__ void sky(float steps) const { *slot = make_float4(0.005f, 0.01f, 0.2f, steps); }
+    __device__ __forceinline__ void grey(float a, float steps) const { *slot = make_float4(a, a, a, steps); }
+    __device__ __forceinline__ void black(float steps) const { *slot = make_float4(0.0f, 0.0f, 0.0f, steps); }
+};
+
+// Loop header + escape test of the primary march, Compute.hlsl:194-199.
+// 0: take a march step; 1: the march is over, shade next; 2: pixel finished (sky).
+template <class Sink>
+__device__ __forceinline__ int check_primary(const RenderParams &P, const RayState &r, const Sink &dst)
+{
+    if ((r.prox > P.margin * 2.0f || r.prox < 0.0f) && r.i < 100) {
+        if (dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > P.limit) {
+            dst.sky((float)r.i);
+            return 2;
+        }
+        return 0;
+    }
+    return 1;
+}
+
+// Compute.hlsl:205-213: turn towards the light, Lambert term from the gradient.
+// true: pixel finished (faces away).  Otherwise the lane enters the shadow march.
+template <class CursorT, class Sink>
+__device__ __forceinline__ bool shade(const RenderParams &P, RayState &r, const CursorT &c, const Sink &dst)
+{
+    float lx = P.lightx - r.px, ly = P.lighty - r.py, lz = P.lightz - r.pz;
+    float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+    r.dx = lx * rl; r.dy = ly * rl; r.dz = lz * rl;
+    r.px = __builtin_fmaf(r.dx, P.margin, r.px);
+    r.py = __builtin_fmaf(r.dy, P.margin, r.py);
+    r.pz = __builtin_fmaf(r.dz, P.margin, r.pz);
+    float gx, gy, gz;
+    gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
+    float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
+    r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
+    if (r.angle < 0.0f) {
+        dst.black((float)r.i);
+        return true;
+    }
+    lx = P.lightx - r.px; ly = P.lighty - r.py; lz = P.lightz - r.pz;
+    r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+    r.phase = PH_SHADOW;
+    r.j = 0;
+    return false;
+}
+
+// Loop header and the three exits of the shadow march, Compute.hlsl:214-223,229.
+// true: pixel finished.
+template <class CursorT, class Sink>
+__device__ __forceinline__ bool check_shadow(const RenderParams &P, const RayState &r, const CursorT &c, const Sink &dst)
+{
+    if (!(r.j < 40 && r.prox > -P.margin)) {
+        dst.black((float)(r.i + r.j));  // :229
+        return true;
+    }
+    if (r.prox > r.dist || (r.px < 0.0f || r.py < 0.0f || r.pz < 0.0f) ||
+        (r.px > 1.0f || r.py > 1.0f || r.pz > 1.0f)) {           // :215-219
+        float a = r.angle / (r.dist * r.dist) * P.k_strength;
+        dst.grey(a, (float)(r.i + r.j));
+        return true;
+    }
+    if (r.prox < P.margin) {                                       // :221-223
+        float gx, gy, gz;
+        gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
+        if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) {
+            dst.black((float)(r.i + r.j));
+            return true;
+        }
+    }
+    return false;
+}
+
+// The three pieces in program order: what one lane does between two march steps.
+template <class CursorT, class Sink>
+__device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, const CursorT &c, const Sink &dst)
+{
+    if (r.phase == PH_PRIMARY) {
+        int s = check_primary(P, r, dst);
+        if (s == 0) return false;
+        if (s == 2) return true;
+        if (shade(P, r, c, dst)) return true;
+    }
+    return check_shadow(P, r, c, dst);
+}
+
+// find + interpol_world + advance: Compute.hlsl:200-202 / :225-227
+template <class CursorT>
+__device__ __forceinline__ uint32_t march_step(const RenderParams &P, RayState &r, CursorT &c,
+                                               int32_t *stack, uint32_t stride)
+{
+    uint32_t reads = find(c, P.nodes, P.n_nodes, stack, stride, r.px, r.py, r.pz);
+    r.prox = interpol_world(c.cell(), r.px, r.py, r.pz);
+    float step = r.phase ? r.prox + P.margin : r.prox;
+    r.px = __builtin_fmaf(r.dx, step, r.px);
+    r.py = __builtin_fmaf(r.dy, step, r.py);
+    r.pz = __builtin_fmaf(r.dz, step, r.pz);
+    if (r.phase) r.j++; else r.i++;
+    return reads;
+}
+
+__device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned long long nodes,
+                                               unsigned long long samples, unsigned long long steps)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        nodes += __shfl_down(nodes, off);
+        samples += __shfl_down(samples, off);
+        steps += __shfl_down(steps, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&P.counters[0], nodes);
+        atomicAdd(&P.counters[1], samples);
+        atomicAdd(&P.counters[2], steps);
+    }
+}
+
+// ---- one lane per pixel; a workgroup of BT threads renders a 16 x (BT/16) tile (BT >= 128)
+// or one 8x8 wave tile (BT = 64) ------------------------------------------------
+template <bool STACK, bool COUNT, int BT>
+__global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams P)
+{
+    __shared__ int32_t stack_lds[STACK ? MAX_STACK * BT : 1];
+    constexpr uint32_t TW = BT >= 128 ? 16 : 8, TH = BT / 8 / (TW / 8);   // tile = TW x TH pixels
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give
+    // each of the 8 residue classes one contiguous run of tiles (bijective for
+    // any grid size).
+    const uint32_t nb = gridDim.x, bid = blockIdx.x;
+    uint32_t tile;
+    if (P.tile_order == 2) {          // one contiguous slab of tiles per XCD (load-imbalanced: kept for A/B runs)
+        const uint32_t q = nb >> 3, rem = nb & 7u, xcd = bid & 7u;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    } else if (P.tile_order == 1) {   // dispatch order = row-major tile order
+        tile = bid;
+    } else {                          // default: XCD k renders tile rows k, k+8, ... (grid padded to 8*ceil(tiles_y/8) rows)
+        const uint32_t xcd = bid & 7u, j = bid >> 3;           // j-th block of this XCD
+        const uint32_t r = j / P.tiles_x, cx = j - r * P.tiles_x;
+        const uint32_t row = r * 8 + xcd;
+        tile = row < P.tiles_y ? row * P.tiles_x + cx : 0xFFFFFFFFu;
+    }
+    if (tile >= P.n_tiles) return;
+    const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    constexpr uint32_t WX = TW / 8;                        // waves side by side in a tile
+    const uint32_t x = tx * TW + (wave % WX) * 8 + (lane & 7u);
+    const uint32_t yl = ty * TH + (wave / WX) * 8 + (lane >> 3);
+    unsigned long long cn = 0, cs = 0, ct = 0;
+    bool live = x < P.width && yl < P.nrows_out;
+    uint32_t y = 0;
+    if (live) { y = global_row(P, yl); live = y < P.height; }
+    if (live) {
+        RayState r;
+        typename CursorOf<STACK>::type c;
+        const NodeRec root = P.nodes[0];
+        start_pixel(P, root, x, y, r, c);
+        const size_t pidx = (size_t)yl * P.width + x;
+        const FrameSink dst{P.out_mode == 0u ? P.out + pidx : reinterpret_cast<float4 *>(reinterpret_cast<uint32_t *>(P.out) + pidx),
+                            P.out_mode, P.sky8};
+        while (!pre_step(P, r, c, dst)) {
+            uint32_t reads = march_step(P, r, c, stack_lds + tid, BT);
+            if (COUNT) { cn += reads; cs += 1; }
+        }
+        if (COUNT) ct = (unsigned long long)(r.i + r.j);
+    }
+    if (COUNT) flush_counters(P, cn, cs, ct);
+}
+
+// ---- persistent waves with lane refill and state batching (wavefront ray compaction) --
+// One wave per workgroup, as many workgroups as the chip holds.  Lane states:
+// PRIMARY / SHADOW (marching), SHADE (march over, shading pending), IDLE (no pixel).
+//   * refill: pixels are numbered in 8x8-tile order, p = tile*64 + (y&7)*8 + (x&7).  A wave
+//     owns the range [cur, end) of one tile at a time and hands the next pixels of it to its
+//     idle lanes: rank = number of idle lanes below me (ballot + mbcnt), lane gets pixel
+//     cur + rank.  Tiles come from 8 atomic queues, one per XCD label (blockIdx & 7): queue q
+//     holds tile rows q, q+8, ... (the plain kernel's mapping), and a wave whose queue is
+//     empty steals from the next ones.
+//   * batching: refill runs only once REFILL_MIN lanes are idle, shading only once SHADE_MIN
+//     lanes wait for it (or nothing else can run), so those long divergent blocks execute
+//     for many lanes at a time instead of once per straggler.
+// A pixel's result depends on its coordinates only, so the image is the plain kernel's
+// bit for bit.  Exit: every wave leaves once all queues are exhausted and its lanes idle.
+constexpr int REFILL_MIN = 12;
+constexpr int SHADE_MIN = 8;
+
+template <bool STACK, bool COUNT>
+__global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderParams P)
+{
+    __shared__ int32_t stack_lds[STACK ? MAX_STACK * 64 : 1];
+    __shared__ float4 out_lds[64];
+    const uint32_t lane = threadIdx.x;
+    const NodeRec root = P.nodes[0];
+    const LdsSink dst{&out_lds[lane]};
+    unsigned long long cn = 0, cs = 0, ct = 0;
+    RayState r;
+    typename CursorOf<STACK>::type c;
+    uint32_t pix = 0;           // x | yl << 16
+    uint32_t cur = 0, end = 0;  // wave-uniform: pixel range of the current tile
+    uint32_t q = blockIdx.x & 7u, tried = 0;   // wave-uniform: queue in use, queues found empty
+    bool more = true, first = true;   // wave-uniform
+    r.px = r.py = r.pz = r.dx = r.dy = r.dz = r.prox = r.angle = r.dist = 0.0f;
+    r.i = r.j = 0;
+    r.phase = PH_IDLE;
+    c.reset(root);
+    const uint32_t rows_q = (P.tiles_y + 7u) >> 3;         // tile rows per queue (upper bound)
+
+    for (;;) {
+        unsigned long long m_idle = __ballot(r.phase >= PH_IDLE);
+        int n_idle = __popcll(m_idle);
+        int n_shade = __popcll(__ballot(r.phase == PH_SHADE));
+        int n_march = 64 - n_idle - n_shade;
+        if (n_idle >= REFILL_MIN || (n_march == 0 && n_shade == 0)) {
+            // flush the colours of the pixels finished since the last refill: one batch of
+            // stores, whose completion the wave waits for once (behind start_pixel's work)
+            if (r.phase == PH_DONE) {
+                const size_t pidx = (size_t)(pix >> 16) * P.width + (pix & 0xFFFFu);
+                if (P.out_mode == 0u) P.out[pidx] = out_lds[lane];
+                else reinterpret_cast<uint32_t *>(P.out)[pidx] = display8(out_lds[lane], P.out_mode);
+                r.phase = PH_IDLE;
+            }
+            while (more && n_idle > 0) {
+                if (cur == end) {
+                    // first tile of a wave: its own index within its queue, no atomic (all
+                    // waves start together; thousands of simultaneous adds on one word
+                    // serialise at ~90 per microsecond).  Later tiles: the queue head, one
+                    // 128-byte line per queue, counts on from where the static ones end.
+                    uint32_t t = blockIdx.x >> 3;
+                    if (!first) {
+                        if (lane == 0) t = atomicAdd(P.queue + q * 32u, 1u);
+                        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + ((gridDim.x + 7u - q) >> 3);
+                    }
+                    first = false;
+                    const uint32_t trow = (t / P.tiles_x) * 8u + q;
+                    if (t >= rows_q * P.tiles_x || trow >= P.tiles_y) {   // this queue is empty: steal
+                        q = (q + 1u) & 7u;
+                        if (++tried >= 8u) more = false;
+                        continue;
+                    }
+                    cur = (trow * P.tiles_x + (t % P.tiles_x)) * 64u;
+                    end = cur + 64u;
+                }
+                uint32_t take = min((uint32_t)n_idle, end - cur);
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_idle >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m_idle, 0u));
+                if (r.phase >= PH_IDLE && rank < take) {
+                    uint32_t p = cur + rank, tile = p >> 6, qq = p & 63u;
+                    uint32_t x = (tile % P.tiles_x) * 8 + (qq & 7u);
+                    uint32_t yl = (tile / P.tiles_x) * 8 + (qq >> 3);
+                    if (x < P.width && yl < P.nrows_out) {
+                        uint32_t y = global_row(P, yl);
+                        if (y < P.height) {
+                            start_pixel(P, root, x, y, r, c);
+                            pix = x | (yl << 16);
+                        }
+                    }
+                }
+                cur += take;
+                m_idle = __ballot(r.phase >= PH_IDLE);
+                n_idle = __popcll(m_idle);
+            }
+            n_march = 64 - n_idle - n_shade;
+        }
+        if (n_march == 0 && n_shade == 0) {
+            if (!more) break;
+            continue;
+        }
+        if (n_shade >= SHADE_MIN || n_march == 0) {
+            if (r.phase == PH_SHADE) {
+                r.phase = PH_PRIMARY;
+                if (shade(P, r, c, dst)) {
+                    if (COUNT) ct += (unsigned long long)(r.i + r.j);
+                    r.phase = PH_DONE;
+                }
+            }
+        }
+        if (r.phase <= PH_SHADOW) {
+            bool done = false;
+            if (r.phase == PH_PRIMARY) {
+                int s = check_primary(P, r, dst);
+                if (s == 1) r.phase = PH_SHADE;
+                done = s == 2;
+            } else {
+                done = check_shadow(P, r, c, dst);
+            }
+            if (done) {
+                if (COUNT) ct += (unsigned long long)(r.i + r.j);
+                r.phase = PH_DONE;
+            } else if (r.phase <= PH_SHADOW) {
+                uint32_t reads = march_step(P, r, c, stack_lds + lane, 64);
+                if (COUNT) { cn += reads; cs += 1; }
+            }
+        }
+    }
+    if (COUNT) flush_counters(P, cn, cs, ct);
+}
+
+// ---- path-traced mode (BASELINE config 5) -----------------------------------------------
+// Not in the reference (README "plans" only); defined by o_pixel_pt in oracle/sdf_oracle.c:
+// per pixel spp samples, each a jittered camera ray followed by up to 1 + max_bounces
+// segments built from the reference's own pieces (primary march, shading, shadow march)
+// chained by cosine-weighted diffuse bounces; PCG-hash RNG; no transcendental function.
+// The oracle writes that as four nested loops.  After the first bounce every lane of a wave
+// is somewhere else in them, and nested loops would run one lane group at a time; here, as
+// in k_plain, a lane is a state machine -- MARCH (a segment's march) or SHADOW (its shadow
+// march) -- around ONE find + sample + advance body, so whatever phase the 64 lanes are in,
+// they share the instruction stream of the expensive part.  The arithmetic and its order per
+// pixel are the oracle's; only the control flow differs.  One lane per pixel, one 8x8 tile
+// per wave, the plain kernel's XCD-interleaved tile rows.
+template <bool STACK, bool COUNT>
+__global__ __launch_bounds__(64) void k_path(RenderParams P)
+{
+    __shared__ int32_t stack_lds[STACK ? MAX_STACK * 64 : 1];
+    const uint32_t bid = blockIdx.x, xcd = bid & 7u, jb = bid >> 3;
+    const uint32_t rr = jb / P.tiles_x, cxx = jb - rr * P.tiles_x, row = rr * 8 + xcd;
+    if (row >= P.tiles_y) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t x = cxx * 8 + (lane & 7u), yl = row * 8 + (lane >> 3);
+    unsigned long long cn = 0, cs = 0, ct = 0;
+    bool live = x < P.width && yl < P.nrows_out;
+    uint32_t y = 0;
+    if (live) { y = global_row(P, yl); live = y < P.height; }
+    if (live) {
+        typedef typename CursorOf<STACK>::type CursorT;
+        const NodeRec root = P.nodes[0];
+        const uint32_t p = y * P.width + x;
+        const float margin = P.margin;
+        int32_t *stack = stack_lds + lane;
+        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+        uint32_t steps = 0;
+        // lane state
+        CursorT c;
+        float mx, my, mz;        // the position being marched (segment, then shadow ray)
+        float ux, uy, uz;        // its direction (segment direction, then direction to the light)
+        float hx = 0, hy = 0, hz = 0;   // the hit point, kept while the shadow ray marches
+        float n0 = 0, n1 = 0, n2 = 0;   // the hit normal, facing the incoming ray
+        float T = 1.0f, prox = 1.0f, angle = 0.0f, dist = 0.0f;
+        uint32_t s = 0, b = 0;
+        int it = 0;              // i of the segment march, or j of the shadow march
+        bool shadow = false;
+
+        // start of sample s: reset cursor, jittered camera ray (o_pixel_pt's sample loop head)
+        c.reset(root);
+        mx = P.posx; my = P.posy; mz = P.posz;
+        ray_f(P, (float)x + rnd(P.pt_seed, p, 0, 0, 0), (float)y + rnd(P.pt_seed, p, 0, 0, 1), ux, uy, uz);
+
+        for (;;) {
+            // ---- everything between two march steps --------------------------------------
+            bool bounce = false, end_sample = false;
+            if (!shadow) {
+                if ((prox > margin * 2.0f || prox < 0.0f) && it < 100) {
+                    if (dot3(mx, my, mz, mx, my, mz) > P.limit) {            // escaped: sky
+                        steps += (uint32_t)it;
+                        acc0 = __builtin_fmaf(T, 0.005f, acc0); acc1 = __builtin_fmaf(T, 0.01f, acc1); acc2 = __builtin_fmaf(T, 0.2f, acc2);
+                        end_sample = true;
+                    }
+                } else {                                                     // hit: shade (Compute.hlsl:205-213)
+                    steps += (uint32_t)it;
+                    float lx = P.lightx - mx, ly = P.lighty - my, lz = P.lightz - mz;
+                    const float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+                    const float L0 = lx * rl, L1 = ly * rl, L2 = lz * rl;
+                    mx = __builtin_fmaf(L0, margin, mx); my = __builtin_fmaf(L1, margin, my); mz = __builtin_fmaf(L2, margin, mz);
+                    float g0, g1, g2;
+                    gradient(c.cell(), mx, my, mz, g0, g1, g2);
+                    const float rg = 1.0f / sqrtf(dot3(g0, g1, g2, g0, g1, g2));
+                    n0 = g0 * rg; n1 = g1 * rg; n2 = g2 * rg;
+                    angle = dot3(L0, L1, L2, n0, n1, n2);
+                    // the bounce needs the normal facing the incoming ray; decide now, while
+                    // the incoming direction is still in (ux, uy, uz)
+                    const bool flip = dot3(n0, n1, n2, ux, uy, uz) > 0.0f;
+                    hx = mx; hy = my; hz = mz;
+                    if (!(angle < 0.0f)) {
+                        lx = P.lightx - mx; ly = P.lighty - my; lz = P.lightz - mz;
+                        dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+                        ux = L0; uy = L1; uz = L2;
+                        shadow = true;
+                        it = 0;
+                    } else {
+                        bounce = true;
+                    }
+                    if (flip) { n0 = -n0; n1 = -n1; n2 = -n2; }
+                }
+            }
+            if (shadow) {                                                    // Compute.hlsl:214-223
+                bool over = false;
+                if (!(it < 40 && prox > -margin)) {
+                    over = true;
+                } else if (prox > dist || (mx < 0.0f || my < 0.0f || mz < 0.0f) ||
+                           (mx > 1.0f || my > 1.0f || mz > 1.0f)) {
+                    // angle was computed with the unflipped normal; n is stored flipped
+                    const float e = T * (P.pt_albedo * (angle / (dist * dist) * P.k_strength));
+                    acc0 += e; acc1 += e; acc2 += e;
+                    over = true;
+                } else if (prox < margin) {
+                    float q0, q1, q2;
+                    gradient(c.cell(), mx, my, mz, q0, q1, q2);
+                    if (dot3(q0, q1, q2, ux, uy, uz) < 0.0f) over = true;
+                }
+                if (over) {
+                    steps += (uint32_t)it;
+                    shadow = false;
+                    bounce = true;
+                }
+            }
+            if (bounce) {
+                if (b == P.pt_bounces) {
+                    end_sample = true;
+                } else {                                                     // o_pixel_pt "diffuse bounce"
+                    float u0 = n0, u1 = n1, u2 = n2, q = 1.0f;
+                    for (uint32_t a = 0; a < 8; a++) {
+                        const float c0 = rnd(P.pt_seed, p, s, b + 1, 3 * a) * 2.0f - 1.0f;
+                        const float c1 = rnd(P.pt_seed, p, s, b + 1, 3 * a + 1) * 2.0f - 1.0f;
+                        const float c2 = rnd(P.pt_seed, p, s, b + 1, 3 * a + 2) * 2.0f - 1.0f;
+                        const float qq = dot3(c0, c1, c2, c0, c1, c2);
+                        if (qq <= 1.0f && qq > 1e-12f) { u0 = c0; u1 = c1; u2 = c2; q = qq; break; }
+                    }
+                    const float ru = 1.0f / sqrtf(q);
+                    float d0 = __builtin_fmaf(u0, ru, n0), d1 = __builtin_fmaf(u1, ru, n1), d2 = __builtin_fmaf(u2, ru, n2);
+                    float qd = dot3(d0, d1, d2, d0, d1, d2);
+                    if (!(qd > 1e-12f)) { d0 = n0; d1 = n1; d2 = n2; qd = dot3(n0, n1, n2, n0, n1, n2); }
+                    const float rd = 1.0f / sqrtf(qd);
+                    ux = d0 * rd; uy = d1 * rd; uz = d2 * rd;
+                    const float off = margin * 4.0f;
+                    mx = __builtin_fmaf(n0, off, hx); my = __builtin_fmaf(n1, off, hy); mz = __builtin_fmaf(n2, off, hz);
+                    T *= P.pt_albedo;
+                    b++;
+                    prox = 1.0f;
+                    it = 0;
+                    continue;                   // the new segment starts with its loop-header checks
+                }
+            }
+            if (end_sample) {
+                s++;
+                if (s == P.pt_spp) break;
+                c.reset(root);
+                mx = P.posx; my = P.posy; mz = P.posz;
+                ray_f(P, (float)x + rnd(P.pt_seed, p, s, 0, 0), (float)y + rnd(P.pt_seed, p, s, 0, 1), ux, uy, uz);
+                T = 1.0f; b = 0; prox = 1.0f; it = 0;
+                continue;
+            }
+            // ---- one march step of the segment or of the shadow ray -----------------------
+            uint32_t reads = find(c, P.nodes, P.n_nodes, stack, 64, mx, my, mz);
+            prox = interpol_world(c.cell(), mx, my, mz);
+            if (COUNT) { cn += reads; cs += 1; }
+            const float st = shadow ? prox + margin : prox;
+            mx = __builtin_fmaf(ux, st, mx);
+            my = __builtin_fmaf(uy, st, my);
+            mz = __builtin_fmaf(uz, st, mz);
+            it++;
+        }
+        const float inv = (float)P.pt_spp;
+        P.out[(size_t)yl * P.width + x] = make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps);
+        if (COUNT) ct = steps;
+    }
+    if (COUNT) flush_counters(P, cn, cs, ct);
+}
+
+}  // namespace sdfhip
