@@ -81,7 +81,7 @@ def main():
     import torch.distributed as dist
 
     import sdfbox_amd as sb
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands
+    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
@@ -125,10 +125,14 @@ def main():
         raise SystemExit("--spp excludes --display and --compact")
 
     layout = BandLayout(H, world, args.band_rows)
-    # sharded: G frames share one gather; nbuf groups are in flight (so G*nbuf frames)
-    G = (args.gather_every if args.gather_every > 0 else 4) if sharded else 1
+    # sharded: G frames share one launch (grid.y = frame) and one gather; nbuf groups are in
+    # flight (so G*nbuf frames).  A rank's share is mostly the serial tail of its longest
+    # pixels: G frames in one grid share that tail
+    G = (args.gather_every if args.gather_every > 0 else min(8, max(4, world))) if sharded else 1
+    if pt is not None or compact:
+        G = 1 if not sharded else G            # those kernels render one frame per launch
     nbuf = args.frames_in_flight if args.frames_in_flight > 0 else 2
-    streams = [[torch.cuda.Stream() for _ in range(G)] for _ in range(nbuf)]   # one per frame in flight
+    streams = [torch.cuda.Stream() for _ in range(nbuf)]                       # one per group in flight
     main = torch.cuda.current_stream().cuda_stream
     rows_local = layout.rows_per_rank if sharded else H
     local = [torch.zeros((G, rows_local, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
@@ -150,6 +154,8 @@ def main():
     pending = [None] * nbuf
     ev = []                               # (start, end) HIP events around each timed launch
 
+    batched = sharded and pt is None and not compact     # one launch per group (else one per frame)
+
     def finish(slot):
         """Complete the gather issued from group buffer `slot`; rank 0 puts the rows of its G frames
         back in order."""
@@ -157,14 +163,11 @@ def main():
         if w is None:
             return
         if nccl:
-            last = streams[slot][G - 1]
-            with torch.cuda.stream(last):
-                w.wait()                              # the group's last stream waits for its gather
+            with torch.cuda.stream(streams[slot]):
+                w.wait()                              # the group's stream waits for its gather
                 if rank == 0:
                     deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout,
-                                 stream=last.cuda_stream, pixel_bytes=px_bytes, frames=G)
-            for s in streams[slot][:G - 1]:           # the group buffer is free again for all its streams
-                s.wait_stream(last)
+                                 stream=streams[slot].cuda_stream, pixel_bytes=px_bytes, frames=G)
         elif rank == 0:                               # gloo rehearsal: through host buffers
             gathered[slot].copy_(torch.stack(w).cuda())
             deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=main,
@@ -175,27 +178,36 @@ def main():
         slot = group % nbuf
         if within == 0:
             finish(slot)                              # the slot's previous group must be complete
-        s = streams[slot][within]                     # every frame of the group on its own stream
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(s)
-        render(local[slot][within], s.cuda_stream)
-        if timed:
-            e1.record(s)
-            ev.append((e0, e1))
-        if not sharded or not (within == G - 1 or last):
+        s = streams[slot]
+        group_ends = within == G - 1 or last
+        if batched:
+            if not group_ends:
+                return                                # the whole group is one launch, issued at its end
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+            render_bands_batch(scene, [cam] * (within + 1), W, layout, rank, local[slot].data_ptr(), flags=flags,
+                               stream=s.cuda_stream)
+            if timed:
+                e1.record(s)
+                ev.append((e0, e1, within + 1))
+        else:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+            render(local[slot][within], s.cuda_stream)
+            if timed:
+                e1.record(s)
+                ev.append((e0, e1, 1))
+        if not sharded or not group_ends:
             return
-        # one collective for the whole group (a partial last group is gathered whole, too),
-        # ordered behind all of the group's renders
-        tail = streams[slot][G - 1]
-        for o in streams[slot][:G - 1]:
-            tail.wait_stream(o)
+        # one collective for the whole group (a partial last group is gathered whole, too)
         if nccl:
             glist = list(gathered[slot].unbind(0)) if rank == 0 else None
-            with torch.cuda.stream(tail):
+            with torch.cuda.stream(s):                # the collective orders itself behind this stream's renders
                 pending[slot] = dist.gather(local[slot], glist, dst=0, async_op=True)
         else:
-            tail.synchronize()
+            s.synchronize()
             host = local[slot].cpu()
             glist = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
             dist.gather(host, glist, dst=0)
@@ -240,7 +252,8 @@ def main():
         counters = c.cpu()
     # average duration of the ray-march launch over the timed region (HIP events on the
     # stream each launch went to; with frames in flight the launches overlap each other)
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+    frames_per_launch = float(np.mean([n for _, _, n in ev]))
 
     check_ok = None
     if args.check and sharded and rank == 0:
@@ -258,7 +271,7 @@ def main():
     if rank == 0:
         sec_per_step = elapsed / args.steps
         peak = 8000.0                                  # GB/s, HBM3E spec (MI355X_MICROARCH.md)
-        achieved = alg_bytes_rank / (kernel_ms * 1e-3) / 1e9
+        achieved = alg_bytes_rank * frames_per_launch / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "Mray/s (primary rays; frame W*H / time per frame)",
             "value": round(W * H * max(1, args.spp) / sec_per_step / 1e6, 2),
@@ -294,7 +307,8 @@ def main():
                 "frac": round(achieved / peak, 4),
                 "traffic": None if (args.display or pt is not None) else load_traffic(W, H, scene_name, world),
                 "kernel_ms": round(kernel_ms, 4),
-                "algorithmic_bytes_per_launch": int(alg_bytes_rank),
+                "algorithmic_bytes_per_launch": int(alg_bytes_rank * frames_per_launch),
+                "frames_per_launch": frames_per_launch,
             },
         }
         if check_ok is not None:

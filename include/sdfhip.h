@@ -250,6 +250,18 @@ SDFHIP_API int sdfhip_render_display(sdfhip_scene *scene, const sdfhip_info *inf
                                      uint32_t width, uint32_t height, uint32_t flags, int debug,
                                      uint8_t *rgba8_out, sdfhip_stats *stats);
 
+/* Several frames in one launch: infos[0..n_frames-1] (n_frames <= 8) are rendered into
+ * d_rgba_out[f * nrows_out * width ...], each with its own camera block; same band
+ * arguments as sdfhip_render_device.  For sharded rendering, where one rank's share of a
+ * frame is little work behind the serial tail of its longest pixels: the frames of a
+ * gather group share that tail.  Plain kernel only (no COMPACT / COUNT flags). */
+SDFHIP_API int sdfhip_render_batch_device(sdfhip_scene *scene, const sdfhip_info *infos,
+                                          uint32_t n_frames, uint32_t width, uint32_t height,
+                                          uint32_t band_rows, uint32_t band_first,
+                                          uint32_t band_stride, uint32_t nrows_out,
+                                          uint32_t flags, float *d_rgba_out, void *stream,
+                                          sdfhip_stats *stats);
+
 /* Rank-0 helper for the tile gather: scatter `world` compact band buffers back into
  * row order.  One gather may carry several frames (fewer, larger messages):
  * d_gathered is [world][frames][rows_per_rank][width] pixels, d_frame is

@@ -31,7 +31,17 @@ namespace sdfhip {
 typedef uint4 NodeRec;
 
 
-// Kernel parameters: the Info block unpacked (Logic.cs:407-420) + frame geometry.
+// The camera part of the Info block, unpacked (Logic.cs:407-420).
+struct FrameInfo {
+    float h0x, h0y, h0z, h1x, h1y, h1z, h2x, h2y, h2z;  // heading rows
+    float posx, posy, posz, margin;
+    float screen_w, screen_h, limit;
+    float lightx, lighty, lightz;
+    float fov, k_strength;     // k_strength = exp2f(strength) - 1, evaluated on the host
+};
+constexpr int MAX_BATCH = 8;   // frames one k_plain launch can render (grid.y)
+
+// Kernel parameters: scene, frame geometry, and the camera block of every frame of the launch.
 struct RenderParams {
     const NodeRec *nodes;
     uint32_t n_nodes;
@@ -39,11 +49,13 @@ struct RenderParams {
     uint32_t width, height;    // full frame
     uint32_t band_rows, band_first, band_stride, nrows_out;
     uint32_t tiles_x, tiles_y, n_tiles;   // 8x8 (compact) or 16x16 (plain) tiles of the local rows
-    float h0x, h0y, h0z, h1x, h1y, h1z, h2x, h2y, h2z;  // heading rows
-    float posx, posy, posz, margin;
-    float screen_w, screen_h, limit;
-    float lightx, lighty, lightz;
-    float fov, k_strength;     // k_strength = exp2f(strength) - 1, evaluated on the host
+    // frames[f]: camera of frame f of a batched launch (k_plain: f = blockIdx.y, output at
+    // out + f * nrows_out * width pixels; the other kernels render frames[0] only).  A rank's
+    // share of a sharded frame is mostly the serial tail of its longest pixels; several frames
+    // in one grid share that tail.  The kernels read these through a const reference into the
+    // kernel-argument segment (scalar loads), never through a modified copy.
+    uint32_t n_frames;
+    FrameInfo frames[MAX_BATCH];
     unsigned long long *counters;  // [0] nodes [1] samples [2] steps (COUNT builds)
     uint32_t *queue;           // tile queue head (compact kernels)
     uint32_t tile_order;       // k_plain: blockIdx -> tile mapping (tuning knob, flags bits 8..11)
@@ -357,15 +369,15 @@ __device__ __forceinline__ void gradient(const Cell &c, float px, float py, floa
 }
 
 // ray, Compute.hlsl:163-168
-__device__ __forceinline__ void ray(const RenderParams &P, uint32_t cx, uint32_t cy, float &dx,
+__device__ __forceinline__ void ray(const FrameInfo &I, uint32_t cx, uint32_t cy, float &dx,
                                     float &dy, float &dz)
 {
-    float sx = (float)cx / P.screen_h - P.screen_w / P.screen_h * 0.5f;
-    float sy = (float)cy / P.screen_h - 0.5f;
-    float vx = sx * P.fov, vy = sy * P.fov, vz = 0.5f;
-    float d0 = dot3(vx, vy, vz, P.h0x, P.h0y, P.h0z);
-    float d1 = dot3(vx, vy, vz, P.h1x, P.h1y, P.h1z);
-    float d2 = dot3(vx, vy, vz, P.h2x, P.h2y, P.h2z);
+    float sx = (float)cx / I.screen_h - I.screen_w / I.screen_h * 0.5f;
+    float sy = (float)cy / I.screen_h - 0.5f;
+    float vx = sx * I.fov, vy = sy * I.fov, vz = 0.5f;
+    float d0 = dot3(vx, vy, vz, I.h0x, I.h0y, I.h0z);
+    float d1 = dot3(vx, vy, vz, I.h1x, I.h1y, I.h1z);
+    float d2 = dot3(vx, vy, vz, I.h2x, I.h2y, I.h2z);
     float rl = 1.0f / sqrtf(dot3(d0, d1, d2, d0, d1, d2));
     dx = d0 * rl;
     dy = d1 * rl;
@@ -386,14 +398,14 @@ __device__ __forceinline__ float rnd(uint32_t seed, uint32_t p, uint32_t s, uint
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 // ray() through a fractional pixel coordinate
-__device__ __forceinline__ void ray_f(const RenderParams &P, float fx, float fy, float &dx, float &dy, float &dz)
+__device__ __forceinline__ void ray_f(const FrameInfo &I, float fx, float fy, float &dx, float &dy, float &dz)
 {
-    float sx = fx / P.screen_h - P.screen_w / P.screen_h * 0.5f;
-    float sy = fy / P.screen_h - 0.5f;
-    float vx = sx * P.fov, vy = sy * P.fov, vz = 0.5f;
-    float d0 = dot3(vx, vy, vz, P.h0x, P.h0y, P.h0z);
-    float d1 = dot3(vx, vy, vz, P.h1x, P.h1y, P.h1z);
-    float d2 = dot3(vx, vy, vz, P.h2x, P.h2y, P.h2z);
+    float sx = fx / I.screen_h - I.screen_w / I.screen_h * 0.5f;
+    float sy = fy / I.screen_h - 0.5f;
+    float vx = sx * I.fov, vy = sy * I.fov, vz = 0.5f;
+    float d0 = dot3(vx, vy, vz, I.h0x, I.h0y, I.h0z);
+    float d1 = dot3(vx, vy, vz, I.h1x, I.h1y, I.h1z);
+    float d2 = dot3(vx, vy, vz, I.h2x, I.h2y, I.h2z);
     float rl = 1.0f / sqrtf(dot3(d0, d1, d2, d0, d1, d2));
     dx = d0 * rl;
     dy = d1 * rl;

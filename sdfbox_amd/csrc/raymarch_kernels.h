@@ -50,12 +50,12 @@ __device__ __forceinline__ uint32_t global_row(const RenderParams &P, uint32_t y
 }
 
 template <class CursorT>
-__device__ __forceinline__ void start_pixel(const RenderParams &P, const NodeRec &root, uint32_t x,
+__device__ __forceinline__ void start_pixel(const FrameInfo &I, const NodeRec &root, uint32_t x,
                                             uint32_t y, RayState &r, CursorT &c)
 {
     // Compute.hlsl:182-191
-    r.px = P.posx; r.py = P.posy; r.pz = P.posz;
-    ray(P, x, y, r.dx, r.dy, r.dz);
+    r.px = I.posx; r.py = I.posy; r.pz = I.posz;
+    ray(I, x, y, r.dx, r.dy, r.dz);
     r.prox = 1.0f;
     r.angle = 0.0f; r.dist = 0.0f;
     r.i = 0; r.j = 0; r.phase = PH_PRIMARY;
@@ -126,10 +126,10 @@ struct LdsSink {
 // Loop header + escape test of the primary march, Compute.hlsl:194-199.
 // 0: take a march step; 1: the march is over, shade next; 2: pixel finished (sky).
 template <class Sink>
-__device__ __forceinline__ int check_primary(const RenderParams &P, const RayState &r, const Sink &dst)
+__device__ __forceinline__ int check_primary(const FrameInfo &I, const RayState &r, const Sink &dst)
 {
-    if ((r.prox > P.margin * 2.0f || r.prox < 0.0f) && r.i < 100) {
-        if (dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > P.limit) {
+    if ((r.prox > I.margin * 2.0f || r.prox < 0.0f) && r.i < 100) {
+        if (dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit) {
             dst.sky((float)r.i);
             return 2;
         }
@@ -141,14 +141,14 @@ __device__ __forceinline__ int check_primary(const RenderParams &P, const RaySta
 // Compute.hlsl:205-213: turn towards the light, Lambert term from the gradient.
 // true: pixel finished (faces away).  Otherwise the lane enters the shadow march.
 template <class CursorT, class Sink>
-__device__ __forceinline__ bool shade(const RenderParams &P, RayState &r, const CursorT &c, const Sink &dst)
+__device__ __forceinline__ bool shade(const FrameInfo &I, RayState &r, const CursorT &c, const Sink &dst)
 {
-    float lx = P.lightx - r.px, ly = P.lighty - r.py, lz = P.lightz - r.pz;
+    float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;
     float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
     r.dx = lx * rl; r.dy = ly * rl; r.dz = lz * rl;
-    r.px = __builtin_fmaf(r.dx, P.margin, r.px);
-    r.py = __builtin_fmaf(r.dy, P.margin, r.py);
-    r.pz = __builtin_fmaf(r.dz, P.margin, r.pz);
+    r.px = __builtin_fmaf(r.dx, I.margin, r.px);
+    r.py = __builtin_fmaf(r.dy, I.margin, r.py);
+    r.pz = __builtin_fmaf(r.dz, I.margin, r.pz);
     float gx, gy, gz;
     gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
     float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
@@ -157,7 +157,7 @@ __device__ __forceinline__ bool shade(const RenderParams &P, RayState &r, const 
         dst.black((float)r.i);
         return true;
     }
-    lx = P.lightx - r.px; ly = P.lighty - r.py; lz = P.lightz - r.pz;
+    lx = I.lightx - r.px; ly = I.lighty - r.py; lz = I.lightz - r.pz;
     r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
     r.phase = PH_SHADOW;
     r.j = 0;
@@ -167,19 +167,19 @@ __device__ __forceinline__ bool shade(const RenderParams &P, RayState &r, const 
 // Loop header and the three exits of the shadow march, Compute.hlsl:214-223,229.
 // true: pixel finished.
 template <class CursorT, class Sink>
-__device__ __forceinline__ bool check_shadow(const RenderParams &P, const RayState &r, const CursorT &c, const Sink &dst)
+__device__ __forceinline__ bool check_shadow(const FrameInfo &I, const RayState &r, const CursorT &c, const Sink &dst)
 {
-    if (!(r.j < 40 && r.prox > -P.margin)) {
+    if (!(r.j < 40 && r.prox > -I.margin)) {
         dst.black((float)(r.i + r.j));  // :229
         return true;
     }
     if (r.prox > r.dist || (r.px < 0.0f || r.py < 0.0f || r.pz < 0.0f) ||
         (r.px > 1.0f || r.py > 1.0f || r.pz > 1.0f)) {           // :215-219
-        float a = r.angle / (r.dist * r.dist) * P.k_strength;
+        float a = r.angle / (r.dist * r.dist) * I.k_strength;
         dst.grey(a, (float)(r.i + r.j));
         return true;
     }
-    if (r.prox < P.margin) {                                       // :221-223
+    if (r.prox < I.margin) {                                       // :221-223
         float gx, gy, gz;
         gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
         if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) {
@@ -192,25 +192,25 @@ __device__ __forceinline__ bool check_shadow(const RenderParams &P, const RaySta
 
 // The three pieces in program order: what one lane does between two march steps.
 template <class CursorT, class Sink>
-__device__ __forceinline__ bool pre_step(const RenderParams &P, RayState &r, const CursorT &c, const Sink &dst)
+__device__ __forceinline__ bool pre_step(const FrameInfo &I, RayState &r, const CursorT &c, const Sink &dst)
 {
     if (r.phase == PH_PRIMARY) {
-        int s = check_primary(P, r, dst);
+        int s = check_primary(I, r, dst);
         if (s == 0) return false;
         if (s == 2) return true;
-        if (shade(P, r, c, dst)) return true;
+        if (shade(I, r, c, dst)) return true;
     }
-    return check_shadow(P, r, c, dst);
+    return check_shadow(I, r, c, dst);
 }
 
 // find + interpol_world + advance: Compute.hlsl:200-202 / :225-227
 template <class CursorT>
-__device__ __forceinline__ uint32_t march_step(const RenderParams &P, RayState &r, CursorT &c,
+__device__ __forceinline__ uint32_t march_step(const RenderParams &P, const FrameInfo &I, RayState &r, CursorT &c,
                                                int32_t *stack, uint32_t stride)
 {
     uint32_t reads = find(c, P.nodes, P.n_nodes, stack, stride, r.px, r.py, r.pz);
     r.prox = interpol_world(c.cell(), r.px, r.py, r.pz);
-    float step = r.phase ? r.prox + P.margin : r.prox;
+    float step = r.phase ? r.prox + I.margin : r.prox;
     r.px = __builtin_fmaf(r.dx, step, r.px);
     r.py = __builtin_fmaf(r.dy, step, r.py);
     r.pz = __builtin_fmaf(r.dz, step, r.pz);
@@ -238,6 +238,7 @@ __device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned l
 template <bool STACK, bool COUNT, int BT>
 __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams P)
 {
+    const FrameInfo &I = P.frames[blockIdx.y];       // batched launch: one frame per grid.y
     __shared__ int32_t stack_lds[STACK ? MAX_STACK * BT : 1];
     constexpr uint32_t TW = BT >= 128 ? 16 : 8, TH = BT / 8 / (TW / 8);   // tile = TW x TH pixels
     // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give
@@ -270,12 +271,12 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
         RayState r;
         typename CursorOf<STACK>::type c;
         const NodeRec root = P.nodes[0];
-        start_pixel(P, root, x, y, r, c);
-        const size_t pidx = (size_t)yl * P.width + x;
+        start_pixel(I, root, x, y, r, c);
+        const size_t pidx = ((size_t)blockIdx.y * P.nrows_out + yl) * P.width + x;
         const FrameSink dst{P.out_mode == 0u ? P.out + pidx : reinterpret_cast<float4 *>(reinterpret_cast<uint32_t *>(P.out) + pidx),
                             P.out_mode, P.sky8};
-        while (!pre_step(P, r, c, dst)) {
-            uint32_t reads = march_step(P, r, c, stack_lds + tid, BT);
+        while (!pre_step(I, r, c, dst)) {
+            uint32_t reads = march_step(P, I, r, c, stack_lds + tid, BT);
             if (COUNT) { cn += reads; cs += 1; }
         }
         if (COUNT) ct = (unsigned long long)(r.i + r.j);
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
     __shared__ int32_t stack_lds[STACK ? MAX_STACK * 64 : 1];
     __shared__ float4 out_lds[64];
     const uint32_t lane = threadIdx.x;
+    const FrameInfo &I = P.frames[0];
     const NodeRec root = P.nodes[0];
     const LdsSink dst{&out_lds[lane]};
     unsigned long long cn = 0, cs = 0, ct = 0;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
                     if (x < P.width && yl < P.nrows_out) {
                         uint32_t y = global_row(P, yl);
                         if (y < P.height) {
-                            start_pixel(P, root, x, y, r, c);
+                            start_pixel(I, root, x, y, r, c);
                             pix = x | (yl << 16);
                         }
                     }
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
         if (n_shade >= SHADE_MIN || n_march == 0) {
             if (r.phase == PH_SHADE) {
                 r.phase = PH_PRIMARY;
-                if (shade(P, r, c, dst)) {
+                if (shade(I, r, c, dst)) {
                     if (COUNT) ct += (unsigned long long)(r.i + r.j);
                     r.phase = PH_DONE;
                 }
@@ -393,17 +395,17 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
         if (r.phase <= PH_SHADOW) {
             bool done = false;
             if (r.phase == PH_PRIMARY) {
-                int s = check_primary(P, r, dst);
+                int s = check_primary(I, r, dst);
                 if (s == 1) r.phase = PH_SHADE;
                 done = s == 2;
             } else {
-                done = check_shadow(P, r, c, dst);
+                done = check_shadow(I, r, c, dst);
             }
             if (done) {
                 if (COUNT) ct += (unsigned long long)(r.i + r.j);
                 r.phase = PH_DONE;
             } else if (r.phase <= PH_SHADOW) {
-                uint32_t reads = march_step(P, r, c, stack_lds + lane, 64);
+                uint32_t reads = march_step(P, I, r, c, stack_lds + lane, 64);
                 if (COUNT) { cn += reads; cs += 1; }
             }
         }
@@ -438,9 +440,10 @@ __global__ __launch_bounds__(64) void k_path(RenderParams P)
     if (live) { y = global_row(P, yl); live = y < P.height; }
     if (live) {
         typedef typename CursorOf<STACK>::type CursorT;
+        const FrameInfo &I = P.frames[0];
         const NodeRec root = P.nodes[0];
         const uint32_t p = y * P.width + x;
-        const float margin = P.margin;
+        const float margin = I.margin;
         int32_t *stack = stack_lds + lane;
         float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
         uint32_t steps = 0;
@@ -457,22 +460,22 @@ __global__ __launch_bounds__(64) void k_path(RenderParams P)
 
         // start of sample s: reset cursor, jittered camera ray (o_pixel_pt's sample loop head)
         c.reset(root);
-        mx = P.posx; my = P.posy; mz = P.posz;
-        ray_f(P, (float)x + rnd(P.pt_seed, p, 0, 0, 0), (float)y + rnd(P.pt_seed, p, 0, 0, 1), ux, uy, uz);
+        mx = I.posx; my = I.posy; mz = I.posz;
+        ray_f(I, (float)x + rnd(P.pt_seed, p, 0, 0, 0), (float)y + rnd(P.pt_seed, p, 0, 0, 1), ux, uy, uz);
 
         for (;;) {
             // ---- everything between two march steps --------------------------------------
             bool bounce = false, end_sample = false;
             if (!shadow) {
                 if ((prox > margin * 2.0f || prox < 0.0f) && it < 100) {
-                    if (dot3(mx, my, mz, mx, my, mz) > P.limit) {            // escaped: sky
+                    if (dot3(mx, my, mz, mx, my, mz) > I.limit) {            // escaped: sky
                         steps += (uint32_t)it;
                         acc0 = __builtin_fmaf(T, 0.005f, acc0); acc1 = __builtin_fmaf(T, 0.01f, acc1); acc2 = __builtin_fmaf(T, 0.2f, acc2);
                         end_sample = true;
                     }
                 } else {                                                     // hit: shade (Compute.hlsl:205-213)
                     steps += (uint32_t)it;
-                    float lx = P.lightx - mx, ly = P.lighty - my, lz = P.lightz - mz;
+                    float lx = I.lightx - mx, ly = I.lighty - my, lz = I.lightz - mz;
                     const float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
                     const float L0 = lx * rl, L1 = ly * rl, L2 = lz * rl;
                     mx = __builtin_fmaf(L0, margin, mx); my = __builtin_fmaf(L1, margin, my); mz = __builtin_fmaf(L2, margin, mz);
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(64) void k_path(RenderParams P)
                     const bool flip = dot3(n0, n1, n2, ux, uy, uz) > 0.0f;
                     hx = mx; hy = my; hz = mz;
                     if (!(angle < 0.0f)) {
-                        lx = P.lightx - mx; ly = P.lighty - my; lz = P.lightz - mz;
+                        lx = I.lightx - mx; ly = I.lighty - my; lz = I.lightz - mz;
                         dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
                         ux = L0; uy = L1; uz = L2;
                         shadow = true;
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(64) void k_path(RenderParams P)
                 } else if (prox > dist || (mx < 0.0f || my < 0.0f || mz < 0.0f) ||
                            (mx > 1.0f || my > 1.0f || mz > 1.0f)) {
                     // angle was computed with the unflipped normal; n is stored flipped
-                    const float e = T * (P.pt_albedo * (angle / (dist * dist) * P.k_strength));
+                    const float e = T * (P.pt_albedo * (angle / (dist * dist) * I.k_strength));
                     acc0 += e; acc1 += e; acc2 += e;
                     over = true;
                 } else if (prox < margin) {
@@ -549,8 +552,8 @@ __global__ __launch_bounds__(64) void k_path(RenderParams P)
                 s++;
                 if (s == P.pt_spp) break;
                 c.reset(root);
-                mx = P.posx; my = P.posy; mz = P.posz;
-                ray_f(P, (float)x + rnd(P.pt_seed, p, s, 0, 0), (float)y + rnd(P.pt_seed, p, s, 0, 1), ux, uy, uz);
+                mx = I.posx; my = I.posy; mz = I.posz;
+                ray_f(I, (float)x + rnd(P.pt_seed, p, s, 0, 0), (float)y + rnd(P.pt_seed, p, s, 0, 1), ux, uy, uz);
                 T = 1.0f; b = 0; prox = 1.0f; it = 0;
                 continue;
             }

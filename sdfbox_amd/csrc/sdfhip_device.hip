@@ -211,8 +211,11 @@ void launch_pair(bool compact, int bt, dim3 grid, hipStream_t st, const RenderPa
 int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32_t height,
                 uint32_t band_rows, uint32_t band_first, uint32_t band_stride, uint32_t nrows_out,
                 uint32_t flags, float *d_out, hipStream_t st, sdfhip_stats *stats,
-                const sdfhip_pathtrace *pt = nullptr)
+                const sdfhip_pathtrace *pt = nullptr, uint32_t n_frames = 1)
 {
+    // `info` points at n_frames consecutive Info blocks (batched launch: plain kernel only)
+    if (n_frames == 0 || n_frames > (uint32_t)MAX_BATCH)
+        return fail(SDFHIP_ERR_ARG, "render: n_frames %u outside 1..%d", n_frames, MAX_BATCH);
     if (width == 0 || height == 0 || nrows_out == 0 || band_rows == 0 || band_stride == 0)
         return fail(SDFHIP_ERR_ARG, "render: zero-sized frame or band");
     if ((uint64_t)width * nrows_out > 0x7FFFFFFFull)
@@ -246,16 +249,23 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     P.tiles_x = (width + tile_w - 1) / tile_w;
     P.tiles_y = (nrows_out + tile_h - 1) / tile_h;
     P.n_tiles = P.tiles_x * P.tiles_y;
-    P.h0x = info->heading[0][0]; P.h0y = info->heading[0][1]; P.h0z = info->heading[0][2];
-    P.h1x = info->heading[1][0]; P.h1y = info->heading[1][1]; P.h1z = info->heading[1][2];
-    P.h2x = info->heading[2][0]; P.h2y = info->heading[2][1]; P.h2z = info->heading[2][2];
-    P.posx = info->position[0]; P.posy = info->position[1]; P.posz = info->position[2];
-    P.margin = info->margin;
-    P.screen_w = info->screen_size[0]; P.screen_h = info->screen_size[1];
-    P.limit = info->limit;
-    P.lightx = info->light[0]; P.lighty = info->light[1]; P.lightz = info->light[2];
-    P.fov = info->fov;
-    P.k_strength = exp2f(info->strength) - 1.0f;   // Compute.hlsl:216, once per frame
+    auto unpack = [](const sdfhip_info *in, FrameInfo &I) {
+        I.h0x = in->heading[0][0]; I.h0y = in->heading[0][1]; I.h0z = in->heading[0][2];
+        I.h1x = in->heading[1][0]; I.h1y = in->heading[1][1]; I.h1z = in->heading[1][2];
+        I.h2x = in->heading[2][0]; I.h2y = in->heading[2][1]; I.h2z = in->heading[2][2];
+        I.posx = in->position[0]; I.posy = in->position[1]; I.posz = in->position[2];
+        I.margin = in->margin;
+        I.screen_w = in->screen_size[0]; I.screen_h = in->screen_size[1];
+        I.limit = in->limit;
+        I.lightx = in->light[0]; I.lighty = in->light[1]; I.lightz = in->light[2];
+        I.fov = in->fov;
+        I.k_strength = exp2f(in->strength) - 1.0f;   // Compute.hlsl:216, once per frame
+    };
+    P.n_frames = n_frames;
+    memset(P.frames, 0, sizeof P.frames);
+    for (uint32_t f = 0; f < n_frames; f++) unpack(info + f, P.frames[f]);
+    if (n_frames > 1 && (compact || pt || count))
+        return fail(SDFHIP_ERR_ARG, "render_batch: only the plain kernel, without counting, renders several frames per launch");
     P.out_mode = out_mode;
     {   // the sky constant of Compute.hlsl:196 through DisplayFrag.hlsl:24, alpha excluded
         auto q = [](float c) { float v = powf(c, 1.0f / 2.2f); v = v > 1.0f ? 1.0f : (v > 0.0f ? v : 0.0f); return (uint32_t)(v * 255.0f + 0.5f); };
@@ -273,7 +283,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         uint32_t blocks = (uint32_t)s->cu_count * 32u;   // one wave per workgroup, 32 waves per CU
         grid = dim3(blocks < P.n_tiles ? blocks : (P.n_tiles ? P.n_tiles : 1));
     } else {
-        grid = dim3(P.tile_order == 0 ? 8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x : P.n_tiles);
+        grid = dim3(P.tile_order == 0 ? 8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x : P.n_tiles, n_frames);
     }
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     if (pt) {
@@ -315,6 +325,19 @@ extern "C" int sdfhip_render_device(sdfhip_scene *s, const sdfhip_info *info, ui
     hipStream_t st = (hipStream_t)stream;   // NULL = the HIP default stream, as everywhere in HIP
     return render_impl(s, info, width, height, band_rows, band_first, band_stride, nrows_out, flags,
                        d_rgba_out, st, stats);
+}
+
+extern "C" int sdfhip_render_batch_device(sdfhip_scene *s, const sdfhip_info *infos, uint32_t n_frames,
+                                          uint32_t width, uint32_t height, uint32_t band_rows,
+                                          uint32_t band_first, uint32_t band_stride, uint32_t nrows_out,
+                                          uint32_t flags, float *d_rgba_out, void *stream, sdfhip_stats *stats)
+{
+    if (!s || !infos || !d_rgba_out) return fail(SDFHIP_ERR_ARG, "render_batch_device: null argument");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render_batch_device: hipSetDevice(%d) failed", s->device);
+    return render_impl(s, infos, width, height, band_rows, band_first, band_stride, nrows_out, flags,
+                       d_rgba_out, (hipStream_t)stream, stats, nullptr, n_frames);
 }
 
 extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t width,

@@ -52,6 +52,20 @@ class Scene:
                                 out.ctypes.data, ctypes.byref(st) if want_stats else None))
         return (out, st) if want_stats else out
 
+    def DrawBatchDevice(self, states, width, height, out_ptr, nrows_out=None, band_rows=None,
+                        band_first=0, band_stride=1, flags=_lib.KERNEL_AUTO, stream=None, stats=None):
+        """Several frames (<= 8 cameras) in one launch into out_ptr[f][nrows_out][width] pixels."""
+        infos = (Info * len(states))(*[s if isinstance(s, Info) else s.State for s in states])
+        if nrows_out is None:
+            nrows_out = height
+        if band_rows is None:
+            band_rows = height
+        check(lib.sdfhip_render_batch_device(self._h, infos, len(states), int(width), int(height),
+                                             int(band_rows), int(band_first), int(band_stride),
+                                             int(nrows_out), int(flags), ctypes.c_void_p(int(out_ptr)),
+                                             ctypes.c_void_p(int(stream)) if stream else None,
+                                             ctypes.byref(stats) if stats is not None else None))
+
     def DrawPath(self, state, width, height, pt=None, flags=_lib.KERNEL_AUTO, want_stats=False):
         """Path-traced frame (BASELINE config 5; defined by the oracle's o_pixel_pt): host array
         (H, W, 4) float32, mean radiance + step count."""

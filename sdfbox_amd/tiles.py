@@ -56,6 +56,15 @@ def render_bands(scene, state, width, layout, rank, out_ptr, flags=0, stream=Non
         scene.DrawPathDevice(state, width, layout.height, out_ptr, pt=pt, **kw)
 
 
+def render_bands_batch(scene, states, width, layout, rank, out_ptr, flags=0, stream=None, stats=None):
+    """`rank`'s bands of several frames (one camera each) in ONE launch, into
+    out_ptr[frame][rows_per_rank][width]: the frames of a gather group share the serial tail of
+    the share's longest pixels."""
+    scene.DrawBatchDevice(states, width, layout.height, out_ptr, nrows_out=layout.rows_per_rank,
+                          band_rows=layout.band_rows, band_first=rank, band_stride=layout.world,
+                          flags=flags, stream=stream, stats=stats)
+
+
 def deinterleave(device, gathered_ptr, frame_ptr, width, layout, stream=None, pixel_bytes=16, frames=1):
     """Rank 0: gathered compact buffers (world x frames x rows_per_rank x width pixels) ->
     frames x height x width.  pixel_bytes: 16 for RGBA32F frames, 4 for RGBA8 frames of the

@@ -284,6 +284,44 @@ def test_display_bands_reassemble(sb, gpu_scenes):
     assert torch.equal(frame.to(torch.int64) & 0xFFFFFFFF, full)
 
 
+def test_batched_launch_renders_each_camera(sb, gpu_scenes):
+    # several frames in one launch (grid.y = frame): each with its own camera block, bands included
+    import torch
+    from sdfbox_amd.tiles import BandLayout
+    scene = gpu_scenes["torus_d6"]
+    W, H = 150, 90
+    cams = [make_camera(n, W, H) for n in ("default", "rotated", "closeup")]
+    cams[1].State.margin = 0.002; cams[2].State.strength = 1.5; cams[2].State.fov = 0.7
+    stream = torch.cuda.current_stream().cuda_stream
+    for kern in (sb.KERNEL_STACK, sb.KERNEL_GENERIC):
+        full = [torch.from_numpy(scene.Draw(c, W, H, kern)).cuda() for c in cams]
+        out = torch.zeros((3, H, W, 4), dtype=torch.float32, device="cuda")
+        scene.DrawBatchDevice(cams, W, H, out.data_ptr(), flags=kern, stream=stream)
+        torch.cuda.synchronize()
+        for f in range(3):
+            assert torch.equal(out[f].view(torch.int32), full[f].view(torch.int32)), (kern, f)
+        # a rank's bands of all three frames in one launch
+        lay = BandLayout(H, 4, 16)
+        for rank in (0, 3):
+            part = torch.zeros((3, lay.rows_per_rank, W, 4), dtype=torch.float32, device="cuda")
+            scene.DrawBatchDevice(cams, W, H, part.data_ptr(), nrows_out=lay.rows_per_rank, band_rows=16,
+                                  band_first=rank, band_stride=4, flags=kern, stream=stream)
+            torch.cuda.synchronize()
+            for f in range(3):
+                for lrow, y in lay.rows_of(rank):
+                    assert torch.equal(part[f, lrow].view(torch.int32), full[f][y].view(torch.int32)), (kern, rank, f, y)
+    disp = torch.zeros((3, H, W), dtype=torch.int32, device="cuda")
+    scene.DrawBatchDevice(cams, W, H, disp.data_ptr(), flags=sb.FLAG_DISPLAY, stream=stream)
+    torch.cuda.synchronize()
+    for f in range(3):
+        ref = scene.DrawDisplay(cams[f], W, H).view(np.uint32).reshape(H, W)
+        assert (disp[f].cpu().numpy().view(np.uint32) == ref).all()
+    with pytest.raises(sb.SdfHipError):
+        scene.DrawBatchDevice(cams * 3, W, H, out.data_ptr(), stream=stream)           # 9 > 8 frames
+    with pytest.raises(sb.SdfHipError):
+        scene.DrawBatchDevice(cams, W, H, out.data_ptr(), flags=sb.FLAG_COMPACT, stream=stream)
+
+
 def test_grouped_gather_deinterleave(sb, gpu_scenes):
     # one gather may carry several frames: gathered [world][frames][rows][W] -> [frames][H][W]
     import torch
