@@ -10,8 +10,12 @@
 //   split       = centerValue < 2 * scale && depth < MaxDepth               k_corners
 //   children    = 8 new nodes whose candidates are this node's `possible`   k_children
 // The recursion becomes a loop over levels; the reference's node order (children blocks
-// appended in depth-first pre-order) is restored on the host afterwards, and the values
-// are quantised there with FromFloat / WriteBytes (dllmain.cpp:192-207).
+// appended in depth-first pre-order) is restored afterwards, still on the GPU, from subtree
+// counts (k_subtree, bottom-up) and pre-order ranks (k_emit, top-down), and k_emit also
+// quantises the values as FromFloat / WriteBytes do (dllmain.cpp:192-207): the host receives
+// the finished {parent, children} and byte arrays in one copy each.
+// Device memory comes from three bump arenas (results that live until the end; per-level
+// scratch and candidate lists, ping-ponged between levels), not from one hipMalloc per array.
 //
 // Bit-exactness with oracle/sdfgen_oracle.c (the CPU restatement): same fp32 expressions
 // in the same order, no contraction (-ffp-contract=off), IEEE sqrt and divide; ties in the
@@ -46,6 +50,7 @@ struct LevelArrays {           // one entry per node of the level
     uint32_t *pcount;          // size of `possible`
     float *vals;               // 8 per node
     uint32_t *split;           // 0 / 1
+    uint32_t *block_of;        // rank among the split nodes of the level: children are 8*block_of .. +7 of the next
 };
 
 __device__ __forceinline__ void transform(const GenParams &P, float wx, float wy, float wz, float &x, float &y, float &z)
@@ -70,26 +75,44 @@ __device__ __forceinline__ Best wave_min(Best b)
     return b;
 }
 
+// Reductions over the BT threads that work on one node: BT = 64 (one wavefront, no LDS) for the wide
+// levels, BT = 1024 for the first levels, whose few nodes have the longest candidate lists.
+template <int BT> __device__ __forceinline__ Best node_min(Best b, Best *sh)
+{
+    b = wave_min(b);
+    if constexpr (BT > 64) {
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        __syncthreads();                                 // sh may still be read from the previous use
+        if (lane == 0) sh[wave] = b;
+        __syncthreads();
+        b = sh[0];
+        for (int w = 1; w < BT / 64; w++) if (better(sh[w], b)) b = sh[w];
+    }
+    return b;
+}
+
 // centerValue and |possible| of every node of the level (TrueDistanceAt + the count of GetPossible)
-__global__ __launch_bounds__(64) void k_center(GenParams P, LevelArrays L, const uint32_t *__restrict__ cand,
+template <int BT>
+__global__ __launch_bounds__(BT) void k_center(GenParams P, LevelArrays L, const uint32_t *__restrict__ cand,
                                                uint32_t n_nodes, uint32_t *err)
 {
-    const uint32_t node = blockIdx.x, lane = threadIdx.x;
+    __shared__ Best sh[BT / 64];
+    __shared__ uint32_t shc[BT / 64];
+    const uint32_t node = blockIdx.x, tid = threadIdx.x;
     if (node >= n_nodes) return;
     const float h = 0.5f * P.scale;                      // Vector3(1) * 0.5f * scale
     float cx, cy, cz;
     transform(P, L.px[node] + h, L.py[node] + h, L.pz[node] + h, cx, cy, cz);
     const uint32_t off = L.cand_off[node], cnt = L.cand_cnt[node];
     Best b{INFINITY, 0xFFFFFFFFu};
-    for (uint32_t k = lane; k < cnt; k += 64) {
+    for (uint32_t k = tid; k < cnt; k += BT) {
         const float *v = P.verts + 6 * (size_t)cand[off + k];
         float d = lensq(v[0] - cx, v[1] - cy, v[2] - cz);
         if (d < b.d) { b.d = d; b.k = k; }
     }
-    b = wave_min(b);
+    b = node_min<BT>(b, sh);
     if (b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d)) {    // "Did not find" / "NaN distance"
-        if (lane == 0) atomicExch(err, 2u);
-        if (lane == 0) { L.center_value[node] = 0.0f; L.pcount[node] = 0; }
+        if (tid == 0) { atomicExch(err, 2u); L.center_value[node] = 0.0f; L.pcount[node] = 0; }
         return;
     }
     const float center_value = sqrtf(b.d) / P.gs;
@@ -97,20 +120,29 @@ __global__ __launch_bounds__(64) void k_center(GenParams P, LevelArrays L, const
     r *= P.gs;
     r *= r;
     uint32_t count = 0;
-    for (uint32_t k = lane; k < cnt; k += 64) {
+    for (uint32_t k = tid; k < cnt; k += BT) {
         const float *v = P.verts + 6 * (size_t)cand[off + k];
         if (lensq(v[0] - cx, v[1] - cy, v[2] - cz) < r) count++;
     }
     for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
-    if (lane == 0) { L.center_value[node] = center_value; L.pcount[node] = count; }
+    if constexpr (BT > 64) {
+        if ((tid & 63u) == 0) shc[tid >> 6] = count;
+        __syncthreads();
+        count = 0;
+        for (int w = 0; w < BT / 64; w++) count += shc[w];
+    }
+    if (tid == 0) { L.center_value[node] = center_value; L.pcount[node] = count; }
 }
 
 // `possible` list (stable), the corner values, the split decision
-__global__ __launch_bounds__(64) void k_corners(GenParams P, LevelArrays L, const uint32_t *__restrict__ cand,
+template <int BT>
+__global__ __launch_bounds__(BT) void k_corners(GenParams P, LevelArrays L, const uint32_t *__restrict__ cand,
                                                 const uint32_t *__restrict__ poff, uint32_t *__restrict__ possible,
                                                 uint32_t n_nodes, uint32_t *err)
 {
-    const uint32_t node = blockIdx.x, lane = threadIdx.x;
+    __shared__ Best sh[BT / 64];
+    __shared__ uint32_t kept[2][BT / 64];                // survivors per wavefront, double-buffered over chunks
+    const uint32_t node = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (node >= n_nodes) return;
     const float px = L.px[node], py = L.py[node], pz = L.pz[node];
     const float h = 0.5f * P.scale;
@@ -130,9 +162,9 @@ __global__ __launch_bounds__(64) void k_corners(GenParams P, LevelArrays L, cons
 #pragma unroll
     for (int i = 0; i < 8; i++) best[i] = Best{INFINITY, 0xFFFFFFFFu};
     const uint32_t off = L.cand_off[node], cnt = L.cand_cnt[node], out = poff[node];
-    uint32_t base = 0;
-    for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
-        const uint32_t k = k0 + lane;
+    uint32_t base = 0, flip = 0;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += BT, flip ^= 1u) {
+        const uint32_t k = k0 + tid;
         bool keep = false;
         uint32_t vi = 0;
         float vx = 0, vy = 0, vz = 0;
@@ -143,27 +175,34 @@ __global__ __launch_bounds__(64) void k_corners(GenParams P, LevelArrays L, cons
             keep = lensq(vx - cx, vy - cy, vz - cz) < r;
         }
         const unsigned long long m = __ballot(keep);
+        uint32_t before = 0, all = (uint32_t)__popcll(m);
+        if constexpr (BT > 64) {
+            if (lane == 0) kept[flip][wave] = all;
+            __syncthreads();
+            all = 0;
+            for (uint32_t w = 0; w < BT / 64; w++) { const uint32_t c = kept[flip][w]; before += w < wave ? c : 0u; all += c; }
+        }
         if (keep) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            possible[out + base + rank] = vi;
+            possible[out + base + before + rank] = vi;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 float d = lensq(vx - qx[i], vy - qy[i], vz - qz[i]);
                 if (d < best[i].d) { best[i].d = d; best[i].k = k; }
             }
         }
-        base += (uint32_t)__popcll(m);
+        base += all;
     }
     const int slot = L.slot[node];
-    float myval = 0.0f;                                  // lane i < 8 ends up holding corner i
+    float myval = 0.0f;                                  // thread i < 8 ends up holding corner i
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        Best b = wave_min(best[i]);
+        Best b = node_min<BT>(best[i], sh);
         float val;
         if (i == slot) {
             val = L.inherit[node];                       // n[i] = vals[insert][i], dllmain.cpp:181
         } else if (b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d)) {
-            if (lane == 0) atomicExch(err, 2u);
+            if (tid == 0) atomicExch(err, 2u);
             val = 0.0f;
         } else {                                         // DistanceAt, dllmain.cpp:119-149
             const float *v = P.verts + 6 * (size_t)cand[off + b.k];
@@ -177,10 +216,10 @@ __global__ __launch_bounds__(64) void k_corners(GenParams P, LevelArrays L, cons
             }
             val = md / P.gs;
         }
-        if ((int)lane == i) myval = val;
+        if ((int)tid == i) myval = val;
     }
-    if (lane < 8) L.vals[8 * (size_t)node + lane] = myval;
-    if (lane == 0) L.split[node] = (center_value < P.scale * 2 && P.depth < P.max_depth) ? 1u : 0u;
+    if (tid < 8) L.vals[8 * (size_t)node + tid] = myval;
+    if (tid == 0) L.split[node] = (center_value < P.scale * 2 && P.depth < P.max_depth) ? 1u : 0u;
 }
 
 // the 8 children of every split node (construct's push_back loop + the arguments of its recursion)
@@ -206,30 +245,100 @@ __global__ void k_iota(uint32_t *p, uint32_t n)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
 }
 
-// exclusive scan of n uint32 (one workgroup walks the array in 1024-element chunks); total -> *total
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                uint32_t n, unsigned long long *total)
+// exclusive scan of n uint32 in two launches: per-chunk sums, then every workgroup adds the sums of
+// the chunks before it to the scan of its own chunk; total -> *total
+constexpr uint32_t SCAN_CHUNK = 1024;
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *wsum)   // all threads get the sum
 {
-    __shared__ uint32_t wsum[16];
-    __shared__ unsigned long long carry;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) carry = 0;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + tid;
-        uint32_t v = i < n ? in[i] : 0u, x = v;
-        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if ((int)lane >= o) x += y; }
-        if (lane == 63) wsum[wave] = x;
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    uint32_t s = 0;
+    for (uint32_t w = 0; w < SCAN_CHUNK / 64; w++) s += wsum[w];
+    return s;
+}
+__global__ __launch_bounds__(SCAN_CHUNK) void k_scan_sums(const uint32_t *__restrict__ in, uint32_t *__restrict__ sums, uint32_t n)
+{
+    __shared__ uint32_t wsum[SCAN_CHUNK / 64];
+    const uint32_t i = blockIdx.x * SCAN_CHUNK + threadIdx.x;
+    const uint32_t s = block_sum(i < n ? in[i] : 0u, wsum);
+    if (threadIdx.x == 0) sums[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(SCAN_CHUNK) void k_scan_apply(const uint32_t *__restrict__ in, const uint32_t *__restrict__ sums,
+                                                            uint32_t *__restrict__ out, uint32_t n, unsigned long long *total)
+{
+    __shared__ uint32_t wsum[SCAN_CHUNK / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ unsigned long long w64[SCAN_CHUNK / 64];
+    unsigned long long before = 0;                       // totals may pass 2^32 (the host checks)
+    {
+        unsigned long long mine = 0;
+        for (uint32_t b = tid; b < blockIdx.x; b += SCAN_CHUNK) mine += sums[b];
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        if (lane == 0) w64[wave] = mine;
         __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
-        const unsigned long long c = carry;
-        if (i < n) out[i] = (uint32_t)(c + woff + x - v);
-        __syncthreads();
-        if (tid == 1023) carry = c + woff + x;
-        __syncthreads();
+        for (uint32_t w = 0; w < SCAN_CHUNK / 64; w++) before += w64[w];
     }
-    if (tid == 0) *total = carry;
+    const uint32_t i = blockIdx.x * SCAN_CHUNK + tid;
+    uint32_t v = i < n ? in[i] : 0u, x = v;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if ((int)lane >= o) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
+    if (i < n) out[i] = (uint32_t)(before + woff + x - v);
+    if (i == n - 1) *total = before + woff + x;
+}
+
+// ---- the reference's node order, on the GPU ------------------------------------------------------
+// cnt = number of split nodes in the subtree of a node (itself included); levels bottom-up
+__global__ void k_subtree(const uint32_t *__restrict__ split, const uint32_t *__restrict__ block_of,
+                          const uint32_t *__restrict__ cnt_next, uint32_t *__restrict__ cnt, uint32_t n_nodes)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_nodes) return;
+    uint32_t c = 0;
+    if (split[j]) {
+        c = 1;
+        const uint32_t first = 8 * block_of[j];
+        for (int k = 0; k < 8; k++) c += cnt_next[first + k];
+    }
+    cnt[j] = c;
+}
+// The reference appends the children block of a node when it processes the node, then recurses into
+// the children in order (dllmain.cpp:183-189): the block of a split node with r split nodes before it
+// in pre-order starts at 1 + 8r.  rank(child k of p) = rank(p) + 1 + sum of cnt over its siblings j < k.
+__global__ void k_emit(const uint32_t *__restrict__ split, const int32_t *__restrict__ parent, const float *__restrict__ vals,
+                       const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ rank_up, const int32_t *__restrict__ index_up,
+                       uint32_t *__restrict__ rank, int32_t *__restrict__ index, float scale, uint32_t n_nodes,
+                       int32_t *__restrict__ S, uint8_t *__restrict__ V)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_nodes) return;
+    uint32_t r = 0;
+    int32_t idx = 0, up = -1;
+    if (rank_up) {                                       // not the root
+        const uint32_t p = (uint32_t)parent[c], k = c & 7u;
+        r = rank_up[p] + 1;
+        for (uint32_t j = 0; j < k; j++) r += cnt[c - k + j];
+        idx = (int32_t)(1 + 8 * rank_up[p] + k);
+        up = index_up[p];
+    }
+    rank[c] = r;
+    index[c] = idx;
+    S[2 * (size_t)idx] = up;
+    S[2 * (size_t)idx + 1] = split[c] ? (int32_t)(1 + 8 * r) : -1;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {                        // FromFloat, dllmain.cpp:192-196
+        const float normd = vals[8 * (size_t)c + k] / 2 / scale;
+        const float sat = fminf(fmaxf(normd + 0.25f, 0.0f), 1.0f);
+        const uint32_t b = (uint32_t)floorf(sat * 255);
+        if (k < 4) lo |= b << (8 * k); else hi |= b << (8 * (k - 4));
+    }
+    ((uint2 *)V)[idx] = make_uint2(lo, hi);
 }
 
 }  // namespace sdfhip
@@ -238,47 +347,59 @@ using namespace sdfhip;
 
 namespace {
 
-struct DevBuf {                  // frees what it owns
-    std::vector<void *> ptrs;
-    template <class T> T *alloc(size_t n)
+// Bump allocator over a few large hipMalloc chunks.  reset() makes the memory reusable; work on
+// the (single, in-order) stream that still reads the old contents was launched before whatever
+// is launched to overwrite them, so no synchronisation is needed.
+struct Arena {
+    struct Chunk { char *base; size_t size, used; };
+    std::vector<Chunk> chunks;
+    size_t grow;
+    explicit Arena(size_t grow) : grow(grow) {}
+    Arena(const Arena &) = delete;
+    Arena &operator=(const Arena &) = delete;
+    void *take(size_t bytes)
     {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes == 0) bytes = 256;
+        for (auto &c : chunks)
+            if (c.size - c.used >= bytes) { void *p = c.base + c.used; c.used += bytes; return p; }
+        const size_t size = bytes > grow ? bytes : grow;
         void *p = nullptr;
-        if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
-        ptrs.push_back(p);
-        return (T *)p;
+        if (hipMalloc(&p, size) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        chunks.push_back(Chunk{ (char *)p, size, bytes });
+        grow = grow < ((size_t)1 << 30) ? grow * 2 : grow;
+        return p;
     }
-    void release(void *p)
-    {
-        for (auto &q : ptrs) if (q == p) { (void)hipFree(q); q = nullptr; }
-    }
-    ~DevBuf() { for (void *p : ptrs) if (p) (void)hipFree(p); }
+    template <class T> T *alloc(size_t n) { return (T *)take(n * sizeof(T)); }
+    void reset() { for (auto &c : chunks) c.used = 0; }
+    ~Arena() { for (auto &c : chunks) (void)hipFree(c.base); }
 };
 
-bool alloc_level(DevBuf &d, LevelArrays &L, size_t n)
+// scratch: arrays only the level itself and k_children read; keep: what the final ordering needs
+bool alloc_level(Arena &scratch, Arena &keep, LevelArrays &L, size_t n)
 {
-    L.px = d.alloc<float>(n); L.py = d.alloc<float>(n); L.pz = d.alloc<float>(n);
-    L.inherit = d.alloc<float>(n); L.slot = d.alloc<int32_t>(n); L.parent = d.alloc<int32_t>(n);
-    L.cand_off = d.alloc<uint32_t>(n); L.cand_cnt = d.alloc<uint32_t>(n);
-    L.center_value = d.alloc<float>(n); L.pcount = d.alloc<uint32_t>(n);
-    L.vals = d.alloc<float>(8 * n); L.split = d.alloc<uint32_t>(n);
+    L.px = scratch.alloc<float>(n); L.py = scratch.alloc<float>(n); L.pz = scratch.alloc<float>(n);
+    L.inherit = scratch.alloc<float>(n); L.slot = scratch.alloc<int32_t>(n);
+    L.cand_off = scratch.alloc<uint32_t>(n); L.cand_cnt = scratch.alloc<uint32_t>(n);
+    L.center_value = scratch.alloc<float>(n); L.pcount = scratch.alloc<uint32_t>(n);
+    L.parent = keep.alloc<int32_t>(n); L.vals = keep.alloc<float>(8 * n);
+    L.split = keep.alloc<uint32_t>(n); L.block_of = keep.alloc<uint32_t>(n);
     return L.px && L.py && L.pz && L.inherit && L.slot && L.parent && L.cand_off && L.cand_cnt &&
-           L.center_value && L.pcount && L.vals && L.split;
-}
-void free_level(DevBuf &d, LevelArrays &L)
-{
-    void *all[] = { L.px, L.py, L.pz, L.inherit, L.slot, L.parent, L.cand_off, L.cand_cnt, L.center_value,
-                    L.pcount, L.vals, L.split };
-    for (void *p : all) d.release(p);
+           L.center_value && L.pcount && L.vals && L.split && L.block_of;
 }
 
-float saturate(float x) { return x > 1 ? 1 : (x < 0 ? 0 : x); }
-uint8_t from_float(float f, float scale)               // dllmain.cpp:192-196
+bool scan_u32(Arena &scratch, const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *d_total)
 {
-    float normd = f / 2 / scale;
-    return (uint8_t)floorf(saturate(normd + 0.25f) * 255);
+    const uint32_t chunks = (n + sdfhip::SCAN_CHUNK - 1) / sdfhip::SCAN_CHUNK;
+    uint32_t *sums = scratch.alloc<uint32_t>(chunks);
+    if (!sums) return false;
+    hipLaunchKernelGGL(sdfhip::k_scan_sums, dim3(chunks), dim3(sdfhip::SCAN_CHUNK), 0, 0, in, sums, n);
+    hipLaunchKernelGGL(sdfhip::k_scan_apply, dim3(chunks), dim3(sdfhip::SCAN_CHUNK), 0, 0, in, sums, out, n, d_total);
+    return true;
 }
 
-struct HostLevel { std::vector<int32_t> parent; std::vector<uint32_t> split; std::vector<float> vals; };
+constexpr uint32_t WIDE_LEVEL = 4096;
+struct KeptLevel { LevelArrays L; uint32_t n; uint32_t *cnt, *rank; int32_t *index; };
 
 }  // namespace
 
@@ -288,6 +409,7 @@ struct HostLevel { std::vector<int32_t> parent; std::vector<uint32_t> split; std
         if (e_ != hipSuccess)                                                                   \
             return fail(SDFHIP_ERR_DEVICE, "sdfgen: %s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+#define GEN_NOMEM() fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory")
 
 extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_t depth, sdfhip_octdata *out,
                              sdfhip_sdfgen_stats *stats)
@@ -321,19 +443,20 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
     struct Restore { int prev; ~Restore() { if (prev >= 0) (void)hipSetDevice(prev); } } restore{prev};
 
     try {
-        DevBuf d;
-        float *d_verts = d.alloc<float>(6 * (size_t)n);
-        uint32_t *d_err = d.alloc<uint32_t>(1);
-        unsigned long long *d_total = d.alloc<unsigned long long>(1);
-        uint32_t *cand = d.alloc<uint32_t>(n);
-        if (!d_verts || !d_err || !d_total || !cand) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory");
+        Arena keep((size_t)64 << 20), scratch[2] = { Arena((size_t)32 << 20), Arena((size_t)32 << 20) },
+              lists[2] = { Arena((size_t)64 << 20), Arena((size_t)64 << 20) };
+        float *d_verts = keep.alloc<float>(6 * (size_t)n);
+        uint32_t *d_err = keep.alloc<uint32_t>(1);
+        unsigned long long *d_total = keep.alloc<unsigned long long>(1);
+        uint32_t *cand = lists[0].alloc<uint32_t>(n);
+        if (!d_verts || !d_err || !d_total || !cand) return GEN_NOMEM();
         GEN_TRY(hipMemcpy(d_verts, verts6, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
         GEN_TRY(hipMemset(d_err, 0, sizeof(uint32_t)));
         hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, 0, cand, n);
         P.verts = d_verts;
 
         LevelArrays L;
-        if (!alloc_level(d, L, 1)) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory");
+        if (!alloc_level(scratch[0], keep, L, 1)) return GEN_NOMEM();
         {   // the root: construct(all, 0, 0, -1, 0)
             const float z = 0.0f; const int32_t m1 = -1; const uint32_t zero = 0;
             GEN_TRY(hipMemcpy(L.px, &z, 4, hipMemcpyHostToDevice)); GEN_TRY(hipMemcpy(L.py, &z, 4, hipMemcpyHostToDevice));
@@ -341,85 +464,75 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
             GEN_TRY(hipMemcpy(L.slot, &m1, 4, hipMemcpyHostToDevice)); GEN_TRY(hipMemcpy(L.parent, &m1, 4, hipMemcpyHostToDevice));
             GEN_TRY(hipMemcpy(L.cand_off, &zero, 4, hipMemcpyHostToDevice)); GEN_TRY(hipMemcpy(L.cand_cnt, &n, 4, hipMemcpyHostToDevice));
         }
-        std::vector<HostLevel> levels;
+        std::vector<KeptLevel> levels;
         uint32_t n_nodes = 1;
+        size_t total_nodes = 0;
         unsigned long long cand_entries = n;
         for (int lvl = 0;; lvl++) {
+            Arena &mine = scratch[lvl & 1], &other = scratch[(lvl + 1) & 1];
             P.depth = lvl;
             P.scale = ldexpf(1.0f, -lvl);                 // powf(0.5, depth)
-            uint32_t *poff = d.alloc<uint32_t>(n_nodes), *block_of = d.alloc<uint32_t>(n_nodes);
-            if (!poff || !block_of) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory");
-            hipLaunchKernelGGL(k_center, dim3(n_nodes), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
-            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, 0, L.pcount, poff, n_nodes, d_total);
+            uint32_t *poff = mine.alloc<uint32_t>(n_nodes);
+            if (!poff) return GEN_NOMEM();
+            const bool wide = n_nodes >= WIDE_LEVEL;      // enough nodes to fill the GPU with one wavefront each
+            if (wide) hipLaunchKernelGGL(k_center<64>, dim3(n_nodes), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
+            else hipLaunchKernelGGL(k_center<1024>, dim3(n_nodes), dim3(1024), 0, 0, P, L, cand, n_nodes, d_err);
+            if (!scan_u32(mine, L.pcount, poff, n_nodes, d_total)) return GEN_NOMEM();
             unsigned long long total = 0;
             GEN_TRY(hipMemcpy(&total, d_total, sizeof total, hipMemcpyDeviceToHost));
             if (total > 0xFFFFFFF0ull) return fail(SDFHIP_ERR_NOMEM, "sdfgen: candidate lists of level %d exceed 2^32 entries", lvl);
-            uint32_t *possible = d.alloc<uint32_t>((size_t)total);
+            lists[(lvl + 1) & 1].reset();                 // the lists of level lvl-1: dead since k_children of lvl-1
+            uint32_t *possible = lists[(lvl + 1) & 1].alloc<uint32_t>((size_t)total);
             if (!possible) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory for %llu candidate entries", total);
             cand_entries += total;
-            hipLaunchKernelGGL(k_corners, dim3(n_nodes), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
-            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, 0, L.split, block_of, n_nodes, d_total);
-            unsigned long long n_split = 0;
-            GEN_TRY(hipMemcpy(&n_split, d_total, sizeof n_split, hipMemcpyDeviceToHost));
-            uint32_t err = 0;
-            GEN_TRY(hipMemcpy(&err, d_err, sizeof err, hipMemcpyDeviceToHost));
-            if (err) return fail(SDFHIP_ERR_ARG, "sdfgen: a cell at depth %d has no candidate point left (the reference throws \"Did not find\")", lvl);
-            // keep this level's results for the host-side assembly
-            HostLevel hl;
-            hl.parent.resize(n_nodes); hl.split.resize(n_nodes); hl.vals.resize(8 * (size_t)n_nodes);
-            GEN_TRY(hipMemcpy(hl.parent.data(), L.parent, n_nodes * 4, hipMemcpyDeviceToHost));
-            GEN_TRY(hipMemcpy(hl.split.data(), L.split, n_nodes * 4, hipMemcpyDeviceToHost));
-            GEN_TRY(hipMemcpy(hl.vals.data(), L.vals, 8 * (size_t)n_nodes * 4, hipMemcpyDeviceToHost));
-            levels.push_back(std::move(hl));
+            if (wide) hipLaunchKernelGGL(k_corners<64>, dim3(n_nodes), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            else hipLaunchKernelGGL(k_corners<1024>, dim3(n_nodes), dim3(1024), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            if (!scan_u32(mine, L.split, L.block_of, n_nodes, d_total)) return GEN_NOMEM();
+            struct { unsigned long long n_split; uint32_t err; } back;
+            GEN_TRY(hipMemcpy(&back.n_split, d_total, sizeof back.n_split, hipMemcpyDeviceToHost));
+            GEN_TRY(hipMemcpy(&back.err, d_err, sizeof back.err, hipMemcpyDeviceToHost));
+            if (back.err) return fail(SDFHIP_ERR_ARG, "sdfgen: a cell at depth %d has no candidate point left (the reference throws \"Did not find\")", lvl);
+            levels.push_back(KeptLevel{ L, n_nodes, nullptr, nullptr, nullptr });
+            total_nodes += n_nodes;
+            const unsigned long long n_split = back.n_split;
             if (n_split == 0) break;
-            if (8 * n_split > 0x7FFFFFF0ull) return fail(SDFHIP_ERR_NOMEM, "sdfgen: more than 2^31 nodes");
+            if (total_nodes + 8 * n_split > 0x7FFFFFF0ull) return fail(SDFHIP_ERR_NOMEM, "sdfgen: more than 2^31 nodes");
+            other.reset();                                // scratch of level lvl-1
             LevelArrays N;
-            if (!alloc_level(d, N, (size_t)(8 * n_split))) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory");
-            hipLaunchKernelGGL(k_children, dim3((8 * n_nodes + 255) / 256), dim3(256), 0, 0, L, N, block_of, poff,
+            if (!alloc_level(other, keep, N, (size_t)(8 * n_split))) return GEN_NOMEM();
+            hipLaunchKernelGGL(k_children, dim3((8 * n_nodes + 255) / 256), dim3(256), 0, 0, L, N, L.block_of, poff,
                                P.scale / 2, n_nodes);
-            GEN_TRY(hipDeviceSynchronize());
-            free_level(d, L);
-            d.release(cand); d.release(poff); d.release(block_of);
             L = N;
             cand = possible;
             n_nodes = (uint32_t)(8 * n_split);
         }
-        GEN_TRY(hipDeviceSynchronize());
 
-        // ---- host: the reference's node order and bytes ------------------------------------
-        // children block of split node j of level l = nodes 8*b .. 8*b+7 of level l+1, b = rank of j
-        // among the split nodes of its level.  The reference appends a node's block when it
-        // processes the node and then recurses into the children in order: pre-order.
-        size_t total_nodes = 0;
-        for (auto &hl : levels) total_nodes += hl.parent.size();
-        std::vector<std::vector<uint32_t>> first_child(levels.size());
-        for (size_t l = 0; l < levels.size(); l++) {
-            first_child[l].assign(levels[l].split.size(), 0xFFFFFFFFu);
-            uint32_t b = 0;
-            for (size_t j = 0; j < levels[l].split.size(); j++)
-                if (levels[l].split[j]) first_child[l][j] = 8 * b++;
+        // ---- the reference's node order and bytes (k_subtree bottom-up, k_emit top-down) ----
+        int32_t *d_S = keep.alloc<int32_t>(2 * total_nodes);
+        uint8_t *d_V = keep.alloc<uint8_t>(8 * total_nodes);
+        if (!d_S || !d_V) return GEN_NOMEM();
+        for (auto &kl : levels) {
+            kl.cnt = keep.alloc<uint32_t>(kl.n); kl.rank = keep.alloc<uint32_t>(kl.n); kl.index = keep.alloc<int32_t>(kl.n);
+            if (!kl.cnt || !kl.rank || !kl.index) return GEN_NOMEM();
         }
+        for (int l = (int)levels.size() - 1; l >= 0; l--) {
+            KeptLevel &kl = levels[l];
+            const uint32_t *next = l + 1 < (int)levels.size() ? levels[l + 1].cnt : nullptr;   // the last level splits nothing
+            hipLaunchKernelGGL(k_subtree, dim3((kl.n + 255) / 256), dim3(256), 0, 0, kl.L.split, kl.L.block_of, next, kl.cnt, kl.n);
+        }
+        for (size_t l = 0; l < levels.size(); l++) {
+            KeptLevel &kl = levels[l];
+            hipLaunchKernelGGL(k_emit, dim3((kl.n + 255) / 256), dim3(256), 0, 0, kl.L.split, kl.L.parent, kl.L.vals, kl.cnt,
+                               l ? levels[l - 1].rank : nullptr, l ? levels[l - 1].index : nullptr, kl.rank, kl.index,
+                               ldexpf(1.0f, -(int)l), kl.n, d_S, d_V);
+        }
+        GEN_TRY(hipGetLastError());
         int32_t *S = (int32_t *)malloc(total_nodes * 8);
         uint8_t *V = (uint8_t *)malloc(total_nodes * 8);
         if (!S || !V) { free(S); free(V); return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of host memory for %zu nodes", total_nodes); }
-        struct Item { uint32_t level, j; int32_t new_index, new_parent; };
-        std::vector<Item> stack;
-        stack.push_back(Item{ 0, 0, 0, -1 });
-        size_t next = 1;
-        while (!stack.empty()) {
-            Item it = stack.back(); stack.pop_back();
-            const HostLevel &hl = levels[it.level];
-            const float scale = ldexpf(1.0f, -(int)it.level);
-            for (int k = 0; k < 8; k++) V[(size_t)it.new_index * 8 + k] = from_float(hl.vals[8 * (size_t)it.j + k], scale);
-            S[2 * (size_t)it.new_index] = it.new_parent;
-            const uint32_t fc = first_child[it.level][it.j];
-            if (fc == 0xFFFFFFFFu) { S[2 * (size_t)it.new_index + 1] = -1; continue; }
-            const int32_t block = (int32_t)next;
-            next += 8;
-            S[2 * (size_t)it.new_index + 1] = block;
-            // pre-order: child 0's subtree is numbered first -> push the children in reverse
-            for (int k = 7; k >= 0; k--) stack.push_back(Item{ it.level + 1, fc + (uint32_t)k, block + k, it.new_index });
-        }
+        hipError_t e1 = hipMemcpy(S, d_S, total_nodes * 8, hipMemcpyDeviceToHost);
+        hipError_t e2 = e1 == hipSuccess ? hipMemcpy(V, d_V, total_nodes * 8, hipMemcpyDeviceToHost) : e1;
+        if (e2 != hipSuccess) { free(S); free(V); return fail(SDFHIP_ERR_DEVICE, "sdfgen: copying the tree back failed: %s", hipGetErrorString(e2)); }
         out->length = (uint32_t)total_nodes; out->structs = S; out->values = V;
         if (stats) {
             stats->nodes = (uint32_t)total_nodes;
