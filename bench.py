@@ -271,6 +271,7 @@ def main():
     if rank == 0:
         sec_per_step = elapsed / args.steps
         peak = 8000.0                                  # GB/s, HBM3E spec (MI355X_MICROARCH.md)
+        copy_gbs = measured_copy_bandwidth()           # the box's own figure beside the nameplate
         achieved = alg_bytes_rank * frames_per_launch / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "Mray/s (primary rays; frame W*H / time per frame)",
@@ -309,6 +310,8 @@ def main():
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes_rank * frames_per_launch),
                 "frames_per_launch": frames_per_launch,
+                "measured_copy_gbs": copy_gbs,
+                "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
             },
         }
         if check_ok is not None:
@@ -321,6 +324,25 @@ def main():
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_copy_bandwidth(nbytes=1 << 30, reps=10):
+    """Device-to-device copy of 1 GiB, read + written bytes per second in GB/s: what this
+    box's HBM delivers to a streaming kernel, reported next to the 8 TB/s nameplate."""
+    import torch
+    try:
+        src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            dst.copy_(src)
+        b.record()
+        torch.cuda.synchronize()
+        return round(2 * nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9, 1)
+    except RuntimeError:
+        return None
 
 
 def load_traffic(W, H, scene_name, world):
