@@ -59,6 +59,12 @@ def parse():
                     help="path-traced mode (BASELINE config 5: --size 3840x2160 --spp 16): spp jittered camera "
                          "rays per pixel + 3 diffuse bounces; Mray/s then counts W*H*spp camera rays")
     ap.add_argument("--check", action="store_true", help="verify the assembled frame against a whole-frame render")
+    ap.add_argument("--rank0-weight", type=float, default=0.0,
+                    help="sharded runs: rank 0's share of the frame as a fraction of a peer's share "
+                         "(0 = measure at start-up so that render + assembly on rank 0 takes as long as a peer's render)")
+    ap.add_argument("--wire", type=int, default=1,
+                    help="sharded runs: 1 = ranks send 8-byte wire pixels and rank 0 expands them to the RGBA32F "
+                         "frame (lossless, half the xGMI bytes); 0 = ranks send RGBA32F pixels")
     return ap.parse_args()
 
 
@@ -121,10 +127,24 @@ def main():
     flags = kflag | (sb.FLAG_COMPACT if compact else 0) | (sb.FLAG_DISPLAY if args.display else 0)
     px_shape, px_dtype, px_bytes = ((), torch.int32, 4) if args.display else ((4,), torch.float32, 16)
     pt = sb.PathTrace(spp=args.spp) if args.spp > 0 else None
+    # what travels in the gather: the frame's own pixels, or 8-byte wire pixels that rank 0 expands
+    # to the RGBA32F frame while it restores row order (lossless; sdfbox_amd/tiles.py)
+    wire = sharded and args.wire == 1 and not args.display and pt is None and not compact
+    wpx_shape, wpx_dtype, wpx_bytes = ((2,), torch.int32, 8) if wire else (px_shape, px_dtype, px_bytes)
+    if wire:
+        flags |= sb.FLAG_WIRE
     if pt is not None and (args.display or compact):
         raise SystemExit("--spp excludes --display and --compact")
 
-    layout = BandLayout(H, world, args.band_rows)
+    # rank 0 also assembles the frame (de-interleave + wire expansion of every rank's rows), so it
+    # renders a smaller share: --rank0-weight, or measured here before anything is timed
+    w0 = args.rank0_weight if world > 1 else 1.0
+    if sharded and world > 1 and w0 <= 0:
+        w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, wpx_shape, wpx_dtype, wpx_bytes,
+                                  rank, nccl, pt, compact)
+    if (H + args.band_rows - 1) // args.band_rows > 512 or w0 > 0.98:
+        w0 = 1.0
+    layout = BandLayout(H, world, args.band_rows, w0)
     # sharded: G frames share one launch (grid.y = frame) and one gather; nbuf groups are in
     # flight (so G*nbuf frames).  A rank's share is mostly the serial tail of its longest
     # pixels: G frames in one grid share that tail
@@ -135,10 +155,10 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(nbuf)]                       # one per group in flight
     main = torch.cuda.current_stream().cuda_stream
     rows_local = layout.rows_per_rank if sharded else H
-    local = [torch.zeros((G, rows_local, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
+    local = [torch.zeros((G, rows_local, W) + wpx_shape, dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
     gathered = frame = None
     if sharded and rank == 0:
-        gathered = [torch.zeros((world, G, layout.rows_per_rank, W) + px_shape, dtype=px_dtype, device="cuda")
+        gathered = [torch.zeros((world, G, layout.rows_per_rank, W) + wpx_shape, dtype=wpx_dtype, device="cuda")
                     for _ in range(nbuf)]
         frame = [torch.zeros((G, H, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
 
@@ -167,11 +187,11 @@ def main():
                 w.wait()                              # the group's stream waits for its gather
                 if rank == 0:
                     deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout,
-                                 stream=streams[slot].cuda_stream, pixel_bytes=px_bytes, frames=G)
+                                 stream=streams[slot].cuda_stream, pixel_bytes=wpx_bytes, frames=G)
         elif rank == 0:                               # gloo rehearsal: through host buffers
             gathered[slot].copy_(torch.stack(w).cuda())
             deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=main,
-                         pixel_bytes=px_bytes, frames=G)
+                         pixel_bytes=wpx_bytes, frames=G)
 
     def step(k, timed=False, last=False):
         group, within = divmod(k, G)
@@ -228,7 +248,7 @@ def main():
     render(local[0], main, stats=st, fl=flags | sb.FLAG_COUNT)
     torch.cuda.synchronize()
     my_pixels = len(layout.rows_of(rank)) * W if sharded else W * H
-    alg_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + px_bytes * my_pixels
+    alg_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + wpx_bytes * my_pixels   # SURVEY.md 8d (bytes this rank's kernel stores)
     counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps], dtype=torch.float64)
     kernel_used = st.kernel_used
 
@@ -261,7 +281,7 @@ def main():
         if pt is not None:
             scene.DrawPathDevice(cam, W, H, ref.data_ptr(), pt=pt, flags=flags, stream=main)
         else:
-            scene.DrawDevice(cam, W, H, ref.data_ptr(), flags=flags, stream=main)
+            scene.DrawDevice(cam, W, H, ref.data_ptr(), flags=flags & ~sb.FLAG_WIRE, stream=main)
         torch.cuda.synchronize()
         # every frame of every group buffer that the timed steps filled
         filled = [(g % nbuf, w) for g in range(max(0, (args.steps - 1) // G + 1 - nbuf), (args.steps - 1) // G + 1)
@@ -293,9 +313,13 @@ def main():
                 "kernel": ("path/" if pt is not None else "") +
                           ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else ""),
                 "parallelism": "1 GPU" if not sharded else
-                               f"{world} GPU(s), {args.band_rows}-row bands round-robin + gather to rank 0 ({args.backend})",
+                               f"{world} GPU(s), {args.band_rows}-row bands " +
+                               ("round-robin" if not layout.weighted else
+                                f"dealt by weight (rank 0: {layout.rank0_weight:.3f} of a peer's share)") +
+                               f" + gather to rank 0 ({args.backend})",
                 "frames_in_flight": nbuf * G,
                 "frames_per_gather": G if sharded else None,
+                "gather_pixel_bytes": wpx_bytes if sharded else None,
                 "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
                 "gstep_per_s": round(float(counters[2]) / sec_per_step / 1e9, 3),
                 "scene_build_s": round(t_gen, 2),
@@ -324,6 +348,64 @@ def main():
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, wpx_shape, wpx_dtype, wpx_bytes, rank, nccl, pt, compact):
+    """Rank 0 also assembles the frame (de-interleave and wire expansion of all ranks' rows), so an
+    even deal makes it the slowest rank.  Before anything is timed, rank 0 tries layouts that give it
+    0.5 .. 1.0 of a peer's share: for each it times its own work (render + assembly) and the largest
+    peer share (rank 1's, which it can render itself: the scene is replicated), and every rank then
+    receives the weight with the smallest max of the two."""
+    import torch
+    import torch.distributed as dist
+    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch
+    w = torch.ones(1, dtype=torch.float64)
+    if rank == 0:
+        G = 1 if (pt is not None or compact) else min(8, max(4, world))
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        full_shape, full_dtype = ((), torch.int32) if wpx_bytes == 4 else ((4,), torch.float32)
+        frame = torch.zeros((G, H, W) + full_shape, dtype=full_dtype, device="cuda")
+        n = 3 if pt is not None else 12
+
+        def work(lay, r, local, gathered):
+            def one(k):
+                s = streams[k % 2].cuda_stream
+                if G > 1:
+                    render_bands_batch(scene, [cam] * G, W, lay, r, local[k % 2].data_ptr(), flags=flags, stream=s)
+                else:
+                    render_bands(scene, cam, W, lay, r, local[k % 2].data_ptr(), flags=flags, stream=s, pt=pt)
+                if r == 0:
+                    deinterleave(torch.cuda.current_device(), gathered.data_ptr(), frame.data_ptr(), W, lay,
+                                 stream=s, pixel_bytes=wpx_bytes, frames=G)
+            best = 1e9
+            for _ in range(2):
+                one(0); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(n):
+                    one(k)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / (n * G))
+            return best
+
+        tried = []
+        for cand in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5):
+            lay = BandLayout(H, world, band_rows, cand)
+            local = [torch.zeros((G, lay.rows_per_rank, W) + wpx_shape, dtype=wpx_dtype, device="cuda") for _ in range(2)]
+            gathered = torch.zeros((world, G, lay.rows_per_rank, W) + wpx_shape, dtype=wpx_dtype, device="cuda")
+            t0, t1 = work(lay, 0, local, gathered), work(lay, 1, local, gathered)
+            tried.append((max(t0, t1), cand, t0, t1))
+            del local, gathered
+            if t0 <= t1:                               # rank 0 is no longer the slowest: a smaller share only loads the peers
+                break
+        _, best, t0, t1 = min(tried)
+        w[0] = best
+        print("[bench] rank-0 share search: " + ", ".join(f"w={c:.2f}: rank0 {a * 1e3:.4f} / peer {b * 1e3:.4f} ms" for _, c, a, b in tried)
+              + f" -> {best:.2f}", file=sys.stderr)
+        torch.cuda.empty_cache()
+    if nccl:
+        w = w.cuda()
+    dist.broadcast(w, src=0)
+    return float(w.item())
 
 
 def measured_copy_bandwidth(nbytes=1 << 30, reps=10):

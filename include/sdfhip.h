@@ -76,6 +76,8 @@ enum {
     SDFHIP_FLAG_COUNT = 0x20,     /* also count algorithmic node/sample reads (slower)     */
     SDFHIP_FLAG_DISPLAY = 0x40,   /* fused display pass: output is RGBA8, gamma 1/2.2 (DisplayFrag.hlsl:24) */
     SDFHIP_FLAG_DISPLAY_DEBUG = 0x80, /* fused display pass, debug heat map w/140 (DisplayFrag.hlsl:21-22) */
+    SDFHIP_FLAG_WIRE = 0x10000,   /* sdfhip_render_device / _batch_device only: 8-byte wire pixels for the
+                                     tile gather (see sdfhip_deinterleave_device), lossless */
     /* tuning knobs for A/B measurements (0 = the default): bits 8..11 blockIdx -> tile
      * order of the plain kernel (1 row-major, 2 one slab per XCD), bits 12..15 workgroup
      * size (1 = 64, 2 = 128, 3 = 256 threads).  Results never depend on them. */
@@ -265,13 +267,36 @@ SDFHIP_API int sdfhip_render_batch_device(sdfhip_scene *scene, const sdfhip_info
 /* Rank-0 helper for the tile gather: scatter `world` compact band buffers back into
  * row order.  One gather may carry several frames (fewer, larger messages):
  * d_gathered is [world][frames][rows_per_rank][width] pixels, d_frame is
- * [frames][height][width].  pixel_bytes = 16 (RGBA32F) or 4 (RGBA8).  Asynchronous
- * on `stream`. */
+ * [frames][height][width].  pixel_bytes = 16 (RGBA32F) or 4 (RGBA8): both sides hold
+ * such pixels.  pixel_bytes = 8: d_gathered holds the wire pixels that
+ * SDFHIP_FLAG_WIRE renders make -- every pixel Compute.hlsl writes is (a, a, a, n), or the
+ * sky constant (0.005, 0.01, 0.2, n), so {bits of a, n | sky << 31} carries it in half the
+ * bytes over xGMI -- and d_frame receives the RGBA32F frame, bit for bit what a render
+ * without the flag writes.  Asynchronous on `stream`. */
 SDFHIP_API int sdfhip_deinterleave_device(int device, const void *d_gathered, void *d_frame,
                                           uint32_t width, uint32_t height,
                                           uint32_t band_rows, uint32_t world,
                                           uint32_t rows_per_rank, uint32_t pixel_bytes,
                                           uint32_t frames, void *stream);
+
+/* Layouts that give the ranks unequal shares of the frame (rank 0 also assembles the frame, so it
+ * should render less): the bands a rank renders come as an explicit list instead of "every
+ * band_stride-th".  Local band i of the compact output (rows i*band_rows .. of nrows_out) is band
+ * bands[i] of the frame; n_bands <= 512.  n_frames consecutive Info blocks render in one launch as
+ * in sdfhip_render_batch_device; pt != NULL selects the path-traced mode (one frame). */
+SDFHIP_API int sdfhip_render_bands_device(sdfhip_scene *scene, const sdfhip_info *infos, uint32_t n_frames,
+                                          const sdfhip_pathtrace *pt, uint32_t width, uint32_t height,
+                                          uint32_t band_rows, const uint16_t *bands, uint32_t n_bands,
+                                          uint32_t nrows_out, uint32_t flags, float *d_rgba_out, void *stream,
+                                          sdfhip_stats *stats);
+
+/* sdfhip_deinterleave_device for such a layout: owner[b] = the rank that rendered band b of the frame
+ * (ceil(height / band_rows) entries, at most 512; world <= 64); a rank's bands sit in its buffer in
+ * increasing band order. */
+SDFHIP_API int sdfhip_deinterleave_bands_device(int device, const void *d_gathered, void *d_frame,
+                                                uint32_t width, uint32_t height, uint32_t band_rows,
+                                                uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
+                                                uint32_t pixel_bytes, uint32_t frames, void *stream);
 
 /* Test hook: the kernel's R8_UNorm decode of bytes 0..255 (256 floats to the
  * host), checked exhaustively against byte/255.0f. */

@@ -29,6 +29,7 @@ OK, ERR_ARG, ERR_IO, ERR_BAD_TREE, ERR_DEVICE, ERR_NOMEM = range(6)
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_STACK = 0, 1, 2
 FLAG_COMPACT, FLAG_COUNT, FLAG_DISPLAY, FLAG_DISPLAY_DEBUG = 0x10, 0x20, 0x40, 0x80
+FLAG_WIRE = 0x10000
 SHAPE_SPHERE, SHAPE_TORUS, SHAPE_GYROID = 0, 1, 2
 
 
@@ -145,6 +146,12 @@ _SIG = {
                                          _c.c_int, _vp, _c.POINTER(Stats)]),
     "sdfhip_deinterleave_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32,
                                               _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+    "sdfhip_render_bands_device": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.POINTER(PathTrace), _c.c_uint32,
+                                              _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_uint16), _c.c_uint32,
+                                              _c.c_uint32, _c.c_uint32, _vp, _vp, _c.POINTER(Stats)]),
+    "sdfhip_deinterleave_bands_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                                    _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_uint8), _c.c_uint32,
+                                                    _c.c_uint32, _vp]),
     "sdfhip_debug_unorm_table": (_c.c_int, [_c.c_int, _vp]),
 }
 # every symbol include/sdfhip.h declares must be exported: fail at import otherwise

@@ -40,6 +40,7 @@ struct FrameInfo {
     float fov, k_strength;     // k_strength = exp2f(strength) - 1, evaluated on the host
 };
 constexpr int MAX_BATCH = 8;   // frames one k_plain launch can render (grid.y)
+constexpr int MAX_BAND_LIST = 512;   // bands one launch can be handed as an explicit list
 
 // Kernel parameters: scene, frame geometry, and the camera block of every frame of the launch.
 struct RenderParams {
@@ -48,6 +49,11 @@ struct RenderParams {
     float4 *out;               // compact rows: nrows_out x width
     uint32_t width, height;    // full frame
     uint32_t band_rows, band_first, band_stride, nrows_out;
+    // n_band_list != 0: local band i is band band_list[i] of the frame (an explicit list instead of
+    // every band_stride-th band: layouts that give the ranks unequal shares).  Read-only, so the
+    // kernels index it in the kernel-argument segment.
+    uint32_t n_band_list;
+    uint16_t band_list[MAX_BAND_LIST];
     uint32_t tiles_x, tiles_y, n_tiles;   // 8x8 (compact) or 16x16 (plain) tiles of the local rows
     // frames[f]: camera of frame f of a batched launch (k_plain: f = blockIdx.y, output at
     // out + f * nrows_out * width pixels; the other kernels render frames[0] only).  A rank's
@@ -60,7 +66,8 @@ struct RenderParams {
     uint32_t *queue;           // tile queue head (compact kernels)
     uint32_t tile_order;       // k_plain: blockIdx -> tile mapping (tuning knob, flags bits 8..11)
     // fused display pass (DisplayFrag.hlsl): out_mode 0 = RGBA32F frame, 1 = gamma RGBA8,
-    // 2 = step-count heat map RGBA8; out8 aliases `out` as one uint32 per pixel
+    // 2 = step-count heat map RGBA8 (`out` aliased as one uint32 per pixel), 3 = wire pixels of the
+    // tile gather (`out` aliased as one uint2 per pixel)
     uint32_t out_mode;
     uint32_t sky8;             // the sky constant through the display pass (host-computed, alpha excluded)
     // path-traced mode (k_path): samples per pixel, diffuse bounces, RNG seed, albedo

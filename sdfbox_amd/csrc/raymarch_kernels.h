@@ -45,8 +45,9 @@ struct RayState {
 
 __device__ __forceinline__ uint32_t global_row(const RenderParams &P, uint32_t yl)
 {
-    uint32_t band = yl / P.band_rows;
-    return (P.band_first + band * P.band_stride) * P.band_rows + (yl - band * P.band_rows);
+    const uint32_t band = yl / P.band_rows, within = yl - band * P.band_rows;
+    if (P.n_band_list) return band < P.n_band_list ? P.band_list[band] * P.band_rows + within : 0xFFFFFFFFu;
+    return (P.band_first + band * P.band_stride) * P.band_rows + within;
 }
 
 template <class CursorT>
@@ -94,17 +95,29 @@ __device__ __forceinline__ uint32_t display8(const float4 &v, uint32_t mode)
 // load, so a global store per finished pixel would stall the very next node load of
 // the whole wave behind the store's completion).  Every finished pixel is the sky
 // constant, black, or a grey level, which keeps the display pass to one pow.
+// mode 3 is the wire format of the tile gather (8 bytes per pixel, lossless): the grey level's
+// bits and the step count, bit 31 of the count word marking a sky pixel (wire_expand undoes it).
+constexpr uint32_t WIRE_SKY = 0x80000000u;
+__device__ __forceinline__ float4 wire_expand(uint2 w)
+{
+    const float steps = (float)(w.y & ~WIRE_SKY);
+    if (w.y & WIRE_SKY) return make_float4(0.005f, 0.01f, 0.2f, steps);
+    const float a = __uint_as_float(w.x);
+    return make_float4(a, a, a, steps);
+}
 struct FrameSink {
-    float4 *p;            // RGBA32F pixel, or (as uint32_t *) the RGBA8 pixel
+    float4 *p;            // RGBA32F pixel, or (as uint32_t *) the RGBA8 pixel, or (as uint2 *) the wire pixel
     uint32_t mode, sky8;
     __device__ __forceinline__ void sky(float steps) const
     {
         if (mode == 0u) *p = make_float4(0.005f, 0.01f, 0.2f, steps);
+        else if (mode == 3u) *reinterpret_cast<uint2 *>(p) = make_uint2(0u, (uint32_t)steps | WIRE_SKY);
         else *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : (sky8 | alpha8(steps));
     }
     __device__ __forceinline__ void grey(float a, float steps) const
     {
         if (mode == 0u) *p = make_float4(a, a, a, steps);
+        else if (mode == 3u) *reinterpret_cast<uint2 *>(p) = make_uint2(__float_as_uint(a), (uint32_t)steps);
         else {
             uint32_t q = gamma8(a);
             *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : (q | (q << 8) | (q << 16) | alpha8(steps));
@@ -113,6 +126,7 @@ struct FrameSink {
     __device__ __forceinline__ void black(float steps) const
     {
         if (mode == 0u) *p = make_float4(0.0f, 0.0f, 0.0f, steps);
+        else if (mode == 3u) *reinterpret_cast<uint2 *>(p) = make_uint2(0u, (uint32_t)steps);
         else *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : alpha8(steps);
     }
 };
@@ -273,7 +287,9 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
         const NodeRec root = P.nodes[0];
         start_pixel(I, root, x, y, r, c);
         const size_t pidx = ((size_t)blockIdx.y * P.nrows_out + yl) * P.width + x;
-        const FrameSink dst{P.out_mode == 0u ? P.out + pidx : reinterpret_cast<float4 *>(reinterpret_cast<uint32_t *>(P.out) + pidx),
+        const FrameSink dst{P.out_mode == 0u ? P.out + pidx :
+                            P.out_mode == 3u ? reinterpret_cast<float4 *>(reinterpret_cast<uint2 *>(P.out) + pidx) :
+                                               reinterpret_cast<float4 *>(reinterpret_cast<uint32_t *>(P.out) + pidx),
                             P.out_mode, P.sky8};
         while (!pre_step(I, r, c, dst)) {
             uint32_t reads = march_step(P, I, r, c, stack_lds + tid, BT);

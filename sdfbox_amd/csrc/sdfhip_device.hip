@@ -31,10 +31,19 @@ __global__ void k_fuse(const int2 *__restrict__ structs, const uint2 *__restrict
 }
 
 // Gathered compact band buffers -> frame rows (rank-0 side of the tile gather).
-template <class Pixel>
-__global__ void k_deinterleave(const Pixel *__restrict__ gathered, Pixel *__restrict__ frame,
+// Which rank rendered a band, and where: round robin (n == 0), or an explicit map with
+// src[band] = rank << 10 | local band (layouts with unequal shares).
+struct BandMap {
+    uint32_t n;
+    uint16_t src[MAX_BAND_LIST];
+};
+__device__ __forceinline__ float4 frame_pixel(float4 v) { return v; }
+__device__ __forceinline__ uint32_t frame_pixel(uint32_t v) { return v; }
+__device__ __forceinline__ float4 frame_pixel(uint2 v) { return wire_expand(v); }   // wire pixels (SDFHIP_FLAG_WIRE)
+template <class In, class Out>
+__global__ void k_deinterleave(const In *__restrict__ gathered, Out *__restrict__ frame,
                                uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world,
-                               uint32_t rows_per_rank, uint32_t frames)
+                               uint32_t rows_per_rank, uint32_t frames, const BandMap M)
 {
     // gathered: [world][frames][rows_per_rank][width]  ->  frame: [frames][height][width]
     size_t per_frame = (size_t)width * height, total = per_frame * frames;
@@ -44,8 +53,9 @@ __global__ void k_deinterleave(const Pixel *__restrict__ gathered, Pixel *__rest
         size_t r = i - (size_t)f * per_frame;
         uint32_t y = (uint32_t)(r / width), x = (uint32_t)(r - (size_t)y * width);
         uint32_t band = y / band_rows, rank = band % world, lband = band / world;
+        if (M.n) { const uint32_t e = M.src[band]; rank = e >> 10; lband = e & 1023u; }
         uint32_t yl = lband * band_rows + (y - band * band_rows);
-        frame[i] = gathered[(((size_t)rank * frames + f) * rows_per_rank + yl) * width + x];
+        frame[i] = frame_pixel(gathered[(((size_t)rank * frames + f) * rows_per_rank + yl) * width + x]);
     }
 }
 
@@ -211,7 +221,8 @@ void launch_pair(bool compact, int bt, dim3 grid, hipStream_t st, const RenderPa
 int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32_t height,
                 uint32_t band_rows, uint32_t band_first, uint32_t band_stride, uint32_t nrows_out,
                 uint32_t flags, float *d_out, hipStream_t st, sdfhip_stats *stats,
-                const sdfhip_pathtrace *pt = nullptr, uint32_t n_frames = 1)
+                const sdfhip_pathtrace *pt = nullptr, uint32_t n_frames = 1,
+                const uint16_t *bands = nullptr, uint32_t n_bands = 0)
 {
     // `info` points at n_frames consecutive Info blocks (batched launch: plain kernel only)
     if (n_frames == 0 || n_frames > (uint32_t)MAX_BATCH)
@@ -227,7 +238,10 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     const bool use_stack = kind == SDFHIP_KERNEL_STACK || (kind == SDFHIP_KERNEL_AUTO && s->stack_ok);
     const bool compact = (flags & SDFHIP_FLAG_COMPACT) != 0;
     const bool count = (flags & SDFHIP_FLAG_COUNT) != 0;
-    const uint32_t out_mode = (flags & SDFHIP_FLAG_DISPLAY_DEBUG) ? 2u : ((flags & SDFHIP_FLAG_DISPLAY) ? 1u : 0u);
+    const bool wire = (flags & SDFHIP_FLAG_WIRE) != 0;
+    const uint32_t out_mode = wire ? 3u : (flags & SDFHIP_FLAG_DISPLAY_DEBUG) ? 2u : ((flags & SDFHIP_FLAG_DISPLAY) ? 1u : 0u);
+    if (wire && (compact || pt || (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG))))
+        return fail(SDFHIP_ERR_ARG, "render: wire pixels come from the plain kernel only, without the display pass");
     if (pt) {
         if (pt->spp == 0 || pt->spp > 4096 || pt->max_bounces > 64)
             return fail(SDFHIP_ERR_ARG, "render_path: spp %u (1..4096) or max_bounces %u (0..64) out of range", pt->spp, pt->max_bounces);
@@ -241,6 +255,21 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     P.width = width; P.height = height;
     P.band_rows = band_rows; P.band_first = band_first; P.band_stride = band_stride;
     P.nrows_out = nrows_out;
+    P.n_band_list = 0;
+    memset(P.band_list, 0, sizeof P.band_list);
+    if (bands) {                                      // an explicit band list replaces first/stride
+        if (n_bands == 0 || n_bands > (uint32_t)MAX_BAND_LIST)
+            return fail(SDFHIP_ERR_ARG, "render_bands: %u bands outside 1..%d", n_bands, MAX_BAND_LIST);
+        if ((uint64_t)n_bands * band_rows > nrows_out)
+            return fail(SDFHIP_ERR_ARG, "render_bands: %u bands of %u rows do not fit nrows_out = %u", n_bands, band_rows, nrows_out);
+        const uint32_t frame_bands = (height + band_rows - 1) / band_rows;
+        for (uint32_t i = 0; i < n_bands; i++) {
+            if (bands[i] >= frame_bands)
+                return fail(SDFHIP_ERR_ARG, "render_bands: band %u of a frame with %u bands", (unsigned)bands[i], frame_bands);
+            P.band_list[i] = bands[i];
+        }
+        P.n_band_list = n_bands;
+    }
     P.tile_order = (flags >> 8) & 0xF;
     const uint32_t btsel = (flags >> 12) & 0xF;                       // tuning knob: 0 = default
     const int bt = btsel == 3 ? 256 : (btsel == 2 ? 128 : 64);
@@ -345,6 +374,7 @@ extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t 
 {
     if (!s || !info || !rgba_out) return fail(SDFHIP_ERR_ARG, "render: null argument");
     if (width == 0 || height == 0) return fail(SDFHIP_ERR_ARG, "render: zero-sized frame");
+    if (flags & SDFHIP_FLAG_WIRE) return fail(SDFHIP_ERR_ARG, "render: SDFHIP_FLAG_WIRE is for the device-resident entry points");
     std::lock_guard<std::mutex> lk(s->lock);
     DeviceGuard g(s->device);
     if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render: hipSetDevice(%d) failed", s->device);
@@ -377,6 +407,21 @@ extern "C" int sdfhip_render_path_device(sdfhip_scene *s, const sdfhip_info *inf
     if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render_path_device: hipSetDevice(%d) failed", s->device);
     return render_impl(s, info, width, height, band_rows, band_first, band_stride, nrows_out, flags,
                        d_rgba_out, (hipStream_t)stream, stats, pt);
+}
+
+extern "C" int sdfhip_render_bands_device(sdfhip_scene *s, const sdfhip_info *infos, uint32_t n_frames,
+                                          const sdfhip_pathtrace *pt, uint32_t width, uint32_t height,
+                                          uint32_t band_rows, const uint16_t *bands, uint32_t n_bands,
+                                          uint32_t nrows_out, uint32_t flags, float *d_rgba_out, void *stream,
+                                          sdfhip_stats *stats)
+{
+    if (!s || !infos || !bands || !d_rgba_out) return fail(SDFHIP_ERR_ARG, "render_bands_device: null argument");
+    if (pt && n_frames != 1) return fail(SDFHIP_ERR_ARG, "render_bands_device: the path-traced mode renders one frame per launch");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render_bands_device: hipSetDevice(%d) failed", s->device);
+    return render_impl(s, infos, width, height, band_rows, 0, 1, nrows_out, flags, d_rgba_out,
+                       (hipStream_t)stream, stats, pt, n_frames, bands, n_bands);
 }
 
 extern "C" int sdfhip_render_path(sdfhip_scene *s, const sdfhip_info *info, const sdfhip_pathtrace *pt,
@@ -414,18 +459,32 @@ extern "C" int sdfhip_render_display(sdfhip_scene *s, const sdfhip_info *info, u
     return sdfhip_render(s, info, width, height, flags, reinterpret_cast<float *>(rgba8_out), stats);
 }
 
-extern "C" int sdfhip_deinterleave_device(int device, const void *d_gathered, void *d_frame,
-                                          uint32_t width, uint32_t height, uint32_t band_rows,
-                                          uint32_t world, uint32_t rows_per_rank, uint32_t pixel_bytes,
-                                          uint32_t frames, void *stream)
+static int deinterleave_impl(int device, const void *d_gathered, void *d_frame, uint32_t width, uint32_t height,
+                            uint32_t band_rows, uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
+                            uint32_t pixel_bytes, uint32_t frames, void *stream)
 {
     if (frames == 0) return fail(SDFHIP_ERR_ARG, "deinterleave: frames must be >= 1");
     if (!d_gathered || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
         return fail(SDFHIP_ERR_ARG, "deinterleave: null or zero argument");
-    if (pixel_bytes != 16 && pixel_bytes != 4)
-        return fail(SDFHIP_ERR_ARG, "deinterleave: pixel_bytes must be 16 (RGBA32F) or 4 (RGBA8), got %u", pixel_bytes);
-    uint32_t nbands = (height + band_rows - 1) / band_rows;
+    if (pixel_bytes != 16 && pixel_bytes != 4 && pixel_bytes != 8)
+        return fail(SDFHIP_ERR_ARG, "deinterleave: pixel_bytes must be 16 (RGBA32F), 8 (wire) or 4 (RGBA8), got %u", pixel_bytes);
+    const uint32_t nbands = (height + band_rows - 1) / band_rows;
+    BandMap M;
+    M.n = 0;
+    memset(M.src, 0, sizeof M.src);
     uint32_t need_rows = ((nbands + world - 1) / world) * band_rows;
+    if (owner) {                                      // local band = how many earlier bands the same rank owns
+        if (nbands > (uint32_t)MAX_BAND_LIST || world > 64)
+            return fail(SDFHIP_ERR_ARG, "deinterleave_bands: %u bands (max %d) over %u ranks (max 64)", nbands, MAX_BAND_LIST, world);
+        uint32_t have[64] = { 0 };
+        for (uint32_t b = 0; b < nbands; b++) {
+            if (owner[b] >= world) return fail(SDFHIP_ERR_ARG, "deinterleave_bands: band %u belongs to rank %u of %u", b, (unsigned)owner[b], world);
+            M.src[b] = (uint16_t)((uint32_t)owner[b] << 10 | have[owner[b]]++);
+        }
+        M.n = nbands;
+        need_rows = 0;
+        for (uint32_t r = 0; r < world; r++) need_rows = have[r] * band_rows > need_rows ? have[r] * band_rows : need_rows;
+    }
     if (rows_per_rank < need_rows)
         return fail(SDFHIP_ERR_ARG, "deinterleave: rows_per_rank %u < %u needed for %u bands over %u ranks", rows_per_rank, need_rows, nbands, world);
     DeviceGuard g(device);
@@ -433,15 +492,38 @@ extern "C" int sdfhip_deinterleave_device(int device, const void *d_gathered, vo
     size_t total = (size_t)width * height * frames;
     uint32_t blocks = (uint32_t)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (pixel_bytes == 16)
-        hipLaunchKernelGGL((k_deinterleave<float4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((k_deinterleave<float4, float4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const float4 *)d_gathered, (float4 *)d_frame, width, height, band_rows,
-                           world, rows_per_rank, frames);
+                           world, rows_per_rank, frames, M);
+    else if (pixel_bytes == 8)
+        hipLaunchKernelGGL((k_deinterleave<uint2, float4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const uint2 *)d_gathered, (float4 *)d_frame, width, height, band_rows,
+                           world, rows_per_rank, frames, M);
     else
-        hipLaunchKernelGGL((k_deinterleave<uint32_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((k_deinterleave<uint32_t, uint32_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const uint32_t *)d_gathered, (uint32_t *)d_frame, width, height, band_rows,
-                           world, rows_per_rank, frames);
+                           world, rows_per_rank, frames, M);
     HIP_TRY(hipGetLastError());
     return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_deinterleave_device(int device, const void *d_gathered, void *d_frame,
+                                          uint32_t width, uint32_t height, uint32_t band_rows,
+                                          uint32_t world, uint32_t rows_per_rank, uint32_t pixel_bytes,
+                                          uint32_t frames, void *stream)
+{
+    return deinterleave_impl(device, d_gathered, d_frame, width, height, band_rows, world, rows_per_rank, nullptr,
+                             pixel_bytes, frames, stream);
+}
+
+extern "C" int sdfhip_deinterleave_bands_device(int device, const void *d_gathered, void *d_frame,
+                                                uint32_t width, uint32_t height, uint32_t band_rows,
+                                                uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
+                                                uint32_t pixel_bytes, uint32_t frames, void *stream)
+{
+    if (!owner) return fail(SDFHIP_ERR_ARG, "deinterleave_bands: null owner table");
+    return deinterleave_impl(device, d_gathered, d_frame, width, height, band_rows, world, rows_per_rank, owner,
+                             pixel_bytes, frames, stream);
 }
 
 extern "C" int sdfhip_debug_unorm_table(int device, float *out256)

@@ -66,6 +66,23 @@ class Scene:
                                              ctypes.c_void_p(int(stream)) if stream else None,
                                              ctypes.byref(stats) if stats is not None else None))
 
+    def DrawBandsDevice(self, states, width, height, out_ptr, band_rows, bands, nrows_out=None, pt=None,
+                        flags=_lib.KERNEL_AUTO, stream=None, stats=None):
+        """The listed bands (band indices of the frame, `band_rows` rows each) of one or several
+        frames into out_ptr[f][nrows_out][width] pixels: local band i = bands[i].  pt: path-traced
+        mode (one frame)."""
+        if not isinstance(states, (list, tuple)):
+            states = [states]
+        infos = (Info * len(states))(*[s if isinstance(s, Info) else s.State for s in states])
+        blist = (ctypes.c_uint16 * len(bands))(*[int(b) for b in bands])
+        if nrows_out is None:
+            nrows_out = len(bands) * int(band_rows)
+        check(lib.sdfhip_render_bands_device(self._h, infos, len(states), ctypes.byref(pt) if pt is not None else None,
+                                             int(width), int(height), int(band_rows), blist, len(bands),
+                                             int(nrows_out), int(flags), ctypes.c_void_p(int(out_ptr)),
+                                             ctypes.c_void_p(int(stream)) if stream else None,
+                                             ctypes.byref(stats) if stats is not None else None))
+
     def DrawPath(self, state, width, height, pt=None, flags=_lib.KERNEL_AUTO, want_stats=False):
         """Path-traced frame (BASELINE config 5; defined by the oracle's o_pixel_pt): host array
         (H, W, 4) float32, mean radiance + step count."""

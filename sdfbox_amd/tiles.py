@@ -8,6 +8,13 @@ object rows.  Each rank renders its bands into a compact local buffer of
 `rows_per_rank` rows; one gather per frame brings the buffers to rank 0 over
 xGMI (RCCL send/recv: every peer has its own direct link into rank 0), where
 a small kernel restores row order.  No other collective is on the data path.
+
+The gather is bound by one xGMI link per peer (frame bytes / world over ~77 GB/s
+per direction), and at ~8 Gray/s per GPU an RGBA32F frame would make every
+world size link-bound.  Every pixel the shader writes is (a, a, a, steps) or the
+sky constant, so ranks render 8-byte *wire pixels* (FLAG_WIRE: the bits of a,
+the step count, a sky bit) and rank 0 expands them while restoring row order --
+the assembled RGBA32F frame is bit for bit the single-GPU frame.
 """
 import ctypes
 
@@ -15,25 +22,56 @@ from ._lib import check, lib
 
 
 class BandLayout:
-    """Which rows a rank renders, and where they sit in its compact buffer."""
+    """Which rows a rank renders, and where they sit in its compact buffer.
 
-    def __init__(self, height, world, band_rows=16):
+    rank0_weight = 1: bands are dealt round-robin (band b -> rank b mod world).
+    rank0_weight < 1: rank 0, which also assembles the frame, gets that fraction of a peer's
+    share; bands are dealt by largest remaining credit, so every rank's bands stay spread over
+    the whole frame (sky and object rows in every share).  A rank's bands sit in its compact
+    buffer in increasing band order either way."""
+
+    def __init__(self, height, world, band_rows=16, rank0_weight=1.0):
         if band_rows < 1 or world < 1 or height < 1:
             raise ValueError("BandLayout: height, world and band_rows must be positive")
-        # any band height renders correctly; multiples of 16 keep whole workgroup
-        # tiles (16x16 pixels) inside one band
+        if not 0.0 < rank0_weight <= 1.0:
+            raise ValueError("BandLayout: rank0_weight must be in (0, 1]")
+        # any band height renders correctly; multiples of 8 keep whole 8x8 wave tiles inside one band
         self.height, self.world, self.band_rows = int(height), int(world), int(band_rows)
         self.n_bands = (self.height + self.band_rows - 1) // self.band_rows
-        self.bands_per_rank = (self.n_bands + self.world - 1) // self.world
+        self.rank0_weight = float(rank0_weight) if world > 1 else 1.0
+        self.weighted = self.rank0_weight < 1.0
+        if self.weighted:
+            if self.n_bands > 512 or self.world > 64:
+                raise ValueError("BandLayout: a weighted layout holds at most 512 bands and 64 ranks")
+            # integer credits (no float accumulation: every rank must compute the same deal)
+            unit = 1 << 20
+            w = [int(round(self.rank0_weight * unit))] + [unit] * (self.world - 1)
+            total = sum(w)
+            credit = [0] * self.world
+            self.owner = []
+            for _ in range(self.n_bands):
+                for r in range(self.world):
+                    credit[r] += w[r]
+                best = max(range(self.world), key=lambda r: (credit[r], -r))
+                credit[best] -= total
+                self.owner.append(best)
+        else:
+            self.owner = [b % self.world for b in range(self.n_bands)]
+        self._bands = [[b for b in range(self.n_bands) if self.owner[b] == r] for r in range(self.world)]
+        self._local = [0] * self.n_bands
+        for blist in self._bands:
+            for lb, b in enumerate(blist):
+                self._local[b] = lb
+        self.bands_per_rank = max(len(b) for b in self._bands)
         self.rows_per_rank = self.bands_per_rank * self.band_rows   # equal message sizes
 
     def bands_of(self, rank):
-        return list(range(rank, self.n_bands, self.world))
+        return list(self._bands[rank])
 
     def rows_of(self, rank):
         """[(local_row, global_row)] for every real row of `rank`."""
         out = []
-        for lb, b in enumerate(self.bands_of(rank)):
+        for lb, b in enumerate(self._bands[rank]):
             for r in range(self.band_rows):
                 y = b * self.band_rows + r
                 if y < self.height:
@@ -43,11 +81,15 @@ class BandLayout:
     def source_of(self, y):
         """global row -> (rank, local_row): the inverse used by the de-interleave."""
         b = y // self.band_rows
-        return b % self.world, (b // self.world) * self.band_rows + y % self.band_rows
+        return self.owner[b], self._local[b] * self.band_rows + y % self.band_rows
 
 
 def render_bands(scene, state, width, layout, rank, out_ptr, flags=0, stream=None, stats=None, pt=None):
     """Render `rank`'s bands of the frame into its compact device buffer (pt: path-traced mode)."""
+    if layout.weighted:
+        scene.DrawBandsDevice([state], width, layout.height, out_ptr, layout.band_rows, layout.bands_of(rank),
+                              nrows_out=layout.rows_per_rank, pt=pt, flags=flags, stream=stream, stats=stats)
+        return
     kw = dict(nrows_out=layout.rows_per_rank, band_rows=layout.band_rows, band_first=rank,
               band_stride=layout.world, flags=flags, stream=stream, stats=stats)
     if pt is None:
@@ -60,6 +102,10 @@ def render_bands_batch(scene, states, width, layout, rank, out_ptr, flags=0, str
     """`rank`'s bands of several frames (one camera each) in ONE launch, into
     out_ptr[frame][rows_per_rank][width]: the frames of a gather group share the serial tail of
     the share's longest pixels."""
+    if layout.weighted:
+        scene.DrawBandsDevice(list(states), width, layout.height, out_ptr, layout.band_rows, layout.bands_of(rank),
+                              nrows_out=layout.rows_per_rank, flags=flags, stream=stream, stats=stats)
+        return
     scene.DrawBatchDevice(states, width, layout.height, out_ptr, nrows_out=layout.rows_per_rank,
                           band_rows=layout.band_rows, band_first=rank, band_stride=layout.world,
                           flags=flags, stream=stream, stats=stats)
@@ -68,9 +114,17 @@ def render_bands_batch(scene, states, width, layout, rank, out_ptr, flags=0, str
 def deinterleave(device, gathered_ptr, frame_ptr, width, layout, stream=None, pixel_bytes=16, frames=1):
     """Rank 0: gathered compact buffers (world x frames x rows_per_rank x width pixels) ->
     frames x height x width.  pixel_bytes: 16 for RGBA32F frames, 4 for RGBA8 frames of the
-    fused display pass.  frames > 1: one gather carried several frames."""
+    fused display pass, 8 for wire pixels (FLAG_WIRE renders), which are expanded to the RGBA32F
+    frame on the way.  frames > 1: one gather carried several frames."""
+    st = ctypes.c_void_p(int(stream)) if stream else None
+    if layout.weighted:
+        owner = (ctypes.c_uint8 * layout.n_bands)(*layout.owner)
+        check(lib.sdfhip_deinterleave_bands_device(int(device), ctypes.c_void_p(int(gathered_ptr)),
+                                                   ctypes.c_void_p(int(frame_ptr)), int(width), layout.height,
+                                                   layout.band_rows, layout.world, layout.rows_per_rank, owner,
+                                                   int(pixel_bytes), int(frames), st))
+        return
     check(lib.sdfhip_deinterleave_device(int(device), ctypes.c_void_p(int(gathered_ptr)),
                                          ctypes.c_void_p(int(frame_ptr)), int(width),
                                          layout.height, layout.band_rows, layout.world,
-                                         layout.rows_per_rank, int(pixel_bytes), int(frames),
-                                         ctypes.c_void_p(int(stream)) if stream else None))
+                                         layout.rows_per_rank, int(pixel_bytes), int(frames), st))

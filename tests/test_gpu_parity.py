@@ -343,6 +343,116 @@ def test_grouped_gather_deinterleave(sb, gpu_scenes):
         assert torch.equal(frames[f].view(torch.int32), full[f].view(torch.int32)), f
 
 
+def test_wire_pixels_expand_to_the_same_frame(sb, gpu_scenes):
+    # the gather's 8-byte wire format (FLAG_WIRE) is lossless: ranks render wire pixels, rank 0's
+    # de-interleave expands them, and the frame is the direct RGBA32F render bit for bit --
+    # sky, lit, shadowed and back-facing pixels, single and batched launches, both kernels
+    import torch
+    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, (W, H, world, band_rows) in [("sphere_d4", (128, 96, 1, 96)), ("torus_d6", (150, 90, 3, 16)),
+                                           ("torus_d6", (97, 61, 4, 8))]:
+        scene = gpu_scenes[name]
+        cams = [make_camera(n, W, H) for n in ("default", "rotated", "closeup")]
+        for i, v in enumerate((0.9, 0.1, 0.2)):                          # a light that leaves shadowed and back-facing pixels
+            cams[1].State.light[i] = v
+        lay = BandLayout(H, world, band_rows)
+        for kern in (sb.KERNEL_STACK, sb.KERNEL_GENERIC):
+            full = [torch.from_numpy(scene.Draw(c, W, H, kern)).cuda() for c in cams]
+            kinds = set()
+            for f in full:
+                rgb = f[..., :3]
+                kinds |= {"sky"} if bool((rgb[..., 0] != rgb[..., 1]).any()) else set()
+                kinds |= {"black"} if bool((rgb == 0).all(-1).any()) else set()
+                kinds |= {"lit"} if bool(((rgb[..., 0] == rgb[..., 1]) & (rgb[..., 0] > 0)).any()) else set()
+            assert kinds == {"sky", "black", "lit"}, kinds
+            # one launch per frame
+            gathered = torch.zeros((world, 3, lay.rows_per_rank, W, 2), dtype=torch.int32, device="cuda")
+            for r in range(world):
+                for f, c in enumerate(cams):
+                    render_bands(scene, c, W, lay, r, gathered[r, f].data_ptr(), flags=kern | sb.FLAG_WIRE, stream=stream)
+            frames = torch.full((3, H, W, 4), -1.0, dtype=torch.float32, device="cuda")
+            deinterleave(0, gathered.data_ptr(), frames.data_ptr(), W, lay, stream=stream, pixel_bytes=8, frames=3)
+            torch.cuda.synchronize()
+            for f in range(3):
+                assert torch.equal(frames[f].view(torch.int32), full[f].view(torch.int32)), (name, kern, f)
+            # the three frames in one launch per rank
+            gathered2 = torch.zeros_like(gathered)
+            for r in range(world):
+                render_bands_batch(scene, cams, W, lay, r, gathered2[r].data_ptr(), flags=kern | sb.FLAG_WIRE, stream=stream)
+            torch.cuda.synchronize()
+            assert torch.equal(gathered2, gathered), (name, kern)
+    # wire pixels are for device-resident gathers of the plain kernel only
+    scene = gpu_scenes["sphere_d4"]
+    cam = make_camera("default", 64, 64)
+    buf = torch.zeros((64, 64, 4), dtype=torch.float32, device="cuda")
+    with pytest.raises(sb.SdfHipError):
+        scene.Draw(cam, 64, 64, sb.FLAG_WIRE)
+    with pytest.raises(sb.SdfHipError):
+        scene.DrawDevice(cam, 64, 64, buf.data_ptr(), flags=sb.FLAG_WIRE | sb.FLAG_COMPACT, stream=stream)
+    with pytest.raises(sb.SdfHipError):
+        scene.DrawDevice(cam, 64, 64, buf.data_ptr(), flags=sb.FLAG_WIRE | sb.FLAG_DISPLAY, stream=stream)
+    with pytest.raises(sb.SdfHipError):
+        scene.DrawPathDevice(cam, 64, 64, buf.data_ptr(), pt=sb.PathTrace(spp=1), flags=sb.FLAG_WIRE, stream=stream)
+
+
+def test_weighted_band_layouts_reassemble_the_frame(sb, gpu_scenes):
+    # layouts that give rank 0 a smaller share (it also assembles the frame): explicit band lists
+    # on the render side, an owner table on the de-interleave side; all pixel formats, batched
+    # launches and the path-traced mode
+    import torch
+    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch
+    scene = gpu_scenes["torus_d6"]
+    stream = torch.cuda.current_stream().cuda_stream
+    for (W, H, world, band_rows, w0) in [(160, 100, 3, 8, 0.5), (90, 77, 4, 16, 0.8), (64, 200, 8, 8, 0.775), (70, 50, 2, 24, 0.9)]:
+        lay = BandLayout(H, world, band_rows, w0)
+        assert lay.weighted and len(lay.bands_of(0)) < len(lay.bands_of(1))
+        cams = [make_camera(n, W, H) for n in ("rotated", "closeup")]
+        full = [torch.from_numpy(scene.Draw(c, W, H)).cuda() for c in cams]
+        # RGBA32F and wire pixels, one launch per frame and one per group
+        for pb, shape, dt, fl in ((16, (4,), torch.float32, 0), (8, (2,), torch.int32, sb.FLAG_WIRE)):
+            gathered = torch.zeros((world, 2, lay.rows_per_rank, W) + shape, dtype=dt, device="cuda")
+            for r in range(world):
+                for f, c in enumerate(cams):
+                    render_bands(scene, c, W, lay, r, gathered[r, f].data_ptr(), flags=fl, stream=stream)
+            frames = torch.full((2, H, W, 4), -1.0, dtype=torch.float32, device="cuda")
+            deinterleave(0, gathered.data_ptr(), frames.data_ptr(), W, lay, stream=stream, pixel_bytes=pb, frames=2)
+            batched = torch.zeros_like(gathered)
+            for r in range(world):
+                render_bands_batch(scene, cams, W, lay, r, batched[r].data_ptr(), flags=fl, stream=stream)
+            torch.cuda.synchronize()
+            for f in range(2):
+                assert torch.equal(frames[f].view(torch.int32), full[f].view(torch.int32)), (W, H, world, pb, f)
+            assert torch.equal(batched, gathered), (W, H, world, pb)
+        # RGBA8 frames of the fused display pass
+        ref8 = torch.from_numpy(scene.DrawDisplay(cams[0], W, H).view(np.int32).reshape(H, W)).cuda()
+        g8 = torch.zeros((world, lay.rows_per_rank, W), dtype=torch.int32, device="cuda")
+        for r in range(world):
+            render_bands(scene, cams[0], W, lay, r, g8[r].data_ptr(), flags=sb.FLAG_DISPLAY, stream=stream)
+        f8 = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+        deinterleave(0, g8.data_ptr(), f8.data_ptr(), W, lay, stream=stream, pixel_bytes=4)
+        # path-traced mode
+        pt = sb.PathTrace(spp=2)
+        refp = torch.from_numpy(scene.DrawPath(cams[0], W, H, pt=pt)).cuda()
+        gp = torch.zeros((world, lay.rows_per_rank, W, 4), dtype=torch.float32, device="cuda")
+        for r in range(world):
+            render_bands(scene, cams[0], W, lay, r, gp[r].data_ptr(), stream=stream, pt=pt)
+        fp = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        deinterleave(0, gp.data_ptr(), fp.data_ptr(), W, lay, stream=stream)
+        torch.cuda.synchronize()
+        assert torch.equal(f8, ref8), (W, H, world)
+        assert torch.equal(fp.view(torch.int32), refp.view(torch.int32)), (W, H, world)
+    # argument checks of the band-list entry points
+    cam = make_camera("default", 64, 64)
+    buf = torch.zeros((64, 64, 4), dtype=torch.float32, device="cuda")
+    with pytest.raises(sb.SdfHipError):      # band 8 of a frame with 8 bands
+        scene.DrawBandsDevice([cam], 64, 64, buf.data_ptr(), 8, [0, 8], stream=stream)
+    with pytest.raises(sb.SdfHipError):      # the list does not fit the output rows
+        scene.DrawBandsDevice([cam], 64, 64, buf.data_ptr(), 8, [0, 1, 2], nrows_out=16, stream=stream)
+    with pytest.raises(sb.SdfHipError):      # path-traced mode: one frame per launch
+        scene.DrawBandsDevice([cam, cam], 64, 64, buf.data_ptr(), 8, [0], pt=sb.PathTrace(spp=1), stream=stream)
+
+
 def test_two_handles_render_concurrently(sb, oracle_mod, scenes):
     # upload / render are callable from several threads on different handles
     cam = make_camera("default", 128, 128)

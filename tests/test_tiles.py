@@ -13,8 +13,11 @@ from conftest import REPO, assert_frames_identical, make_camera
 
 def test_band_layout_partitions_every_row_once():
     from sdfbox_amd.tiles import BandLayout
-    for (H, G, B) in [(1080, 8, 16), (1080, 3, 16), (2160, 8, 16), (37, 4, 8), (16, 8, 16), (100, 1, 16), (64, 2, 24)]:
-        lay = BandLayout(H, G, B)
+    for (H, G, B, w0) in [(1080, 8, 16, 1.0), (1080, 3, 16, 1.0), (2160, 8, 16, 1.0), (37, 4, 8, 1.0), (16, 8, 16, 1.0),
+                          (100, 1, 16, 1.0), (64, 2, 24, 1.0),
+                          (1080, 8, 16, 0.775), (1080, 8, 8, 0.775), (2160, 4, 8, 0.86), (1080, 2, 16, 0.93),
+                          (37, 4, 8, 0.5), (16, 8, 16, 0.3), (100, 1, 16, 0.5)]:
+        lay = BandLayout(H, G, B, w0)
         seen = np.zeros(H, dtype=np.int32)
         for r in range(G):
             rows = lay.rows_of(r)
@@ -25,6 +28,61 @@ def test_band_layout_partitions_every_row_once():
                 assert lay.source_of(y) == (r, l)
         assert (seen == 1).all()
         assert lay.rows_per_rank * G >= H
+
+
+def test_weighted_layout_gives_rank0_less_and_spreads_every_share():
+    from sdfbox_amd.tiles import BandLayout
+    even = BandLayout(1080, 8, 8)
+    assert not even.weighted and even.owner == [b % 8 for b in range(even.n_bands)]
+    lay = BandLayout(1080, 8, 8, 0.775)
+    n = [len(lay.bands_of(r)) for r in range(8)]
+    assert lay.weighted and sum(n) == lay.n_bands == 135
+    assert max(n[1:]) - min(n[1:]) <= 1                       # peers equal within one band
+    assert abs(n[0] / (sum(n[1:]) / 7) - 0.775) < 0.06        # rank 0: the requested fraction of a peer's share
+    assert lay.rows_per_rank == max(n) * 8
+    for r in range(8):                                         # no share is a contiguous slab: gaps stay near world bands
+        b = lay.bands_of(r)
+        assert max(np.diff(b)) <= 2 * 8 + 2, (r, b)
+    assert BandLayout(1080, 8, 8, 0.775).owner == lay.owner    # deterministic: every rank computes the same deal
+    with pytest.raises(ValueError):
+        BandLayout(1080, 8, 8, 0.0)
+    with pytest.raises(ValueError):
+        BandLayout(8192, 8, 8, 0.5)                            # 1024 bands > 512 in a weighted layout
+
+
+def wire_pack(img):
+    """numpy model of the kernel's wire pixels (FrameSink mode 3, raymarch_kernels.h): every pixel is
+    (a, a, a, n) or the sky constant (0.005, 0.01, 0.2, n) -> {bits of a, n | sky << 31}."""
+    bits = np.ascontiguousarray(img).view(np.uint32)
+    sky = bits[..., 0] != bits[..., 1]
+    expect_sky = np.array([0.005, 0.01, 0.2], dtype=np.float32).view(np.uint32)
+    assert (bits[sky][:, :3] == expect_sky).all(), "a non-grey pixel that is not the sky constant"
+    assert (bits[~sky][:, 0] == bits[~sky][:, 2]).all()
+    steps = img[..., 3].astype(np.uint32)
+    assert (steps.astype(np.float32) == img[..., 3]).all() and steps.max() < 2 ** 31
+    return np.stack([np.where(sky, 0, bits[..., 0]).astype(np.uint32), steps | (sky.astype(np.uint32) << 31)], axis=-1)
+
+
+def wire_expand(w):
+    sky = (w[..., 1] >> 31) == 1
+    out = np.empty(w.shape[:-1] + (4,), dtype=np.uint32)
+    out[..., 0] = out[..., 1] = out[..., 2] = w[..., 0]
+    out[sky, :3] = np.array([0.005, 0.01, 0.2], dtype=np.float32).view(np.uint32)
+    out[..., 3] = (w[..., 1] & 0x7FFFFFFF).astype(np.float32).view(np.uint32)
+    return out.view(np.float32)
+
+
+def test_wire_pixels_are_lossless_on_oracle_frames(oracle_mod, scenes):
+    # the premise of the 8-byte gather format, checked on the oracle's own frames (NaN greys included)
+    for name in ("sphere_d4", "torus_d6"):
+        od = scenes[name]
+        for camname in ("default", "rotated", "closeup"):
+            cam = make_camera(camname, 96, 64)
+            cam.State.light[0] = 0.9
+            img, _ = oracle_mod.render(od.Structs, od.Values, cam.State, 96, 64)
+            w = wire_pack(img)
+            assert w.dtype == np.uint32 and w.shape == (64, 96, 2)
+            assert (wire_expand(w).view(np.uint32) == img.view(np.uint32)).all(), (name, camname)
 
 
 def numpy_deinterleave(gathered, layout):
@@ -41,7 +99,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _rank_main(rank, world, port, W, H, band_rows, q):
+def _rank_main(rank, world, port, W, H, band_rows, q, rank0_weight=1.0, wire=False):
     sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
     import torch
     import torch.distributed as dist
@@ -52,7 +110,7 @@ def _rank_main(rank, world, port, W, H, band_rows, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     od = sb.torus_d6()
     cam = make_camera("default", W, H)
-    lay = BandLayout(H, world, band_rows)
+    lay = BandLayout(H, world, band_rows, rank0_weight)
     local = np.zeros((lay.rows_per_rank, W, 4), dtype=np.float32)
     # the oracle renders this rank's bands (the GPU kernel's stand-in on CPU)
     for lb, b in enumerate(lay.bands_of(rank)):
@@ -60,24 +118,26 @@ def _rank_main(rank, world, port, W, H, band_rows, q):
         n = min(band_rows, H - y0)
         img, _ = oracle.render(od.Structs, od.Values, cam.State, W, H, row0=y0, nrows=n)
         local[lb * band_rows: lb * band_rows + n] = img
-    t = torch.from_numpy(local)
+    t = torch.from_numpy(wire_pack(local).view(np.int32) if wire else local)
     glist = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
     dist.gather(t, glist, dst=0)
     if rank == 0:
-        frame = numpy_deinterleave(torch.stack(glist).numpy(), lay)
+        got = torch.stack(glist).numpy()
+        frame = numpy_deinterleave(wire_expand(got.view(np.uint32)) if wire else got, lay)
         full, _ = oracle.render(od.Structs, od.Values, cam.State, W, H)
         q.put(bool(((frame.view(np.uint32) == full.view(np.uint32)) | (np.isnan(frame) & np.isnan(full))).all()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,H,band_rows", [(2, 40, 8), (2, 37, 16)])
-def test_two_rank_gather_reassembles_the_frame(world, H, band_rows):
+@pytest.mark.parametrize("world,H,band_rows,rank0_weight,wire", [(2, 40, 8, 1.0, False), (2, 37, 16, 1.0, False),
+                                                                 (2, 56, 8, 0.6, True)])
+def test_two_rank_gather_reassembles_the_frame(world, H, band_rows, rank0_weight, wire):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, 48, H, band_rows, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, 48, H, band_rows, q, rank0_weight, wire)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
