@@ -63,8 +63,8 @@ def parse():
                     help="sharded runs: rank 0's share of the frame as a fraction of a peer's share "
                          "(0 = measure at start-up so that render + assembly on rank 0 takes as long as a peer's render)")
     ap.add_argument("--wire", type=int, default=1,
-                    help="sharded runs: 1 = ranks send 8-byte wire pixels and rank 0 expands them to the RGBA32F "
-                         "frame (lossless, half the xGMI bytes); 0 = ranks send RGBA32F pixels")
+                    help="sharded runs: 1 = ranks send 5-byte wire pixels and rank 0 expands them to the RGBA32F "
+                         "frame (lossless, 5/16 of the xGMI bytes); 0 = ranks send RGBA32F pixels")
     return ap.parse_args()
 
 
@@ -87,7 +87,7 @@ def main():
     import torch.distributed as dist
 
     import sdfbox_amd as sb
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch
+    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch, wire_shape
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
@@ -127,10 +127,13 @@ def main():
     flags = kflag | (sb.FLAG_COMPACT if compact else 0) | (sb.FLAG_DISPLAY if args.display else 0)
     px_shape, px_dtype, px_bytes = ((), torch.int32, 4) if args.display else ((4,), torch.float32, 16)
     pt = sb.PathTrace(spp=args.spp) if args.spp > 0 else None
-    # what travels in the gather: the frame's own pixels, or 8-byte wire pixels that rank 0 expands
+    # what travels in the gather: the frame's own pixels, or 5-byte wire pixels that rank 0 expands
     # to the RGBA32F frame while it restores row order (lossless; sdfbox_amd/tiles.py)
     wire = sharded and args.wire == 1 and not args.display and pt is None and not compact
-    wpx_shape, wpx_dtype, wpx_bytes = ((2,), torch.int32, 8) if wire else (px_shape, px_dtype, px_bytes)
+    wpx_dtype, wpx_bytes = (torch.uint8, 5) if wire else (px_dtype, px_bytes)
+
+    def share_shape(rows):                 # one frame-share of `rows` rows as it is rendered and gathered
+        return wire_shape(rows, W) if wire else (rows, W) + px_shape
     if wire:
         flags |= sb.FLAG_WIRE
     if pt is not None and (args.display or compact):
@@ -140,7 +143,7 @@ def main():
     # renders a smaller share: --rank0-weight, or measured here before anything is timed
     w0 = args.rank0_weight if world > 1 else 1.0
     if sharded and world > 1 and w0 <= 0:
-        w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, wpx_shape, wpx_dtype, wpx_bytes,
+        w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, share_shape, wpx_dtype, wpx_bytes,
                                   rank, nccl, pt, compact)
     if (H + args.band_rows - 1) // args.band_rows > 512 or w0 > 0.98:
         w0 = 1.0
@@ -155,10 +158,10 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(nbuf)]                       # one per group in flight
     main = torch.cuda.current_stream().cuda_stream
     rows_local = layout.rows_per_rank if sharded else H
-    local = [torch.zeros((G, rows_local, W) + wpx_shape, dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
+    local = [torch.zeros((G,) + share_shape(rows_local), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
     gathered = frame = None
     if sharded and rank == 0:
-        gathered = [torch.zeros((world, G, layout.rows_per_rank, W) + wpx_shape, dtype=wpx_dtype, device="cuda")
+        gathered = [torch.zeros((world, G) + share_shape(layout.rows_per_rank), dtype=wpx_dtype, device="cuda")
                     for _ in range(nbuf)]
         frame = [torch.zeros((G, H, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
 
@@ -350,7 +353,7 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, wpx_shape, wpx_dtype, wpx_bytes, rank, nccl, pt, compact):
+def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_shape, wpx_dtype, wpx_bytes, rank, nccl, pt, compact):
     """Rank 0 also assembles the frame (de-interleave and wire expansion of all ranks' rows), so an
     even deal makes it the slowest rank.  Before anything is timed, rank 0 tries layouts that give it
     0.5 .. 1.0 of a peer's share: for each it times its own work (render + assembly) and the largest
@@ -390,8 +393,8 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, wpx_shap
         tried = []
         for cand in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5):
             lay = BandLayout(H, world, band_rows, cand)
-            local = [torch.zeros((G, lay.rows_per_rank, W) + wpx_shape, dtype=wpx_dtype, device="cuda") for _ in range(2)]
-            gathered = torch.zeros((world, G, lay.rows_per_rank, W) + wpx_shape, dtype=wpx_dtype, device="cuda")
+            local = [torch.zeros((G,) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda") for _ in range(2)]
+            gathered = torch.zeros((world, G) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda")
             t0, t1 = work(lay, 0, local, gathered), work(lay, 1, local, gathered)
             tried.append((max(t0, t1), cand, t0, t1))
             del local, gathered

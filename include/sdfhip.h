@@ -76,7 +76,7 @@ enum {
     SDFHIP_FLAG_COUNT = 0x20,     /* also count algorithmic node/sample reads (slower)     */
     SDFHIP_FLAG_DISPLAY = 0x40,   /* fused display pass: output is RGBA8, gamma 1/2.2 (DisplayFrag.hlsl:24) */
     SDFHIP_FLAG_DISPLAY_DEBUG = 0x80, /* fused display pass, debug heat map w/140 (DisplayFrag.hlsl:21-22) */
-    SDFHIP_FLAG_WIRE = 0x10000,   /* sdfhip_render_device / _batch_device only: 8-byte wire pixels for the
+    SDFHIP_FLAG_WIRE = 0x10000,   /* device-resident entry points only: 5-byte wire pixels for the
                                      tile gather (see sdfhip_deinterleave_device), lossless */
     /* tuning knobs for A/B measurements (0 = the default): bits 8..11 blockIdx -> tile
      * order of the plain kernel (1 row-major, 2 one slab per XCD), bits 12..15 workgroup
@@ -268,11 +268,14 @@ SDFHIP_API int sdfhip_render_batch_device(sdfhip_scene *scene, const sdfhip_info
  * row order.  One gather may carry several frames (fewer, larger messages):
  * d_gathered is [world][frames][rows_per_rank][width] pixels, d_frame is
  * [frames][height][width].  pixel_bytes = 16 (RGBA32F) or 4 (RGBA8): both sides hold
- * such pixels.  pixel_bytes = 8: d_gathered holds the wire pixels that
- * SDFHIP_FLAG_WIRE renders make -- every pixel Compute.hlsl writes is (a, a, a, n), or the
- * sky constant (0.005, 0.01, 0.2, n), so {bits of a, n | sky << 31} carries it in half the
- * bytes over xGMI -- and d_frame receives the RGBA32F frame, bit for bit what a render
- * without the flag writes.  Asynchronous on `stream`. */
+ * such pixels.  pixel_bytes = 5: d_gathered holds the wire buffers that
+ * SDFHIP_FLAG_WIRE renders make.  Every pixel Compute.hlsl writes is (a, a, a, n) with
+ * n <= 140 steps, or the sky constant (0.005, 0.01, 0.2, n) with n <= 100, so a frame
+ * of nrows_out x width pixels travels as nrows_out*width floats (the bits of a)
+ * followed by nrows_out*width bytes (n, or 255 - n for a sky pixel) -- 5 instead of 16
+ * bytes per pixel over xGMI (nrows_out*width must be a multiple of 4) -- and d_frame
+ * receives the RGBA32F frame, bit for bit what a render without the flag writes.
+ * Asynchronous on `stream`. */
 SDFHIP_API int sdfhip_deinterleave_device(int device, const void *d_gathered, void *d_frame,
                                           uint32_t width, uint32_t height,
                                           uint32_t band_rows, uint32_t world,

@@ -6,19 +6,19 @@ import sys, time
 sys.path.insert(0, ".")
 import torch
 import sdfbox_amd as sb
-from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands_batch
+from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands_batch, wire_shape
 W, H = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1920x1080").split("x"))
 od = sb.dragon_standin(9); sc = sb.Scene(od)
 cam = sb.Logic(W, H); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
-shape, dt, pb, fl = (2,), torch.int32, 8, sb.FLAG_WIRE
+pb, fl = 5, sb.FLAG_WIRE
 for world, weights in ((2, (1.0, 0.93)), (4, (1.0, 0.86)), (8, (1.0, 0.775, 0.7))):
     G = min(8, max(4, world))
     for band_rows in (8, 16):
         for w0 in weights:
             lay = BandLayout(H, world, band_rows, w0)
             streams = [torch.cuda.Stream() for _ in range(2)]
-            local = [torch.zeros((G, lay.rows_per_rank, W) + shape, dtype=dt, device="cuda") for _ in range(2)]
-            gathered = [torch.zeros((world, G, lay.rows_per_rank, W) + shape, dtype=dt, device="cuda") for _ in range(2)]
+            local = [torch.zeros((G,) + wire_shape(lay.rows_per_rank, W), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            gathered = [torch.zeros((world, G) + wire_shape(lay.rows_per_rank, W), dtype=torch.uint8, device="cuda") for _ in range(2)]
             frames = [torch.zeros((G, H, W, 4), device="cuda") for _ in range(2)]
             res = []
             for rank in sorted({0, 1, world - 1}):

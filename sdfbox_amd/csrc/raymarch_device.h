@@ -67,7 +67,7 @@ struct RenderParams {
     uint32_t tile_order;       // k_plain: blockIdx -> tile mapping (tuning knob, flags bits 8..11)
     // fused display pass (DisplayFrag.hlsl): out_mode 0 = RGBA32F frame, 1 = gamma RGBA8,
     // 2 = step-count heat map RGBA8 (`out` aliased as one uint32 per pixel), 3 = wire pixels of the
-    // tile gather (`out` aliased as one uint2 per pixel)
+    // tile gather (per frame a float plane and a byte plane, 5 bytes per pixel)
     uint32_t out_mode;
     uint32_t sky8;             // the sky constant through the display pass (host-computed, alpha excluded)
     // path-traced mode (k_path): samples per pixel, diffuse bounces, RNG seed, albedo

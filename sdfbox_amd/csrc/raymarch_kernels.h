@@ -95,29 +95,35 @@ __device__ __forceinline__ uint32_t display8(const float4 &v, uint32_t mode)
 // load, so a global store per finished pixel would stall the very next node load of
 // the whole wave behind the store's completion).  Every finished pixel is the sky
 // constant, black, or a grey level, which keeps the display pass to one pow.
-// mode 3 is the wire format of the tile gather (8 bytes per pixel, lossless): the grey level's
-// bits and the step count, bit 31 of the count word marking a sky pixel (wire_expand undoes it).
-constexpr uint32_t WIRE_SKY = 0x80000000u;
-__device__ __forceinline__ float4 wire_expand(uint2 w)
+// mode 3 is the wire format of the tile gather, lossless in 5 bytes per pixel: every pixel main()
+// writes is (a, a, a, n) with n <= 140 steps, or the sky constant (0.005, 0.01, 0.2, n) with n <= 100.
+// A frame's wire buffer is two planes, [rows * width] floats (the bits of a) and then [rows * width]
+// bytes (n, or 255 - n for a sky pixel); wire_expand undoes it.
+__device__ __forceinline__ float4 wire_expand(float a, uint32_t code)
 {
-    const float steps = (float)(w.y & ~WIRE_SKY);
-    if (w.y & WIRE_SKY) return make_float4(0.005f, 0.01f, 0.2f, steps);
-    const float a = __uint_as_float(w.x);
-    return make_float4(a, a, a, steps);
+    if (code > 140u) return make_float4(0.005f, 0.01f, 0.2f, (float)(255u - code));
+    return make_float4(a, a, a, (float)code);
 }
 struct FrameSink {
-    float4 *p;            // RGBA32F pixel, or (as uint32_t *) the RGBA8 pixel, or (as uint2 *) the wire pixel
+    float4 *p;            // RGBA32F pixel, or (as uint32_t *) the RGBA8 pixel, or (as float *) the wire pixel's a
     uint32_t mode, sky8;
+    const char *wire_base;   // mode 3 (wave-uniform): the frame's wire buffer, and its byte plane
+    uint8_t *wire_codes;
+    __device__ __forceinline__ void wire(float a, uint32_t code) const
+    {
+        *reinterpret_cast<float *>(p) = a;
+        wire_codes[(reinterpret_cast<const char *>(p) - wire_base) >> 2] = (uint8_t)code;
+    }
     __device__ __forceinline__ void sky(float steps) const
     {
         if (mode == 0u) *p = make_float4(0.005f, 0.01f, 0.2f, steps);
-        else if (mode == 3u) *reinterpret_cast<uint2 *>(p) = make_uint2(0u, (uint32_t)steps | WIRE_SKY);
+        else if (mode == 3u) wire(0.0f, 255u - (uint32_t)steps);
         else *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : (sky8 | alpha8(steps));
     }
     __device__ __forceinline__ void grey(float a, float steps) const
     {
         if (mode == 0u) *p = make_float4(a, a, a, steps);
-        else if (mode == 3u) *reinterpret_cast<uint2 *>(p) = make_uint2(__float_as_uint(a), (uint32_t)steps);
+        else if (mode == 3u) wire(a, (uint32_t)steps);
         else {
             uint32_t q = gamma8(a);
             *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : (q | (q << 8) | (q << 16) | alpha8(steps));
@@ -126,7 +132,7 @@ struct FrameSink {
     __device__ __forceinline__ void black(float steps) const
     {
         if (mode == 0u) *p = make_float4(0.0f, 0.0f, 0.0f, steps);
-        else if (mode == 3u) *reinterpret_cast<uint2 *>(p) = make_uint2(0u, (uint32_t)steps);
+        else if (mode == 3u) wire(0.0f, (uint32_t)steps);
         else *reinterpret_cast<uint32_t *>(p) = mode == 2u ? heat8(steps) : alpha8(steps);
     }
 };
@@ -286,11 +292,13 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
         typename CursorOf<STACK>::type c;
         const NodeRec root = P.nodes[0];
         start_pixel(I, root, x, y, r, c);
-        const size_t pidx = ((size_t)blockIdx.y * P.nrows_out + yl) * P.width + x;
+        const size_t npx = (size_t)P.nrows_out * P.width, lidx = (size_t)yl * P.width + x;
+        const size_t pidx = (size_t)blockIdx.y * npx + lidx;
+        char *const wire_base = reinterpret_cast<char *>(P.out) + (size_t)blockIdx.y * npx * 5;   // mode 3: this frame's planes
         const FrameSink dst{P.out_mode == 0u ? P.out + pidx :
-                            P.out_mode == 3u ? reinterpret_cast<float4 *>(reinterpret_cast<uint2 *>(P.out) + pidx) :
+                            P.out_mode == 3u ? reinterpret_cast<float4 *>(reinterpret_cast<float *>(wire_base) + lidx) :
                                                reinterpret_cast<float4 *>(reinterpret_cast<uint32_t *>(P.out) + pidx),
-                            P.out_mode, P.sky8};
+                            P.out_mode, P.sky8, wire_base, reinterpret_cast<uint8_t *>(wire_base) + 4 * npx};
         while (!pre_step(I, r, c, dst)) {
             uint32_t reads = march_step(P, I, r, c, stack_lds + tid, BT);
             if (COUNT) { cn += reads; cs += 1; }

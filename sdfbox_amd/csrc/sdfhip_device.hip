@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <type_traits>
 
 
 namespace sdfhip {
@@ -37,9 +38,7 @@ struct BandMap {
     uint32_t n;
     uint16_t src[MAX_BAND_LIST];
 };
-__device__ __forceinline__ float4 frame_pixel(float4 v) { return v; }
-__device__ __forceinline__ uint32_t frame_pixel(uint32_t v) { return v; }
-__device__ __forceinline__ float4 frame_pixel(uint2 v) { return wire_expand(v); }   // wire pixels (SDFHIP_FLAG_WIRE)
+struct WirePlanes {};   // In = WirePlanes: a rank's frame is the two planes SDFHIP_FLAG_WIRE renders make
 template <class In, class Out>
 __global__ void k_deinterleave(const In *__restrict__ gathered, Out *__restrict__ frame,
                                uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world,
@@ -55,7 +54,13 @@ __global__ void k_deinterleave(const In *__restrict__ gathered, Out *__restrict_
         uint32_t band = y / band_rows, rank = band % world, lband = band / world;
         if (M.n) { const uint32_t e = M.src[band]; rank = e >> 10; lband = e & 1023u; }
         uint32_t yl = lband * band_rows + (y - band * band_rows);
-        frame[i] = frame_pixel(gathered[(((size_t)rank * frames + f) * rows_per_rank + yl) * width + x]);
+        if constexpr (std::is_same<In, WirePlanes>::value) {
+            const size_t npx = (size_t)rows_per_rank * width, l = (size_t)yl * width + x;
+            const char *base = reinterpret_cast<const char *>(gathered) + ((size_t)rank * frames + f) * npx * 5;
+            frame[i] = wire_expand(reinterpret_cast<const float *>(base)[l], reinterpret_cast<const uint8_t *>(base)[4 * npx + l]);
+        } else {
+            frame[i] = gathered[(((size_t)rank * frames + f) * rows_per_rank + yl) * width + x];
+        }
     }
 }
 
@@ -242,6 +247,8 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     const uint32_t out_mode = wire ? 3u : (flags & SDFHIP_FLAG_DISPLAY_DEBUG) ? 2u : ((flags & SDFHIP_FLAG_DISPLAY) ? 1u : 0u);
     if (wire && (compact || pt || (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG))))
         return fail(SDFHIP_ERR_ARG, "render: wire pixels come from the plain kernel only, without the display pass");
+    if (wire && ((uint64_t)nrows_out * width) % 4 != 0)
+        return fail(SDFHIP_ERR_ARG, "render: wire buffers need nrows_out * width to be a multiple of 4 (the byte plane follows the float plane)");
     if (pt) {
         if (pt->spp == 0 || pt->spp > 4096 || pt->max_bounces > 64)
             return fail(SDFHIP_ERR_ARG, "render_path: spp %u (1..4096) or max_bounces %u (0..64) out of range", pt->spp, pt->max_bounces);
@@ -466,8 +473,10 @@ static int deinterleave_impl(int device, const void *d_gathered, void *d_frame, 
     if (frames == 0) return fail(SDFHIP_ERR_ARG, "deinterleave: frames must be >= 1");
     if (!d_gathered || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
         return fail(SDFHIP_ERR_ARG, "deinterleave: null or zero argument");
-    if (pixel_bytes != 16 && pixel_bytes != 4 && pixel_bytes != 8)
-        return fail(SDFHIP_ERR_ARG, "deinterleave: pixel_bytes must be 16 (RGBA32F), 8 (wire) or 4 (RGBA8), got %u", pixel_bytes);
+    if (pixel_bytes != 16 && pixel_bytes != 4 && pixel_bytes != 5)
+        return fail(SDFHIP_ERR_ARG, "deinterleave: pixel_bytes must be 16 (RGBA32F), 5 (wire) or 4 (RGBA8), got %u", pixel_bytes);
+    if (pixel_bytes == 5 && ((size_t)rows_per_rank * width) % 4 != 0)
+        return fail(SDFHIP_ERR_ARG, "deinterleave: wire buffers need rows_per_rank * width to be a multiple of 4");
     const uint32_t nbands = (height + band_rows - 1) / band_rows;
     BandMap M;
     M.n = 0;
@@ -495,9 +504,9 @@ static int deinterleave_impl(int device, const void *d_gathered, void *d_frame, 
         hipLaunchKernelGGL((k_deinterleave<float4, float4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const float4 *)d_gathered, (float4 *)d_frame, width, height, band_rows,
                            world, rows_per_rank, frames, M);
-    else if (pixel_bytes == 8)
-        hipLaunchKernelGGL((k_deinterleave<uint2, float4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const uint2 *)d_gathered, (float4 *)d_frame, width, height, band_rows,
+    else if (pixel_bytes == 5)
+        hipLaunchKernelGGL((k_deinterleave<WirePlanes, float4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const WirePlanes *)d_gathered, (float4 *)d_frame, width, height, band_rows,
                            world, rows_per_rank, frames, M);
     else
         hipLaunchKernelGGL((k_deinterleave<uint32_t, uint32_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,

@@ -12,9 +12,10 @@ a small kernel restores row order.  No other collective is on the data path.
 The gather is bound by one xGMI link per peer (frame bytes / world over ~77 GB/s
 per direction), and at ~8 Gray/s per GPU an RGBA32F frame would make every
 world size link-bound.  Every pixel the shader writes is (a, a, a, steps) or the
-sky constant, so ranks render 8-byte *wire pixels* (FLAG_WIRE: the bits of a,
-the step count, a sky bit) and rank 0 expands them while restoring row order --
-the assembled RGBA32F frame is bit for bit the single-GPU frame.
+sky constant, so ranks render 5-byte *wire pixels* (FLAG_WIRE: per frame a plane
+of floats -- the bits of a -- followed by a plane of bytes -- the step count, or
+255 minus it for a sky pixel; `wire_shape`) and rank 0 expands them while restoring
+row order -- the assembled RGBA32F frame is bit for bit the single-GPU frame.
 """
 import ctypes
 
@@ -84,6 +85,14 @@ class BandLayout:
         return self.owner[b], self._local[b] * self.band_rows + y % self.band_rows
 
 
+def wire_shape(rows, width):
+    """Shape of the uint8 tensor that holds one frame-share of `rows` x `width` wire pixels: the
+    first 4 * rows * width bytes are the float plane, the last rows * width the byte plane."""
+    if (rows * width) % 4:
+        raise ValueError("wire buffers need rows * width to be a multiple of 4")
+    return (5, rows, width)
+
+
 def render_bands(scene, state, width, layout, rank, out_ptr, flags=0, stream=None, stats=None, pt=None):
     """Render `rank`'s bands of the frame into its compact device buffer (pt: path-traced mode)."""
     if layout.weighted:
@@ -114,8 +123,8 @@ def render_bands_batch(scene, states, width, layout, rank, out_ptr, flags=0, str
 def deinterleave(device, gathered_ptr, frame_ptr, width, layout, stream=None, pixel_bytes=16, frames=1):
     """Rank 0: gathered compact buffers (world x frames x rows_per_rank x width pixels) ->
     frames x height x width.  pixel_bytes: 16 for RGBA32F frames, 4 for RGBA8 frames of the
-    fused display pass, 8 for wire pixels (FLAG_WIRE renders), which are expanded to the RGBA32F
-    frame on the way.  frames > 1: one gather carried several frames."""
+    fused display pass, 5 for wire buffers (FLAG_WIRE renders: per rank and frame a `wire_shape`
+    block), which are expanded to the RGBA32F frame on the way.  frames > 1: one gather carried several frames."""
     st = ctypes.c_void_p(int(stream)) if stream else None
     if layout.weighted:
         owner = (ctypes.c_uint8 * layout.n_bands)(*layout.owner)

@@ -344,11 +344,11 @@ def test_grouped_gather_deinterleave(sb, gpu_scenes):
 
 
 def test_wire_pixels_expand_to_the_same_frame(sb, gpu_scenes):
-    # the gather's 8-byte wire format (FLAG_WIRE) is lossless: ranks render wire pixels, rank 0's
+    # the gather's 5-byte wire format (FLAG_WIRE) is lossless: ranks render wire pixels, rank 0's
     # de-interleave expands them, and the frame is the direct RGBA32F render bit for bit --
     # sky, lit, shadowed and back-facing pixels, single and batched launches, both kernels
     import torch
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch
+    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch, wire_shape
     stream = torch.cuda.current_stream().cuda_stream
     for name, (W, H, world, band_rows) in [("sphere_d4", (128, 96, 1, 96)), ("torus_d6", (150, 90, 3, 16)),
                                            ("torus_d6", (97, 61, 4, 8))]:
@@ -367,12 +367,12 @@ def test_wire_pixels_expand_to_the_same_frame(sb, gpu_scenes):
                 kinds |= {"lit"} if bool(((rgb[..., 0] == rgb[..., 1]) & (rgb[..., 0] > 0)).any()) else set()
             assert kinds == {"sky", "black", "lit"}, kinds
             # one launch per frame
-            gathered = torch.zeros((world, 3, lay.rows_per_rank, W, 2), dtype=torch.int32, device="cuda")
+            gathered = torch.zeros((world, 3) + wire_shape(lay.rows_per_rank, W), dtype=torch.uint8, device="cuda")
             for r in range(world):
                 for f, c in enumerate(cams):
                     render_bands(scene, c, W, lay, r, gathered[r, f].data_ptr(), flags=kern | sb.FLAG_WIRE, stream=stream)
             frames = torch.full((3, H, W, 4), -1.0, dtype=torch.float32, device="cuda")
-            deinterleave(0, gathered.data_ptr(), frames.data_ptr(), W, lay, stream=stream, pixel_bytes=8, frames=3)
+            deinterleave(0, gathered.data_ptr(), frames.data_ptr(), W, lay, stream=stream, pixel_bytes=5, frames=3)
             torch.cuda.synchronize()
             for f in range(3):
                 assert torch.equal(frames[f].view(torch.int32), full[f].view(torch.int32)), (name, kern, f)
@@ -401,7 +401,7 @@ def test_weighted_band_layouts_reassemble_the_frame(sb, gpu_scenes):
     # on the render side, an owner table on the de-interleave side; all pixel formats, batched
     # launches and the path-traced mode
     import torch
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch
+    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch, wire_shape
     scene = gpu_scenes["torus_d6"]
     stream = torch.cuda.current_stream().cuda_stream
     for (W, H, world, band_rows, w0) in [(160, 100, 3, 8, 0.5), (90, 77, 4, 16, 0.8), (64, 200, 8, 8, 0.775), (70, 50, 2, 24, 0.9)]:
@@ -410,8 +410,11 @@ def test_weighted_band_layouts_reassemble_the_frame(sb, gpu_scenes):
         cams = [make_camera(n, W, H) for n in ("rotated", "closeup")]
         full = [torch.from_numpy(scene.Draw(c, W, H)).cuda() for c in cams]
         # RGBA32F and wire pixels, one launch per frame and one per group
-        for pb, shape, dt, fl in ((16, (4,), torch.float32, 0), (8, (2,), torch.int32, sb.FLAG_WIRE)):
-            gathered = torch.zeros((world, 2, lay.rows_per_rank, W) + shape, dtype=dt, device="cuda")
+        for pb, fl in ((16, 0), (5, sb.FLAG_WIRE)):
+            if pb == 16:
+                gathered = torch.zeros((world, 2, lay.rows_per_rank, W, 4), dtype=torch.float32, device="cuda")
+            else:
+                gathered = torch.zeros((world, 2) + wire_shape(lay.rows_per_rank, W), dtype=torch.uint8, device="cuda")
             for r in range(world):
                 for f, c in enumerate(cams):
                     render_bands(scene, c, W, lay, r, gathered[r, f].data_ptr(), flags=fl, stream=stream)

@@ -51,29 +51,41 @@ def test_weighted_layout_gives_rank0_less_and_spreads_every_share():
 
 
 def wire_pack(img):
-    """numpy model of the kernel's wire pixels (FrameSink mode 3, raymarch_kernels.h): every pixel is
-    (a, a, a, n) or the sky constant (0.005, 0.01, 0.2, n) -> {bits of a, n | sky << 31}."""
+    """numpy model of the kernel's wire buffer (FrameSink mode 3, raymarch_kernels.h): every pixel is
+    (a, a, a, n), n <= 140, or the sky constant (0.005, 0.01, 0.2, n), n <= 100 -> a plane of floats
+    (the bits of a) followed by a plane of bytes (n, or 255 - n for sky): uint8 [5][rows][W]."""
+    rows, W = img.shape[:2]
     bits = np.ascontiguousarray(img).view(np.uint32)
     sky = bits[..., 0] != bits[..., 1]
     expect_sky = np.array([0.005, 0.01, 0.2], dtype=np.float32).view(np.uint32)
     assert (bits[sky][:, :3] == expect_sky).all(), "a non-grey pixel that is not the sky constant"
     assert (bits[~sky][:, 0] == bits[~sky][:, 2]).all()
     steps = img[..., 3].astype(np.uint32)
-    assert (steps.astype(np.float32) == img[..., 3]).all() and steps.max() < 2 ** 31
-    return np.stack([np.where(sky, 0, bits[..., 0]).astype(np.uint32), steps | (sky.astype(np.uint32) << 31)], axis=-1)
+    assert (steps.astype(np.float32) == img[..., 3]).all()
+    assert steps[sky].max(initial=0) <= 100 and steps[~sky].max(initial=0) <= 140
+    out = np.empty((5, rows, W), dtype=np.uint8)
+    out[:4].reshape(-1).view(np.uint32)[:] = np.where(sky, 0, bits[..., 0]).reshape(-1)
+    out[4] = np.where(sky, 255 - steps, steps).astype(np.uint8)
+    return out
 
 
 def wire_expand(w):
-    sky = (w[..., 1] >> 31) == 1
-    out = np.empty(w.shape[:-1] + (4,), dtype=np.uint32)
-    out[..., 0] = out[..., 1] = out[..., 2] = w[..., 0]
-    out[sky, :3] = np.array([0.005, 0.01, 0.2], dtype=np.float32).view(np.uint32)
-    out[..., 3] = (w[..., 1] & 0x7FFFFFFF).astype(np.float32).view(np.uint32)
-    return out.view(np.float32)
+    """[..., 5, rows, W] uint8 -> [..., rows, W, 4] float32"""
+    lead, (rows, W) = w.shape[:-3], w.shape[-2:]
+    flat = np.ascontiguousarray(w).reshape((-1, 5, rows, W))
+    out = np.empty((flat.shape[0], rows, W, 4), dtype=np.uint32)
+    for k in range(flat.shape[0]):
+        a = flat[k, :4].reshape(-1).view(np.uint32).reshape(rows, W)
+        code = flat[k, 4].astype(np.uint32)
+        sky = code > 140
+        out[k, ..., 0] = out[k, ..., 1] = out[k, ..., 2] = a
+        out[k][sky, :3] = np.array([0.005, 0.01, 0.2], dtype=np.float32).view(np.uint32)
+        out[k, ..., 3] = np.where(sky, 255 - code, code).astype(np.float32).view(np.uint32)
+    return out.view(np.float32).reshape(lead + (rows, W, 4))
 
 
 def test_wire_pixels_are_lossless_on_oracle_frames(oracle_mod, scenes):
-    # the premise of the 8-byte gather format, checked on the oracle's own frames (NaN greys included)
+    # the premise of the 5-byte gather format, checked on the oracle's own frames (NaN greys included)
     for name in ("sphere_d4", "torus_d6"):
         od = scenes[name]
         for camname in ("default", "rotated", "closeup"):
@@ -81,7 +93,7 @@ def test_wire_pixels_are_lossless_on_oracle_frames(oracle_mod, scenes):
             cam.State.light[0] = 0.9
             img, _ = oracle_mod.render(od.Structs, od.Values, cam.State, 96, 64)
             w = wire_pack(img)
-            assert w.dtype == np.uint32 and w.shape == (64, 96, 2)
+            assert w.dtype == np.uint8 and w.shape == (5, 64, 96)
             assert (wire_expand(w).view(np.uint32) == img.view(np.uint32)).all(), (name, camname)
 
 
@@ -118,12 +130,12 @@ def _rank_main(rank, world, port, W, H, band_rows, q, rank0_weight=1.0, wire=Fal
         n = min(band_rows, H - y0)
         img, _ = oracle.render(od.Structs, od.Values, cam.State, W, H, row0=y0, nrows=n)
         local[lb * band_rows: lb * band_rows + n] = img
-    t = torch.from_numpy(wire_pack(local).view(np.int32) if wire else local)
+    t = torch.from_numpy(wire_pack(local) if wire else local)
     glist = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
     dist.gather(t, glist, dst=0)
     if rank == 0:
         got = torch.stack(glist).numpy()
-        frame = numpy_deinterleave(wire_expand(got.view(np.uint32)) if wire else got, lay)
+        frame = numpy_deinterleave(wire_expand(got) if wire else got, lay)
         full, _ = oracle.render(od.Structs, od.Values, cam.State, W, H)
         q.put(bool(((frame.view(np.uint32) == full.view(np.uint32)) | (np.isnan(frame) & np.isnan(full))).all()))
     dist.barrier()
