@@ -252,7 +252,7 @@ def main():
     torch.cuda.synchronize()
     my_pixels = len(layout.rows_of(rank)) * W if sharded else W * H
     alg_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + wpx_bytes * my_pixels   # SURVEY.md 8d (bytes this rank's kernel stores)
-    counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps], dtype=torch.float64)
+    counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays], dtype=torch.float64)
     kernel_used = st.kernel_used
 
     # ---- warm-up, then the timed region ---------------------------------------------------
@@ -325,6 +325,7 @@ def main():
                 "gather_pixel_bytes": wpx_bytes if sharded else None,
                 "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
                 "gstep_per_s": round(float(counters[2]) / sec_per_step / 1e9, 3),
+                "shadow_rays_per_frame": int(counters[3]),
                 "scene_build_s": round(t_gen, 2),
             },
             "roofline": {

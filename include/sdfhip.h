@@ -95,6 +95,8 @@ typedef struct sdfhip_stats {
     uint64_t n_steps;       /* sum of the alpha channel (march steps)         */
     uint32_t kernel_used;   /* SDFHIP_KERNEL_GENERIC or _STACK (| COMPACT)    */
     uint32_t pad_;
+    uint64_t n_shadow_rays; /* with SDFHIP_FLAG_COUNT: pixels (path vertices) */
+                            /* that cast a shadow ray, Compute.hlsl:213       */
 } sdfhip_stats;
 
 /* ---- errors ------------------------------------------------------------ */

@@ -60,14 +60,14 @@ def _info_buf(info):
 
 def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1, per_pixel_nodes=False,
            row_step=1):
-    """-> (rgba[nrows, W, 4] f32, counters[3] u64 (nodes, samples, steps)[, nodes per pixel])."""
+    """-> (rgba[nrows, W, 4] f32, counters[4] u64 (nodes, samples, steps, shadow rays)[, nodes per pixel])."""
     structs = np.ascontiguousarray(structs, dtype=np.int32)
     values = np.ascontiguousarray(values, dtype=np.uint8)
     n = structs.size // 2
     if nrows is None:
         nrows = (height - row0 + row_step - 1) // row_step
     out = np.zeros((nrows, width, 4), dtype=np.float32)
-    cnt = np.zeros(3, dtype=np.uint64)
+    cnt = np.zeros(4, dtype=np.uint64)
     pix = np.zeros((nrows, width), dtype=np.uint32) if per_pixel_nodes else None
     ib = _info_buf(info)
     rc = lib().oracle_render_rows(structs.ctypes.data, values.ctypes.data, n, ctypes.addressof(ib),
@@ -80,13 +80,13 @@ def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1,
 
 def render_pt(structs, values, info, width, height, spp=16, max_bounces=3, seed=0x5DFB0C5, albedo=0.8,
               row0=0, nrows=None, nthreads=1, row_step=1):
-    """Path-traced mode (BASELINE config 5): -> (rgba[nrows, W, 4] f32, counters[3] u64)."""
+    """Path-traced mode (BASELINE config 5): -> (rgba[nrows, W, 4] f32, counters[4] u64)."""
     structs = np.ascontiguousarray(structs, dtype=np.int32)
     values = np.ascontiguousarray(values, dtype=np.uint8)
     if nrows is None:
         nrows = (height - row0 + row_step - 1) // row_step
     out = np.zeros((nrows, width, 4), dtype=np.float32)
-    cnt = np.zeros(3, dtype=np.uint64)
+    cnt = np.zeros(4, dtype=np.uint64)
     ib = _info_buf(info)
     rc = lib().oracle_render_rows_pt(structs.ctypes.data, values.ctypes.data, structs.size // 2,
                                      ctypes.addressof(ib), width, row0, nrows, row_step, int(spp),
@@ -101,7 +101,7 @@ def pixel(structs, values, info, x, y):
     structs = np.ascontiguousarray(structs, dtype=np.int32)
     values = np.ascontiguousarray(values, dtype=np.uint8)
     out = np.zeros(4, dtype=np.float32)
-    cnt = np.zeros(3, dtype=np.uint64)
+    cnt = np.zeros(4, dtype=np.uint64)
     ib = _info_buf(info)
     lib().oracle_pixel(structs.ctypes.data, values.ctypes.data, structs.size // 2,
                        ctypes.addressof(ib), int(x), int(y), out.ctypes.data, cnt.ctypes.data)

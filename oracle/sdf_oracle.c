@@ -224,7 +224,7 @@ O_INLINE void o_ray(const o_info *inf, uint32_t cx, uint32_t cy, float dir[3])
 
 /* main, Compute.hlsl:180-231.  out = rgba; counters accumulate in t. */
 O_INLINE void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_m1,
-                    uint32_t cx, uint32_t cy, float out[4], uint64_t cnt[3])
+                    uint32_t cx, uint32_t cy, float out[4], uint64_t cnt[4])
 {
     o_ctx t;
     t.sc = sc;
@@ -271,6 +271,7 @@ O_INLINE void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_
         /* dist = length(inf.light - pos) / 2 */
         lx = inf->light[0] - px; ly = inf->light[1] - py; lz = inf->light[2] - pz;
         float dist = sqrtf(o_dot(lx, ly, lz, lx, ly, lz)) / 2.0f;
+        cnt[3]++;                          /* a shadow ray is cast */
         for (j = 0; j < 40 && prox > -margin; j++) {
             if (prox > dist || (px < 0.0f || py < 0.0f || pz < 0.0f) ||
                 (px > 1.0f || py > 1.0f || pz > 1.0f)) {
@@ -342,7 +343,7 @@ O_INLINE void o_ray_f(const o_info *inf, float fx, float fy, float dir[3])
 
 O_INLINE void o_pixel_pt(const o_scene *sc, const o_info *inf, float k, uint32_t spp,
                          uint32_t max_bounces, uint32_t seed, float albedo, uint32_t frame_w,
-                         uint32_t cx, uint32_t cy, float out[4], uint64_t cnt[3])
+                         uint32_t cx, uint32_t cy, float out[4], uint64_t cnt[4])
 {
     o_ctx t;
     t.sc = sc;
@@ -391,6 +392,7 @@ O_INLINE void o_pixel_pt(const o_scene *sc, const o_info *inf, float k, uint32_t
                 lx = inf->light[0] - px; ly = inf->light[1] - py; lz = inf->light[2] - pz;
                 float dist = sqrtf(o_dot(lx, ly, lz, lx, ly, lz)) / 2.0f;
                 int j, lit = 0;
+                cnt[3]++;                  /* a shadow ray is cast */
                 for (j = 0; j < 40 && sprox > -margin; j++) {
                     if (sprox > dist || (sx < 0.0f || sy < 0.0f || sz < 0.0f) ||
                         (sx > 1.0f || sy > 1.0f || sz > 1.0f)) { lit = 1; break; }
@@ -450,7 +452,7 @@ typedef struct {
     int tid, nthreads;
     float *rgba;          /* nrows x W x 4, row-major, row 0 = global row0 */
     uint32_t *pix_nodes;  /* optional: nrows x W algorithmic node reads per pixel */
-    uint64_t cnt[3];
+    uint64_t cnt[4];
     uint32_t pt_spp, pt_bounces, pt_seed, frame_w;   /* path-traced mode when pt_spp > 0 */
     float pt_albedo;
 } o_job;
@@ -477,9 +479,9 @@ O_CLONES static void *o_worker_impl(void *arg)
 
 /* Render the nrows rows y = row0 + r*row_step (r = 0..nrows-1) of a W-wide
  * frame into compact rows of `rgba`.  Pixel (x, y) uses the dispatch-thread id
- * (x, y) exactly as Compute.hlsl:180 does.  counters[0..2]
- * receive node reads, samples, march steps summed over the rendered pixels
- * (may be NULL).  Rows are interleaved over `nthreads` pthreads. */
+ * (x, y) exactly as Compute.hlsl:180 does.  counters[0..3]
+ * receive node reads, samples, march steps and shadow rays cast, summed over the
+ * rendered pixels (may be NULL).  Rows are interleaved over `nthreads` pthreads. */
 static void *o_worker(void *arg) { return o_worker_impl(arg); }
 
 static int o_render_rows(const int32_t *structs, const uint8_t *values, uint32_t n,
@@ -511,9 +513,9 @@ static int o_render_rows(const int32_t *structs, const uint8_t *values, uint32_t
         for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
     }
     if (counters) {
-        counters[0] = counters[1] = counters[2] = 0;
+        counters[0] = counters[1] = counters[2] = counters[3] = 0;
         for (int t = 0; t < nthreads; t++)
-            for (int c = 0; c < 3; c++) counters[c] += jobs[t].cnt[c];
+            for (int c = 0; c < 4; c++) counters[c] += jobs[t].cnt[c];
     }
     free(jobs); free(th);
     return 0;
@@ -538,14 +540,14 @@ int oracle_render_rows_pt(const int32_t *structs, const uint8_t *values, uint32_
                          nthreads, spp, max_bounces, seed, albedo);
 }
 
-/* One pixel, for unit tests.  out[4] = rgba, cnt[3] = nodes, samples, steps. */
+/* One pixel, for unit tests.  out[4] = rgba, cnt[4] = nodes, samples, steps, shadow rays. */
 O_CLONES void oracle_pixel(const int32_t *structs, const uint8_t *values, uint32_t n,
                   const void *info112, uint32_t x, uint32_t y, float *out, uint64_t *cnt)
 {
     o_scene sc = { structs, values, n };
     o_info inf;
     memcpy(&inf, info112, sizeof inf);
-    cnt[0] = cnt[1] = cnt[2] = 0;
+    cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
     o_pixel(&sc, &inf, exp2f(inf.strength) - 1.0f, x, y, out, cnt);
 }
 

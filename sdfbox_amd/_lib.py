@@ -70,6 +70,7 @@ class Stats(ctypes.Structure):
         ("n_steps", ctypes.c_uint64),
         ("kernel_used", ctypes.c_uint32),
         ("pad_", ctypes.c_uint32),
+        ("n_shadow_rays", ctypes.c_uint64),
     ]
 
 

@@ -62,7 +62,7 @@ struct RenderParams {
     // kernel-argument segment (scalar loads), never through a modified copy.
     uint32_t n_frames;
     FrameInfo frames[MAX_BATCH];
-    unsigned long long *counters;  // [0] nodes [1] samples [2] steps (COUNT builds)
+    unsigned long long *counters;  // [0] nodes [1] samples [2] steps [3] shadow rays (COUNT builds)
     uint32_t *queue;           // tile queue head (compact kernels)
     uint32_t tile_order;       // k_plain: blockIdx -> tile mapping (tuning knob, flags bits 8..11)
     // fused display pass (DisplayFrag.hlsl): out_mode 0 = RGBA32F frame, 1 = gamma RGBA8,

@@ -239,17 +239,20 @@ __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const Fram
 }
 
 __device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned long long nodes,
-                                               unsigned long long samples, unsigned long long steps)
+                                               unsigned long long samples, unsigned long long steps,
+                                               unsigned long long shadow_rays)
 {
     for (int off = 32; off > 0; off >>= 1) {
         nodes += __shfl_down(nodes, off);
         samples += __shfl_down(samples, off);
         steps += __shfl_down(steps, off);
+        shadow_rays += __shfl_down(shadow_rays, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&P.counters[0], nodes);
         atomicAdd(&P.counters[1], samples);
         atomicAdd(&P.counters[2], steps);
+        atomicAdd(&P.counters[3], shadow_rays);
     }
 }
 
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
     constexpr uint32_t WX = TW / 8;                        // waves side by side in a tile
     const uint32_t x = tx * TW + (wave % WX) * 8 + (lane & 7u);
     const uint32_t yl = ty * TH + (wave / WX) * 8 + (lane >> 3);
-    unsigned long long cn = 0, cs = 0, ct = 0;
+    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0;   // nodes, samples, steps, shadow rays
     bool live = x < P.width && yl < P.nrows_out;
     uint32_t y = 0;
     if (live) { y = global_row(P, yl); live = y < P.height; }
@@ -303,9 +306,9 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
             uint32_t reads = march_step(P, I, r, c, stack_lds + tid, BT);
             if (COUNT) { cn += reads; cs += 1; }
         }
-        if (COUNT) ct = (unsigned long long)(r.i + r.j);
+        if (COUNT) { ct = (unsigned long long)(r.i + r.j); cr = r.phase == PH_SHADOW ? 1u : 0u; }   // shade() left the lane in PH_SHADOW
     }
-    if (COUNT) flush_counters(P, cn, cs, ct);
+    if (COUNT) flush_counters(P, cn, cs, ct, cr);
 }
 
 // ---- persistent waves with lane refill and state batching (wavefront ray compaction) --
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
     const FrameInfo &I = P.frames[0];
     const NodeRec root = P.nodes[0];
     const LdsSink dst{&out_lds[lane]};
-    unsigned long long cn = 0, cs = 0, ct = 0;
+    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0;   // nodes, samples, steps, shadow rays
     RayState r;
     typename CursorOf<STACK>::type c;
     uint32_t pix = 0;           // x | yl << 16
@@ -413,6 +416,8 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
                 if (shade(I, r, c, dst)) {
                     if (COUNT) ct += (unsigned long long)(r.i + r.j);
                     r.phase = PH_DONE;
+                } else if (COUNT) {
+                    cr += 1;
                 }
             }
         }
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
             }
         }
     }
-    if (COUNT) flush_counters(P, cn, cs, ct);
+    if (COUNT) flush_counters(P, cn, cs, ct, cr);
 }
 
 // ---- path-traced mode (BASELINE config 5) -----------------------------------------------
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(64) void k_path(RenderParams P)
     if (row >= P.tiles_y) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t x = cxx * 8 + (lane & 7u), yl = row * 8 + (lane >> 3);
-    unsigned long long cn = 0, cs = 0, ct = 0;
+    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0;   // nodes, samples, steps, shadow rays
     bool live = x < P.width && yl < P.nrows_out;
     uint32_t y = 0;
     if (live) { y = global_row(P, yl); live = y < P.height; }
@@ -517,6 +522,7 @@ __global__ __launch_bounds__(64) void k_path(RenderParams P)
                         dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
                         ux = L0; uy = L1; uz = L2;
                         shadow = true;
+                        if (COUNT) cr += 1;
                         it = 0;
                     } else {
                         bounce = true;
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(64) void k_path(RenderParams P)
         P.out[(size_t)yl * P.width + x] = make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps);
         if (COUNT) ct = steps;
     }
-    if (COUNT) flush_counters(P, cn, cs, ct);
+    if (COUNT) flush_counters(P, cn, cs, ct, cr);
 }
 
 }  // namespace sdfhip

@@ -83,7 +83,7 @@ struct sdfhip_scene {
     void *alloc;            // hipMalloc'ed block holding the records
     NodeRec *nodes;         // = alloc + 112: node 1 (first sibling block) starts a 128-B line
     hipStream_t stream;
-    unsigned long long *d_counters;  // 3 x u64
+    unsigned long long *d_counters;  // 4 x u64: nodes, samples, steps, shadow rays
     uint32_t *d_queue;
     float4 *d_frame;        // grown on demand by sdfhip_render
     size_t frame_cap;
@@ -183,7 +183,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if ((e = hipEventCreate(&s->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(&s->alloc, (size_t)n * 16 + 128)) != hipSuccess) return bail(e, "hipMalloc(records)");
     s->nodes = reinterpret_cast<NodeRec *>(static_cast<char *>(s->alloc) + 112);
-    if ((e = hipMalloc((void **)&s->d_counters, 3 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMalloc((void **)&s->d_queue, 8 * 32 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(queue)");
     if ((e = hipMalloc(&d_s, bytes)) != hipSuccess) return bail(e, "hipMalloc(structs)");
     if ((e = hipMalloc(&d_v, bytes)) != hipSuccess) return bail(e, "hipMalloc(values)");
@@ -312,7 +312,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     P.counters = s->d_counters;
     P.queue = s->d_queue;
 
-    if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 3 * sizeof(unsigned long long), st));
+    if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), st));
     if (compact) HIP_TRY(hipMemsetAsync(s->d_queue, 0, 8 * 32 * sizeof(uint32_t), st));
     dim3 grid;
     if (compact) {
@@ -338,10 +338,10 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         stats->kernel_used = (use_stack ? SDFHIP_KERNEL_STACK : SDFHIP_KERNEL_GENERIC) |
                              (compact ? SDFHIP_FLAG_COMPACT : 0u);
         if (count) {
-            unsigned long long h[3];
+            unsigned long long h[4];
             HIP_TRY(hipMemcpyAsync(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            stats->n_nodes = h[0]; stats->n_samples = h[1]; stats->n_steps = h[2];
+            stats->n_nodes = h[0]; stats->n_samples = h[1]; stats->n_steps = h[2]; stats->n_shadow_rays = h[3];
         }
     }
     return SDFHIP_OK;

@@ -49,7 +49,7 @@ def test_golden_frames(sb, gpu_scenes, variant):
             cam = make_camera(cname, 64, 64)
             img, st = scene.Draw(cam, 64, 64, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
             assert_frames_identical(img, g[f"{sname}/{cname}/rgba"], f"{variant} {sname}/{cname}")
-            assert [st.n_nodes, st.n_samples, st.n_steps] == g[f"{sname}/{cname}/counters"].tolist()
+            assert [st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays] == g[f"{sname}/{cname}/counters"].tolist()
             img2 = scene.Draw(cam, 64, 64, flags_of(sb, variant))          # non-counting build of the kernel
             assert_frames_identical(img2, img, f"{variant} count vs no-count")
 
@@ -65,7 +65,7 @@ def test_against_oracle_cfg1_and_ragged_sizes(sb, oracle_mod, scenes, gpu_scenes
         ref, cnt = oracle_mod.render(scenes[sname].Structs, scenes[sname].Values, cam.State, W, H, nthreads=8)
         img, st = gpu_scenes[sname].Draw(cam, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
         assert_frames_identical(img, ref, f"{variant} {sname} {W}x{H}")
-        assert (st.n_nodes, st.n_samples, st.n_steps) == tuple(int(c) for c in cnt)
+        assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
 
 
 def test_tuning_knobs_never_change_results(sb, gpu_scenes):
@@ -100,7 +100,7 @@ def test_camera_edge_cases(sb, oracle_mod, scenes, gpu_scenes):
         for variant in ALL_VARIANTS:
             img, st = scene.Draw(cam, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
             assert_frames_identical(img, ref, f"{what} / {variant}")
-            assert (st.n_nodes, st.n_samples, st.n_steps) == tuple(int(c) for c in cnt), what
+            assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), what
 
 
 def _chain_tree(depth):
@@ -136,7 +136,7 @@ def test_degenerate_and_deep_trees(sb, oracle_mod):
         for variant in ALL_VARIANTS:
             img, st = sc.Draw(cam2, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
             assert_frames_identical(img, ref, f"depth 12 / {variant}")
-            assert (st.n_nodes, st.n_samples, st.n_steps) == tuple(int(c) for c in cnt)
+            assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
     # depth 14: the reference's `iterations < 12` cap binds; only the generic kernel
     # reproduces that, AUTO must pick it and an explicit STACK request is refused
     s, v = _chain_tree(14)
@@ -148,7 +148,7 @@ def test_degenerate_and_deep_trees(sb, oracle_mod):
             img, st = sc.Draw(cam2, W, H, fl | sb.FLAG_COUNT, want_stats=True)
             assert (st.kernel_used & 0xF) == sb.KERNEL_GENERIC
             assert_frames_identical(img, ref, "depth 14 / generic")
-            assert (st.n_nodes, st.n_samples, st.n_steps) == tuple(int(c) for c in cnt)
+            assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
         with pytest.raises(sb.SdfHipError):
             sc.Draw(cam2, W, H, sb.KERNEL_STACK)
 
@@ -166,7 +166,7 @@ def test_inconsistent_parent_links_use_the_generic_kernel(sb, oracle_mod, scenes
         assert not sc.stack_kernel_ok
         img, st = sc.Draw(cam, 80, 80, sb.KERNEL_AUTO | sb.FLAG_COUNT, want_stats=True)
         assert_frames_identical(img, ref, "inconsistent tree")
-        assert (st.n_nodes, st.n_samples, st.n_steps) == tuple(int(c) for c in cnt)
+        assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
     s = od.Structs.copy(); s[3, 1] = od.Length          # out of range -> refused at upload, nothing reaches the GPU
     with pytest.raises(sb.SdfHipError) as e:
         sb.Scene(sb.OctData(s, od.Values))
@@ -204,7 +204,7 @@ def test_path_traced_mode(sb, oracle_mod, scenes, gpu_scenes, kernel):
         cam = make_camera("default", 48, 32)
         img, st = gpu_scenes[sname].DrawPath(cam, 48, 32, sb.PathTrace(spp=4), flags=fl | sb.FLAG_COUNT, want_stats=True)
         assert_frames_identical(img, g[f"{sname}/path4/rgba"], f"{kernel} {sname} golden path4")
-        assert [st.n_nodes, st.n_samples, st.n_steps] == g[f"{sname}/path4/counters"].tolist()
+        assert [st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays] == g[f"{sname}/path4/counters"].tolist()
         for cname, (W, H), pt in (("rotated", (61, 37), sb.PathTrace(spp=16, max_bounces=3)),
                                   ("closeup", (40, 40), sb.PathTrace(spp=3, max_bounces=5, seed=7, albedo=0.5)),
                                   ("default", (33, 20), sb.PathTrace(spp=2, max_bounces=0))):
@@ -213,7 +213,7 @@ def test_path_traced_mode(sb, oracle_mod, scenes, gpu_scenes, kernel):
                                             max_bounces=pt.max_bounces, seed=pt.seed, albedo=pt.albedo, nthreads=8)
             img, st = gpu_scenes[sname].DrawPath(cam, W, H, pt, flags=fl | sb.FLAG_COUNT, want_stats=True)
             assert_frames_identical(img, ref, f"{kernel} {sname}/{cname} path")
-            assert (st.n_nodes, st.n_samples, st.n_steps) == tuple(int(c) for c in cnt)
+            assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
             assert_frames_identical(gpu_scenes[sname].DrawPath(cam, W, H, pt, flags=fl), img, "count vs no-count")
     with pytest.raises(sb.SdfHipError):
         gpu_scenes["sphere_d4"].DrawPath(make_camera("default", 8, 8), 8, 8, sb.PathTrace(spp=0))
@@ -504,7 +504,7 @@ def test_full_size_properties(sb, oracle_mod, dragon, size, view):
     # (1) every kernel variant produces the same bits, and the same algorithmic counters
     for variant in ALL_VARIANTS[1:]:
         assert_frames_identical(imgs[variant], base, f"{variant} vs generic at {W}x{H}")
-        for f in ("n_nodes", "n_samples", "n_steps"):
+        for f in ("n_nodes", "n_samples", "n_steps", "n_shadow_rays"):
             assert getattr(stats[variant], f) == getattr(stats["generic"], f)
     # (2) alpha is the step count: integers in [0, 140], summing to the step counter;
     #     one sample per step
@@ -592,4 +592,4 @@ def test_fuzz_random_trees_and_on_grid_cameras(sb, oracle_mod, seed):
             for variant in ALL_VARIANTS:
                 img, st = sc.Draw(cam, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
                 assert_frames_identical(img, ref, f"seed {seed} cam {ci} {variant}")
-                assert (st.n_nodes, st.n_samples, st.n_steps) == tuple(int(c) for c in cnt), (seed, ci, variant)
+                assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), (seed, ci, variant)
