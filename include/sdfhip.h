@@ -195,6 +195,15 @@ SDFHIP_API int sdfhip_scene_free(sdfhip_scene *scene);
 SDFHIP_API int sdfhip_scene_info(const sdfhip_scene *scene, uint32_t *n, uint32_t *depth,
                                  int *stack_kernel_ok, int *device);
 
+/* The top grid the upload built for the cursor-stack kernels: for every cell of octree level
+ * `level`, the record of the deepest node of that level or above that contains it, so that a
+ * find() that restarts near the root takes one load instead of `level` dependent ones (results
+ * and algorithmic counts are unchanged).  level = 0, bytes = 0: none (inconsistent or deeper than
+ * 12 levels: generic kernel).  The level is the tree's depth, at most 8, limited so that the grid
+ * (16 bytes per cell) is no larger than the tree's own records; the environment variable
+ * SDFHIP_TOP_GRID_LEVEL (0..9) overrides it at upload. */
+SDFHIP_API int sdfhip_scene_top_grid(const sdfhip_scene *scene, int32_t *level, uint64_t *bytes);
+
 /* Replaces: Program.Draw's UpdateBuffer(info) + DispatchSized(W, H, 1),
  * SdfBox/Program.cs:81,94 (kernel: Compute.hlsl:180-231).  Renders the whole
  * W x H frame and copies it to `rgba_out` (host, W*H*4 floats, row-major,

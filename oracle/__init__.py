@@ -78,6 +78,21 @@ def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1,
     return (out, cnt, pix) if per_pixel_nodes else (out, cnt)
 
 
+def descent_levels(structs, values, info, width, height, nthreads=8, row_step=1):
+    """Analysis (scripts/descent_levels.py): node records loaded by find()'s descents, by the octree
+    level of the loaded node -> uint64[16].  Not thread-safe against other renders."""
+    hist = np.zeros(16, dtype=np.uint64)
+    L = lib()
+    L.oracle_level_histogram.argtypes = [ctypes.c_void_p]
+    L.oracle_level_histogram.restype = None
+    L.oracle_level_histogram(hist.ctypes.data)
+    try:
+        _, cnt = render(structs, values, info, width, height, nthreads=nthreads, row_step=row_step)
+    finally:
+        L.oracle_level_histogram(None)
+    return hist, cnt
+
+
 def render_pt(structs, values, info, width, height, spp=16, max_bounces=3, seed=0x5DFB0C5, albedo=0.8,
               row0=0, nrows=None, nthreads=1, row_step=1):
     """Path-traced mode (BASELINE config 5): -> (rgba[nrows, W, 4] f32, counters[4] u64)."""

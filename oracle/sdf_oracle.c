@@ -115,6 +115,11 @@ O_INLINE int o_inside(const o_cube *b, float px, float py, float pz)
            (px <= hx && py <= hy && pz <= hz);
 }
 
+/* Analysis hook (scripts/descent_levels.py): when set, every node record a descent loads is
+ * counted by the octree level of that node (1..12).  NULL in every other use. */
+static uint64_t *g_level_hist;
+void oracle_level_histogram(uint64_t *hist16) { g_level_hist = hist16; }
+
 /* find, Compute.hlsl:88-108 */
 O_INLINE void o_find(o_ctx *t, float px, float py, float pz)
 {
@@ -142,6 +147,8 @@ O_INLINE void o_find(o_ctx *t, float px, float py, float pz)
         t->n_nodes++;
         o_scale_down(&t->box, dx, dy, dz);
         iterations++;
+        if (__builtin_expect(g_level_hist != NULL, 0))
+            __atomic_fetch_add(&g_level_hist[(-ilogbf(t->box.scale)) & 15], 1, __ATOMIC_RELAXED);
     }
 }
 

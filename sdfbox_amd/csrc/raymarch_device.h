@@ -42,10 +42,14 @@ struct FrameInfo {
 constexpr int MAX_BATCH = 8;   // frames one k_plain launch can render (grid.y)
 constexpr int MAX_BAND_LIST = 512;   // bands one launch can be handed as an explicit list
 
+struct TopCell { uint32_t link, v0, v1, pad; };   // a cell of the top grid, see below (cursor-stack kernels)
+
 // Kernel parameters: scene, frame geometry, and the camera block of every frame of the launch.
 struct RenderParams {
     const NodeRec *nodes;
     uint32_t n_nodes;
+    const TopCell *top;        // top grid (cursor-stack kernels) of level top_level, or null
+    int32_t top_level;
     float4 *out;               // compact rows: nrows_out x width
     uint32_t width, height;    // full frame
     uint32_t band_rows, band_first, band_stride, nrows_out;
@@ -171,7 +175,7 @@ __device__ __forceinline__ int descend_box(CursorG &c, float px, float py, float
 // through memory exactly as the shader does (the entry read of data[index] is
 // served from the registers that already hold that record).  Returns the number
 // of node records the *reference* reads in this call.
-__device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__ nodes,
+__device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__ nodes, const void *, int,
                                          uint32_t n_nodes, int32_t *, uint32_t, float px, float py, float pz)
 {
     uint32_t reads = 1;
@@ -227,6 +231,18 @@ __device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__
 // for any mix of levels) when the path went down through it.
 constexpr int LM = 12;
 
+// Top grid.  Far from the surface the cells are coarse and a march step usually leaves its cell
+// through a face of a shallow ancestor: half of all records a descent loads belong to levels 1-3,
+// 87 % to levels 1-6 (scripts/descent_levels.py), each one a dependent load.  The grid holds, for
+// every cell of level TG, the record of the deepest node of level <= TG that contains it:
+// {children (28 bits, sign-extended) | level << 28, values}.  A descent that restarts above level
+// TG takes ONE load from the grid instead of up to TG dependent loads, and ends in the same node.
+// TG is chosen per scene at upload (RenderParams::top_level); top == nullptr disables it.
+__host__ __device__ __forceinline__ uint32_t top_link(int32_t children, uint32_t level)
+{
+    return ((uint32_t)children & 0x0FFFFFFFu) | (level << 28);
+}
+
 struct CursorS {
     int32_t ax, ay, az;      // lower * 2^LM
     int32_t level;
@@ -268,6 +284,7 @@ __device__ __forceinline__ int bitlen(uint32_t x) { return 32 - __clz((int)x); }
 // branch in find() picks it).
 template <bool ON_GRID>
 __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict__ nodes,
+                                           const TopCell *__restrict__ top, const int TG,
                                            int32_t *__restrict__ stack, uint32_t stride,
                                            int32_t Ax, int32_t Ay, int32_t Az, bool gx, bool gy, bool gz)
 {
@@ -286,7 +303,8 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
     uint32_t reads = 1u + (uint32_t)k;
     if (k > 0) {
         c.level -= k;
-        c.children = stack[(uint32_t)c.level * stride];
+        // an ancestor has children (consistent tree); above the top grid their index is not needed
+        c.children = (top && c.level < TG) ? 0 : stack[(uint32_t)c.level * stride];
     }
     if (c.children >= 0) {
         // where the descent reads its octant bits from (see above), clamped into the cube
@@ -298,7 +316,19 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
             Dz = (((uint32_t)(c.az ^ Az) >> tt) == 0u) ? Az : Bz;
         }
         Dx = min(max(Dx, 0), 4095); Dy = min(max(Dy, 0), 4095); Dz = min(max(Dz, 0), 4095);
-        do {
+        if (top && c.level < TG) {
+            // through the top grid: the node this descent reaches at level TG (or the leaf above it)
+            const int sh = LM - TG;
+            const uint32_t cellidx = ((uint32_t)Dx >> sh) | (((uint32_t)Dy >> sh) << TG) | (((uint32_t)Dz >> sh) << (2 * TG));
+            const uint4 e = reinterpret_cast<const uint4 *>(top)[cellidx];
+            const int lvl = (int)(e.x >> 28);
+            reads += (uint32_t)(lvl - c.level);
+            c.level = lvl;
+            c.children = (int32_t)(e.x << 4) >> 4;
+            c.v0 = e.y;
+            c.v1 = e.z;
+        }
+        while (c.children >= 0) {
             stack[(uint32_t)c.level * stride] = c.children;
             const int sb = LM - 1 - c.level;
             uint32_t p = ((uint32_t)Dx >> sb & 1u) | (((uint32_t)Dy >> sb & 1u) << 1) | (((uint32_t)Dz >> sb & 1u) << 2);
@@ -312,7 +342,7 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
             asm volatile("" : "+v"(c.v0), "+v"(c.v1));
             c.level++;
             reads++;
-        } while (c.children >= 0);
+        }
         const int32_t keep = ~((1 << (LM - c.level)) - 1);
         c.ax = Dx & keep; c.ay = Dy & keep; c.az = Dz & keep;
     } else if (k > 0) {
@@ -324,15 +354,15 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
     return reads;
 }
 
-__device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, uint32_t,
-                                         int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz)
+__device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, const TopCell *__restrict__ top,
+                                         int top_level, uint32_t, int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz)
 {
     float ux, uy, uz, fx, fy, fz;
     const int32_t Ax = axis_a(px, ux, fx), Ay = axis_a(py, uy, fy), Az = axis_a(pz, uz, fz);
     const bool gx = ux == fx, gy = uy == fy, gz = uz == fz;    // on the 2^-LM grid (false for NaN)
     if (__ballot(gx || gy || gz) == 0ull)
-        return find_s<false>(c, nodes, stack, stride, Ax, Ay, Az, false, false, false);
-    return find_s<true>(c, nodes, stack, stride, Ax, Ay, Az, gx, gy, gz);
+        return find_s<false>(c, nodes, top, top_level, stack, stride, Ax, Ay, Az, false, false, false);
+    return find_s<true>(c, nodes, top, top_level, stack, stride, Ax, Ay, Az, gx, gy, gz);
 }
 
 // Cube::interpol_world -> sample_at, Compute.hlsl:54-58,19-29

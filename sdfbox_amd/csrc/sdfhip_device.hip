@@ -11,10 +11,12 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <type_traits>
+#include <vector>
 
 
 namespace sdfhip {
@@ -28,6 +30,26 @@ __global__ void k_fuse(const int2 *__restrict__ structs, const uint2 *__restrict
         int2 s = structs[i];
         uint2 v = values[i];
         nodes[i] = make_uint4((uint32_t)s.x, (uint32_t)s.y, v.x, v.y);
+    }
+}
+
+// The top grid of the cursor-stack kernels (raymarch_device.h): one thread per level-TG cell walks
+// from the root by the cell's octant bits and stores the record it ends at.
+__global__ void k_top_grid(const NodeRec *__restrict__ nodes, TopCell *__restrict__ top, int TG)
+{
+    const uint32_t total = 1u << (3 * TG), mask = (1u << TG) - 1u;
+    for (uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x; cell < total; cell += gridDim.x * blockDim.x) {
+        const uint32_t cx = cell & mask, cy = (cell >> TG) & mask, cz = cell >> (2 * TG);
+        NodeRec r = nodes[0];
+        uint32_t level = 0;
+        while (level < (uint32_t)TG && (int32_t)r.y >= 0) {
+            const uint32_t sb = (uint32_t)TG - 1u - level;
+            r = nodes[r.y + ((cx >> sb & 1u) | ((cy >> sb & 1u) << 1) | ((cz >> sb & 1u) << 2))];
+            level++;
+        }
+        TopCell t;
+        t.link = top_link((int32_t)r.y, level); t.v0 = r.z; t.v1 = r.w; t.pad = 0;
+        top[cell] = t;
     }
 }
 
@@ -69,6 +91,8 @@ __global__ void k_unorm_table(float *out)
     out[threadIdx.x] = unorm8((float)threadIdx.x);
 }
 
+constexpr int MAX_TOP_LEVEL = 8;
+
 }  // namespace sdfhip
 
 // ===============================================================================
@@ -83,6 +107,8 @@ struct sdfhip_scene {
     void *alloc;            // hipMalloc'ed block holding the records
     NodeRec *nodes;         // = alloc + 112: node 1 (first sibling block) starts a 128-B line
     hipStream_t stream;
+    TopCell *d_top;                  // top grid of the cursor-stack kernels (raymarch_device.h), or null
+    int top_level;
     unsigned long long *d_counters;  // 4 x u64: nodes, samples, steps, shadow rays
     uint32_t *d_queue;
     float4 *d_frame;        // grown on demand by sdfhip_render
@@ -129,6 +155,7 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
         if (s->stream) (void)hipStreamSynchronize(s->stream);
         if (s->alloc) (void)hipFree(s->alloc);
         if (s->d_counters) (void)hipFree(s->d_counters);
+        if (s->d_top) (void)hipFree(s->d_top);
         if (s->d_queue) (void)hipFree(s->d_queue);
         if (s->d_frame) (void)hipFree(s->d_frame);
         if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -165,7 +192,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if (!s) return fail(SDFHIP_ERR_NOMEM, "scene_upload: out of host memory");
     s->device = device; s->n = n; s->depth = depth;
     s->stack_ok = (consistent && depth <= (uint32_t)MAX_STACK) ? 1 : 0;
-    s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr;
+    s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr; s->d_top = nullptr; s->top_level = 0;
     s->d_queue = nullptr; s->d_frame = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
     s->cu_count = prop.multiProcessorCount;
 
@@ -194,10 +221,40 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     hipLaunchKernelGGL(k_fuse, dim3(blocks), dim3(256), 0, s->stream, (const int2 *)d_s,
                        (const uint2 *)d_v, s->nodes, n);
     if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_fuse launch");
+    // top grid: as deep as the tree, at most MAX_TOP_LEVEL, and no larger than the tree's own records
+    // (16 bytes per cell and per node; at least 64 KB).  SDFHIP_TOP_GRID_LEVEL overrides (0 = none).
+    // A grid cell packs a children index into 27 bits + sign.
+    int top_level = 0;
+    {
+        const size_t budget = (size_t)n * 16 > ((size_t)1 << 16) ? (size_t)n * 16 : ((size_t)1 << 16);
+        while (top_level < MAX_TOP_LEVEL && (uint32_t)top_level < depth &&
+               (sizeof(TopCell) << (3 * (top_level + 1))) <= budget)
+            top_level++;
+    }
+    if (const char *env = getenv("SDFHIP_TOP_GRID_LEVEL")) {
+        const int v = atoi(env);
+        if (v >= 0 && v <= 9) top_level = v < (int)depth ? v : (int)depth;
+    }
+    if (s->stack_ok && top_level > 0 && n < (1u << 27)) {
+        const size_t cells = (size_t)1 << (3 * top_level);
+        if ((e = hipMalloc((void **)&s->d_top, cells * sizeof(TopCell))) != hipSuccess) return bail(e, "hipMalloc(top grid)");
+        s->top_level = top_level;
+        const uint32_t tb = (uint32_t)((cells + 255) / 256 < 8192 ? (cells + 255) / 256 : 8192);
+        hipLaunchKernelGGL(k_top_grid, dim3(tb), dim3(256), 0, s->stream, s->nodes, s->d_top, top_level);
+        if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_top_grid launch");
+    }
     if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail(e, "k_fuse");
     (void)hipFree(d_s); d_s = nullptr;
     (void)hipFree(d_v); d_v = nullptr;
     *out = s;
+    return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_scene_top_grid(const sdfhip_scene *s, int32_t *level, uint64_t *bytes)
+{
+    if (!s) return fail(SDFHIP_ERR_ARG, "scene_top_grid: null scene");
+    if (level) *level = s->d_top ? s->top_level : 0;
+    if (bytes) *bytes = s->d_top ? (uint64_t)sizeof(TopCell) << (3 * s->top_level) : 0;
     return SDFHIP_OK;
 }
 
@@ -257,7 +314,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
 
     RenderParams P;
-    P.nodes = s->nodes; P.n_nodes = s->n;
+    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level;
     P.out = reinterpret_cast<float4 *>(d_out);
     P.width = width; P.height = height;
     P.band_rows = band_rows; P.band_first = band_first; P.band_stride = band_stride;

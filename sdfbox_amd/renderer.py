@@ -24,6 +24,9 @@ class Scene:
         check(lib.sdfhip_scene_info(self._h, ctypes.byref(n), ctypes.byref(d), ctypes.byref(ok),
                                     ctypes.byref(dev)))
         self.Length, self.depth, self.stack_kernel_ok = n.value, d.value, bool(ok.value)
+        lvl = ctypes.c_int32(); nb = ctypes.c_uint64()
+        check(lib.sdfhip_scene_top_grid(self._h, ctypes.byref(lvl), ctypes.byref(nb)))
+        self.top_grid_level, self.top_grid_bytes = lvl.value, nb.value
 
     def close(self):
         if self._h:

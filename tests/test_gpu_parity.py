@@ -456,6 +456,48 @@ def test_weighted_band_layouts_reassemble_the_frame(sb, gpu_scenes):
         scene.DrawBandsDevice([cam, cam], 64, 64, buf.data_ptr(), 8, [0], pt=sb.PathTrace(spp=1), stream=stream)
 
 
+def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
+    # the top grid (one load instead of a chain of dependent ones when a descent restarts near the
+    # root) at every level, none included: frames and algorithmic counters stay the oracle's
+    import os
+    rng = np.random.default_rng(7)
+    od6 = scenes["torus_d6"]
+    cases = [(scenes["sphere_d4"], "default"), (od6, "rotated"), (od6, "closeup")]
+    W, H = 96, 80
+    prev = os.environ.get("SDFHIP_TOP_GRID_LEVEL")
+    try:
+        for od, camname in cases:
+            cam = make_camera(camname, W, H)
+            ongrid = sb.Logic(W, H); ongrid.Position = (0.25, 0.5, -0.125); ongrid.Heading = (0.0, 0.0)   # rays along cell faces
+            refs = [oracle_mod.render(od.Structs, od.Values, c.State, W, H) for c in (cam, ongrid)]
+            levels_seen = set()
+            for lv in ("0", "1", "2", "3", "4", "5", "6", None):
+                if lv is None:
+                    os.environ.pop("SDFHIP_TOP_GRID_LEVEL", None)
+                else:
+                    os.environ["SDFHIP_TOP_GRID_LEVEL"] = lv
+                with sb.Scene(od) as scene:
+                    levels_seen.add(scene.top_grid_level)
+                    assert scene.top_grid_level <= scene.depth
+                    assert scene.top_grid_bytes == (16 << (3 * scene.top_grid_level) if scene.top_grid_level else 0)
+                    if lv is None:       # the default: as deep as the tree allows within the tree's own size
+                        assert 1 <= scene.top_grid_level and scene.top_grid_bytes <= max(16 * od.Length, 1 << 16)
+                    for c, (ref, cnt) in zip((cam, ongrid), refs):
+                        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT):
+                            img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
+                            assert_frames_identical(img, ref, f"top grid {lv}")
+                            assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), lv
+                        pimg = scene.DrawPath(c, W, H, pt=sb.PathTrace(spp=2))
+                        pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
+                        assert_frames_identical(pimg, pref, f"top grid {lv}, path-traced")
+            assert len(levels_seen) >= 4
+    finally:
+        if prev is None:
+            os.environ.pop("SDFHIP_TOP_GRID_LEVEL", None)
+        else:
+            os.environ["SDFHIP_TOP_GRID_LEVEL"] = prev
+
+
 def test_two_handles_render_concurrently(sb, oracle_mod, scenes):
     # upload / render are callable from several threads on different handles
     cam = make_camera("default", 128, 128)
