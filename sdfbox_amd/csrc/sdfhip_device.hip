@@ -49,7 +49,7 @@ __global__ void k_top_grid(const NodeRec *__restrict__ nodes, TopCell *__restric
         }
         TopCell t;
         t.link = top_link((int32_t)r.y, level); t.v0 = r.z; t.v1 = r.w; t.pad = 0;
-        top[cell] = t;
+        top[top_index(cx, cy, cz, TG)] = t;
     }
 }
 
