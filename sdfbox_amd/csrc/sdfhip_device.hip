@@ -236,12 +236,19 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
         if (v >= 0 && v <= 9) top_level = v < (int)depth ? v : (int)depth;
     }
     if (s->stack_ok && top_level > 0 && n < (1u << 27)) {
-        const size_t cells = (size_t)1 << (3 * top_level);
-        if ((e = hipMalloc((void **)&s->d_top, cells * sizeof(TopCell))) != hipSuccess) return bail(e, "hipMalloc(top grid)");
-        s->top_level = top_level;
-        const uint32_t tb = (uint32_t)((cells + 255) / 256 < 8192 ? (cells + 255) / 256 : 8192);
-        hipLaunchKernelGGL(k_top_grid, dim3(tb), dim3(256), 0, s->stream, s->nodes, s->d_top, top_level);
-        if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_top_grid launch");
+        // the grid is an accelerator, not part of the scene: without memory for it, shrink it
+        while (top_level > 0 && hipMalloc((void **)&s->d_top, sizeof(TopCell) << (3 * top_level)) != hipSuccess) {
+            (void)hipGetLastError();
+            s->d_top = nullptr;
+            top_level--;
+        }
+        if (top_level > 0) {
+            const size_t ncell = (size_t)1 << (3 * top_level);
+            s->top_level = top_level;
+            const uint32_t tb = (uint32_t)((ncell + 255) / 256 < 8192 ? (ncell + 255) / 256 : 8192);
+            hipLaunchKernelGGL(k_top_grid, dim3(tb), dim3(256), 0, s->stream, s->nodes, s->d_top, top_level);
+            if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_top_grid launch");
+        }
     }
     if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail(e, "k_fuse");
     (void)hipFree(d_s); d_s = nullptr;
