@@ -123,11 +123,17 @@ struct Cell {
     float lx, ly, lz, scale, inv;
     uint32_t v0, v1;
 };
+// What find() hands to the sample that follows it at the same position: nothing (generic cursor),
+// or the position in units of 2^-LM -- an exact power-of-two scaling the cursor-stack find computes
+// anyway (sample_after_find below).
+struct Unscaled {};
+struct Scaled { float x, y, z; };
 
 // ---- generic cursor: float box, links followed through memory ----------------
 // The shader's static `index` + `box` (Compute.hlsl:12,61) plus the record of the
 // node it sits on, kept in registers.
 struct CursorG {
+    typedef Unscaled Pos;
     float lx, ly, lz, scale, inv;
     int32_t parent, children;
     uint32_t v0, v1;
@@ -176,7 +182,7 @@ __device__ __forceinline__ int descend_box(CursorG &c, float px, float py, float
 // served from the registers that already hold that record).  Returns the number
 // of node records the *reference* reads in this call.
 __device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__ nodes, const void *, int,
-                                         uint32_t n_nodes, int32_t *, uint32_t, float px, float py, float pz)
+                                         uint32_t n_nodes, int32_t *, uint32_t, float px, float py, float pz, Unscaled &)
 {
     uint32_t reads = 1;
     while (!inside(c, px, py, pz) && c.parent >= 0) {
@@ -261,6 +267,7 @@ __host__ __device__ __forceinline__ uint32_t top_link(int32_t children, uint32_t
 }
 
 struct CursorS {
+    typedef Scaled Pos;
     int32_t ax, ay, az;      // lower * 2^LM
     int32_t level;
     int32_t children;
@@ -309,13 +316,16 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
     const int32_t By = Ay - ((ON_GRID && gy) ? 1 : 0);
     const int32_t Bz = Az - ((ON_GRID && gz) ? 1 : 0);
     const int s = LM - c.level;
-    int tx = bitlen((uint32_t)(c.ax ^ Ax)), ty = bitlen((uint32_t)(c.ay ^ Ay)), tz = bitlen((uint32_t)(c.az ^ Az));
+    int t;
     if (ON_GRID) {
-        tx = min(tx, bitlen((uint32_t)(c.ax ^ Bx)));
-        ty = min(ty, bitlen((uint32_t)(c.ay ^ By)));
-        tz = min(tz, bitlen((uint32_t)(c.az ^ Bz)));
+        const int tx = min(bitlen((uint32_t)(c.ax ^ Ax)), bitlen((uint32_t)(c.ax ^ Bx)));
+        const int ty = min(bitlen((uint32_t)(c.ay ^ Ay)), bitlen((uint32_t)(c.ay ^ By)));
+        const int tz = min(bitlen((uint32_t)(c.az ^ Az)), bitlen((uint32_t)(c.az ^ Bz)));
+        t = max(max(tx, ty), max(tz, s));
+    } else {
+        // the longest of the three differences = the length of their OR
+        t = max(bitlen((uint32_t)(c.ax ^ Ax) | (uint32_t)(c.ay ^ Ay) | (uint32_t)(c.az ^ Az)), s);
     }
-    int t = max(max(tx, ty), max(tz, s));
     int k = min(t - s, c.level);                 // ascents (Compute.hlsl:93-97)
     uint32_t reads = 1u + (uint32_t)k;
     if (k > 0) {
@@ -372,11 +382,13 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
 }
 
 __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, const TopCell *__restrict__ top,
-                                         int top_level, uint32_t, int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz)
+                                         int top_level, uint32_t, int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz,
+                                         Scaled &u)
 {
     float ux, uy, uz, fx, fy, fz;
     const int32_t Ax = axis_a(px, ux, fx), Ay = axis_a(py, uy, fy), Az = axis_a(pz, uz, fz);
     const bool gx = ux == fx, gy = uy == fy, gz = uz == fz;    // on the 2^-LM grid (false for NaN)
+    u.x = ux; u.y = uy; u.z = uz;
     if (__ballot(gx || gy || gz) == 0ull)
         return find_s<false>(c, nodes, top, top_level, stack, stride, Ax, Ay, Az, false, false, false);
     return find_s<true>(c, nodes, top, top_level, stack, stride, Ax, Ay, Az, gx, gy, gz);
@@ -400,6 +412,30 @@ __device__ __forceinline__ float interpol_world(const Cell &c, float px, float p
     float loadL = bilerp(t.v[0], t.v[1], t.v[2], t.v[3], dx, dy);
     float loadH = bilerp(t.v[4], t.v[5], t.v[6], t.v[7], dx, dy);
     return (lerp(loadL, loadH, dz) - 0.25f) * c.scale * 2.0f;
+}
+
+// interpol_world at the position the preceding find() was called with.
+__device__ __forceinline__ float sample_after_find(const CursorG &c, const Unscaled &, float px, float py, float pz)
+{
+    return interpol_world(c.cell(), px, py, pz);
+}
+// Cursor-stack form: with u = 2^LM * pos and a = 2^LM * lower (both exact),
+// (u - a) * 2^(level - LM) == (pos - lower) * 2^level bit for bit -- rounding is invariant under
+// power-of-two scaling -- which saves the conversion of the anchor back to world units.
+__device__ __forceinline__ float sample_after_find(const CursorS &c, const Scaled &u, float, float, float)
+{
+    const float scale = __int_as_float((127 - c.level) << 23);                 // 2^-level
+    const bool flat = c.v0 == c.v1 && c.v0 == (c.v0 & 0xFFu) * 0x01010101u;    // see interpol_world
+    if (__ballot(!flat) == 0ull)
+        return (unorm8((float)(c.v0 & 0xFFu)) - 0.25f) * scale * 2.0f;
+    const float inv = __int_as_float((127 + c.level - LM) << 23);              // 2^(level - LM)
+    float dx = sat((u.x - (float)c.ax) * inv);
+    float dy = sat((u.y - (float)c.ay) * inv);
+    float dz = sat((u.z - (float)c.az) * inv);
+    Texels t = decode(c.v0, c.v1);
+    float loadL = bilerp(t.v[0], t.v[1], t.v[2], t.v[3], dx, dy);
+    float loadH = bilerp(t.v[4], t.v[5], t.v[6], t.v[7], dx, dy);
+    return (lerp(loadL, loadH, dz) - 0.25f) * scale * 2.0f;
 }
 
 // gradient, Compute.hlsl:112-130 (taps at integer x / y have bilinear weight 0

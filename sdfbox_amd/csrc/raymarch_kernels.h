@@ -228,8 +228,9 @@ template <class CursorT>
 __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const FrameInfo &I, RayState &r, CursorT &c,
                                                int32_t *stack, uint32_t stride)
 {
-    uint32_t reads = find(c, P.nodes, P.top, P.top_level, P.n_nodes, stack, stride, r.px, r.py, r.pz);
-    r.prox = interpol_world(c.cell(), r.px, r.py, r.pz);
+    typename CursorT::Pos u;
+    uint32_t reads = find(c, P.nodes, P.top, P.top_level, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
+    r.prox = sample_after_find(c, u, r.px, r.py, r.pz);
     float step = r.phase ? r.prox + I.margin : r.prox;
     r.px = __builtin_fmaf(r.dx, step, r.px);
     r.py = __builtin_fmaf(r.dy, step, r.py);
@@ -588,8 +589,9 @@ __global__ __launch_bounds__(64) void k_path(RenderParams P)
                 continue;
             }
             // ---- one march step of the segment or of the shadow ray -----------------------
-            uint32_t reads = find(c, P.nodes, P.top, P.top_level, P.n_nodes, stack, 64, mx, my, mz);
-            prox = interpol_world(c.cell(), mx, my, mz);
+            typename CursorT::Pos u;
+            uint32_t reads = find(c, P.nodes, P.top, P.top_level, P.n_nodes, stack, 64, mx, my, mz, u);
+            prox = sample_after_find(c, u, mx, my, mz);
             if (COUNT) { cn += reads; cs += 1; }
             const float st = shadow ? prox + margin : prox;
             mx = __builtin_fmaf(ux, st, mx);
