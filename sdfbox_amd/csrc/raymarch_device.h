@@ -38,6 +38,7 @@ struct FrameInfo {
     float screen_w, screen_h, limit;
     float lightx, lighty, lightz;
     float fov, k_strength;     // k_strength = exp2f(strength) - 1, evaluated on the host
+    float margin2;             // margin * 2 (exact), Compute.hlsl:194
 };
 constexpr int MAX_BATCH = 8;   // frames one k_plain launch can render (grid.y)
 constexpr int MAX_BAND_LIST = 512;   // bands one launch can be handed as an explicit list

@@ -40,7 +40,7 @@ struct RayState {
     float px, py, pz;    // pos
     float dx, dy, dz;    // dir (primary direction, then direction to the light)
     float prox, angle, dist;
-    int i, j, phase;     // PH_*
+    int n, base, phase;  // steps of the current march, steps before it (i = base or n, j = n), PH_*
 };
 
 __device__ __forceinline__ uint32_t global_row(const RenderParams &P, uint32_t yl)
@@ -59,12 +59,12 @@ __device__ __forceinline__ void start_pixel(const FrameInfo &I, const NodeRec &r
     ray(I, x, y, r.dx, r.dy, r.dz);
     r.prox = 1.0f;
     r.angle = 0.0f; r.dist = 0.0f;
-    r.i = 0; r.j = 0; r.phase = PH_PRIMARY;
+    r.n = 0; r.base = 0; r.phase = PH_PRIMARY;
     c.reset(root);
 }
 
 // ---- main() between two find() calls, in three pieces -------------------------
-// A finished pixel's colour (alpha = step count = r.i + r.j) is stored to *dst by the
+// A finished pixel's colour (alpha = step count = r.base + r.n) is stored to *dst by the
 // piece that finishes it.  (Storing there instead of returning the colour keeps four
 // values out of the march loop's phi nodes.)
 
@@ -148,9 +148,9 @@ struct LdsSink {
 template <class Sink>
 __device__ __forceinline__ int check_primary(const FrameInfo &I, const RayState &r, const Sink &dst)
 {
-    if ((r.prox > I.margin * 2.0f || r.prox < 0.0f) && r.i < 100) {
+    if ((r.prox > I.margin2 || r.prox < 0.0f) && r.n < 100) {
         if (dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit) {
-            dst.sky((float)r.i);
+            dst.sky((float)r.n);
             return 2;
         }
         return 0;
@@ -174,13 +174,14 @@ __device__ __forceinline__ bool shade(const FrameInfo &I, RayState &r, const Cur
     float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
     r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
     if (r.angle < 0.0f) {
-        dst.black((float)r.i);
+        dst.black((float)r.n);
         return true;
     }
     lx = I.lightx - r.px; ly = I.lighty - r.py; lz = I.lightz - r.pz;
     r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
     r.phase = PH_SHADOW;
-    r.j = 0;
+    r.base = r.n;                 // i stays, j starts
+    r.n = 0;
     return false;
 }
 
@@ -189,21 +190,21 @@ __device__ __forceinline__ bool shade(const FrameInfo &I, RayState &r, const Cur
 template <class CursorT, class Sink>
 __device__ __forceinline__ bool check_shadow(const FrameInfo &I, const RayState &r, const CursorT &c, const Sink &dst)
 {
-    if (!(r.j < 40 && r.prox > -I.margin)) {
-        dst.black((float)(r.i + r.j));  // :229
+    if (!(r.n < 40 && r.prox > -I.margin)) {
+        dst.black((float)(r.base + r.n));  // :229
         return true;
     }
     if (r.prox > r.dist || (r.px < 0.0f || r.py < 0.0f || r.pz < 0.0f) ||
         (r.px > 1.0f || r.py > 1.0f || r.pz > 1.0f)) {           // :215-219
         float a = r.angle / (r.dist * r.dist) * I.k_strength;
-        dst.grey(a, (float)(r.i + r.j));
+        dst.grey(a, (float)(r.base + r.n));
         return true;
     }
     if (r.prox < I.margin) {                                       // :221-223
         float gx, gy, gz;
         gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
         if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) {
-            dst.black((float)(r.i + r.j));
+            dst.black((float)(r.base + r.n));
             return true;
         }
     }
@@ -235,7 +236,7 @@ __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const Fram
     r.px = __builtin_fmaf(r.dx, step, r.px);
     r.py = __builtin_fmaf(r.dy, step, r.py);
     r.pz = __builtin_fmaf(r.dz, step, r.pz);
-    if (r.phase) r.j++; else r.i++;
+    r.n++;
     return reads;
 }
 
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
             uint32_t reads = march_step(P, I, r, c, stack_lds + tid, BT);
             if (COUNT) { cn += reads; cs += 1; }
         }
-        if (COUNT) { ct = (unsigned long long)(r.i + r.j); cr = r.phase == PH_SHADOW ? 1u : 0u; }   // shade() left the lane in PH_SHADOW
+        if (COUNT) { ct = (unsigned long long)(r.base + r.n); cr = r.phase == PH_SHADOW ? 1u : 0u; }   // shade() left the lane in PH_SHADOW
     }
     if (COUNT) flush_counters(P, cn, cs, ct, cr);
 }
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
     uint32_t q = blockIdx.x & 7u, tried = 0;   // wave-uniform: queue in use, queues found empty
     bool more = true, first = true;   // wave-uniform
     r.px = r.py = r.pz = r.dx = r.dy = r.dz = r.prox = r.angle = r.dist = 0.0f;
-    r.i = r.j = 0;
+    r.n = r.base = 0;
     r.phase = PH_IDLE;
     c.reset(root);
     const uint32_t rows_q = (P.tiles_y + 7u) >> 3;         // tile rows per queue (upper bound)
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
             if (r.phase == PH_SHADE) {
                 r.phase = PH_PRIMARY;
                 if (shade(I, r, c, dst)) {
-                    if (COUNT) ct += (unsigned long long)(r.i + r.j);
+                    if (COUNT) ct += (unsigned long long)(r.base + r.n);
                     r.phase = PH_DONE;
                 } else if (COUNT) {
                     cr += 1;
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
                 done = check_shadow(I, r, c, dst);
             }
             if (done) {
-                if (COUNT) ct += (unsigned long long)(r.i + r.j);
+                if (COUNT) ct += (unsigned long long)(r.base + r.n);
                 r.phase = PH_DONE;
             } else if (r.phase <= PH_SHADOW) {
                 uint32_t reads = march_step(P, I, r, c, stack_lds + lane, 64);

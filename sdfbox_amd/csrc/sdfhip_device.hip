@@ -355,6 +355,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         I.h2x = in->heading[2][0]; I.h2y = in->heading[2][1]; I.h2z = in->heading[2][2];
         I.posx = in->position[0]; I.posy = in->position[1]; I.posz = in->position[2];
         I.margin = in->margin;
+        I.margin2 = in->margin * 2.0f;
         I.screen_w = in->screen_size[0]; I.screen_h = in->screen_size[1];
         I.limit = in->limit;
         I.lightx = in->light[0]; I.lighty = in->light[1]; I.lightz = in->light[2];
