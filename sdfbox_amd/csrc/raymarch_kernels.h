@@ -26,6 +26,9 @@ constexpr int MAX_STACK = LM;          // the shader's own descent limit (Comput
 #ifndef COMPACT_WAVES_PER_SIMD
 #define COMPACT_WAVES_PER_SIMD 8
 #endif
+#ifndef PATH_WAVES_PER_SIMD
+#define PATH_WAVES_PER_SIMD 7
+#endif
 #ifndef PLAIN_WAVES_PER_SIMD
 #define PLAIN_WAVES_PER_SIMD 8          // <= 64 VGPRs: 8 waves per SIMD (2nd launch-bound = waves per SIMD)
 #endif
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
 // pixel are the oracle's; only the control flow differs.  One lane per pixel, one 8x8 tile
 // per wave, the plain kernel's XCD-interleaved tile rows.
 template <bool STACK, bool COUNT>
-__global__ __launch_bounds__(64) void k_path(RenderParams P)
+__global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P)
 {
     __shared__ int32_t stack_lds[STACK ? MAX_STACK * 64 : 1];
     const uint32_t bid = blockIdx.x, xcd = bid & 7u, jb = bid >> 3;
