@@ -32,8 +32,8 @@ DEFAULT_COMPACT = False
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--size", default="1920x1080", help="frame WxH (BASELINE cfg-2: 1920x1080)")
     ap.add_argument("--depth", type=int, default=9, help="octree depth of the dragon stand-in")
     ap.add_argument("--asdf", default=None, help="render this .asdf instead of the synthetic scene")
