@@ -139,22 +139,25 @@ def main():
     if pt is not None and (args.display or compact):
         raise SystemExit("--spp excludes --display and --compact")
 
+    # sharded: G frames share one launch (grid.y = frame) and one gather; nbuf groups are in
+    # flight (so G*nbuf frames).  A rank's share is mostly the serial tail of its longest
+    # pixels: G frames in one grid share that tail (DESIGN.md section 5)
+    G = (args.gather_every if args.gather_every > 0 else 4) if sharded else 1
+    if pt is not None or compact:
+        G = 1 if not sharded else G            # those kernels render one frame per launch
+    # in flight: 2 frames on one GPU; 4 groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4
+    # frames per launch needs 4 launches in flight to fill the chip -- 0.039 -> 0.024 ms per frame at 8 ranks)
+    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (4 if sharded else 2)
+
     # rank 0 also assembles the frame (de-interleave + wire expansion of every rank's rows), so it
     # renders a smaller share: --rank0-weight, or measured here before anything is timed
     w0 = args.rank0_weight if world > 1 else 1.0
     if sharded and world > 1 and w0 <= 0:
         w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, share_shape, wpx_dtype, wpx_bytes,
-                                  rank, nccl, pt, compact)
+                                  rank, nccl, pt, compact, G, nbuf)
     if (H + args.band_rows - 1) // args.band_rows > 512 or w0 > 0.98:
         w0 = 1.0
     layout = BandLayout(H, world, args.band_rows, w0)
-    # sharded: G frames share one launch (grid.y = frame) and one gather; nbuf groups are in
-    # flight (so G*nbuf frames).  A rank's share is mostly the serial tail of its longest
-    # pixels: G frames in one grid share that tail (DESIGN.md section 5)
-    G = (args.gather_every if args.gather_every > 0 else min(8, max(4, world))) if sharded else 1
-    if pt is not None or compact:
-        G = 1 if not sharded else G            # those kernels render one frame per launch
-    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else 2
     streams = [torch.cuda.Stream() for _ in range(nbuf)]                       # one per group in flight
     main = torch.cuda.current_stream().cuda_stream
     rows_local = layout.rows_per_rank if sharded else H
@@ -354,7 +357,8 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_shape, wpx_dtype, wpx_bytes, rank, nccl, pt, compact):
+def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_shape, wpx_dtype, wpx_bytes, rank, nccl, pt, compact,
+                         G, nbuf):
     """Rank 0 also assembles the frame (de-interleave and wire expansion of all ranks' rows), so an
     even deal makes it the slowest rank.  Before anything is timed, rank 0 tries layouts that give it
     0.5 .. 1.0 of a peer's share: for each it times its own work (render + assembly) and the largest
@@ -365,19 +369,19 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
     from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch
     w = torch.ones(1, dtype=torch.float64)
     if rank == 0:
-        G = 1 if (pt is not None or compact) else min(8, max(4, world))
-        streams = [torch.cuda.Stream() for _ in range(2)]
+        streams = [torch.cuda.Stream() for _ in range(nbuf)]
         full_shape, full_dtype = ((), torch.int32) if wpx_bytes == 4 else ((4,), torch.float32)
         frame = torch.zeros((G, H, W) + full_shape, dtype=full_dtype, device="cuda")
-        n = 3 if pt is not None else 12
+        n = 3 if pt is not None else 16
 
         def work(lay, r, local, gathered):
             def one(k):
-                s = streams[k % 2].cuda_stream
-                if G > 1:
-                    render_bands_batch(scene, [cam] * G, W, lay, r, local[k % 2].data_ptr(), flags=flags, stream=s)
+                s = streams[k % nbuf].cuda_stream
+                if pt is None and not compact:
+                    render_bands_batch(scene, [cam] * G, W, lay, r, local[k % nbuf].data_ptr(), flags=flags, stream=s)
                 else:
-                    render_bands(scene, cam, W, lay, r, local[k % 2].data_ptr(), flags=flags, stream=s, pt=pt)
+                    for f in range(G):
+                        render_bands(scene, cam, W, lay, r, local[k % nbuf][f].data_ptr(), flags=flags, stream=s, pt=pt)
                 if r == 0:
                     deinterleave(torch.cuda.current_device(), gathered.data_ptr(), frame.data_ptr(), W, lay,
                                  stream=s, pixel_bytes=wpx_bytes, frames=G)
@@ -394,7 +398,7 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
         tried = []
         for cand in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5):
             lay = BandLayout(H, world, band_rows, cand)
-            local = [torch.zeros((G,) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda") for _ in range(2)]
+            local = [torch.zeros((G,) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
             gathered = torch.zeros((world, G) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda")
             t0, t1 = work(lay, 0, local, gathered), work(lay, 1, local, gathered)
             tried.append((max(t0, t1), cand, t0, t1))

@@ -11,25 +11,25 @@ W, H = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1920x1080").spli
 od = sb.dragon_standin(9); sc = sb.Scene(od)
 cam = sb.Logic(W, H); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
 pb, fl = 5, sb.FLAG_WIRE
-for world, weights in ((2, (1.0, 0.93)), (4, (1.0, 0.86)), (8, (1.0, 0.775, 0.7))):
-    G = min(8, max(4, world))
-    for band_rows in (8, 16):
+for world, weights in ((2, (1.0, 0.9)), (4, (1.0, 0.8)), (8, (1.0, 0.7, 0.6, 0.5))):
+    G, S = 4, 4                      # bench.py's defaults: 4 frames per launch, 4 launches in flight
+    for band_rows in (16,):
         for w0 in weights:
             lay = BandLayout(H, world, band_rows, w0)
-            streams = [torch.cuda.Stream() for _ in range(2)]
-            local = [torch.zeros((G,) + wire_shape(lay.rows_per_rank, W), dtype=torch.uint8, device="cuda") for _ in range(2)]
-            gathered = [torch.zeros((world, G) + wire_shape(lay.rows_per_rank, W), dtype=torch.uint8, device="cuda") for _ in range(2)]
-            frames = [torch.zeros((G, H, W, 4), device="cuda") for _ in range(2)]
+            streams = [torch.cuda.Stream() for _ in range(S)]
+            local = [torch.zeros((G,) + wire_shape(lay.rows_per_rank, W), dtype=torch.uint8, device="cuda") for _ in range(S)]
+            gathered = [torch.zeros((world, G) + wire_shape(lay.rows_per_rank, W), dtype=torch.uint8, device="cuda") for _ in range(S)]
+            frames = [torch.zeros((G, H, W, 4), device="cuda") for _ in range(S)]
             res = []
             for rank in sorted({0, 1, world - 1}):
                 best = 1e9
                 for rep in range(3):
                     torch.cuda.synchronize(); t0 = time.perf_counter()
                     for k in range(24):
-                        s = streams[k % 2].cuda_stream
-                        render_bands_batch(sc, [cam] * G, W, lay, rank, local[k % 2].data_ptr(), flags=fl, stream=s)
+                        s = streams[k % S].cuda_stream
+                        render_bands_batch(sc, [cam] * G, W, lay, rank, local[k % S].data_ptr(), flags=fl, stream=s)
                         if rank == 0:
-                            deinterleave(0, gathered[k % 2].data_ptr(), frames[k % 2].data_ptr(), W, lay, stream=s, pixel_bytes=pb, frames=G)
+                            deinterleave(0, gathered[k % S].data_ptr(), frames[k % S].data_ptr(), W, lay, stream=s, pixel_bytes=pb, frames=G)
                     torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / (24 * G) * 1e3)
                 res.append((rank, best))
             print(f"{W}x{H} world {world} bands of {band_rows} weight {w0}: shares {[len(lay.bands_of(r)) for r in range(world)]} "
