@@ -569,6 +569,19 @@ def test_full_size_properties(sb, oracle_mod, dragon, size, view):
         assert_frames_identical(base[y0:y0 + 8], ref, f"rows {y0}..{y0 + 7} of {W}x{H}")
 
 
+def test_bench_frame_equals_the_oracle_on_every_pixel(sb, oracle_mod, dragon):
+    # BASELINE cfg-2 exactly as bench.py renders it -- 1920x1080, the depth-9 stand-in, the bench
+    # camera -- against the oracle on all 2 073 600 pixels, with the four algorithmic counters
+    od, sc = dragon
+    W, H = 1920, 1080
+    cam = sb.Logic(W, H); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
+    ref, cnt = oracle_mod.render(od.Structs, od.Values, cam.State, W, H, nthreads=os.cpu_count() or 8)
+    img, st = sc.Draw(cam, W, H, sb.FLAG_COUNT, want_stats=True)
+    assert_frames_identical(img, ref, "bench frame")
+    assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
+    assert st.n_nodes == 433305936 and st.n_samples == 52988750          # the figures DESIGN.md section 6 quotes
+
+
 # ---- fuzz: random trees, on-grid cameras, axis-aligned rays ---------------------------------
 def _random_tree(rng, max_depth, p_split, max_nodes=60000):
     """A consistent octree with random splits (DFS pre-order, like SdfGen) and random bytes."""
