@@ -49,8 +49,8 @@ struct TopCell { uint32_t link, v0, v1, pad; };   // a cell of the top grid, see
 struct RenderParams {
     const NodeRec *nodes;
     uint32_t n_nodes;
-    const TopCell *top;        // top grid (cursor-stack kernels) of level top_level, or null
-    int32_t top_level;
+    const TopCell *top;        // top grid (cursor-stack kernels) of level |top_level|, or null;
+    int32_t top_level;         // negative: the grid is as deep as the tree (every leaf is in it)
     float4 *out;               // compact rows: nrows_out x width
     uint32_t width, height;    // full frame
     uint32_t band_rows, band_first, band_stride, nrows_out;
@@ -309,10 +309,32 @@ __device__ __forceinline__ int bitlen(uint32_t x) { return 32 - __clz((int)x); }
 // branch in find() picks it).
 template <bool ON_GRID>
 __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict__ nodes,
-                                           const TopCell *__restrict__ top, const int TG,
+                                           const TopCell *__restrict__ top, const int TG, const bool full,
                                            int32_t *__restrict__ stack, uint32_t stride,
                                            int32_t Ax, int32_t Ay, int32_t Az, bool gx, bool gy, bool gz)
 {
+    if (!ON_GRID && full) {
+        // The grid is as deep as the tree: every leaf is a grid cell or a block of cells, so a
+        // position that left its cell finds its leaf with one load, whatever the restart level
+        // (which is needed for the algorithmic read count only).  Also the first find of a pixel,
+        // which starts on the root.
+        const uint32_t diff = (uint32_t)(c.ax ^ Ax) | (uint32_t)(c.ay ^ Ay) | (uint32_t)(c.az ^ Az);
+        if ((diff >> (LM - c.level)) == 0u && c.children < 0) return 1u;      // still inside the cell
+        const int s0 = LM - c.level;
+        const int k0 = min(max(bitlen(diff), s0) - s0, c.level);              // ascents, Compute.hlsl:93-97
+        const int32_t Dx = min(max(Ax, 0), 4095), Dy = min(max(Ay, 0), 4095), Dz = min(max(Az, 0), 4095);
+        const int sh = LM - TG;
+        const uint4 e = reinterpret_cast<const uint4 *>(top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
+        const int lvl = (int)(e.x >> 28);
+        const uint32_t reads = 1u + (uint32_t)k0 + (uint32_t)(lvl - (c.level - k0));
+        c.level = lvl;
+        c.children = -1;
+        c.v0 = e.y;
+        c.v1 = e.z;
+        const int32_t keep = ~((1 << (LM - lvl)) - 1);
+        c.ax = Dx & keep; c.ay = Dy & keep; c.az = Dz & keep;
+        return reads;
+    }
     const int32_t Bx = Ax - ((ON_GRID && gx) ? 1 : 0);
     const int32_t By = Ay - ((ON_GRID && gy) ? 1 : 0);
     const int32_t Bz = Az - ((ON_GRID && gz) ? 1 : 0);
@@ -390,9 +412,11 @@ __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__
     const int32_t Ax = axis_a(px, ux, fx), Ay = axis_a(py, uy, fy), Az = axis_a(pz, uz, fz);
     const bool gx = ux == fx, gy = uy == fy, gz = uz == fz;    // on the 2^-LM grid (false for NaN)
     u.x = ux; u.y = uy; u.z = uz;
+    const bool full = top_level < 0;                  // the grid reaches the tree's depth (RenderParams::top_level < 0)
+    const int TG = full ? -top_level : top_level;
     if (__ballot(gx || gy || gz) == 0ull)
-        return find_s<false>(c, nodes, top, top_level, stack, stride, Ax, Ay, Az, false, false, false);
-    return find_s<true>(c, nodes, top, top_level, stack, stride, Ax, Ay, Az, gx, gy, gz);
+        return find_s<false>(c, nodes, top, TG, full, stack, stride, Ax, Ay, Az, false, false, false);
+    return find_s<true>(c, nodes, top, TG, full, stack, stride, Ax, Ay, Az, gx, gy, gz);
 }
 
 // Cube::interpol_world -> sample_at, Compute.hlsl:54-58,19-29

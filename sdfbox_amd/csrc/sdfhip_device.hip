@@ -221,11 +221,14 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     hipLaunchKernelGGL(k_fuse, dim3(blocks), dim3(256), 0, s->stream, (const int2 *)d_s,
                        (const uint2 *)d_v, s->nodes, n);
     if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_fuse launch");
-    // top grid: as deep as the tree, at most MAX_TOP_LEVEL, and no larger than the tree's own records
-    // (16 bytes per cell and per node; at least 64 KB).  SDFHIP_TOP_GRID_LEVEL overrides (0 = none).
-    // A grid cell packs a children index into 27 bits + sign.
+    // Top grid.  As deep as the tree when that fits 1/64 of the device's memory (4.5 GB of 288: trees up
+    // to depth 9, 2.1 GB) -- then every leaf is in the grid and a find is one load.  Otherwise at most
+    // MAX_TOP_LEVEL and no larger than the tree's own records (16 bytes per cell and per node; at least
+    // 64 KB).  SDFHIP_TOP_GRID_LEVEL overrides (0 = none).  A cell packs a children index into 27 bits + sign.
     int top_level = 0;
-    {
+    if (depth >= 1 && depth <= 9 && (sizeof(TopCell) << (3 * depth)) <= prop.totalGlobalMem / 64) {
+        top_level = (int)depth;
+    } else {
         const size_t budget = (size_t)n * 16 > ((size_t)1 << 16) ? (size_t)n * 16 : ((size_t)1 << 16);
         while (top_level < MAX_TOP_LEVEL && (uint32_t)top_level < depth &&
                (sizeof(TopCell) << (3 * (top_level + 1))) <= budget)
@@ -321,7 +324,8 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
 
     RenderParams P;
-    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level;
+    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top;
+    P.top_level = (s->d_top && (uint32_t)s->top_level >= s->depth) ? -s->top_level : s->top_level;
     P.out = reinterpret_cast<float4 *>(d_out);
     P.width = width; P.height = height;
     P.band_rows = band_rows; P.band_first = band_first; P.band_stride = band_stride;

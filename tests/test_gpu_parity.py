@@ -480,8 +480,8 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
                     levels_seen.add(scene.top_grid_level)
                     assert scene.top_grid_level <= scene.depth
                     assert scene.top_grid_bytes == (16 << (3 * scene.top_grid_level) if scene.top_grid_level else 0)
-                    if lv is None:       # the default: as deep as the tree allows within the tree's own size
-                        assert 1 <= scene.top_grid_level and scene.top_grid_bytes <= max(16 * od.Length, 1 << 16)
+                    if lv is None:       # the default for shallow trees: as deep as the tree (every leaf in the grid)
+                        assert scene.top_grid_level == scene.depth
                     for c, (ref, cnt) in zip((cam, ongrid), refs):
                         for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT):
                             img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
