@@ -49,8 +49,8 @@ struct TopCell { uint32_t link, v0, v1, pad; };   // a cell of the top grid, see
 struct RenderParams {
     const NodeRec *nodes;
     uint32_t n_nodes;
-    const TopCell *top;        // top grid (cursor-stack kernels) of level |top_level|, or null;
-    int32_t top_level;         // negative: the grid is as deep as the tree (every leaf is in it)
+    const TopCell *top;        // top grid (cursor-stack kernels) of level top_level, or null
+    int32_t top_level;
     float4 *out;               // compact rows: nrows_out x width
     uint32_t width, height;    // full frame
     uint32_t band_rows, band_first, band_stride, nrows_out;
@@ -267,8 +267,12 @@ __host__ __device__ __forceinline__ uint32_t top_link(int32_t children, uint32_t
     return ((uint32_t)children & 0x0FFFFFFFu) | (level << 28);
 }
 
-struct CursorS {
+// FULL: the top grid is as deep as the tree (compile-time, so that the kernels for that case carry
+// neither the ascent arithmetic nor the joins with the general path).
+template <bool FULL>
+struct CursorST {
     typedef Scaled Pos;
+    static constexpr bool full = FULL;
     int32_t ax, ay, az;      // lower * 2^LM
     int32_t level;
     int32_t children;
@@ -307,13 +311,13 @@ __device__ __forceinline__ int bitlen(uint32_t x) { return 32 - __clz((int)x); }
 // ON_GRID = false: no lane of the wave has a coordinate exactly on the 2^-LM grid, so
 // B == A on every axis and the B terms drop out (the common case; the wave-uniform
 // branch in find() picks it).
-template <bool ON_GRID>
-__device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict__ nodes,
-                                           const TopCell *__restrict__ top, const int TG, const bool full,
+template <bool ON_GRID, bool FULL>
+__device__ __forceinline__ uint32_t find_s(CursorST<FULL> &c, const NodeRec *__restrict__ nodes,
+                                           const TopCell *__restrict__ top, const int TG,
                                            int32_t *__restrict__ stack, uint32_t stride,
                                            int32_t Ax, int32_t Ay, int32_t Az, bool gx, bool gy, bool gz)
 {
-    if (!ON_GRID && full) {
+    if (!ON_GRID && FULL) {
         // The grid is as deep as the tree: every leaf is a grid cell or a block of cells, so a
         // position that left its cell finds its leaf with one load, whatever the restart level
         // (which is needed for the algorithmic read count only).  Also the first find of a pixel,
@@ -404,19 +408,18 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
     return reads;
 }
 
-__device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, const TopCell *__restrict__ top,
-                                         int top_level, uint32_t, int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz,
+template <bool FULL>
+__device__ __forceinline__ uint32_t find(CursorST<FULL> &c, const NodeRec *__restrict__ nodes, const TopCell *__restrict__ top,
+                                         int TG, uint32_t, int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz,
                                          Scaled &u)
 {
     float ux, uy, uz, fx, fy, fz;
     const int32_t Ax = axis_a(px, ux, fx), Ay = axis_a(py, uy, fy), Az = axis_a(pz, uz, fz);
     const bool gx = ux == fx, gy = uy == fy, gz = uz == fz;    // on the 2^-LM grid (false for NaN)
     u.x = ux; u.y = uy; u.z = uz;
-    const bool full = top_level < 0;                  // the grid reaches the tree's depth (RenderParams::top_level < 0)
-    const int TG = full ? -top_level : top_level;
     if (__ballot(gx || gy || gz) == 0ull)
-        return find_s<false>(c, nodes, top, TG, full, stack, stride, Ax, Ay, Az, false, false, false);
-    return find_s<true>(c, nodes, top, TG, full, stack, stride, Ax, Ay, Az, gx, gy, gz);
+        return find_s<false, FULL>(c, nodes, top, TG, stack, stride, Ax, Ay, Az, false, false, false);
+    return find_s<true, FULL>(c, nodes, top, TG, stack, stride, Ax, Ay, Az, gx, gy, gz);
 }
 
 // Cube::interpol_world -> sample_at, Compute.hlsl:54-58,19-29
@@ -447,7 +450,8 @@ __device__ __forceinline__ float sample_after_find(const CursorG &c, const Unsca
 // Cursor-stack form: with u = 2^LM * pos and a = 2^LM * lower (both exact),
 // (u - a) * 2^(level - LM) == (pos - lower) * 2^level bit for bit -- rounding is invariant under
 // power-of-two scaling -- which saves the conversion of the anchor back to world units.
-__device__ __forceinline__ float sample_after_find(const CursorS &c, const Scaled &u, float, float, float)
+template <bool FULL>
+__device__ __forceinline__ float sample_after_find(const CursorST<FULL> &c, const Scaled &u, float, float, float)
 {
     const float scale = __int_as_float((127 - c.level) << 23);                 // 2^-level
     const bool flat = c.v0 == c.v1 && c.v0 == (c.v0 & 0xFFu) * 0x01010101u;    // see interpol_world

@@ -33,8 +33,11 @@ constexpr int MAX_STACK = LM;          // the shader's own descent limit (Comput
 #define PLAIN_WAVES_PER_SIMD 8          // <= 64 VGPRs: 8 waves per SIMD (2nd launch-bound = waves per SIMD)
 #endif
 
-template <bool STACK> struct CursorOf { typedef CursorG type; };
-template <> struct CursorOf<true> { typedef CursorS type; };
+// cursor kinds of the kernels: generic, cursor stack, cursor stack with a top grid as deep as the tree
+enum { CUR_GENERIC = 0, CUR_STACK = 1, CUR_STACK_FULL = 2 };
+template <int CUR> struct CursorOf { typedef CursorG type; };
+template <> struct CursorOf<CUR_STACK> { typedef CursorST<false> type; };
+template <> struct CursorOf<CUR_STACK_FULL> { typedef CursorST<true> type; };
 
 // lane states: marching (primary / shadow), march over and shading pending, no pixel
 enum { PH_PRIMARY = 0, PH_SHADOW = 1, PH_SHADE = 2, PH_IDLE = 3, PH_DONE = 4 };   // DONE: idle, colour waiting in LDS
@@ -263,11 +266,11 @@ __device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned l
 
 // ---- one lane per pixel; a workgroup of BT threads renders a 16 x (BT/16) tile (BT >= 128)
 // or one 8x8 wave tile (BT = 64) ------------------------------------------------
-template <bool STACK, bool COUNT, int BT>
+template <int CUR, bool COUNT, int BT>
 __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams P)
 {
     const FrameInfo &I = P.frames[blockIdx.y];       // batched launch: one frame per grid.y
-    __shared__ int32_t stack_lds[STACK ? MAX_STACK * BT : 1];
+    __shared__ int32_t stack_lds[CUR ? MAX_STACK * BT : 1];
     constexpr uint32_t TW = BT >= 128 ? 16 : 8, TH = BT / 8 / (TW / 8);   // tile = TW x TH pixels
     // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give
     // each of the 8 residue classes one contiguous run of tiles (bijective for
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
     if (live) { y = global_row(P, yl); live = y < P.height; }
     if (live) {
         RayState r;
-        typename CursorOf<STACK>::type c;
+        typename CursorOf<CUR>::type c;
         const NodeRec root = P.nodes[0];
         start_pixel(I, root, x, y, r, c);
         const size_t npx = (size_t)P.nrows_out * P.width, lidx = (size_t)yl * P.width + x;
@@ -333,10 +336,10 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
 constexpr int REFILL_MIN = 12;
 constexpr int SHADE_MIN = 8;
 
-template <bool STACK, bool COUNT>
+template <int CUR, bool COUNT>
 __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderParams P)
 {
-    __shared__ int32_t stack_lds[STACK ? MAX_STACK * 64 : 1];
+    __shared__ int32_t stack_lds[CUR ? MAX_STACK * 64 : 1];
     __shared__ float4 out_lds[64];
     const uint32_t lane = threadIdx.x;
     const FrameInfo &I = P.frames[0];
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
     const LdsSink dst{&out_lds[lane]};
     unsigned long long cn = 0, cs = 0, ct = 0, cr = 0;   // nodes, samples, steps, shadow rays
     RayState r;
-    typename CursorOf<STACK>::type c;
+    typename CursorOf<CUR>::type c;
     uint32_t pix = 0;           // x | yl << 16
     uint32_t cur = 0, end = 0;  // wave-uniform: pixel range of the current tile
     uint32_t q = blockIdx.x & 7u, tried = 0;   // wave-uniform: queue in use, queues found empty
@@ -459,10 +462,10 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
 // they share the instruction stream of the expensive part.  The arithmetic and its order per
 // pixel are the oracle's; only the control flow differs.  One lane per pixel, one 8x8 tile
 // per wave, the plain kernel's XCD-interleaved tile rows.
-template <bool STACK, bool COUNT>
+template <int CUR, bool COUNT>
 __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P)
 {
-    __shared__ int32_t stack_lds[STACK ? MAX_STACK * 64 : 1];
+    __shared__ int32_t stack_lds[CUR ? MAX_STACK * 64 : 1];
     const uint32_t bid = blockIdx.x, xcd = bid & 7u, jb = bid >> 3;
     const uint32_t rr = jb / P.tiles_x, cxx = jb - rr * P.tiles_x, row = rr * 8 + xcd;
     if (row >= P.tiles_y) return;
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
     uint32_t y = 0;
     if (live) { y = global_row(P, yl); live = y < P.height; }
     if (live) {
-        typedef typename CursorOf<STACK>::type CursorT;
+        typedef typename CursorOf<CUR>::type CursorT;
         const FrameInfo &I = P.frames[0];
         const NodeRec root = P.nodes[0];
         const uint32_t p = y * P.width + x;

@@ -281,13 +281,13 @@ extern "C" int sdfhip_scene_info(const sdfhip_scene *s, uint32_t *n, uint32_t *d
 
 namespace {
 
-template <bool STACK, bool COUNT>
+template <int CUR, bool COUNT>
 void launch_pair(bool compact, int bt, dim3 grid, hipStream_t st, const RenderParams &P)
 {
-    if (compact)        hipLaunchKernelGGL((k_compact<STACK, COUNT>), grid, dim3(64), 0, st, P);
-    else if (bt == 64)  hipLaunchKernelGGL((k_plain<STACK, COUNT, 64>), grid, dim3(64), 0, st, P);
-    else if (bt == 128) hipLaunchKernelGGL((k_plain<STACK, COUNT, 128>), grid, dim3(128), 0, st, P);
-    else                hipLaunchKernelGGL((k_plain<STACK, COUNT, 256>), grid, dim3(256), 0, st, P);
+    if (compact)        hipLaunchKernelGGL((k_compact<CUR, COUNT>), grid, dim3(64), 0, st, P);
+    else if (bt == 64)  hipLaunchKernelGGL((k_plain<CUR, COUNT, 64>), grid, dim3(64), 0, st, P);
+    else if (bt == 128) hipLaunchKernelGGL((k_plain<CUR, COUNT, 128>), grid, dim3(128), 0, st, P);
+    else                hipLaunchKernelGGL((k_plain<CUR, COUNT, 256>), grid, dim3(256), 0, st, P);
 }
 
 int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32_t height,
@@ -324,8 +324,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
 
     RenderParams P;
-    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top;
-    P.top_level = (s->d_top && (uint32_t)s->top_level >= s->depth) ? -s->top_level : s->top_level;
+    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level;
     P.out = reinterpret_cast<float4 *>(d_out);
     P.width = width; P.height = height;
     P.band_rows = band_rows; P.band_first = band_first; P.band_stride = band_stride;
@@ -391,13 +390,18 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         grid = dim3(P.tile_order == 0 ? 8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x : P.n_tiles, n_frames);
     }
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
+    // cursor kind: generic, cursor stack, or cursor stack with a top grid as deep as the tree
+    const int cur = !use_stack ? CUR_GENERIC : (s->d_top && (uint32_t)s->top_level >= s->depth) ? CUR_STACK_FULL : CUR_STACK;
     if (pt) {
         grid = dim3(8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x);
-        if (use_stack) { if (count) hipLaunchKernelGGL((k_path<true, true>), grid, dim3(64), 0, st, P); else hipLaunchKernelGGL((k_path<true, false>), grid, dim3(64), 0, st, P); }
-        else           { if (count) hipLaunchKernelGGL((k_path<false, true>), grid, dim3(64), 0, st, P); else hipLaunchKernelGGL((k_path<false, false>), grid, dim3(64), 0, st, P); }
+        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(64), 0, st, P); };
+        if (cur == CUR_STACK_FULL) { if (count) go(k_path<CUR_STACK_FULL, true>); else go(k_path<CUR_STACK_FULL, false>); }
+        else if (cur == CUR_STACK) { if (count) go(k_path<CUR_STACK, true>); else go(k_path<CUR_STACK, false>); }
+        else                       { if (count) go(k_path<CUR_GENERIC, true>); else go(k_path<CUR_GENERIC, false>); }
     }
-    else if (use_stack) { if (count) launch_pair<true, true>(compact, bt, grid, st, P); else launch_pair<true, false>(compact, bt, grid, st, P); }
-    else                { if (count) launch_pair<false, true>(compact, bt, grid, st, P); else launch_pair<false, false>(compact, bt, grid, st, P); }
+    else if (cur == CUR_STACK_FULL) { if (count) launch_pair<CUR_STACK_FULL, true>(compact, bt, grid, st, P); else launch_pair<CUR_STACK_FULL, false>(compact, bt, grid, st, P); }
+    else if (cur == CUR_STACK)      { if (count) launch_pair<CUR_STACK, true>(compact, bt, grid, st, P); else launch_pair<CUR_STACK, false>(compact, bt, grid, st, P); }
+    else                            { if (count) launch_pair<CUR_GENERIC, true>(compact, bt, grid, st, P); else launch_pair<CUR_GENERIC, false>(compact, bt, grid, st, P); }
     HIP_TRY(hipGetLastError());
     if (stats) {
         HIP_TRY(hipEventRecord(s->ev1, st));
