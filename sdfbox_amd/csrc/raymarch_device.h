@@ -317,28 +317,6 @@ __device__ __forceinline__ uint32_t find_s(CursorST<FULL> &c, const NodeRec *__r
                                            int32_t *__restrict__ stack, uint32_t stride,
                                            int32_t Ax, int32_t Ay, int32_t Az, bool gx, bool gy, bool gz)
 {
-    if (!ON_GRID && FULL) {
-        // The grid is as deep as the tree: every leaf is a grid cell or a block of cells, so a
-        // position that left its cell finds its leaf with one load, whatever the restart level
-        // (which is needed for the algorithmic read count only).  Also the first find of a pixel,
-        // which starts on the root.
-        const uint32_t diff = (uint32_t)(c.ax ^ Ax) | (uint32_t)(c.ay ^ Ay) | (uint32_t)(c.az ^ Az);
-        if ((diff >> (LM - c.level)) == 0u && c.children < 0) return 1u;      // still inside the cell
-        const int s0 = LM - c.level;
-        const int k0 = min(max(bitlen(diff), s0) - s0, c.level);              // ascents, Compute.hlsl:93-97
-        const int32_t Dx = min(max(Ax, 0), 4095), Dy = min(max(Ay, 0), 4095), Dz = min(max(Az, 0), 4095);
-        const int sh = LM - TG;
-        const uint4 e = reinterpret_cast<const uint4 *>(top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
-        const int lvl = (int)(e.x >> 28);
-        const uint32_t reads = 1u + (uint32_t)k0 + (uint32_t)(lvl - (c.level - k0));
-        c.level = lvl;
-        c.children = -1;
-        c.v0 = e.y;
-        c.v1 = e.z;
-        const int32_t keep = ~((1 << (LM - lvl)) - 1);
-        c.ax = Dx & keep; c.ay = Dy & keep; c.az = Dz & keep;
-        return reads;
-    }
     const int32_t Bx = Ax - ((ON_GRID && gx) ? 1 : 0);
     const int32_t By = Ay - ((ON_GRID && gy) ? 1 : 0);
     const int32_t Bz = Az - ((ON_GRID && gz) ? 1 : 0);
@@ -408,6 +386,52 @@ __device__ __forceinline__ uint32_t find_s(CursorST<FULL> &c, const NodeRec *__r
     return reads;
 }
 
+// find() when the top grid is as deep as the tree: every leaf is a grid cell or a block of cells,
+// so the grid says where the position's leaf is.  What is left of the cursor logic: is the position
+// still in the current cell, and -- on exact cell boundaries (any_on_grid, wave-uniform) -- which of
+// the two adjacent cells does the reference's descent pick (the same A/B rule as find_s).  The ascent
+// count k feeds the algorithmic read count only.  One place updates the cursor, so the two branches
+// join on D and k, not on the cursor.
+__device__ __forceinline__ uint32_t find_full(CursorST<true> &c, const TopCell *__restrict__ top, const int TG,
+                                              int32_t Dx, int32_t Dy, int32_t Dz, bool gx, bool gy, bool gz,
+                                              const bool any_on_grid)
+{
+    const int s = LM - c.level;
+    bool moved;
+    int k;
+    if (!any_on_grid) {
+        const uint32_t diff = (uint32_t)(c.ax ^ Dx) | (uint32_t)(c.ay ^ Dy) | (uint32_t)(c.az ^ Dz);
+        moved = (diff >> s) != 0u;
+        k = min(max(bitlen(diff), s) - s, c.level);
+    } else {
+        const int32_t Bx = Dx - (gx ? 1 : 0), By = Dy - (gy ? 1 : 0), Bz = Dz - (gz ? 1 : 0);
+        const int tx = min(bitlen((uint32_t)(c.ax ^ Dx)), bitlen((uint32_t)(c.ax ^ Bx)));
+        const int ty = min(bitlen((uint32_t)(c.ay ^ Dy)), bitlen((uint32_t)(c.ay ^ By)));
+        const int tz = min(bitlen((uint32_t)(c.az ^ Dz)), bitlen((uint32_t)(c.az ^ Bz)));
+        k = min(max(max(tx, ty), max(tz, s)) - s, c.level);
+        moved = k > 0;
+        const int tt = s + k;                        // LM - (level the descent restarts at), <= LM
+        Dx = (((uint32_t)(c.ax ^ Dx) >> tt) == 0u) ? Dx : Bx;
+        Dy = (((uint32_t)(c.ay ^ Dy) >> tt) == 0u) ? Dy : By;
+        Dz = (((uint32_t)(c.az ^ Dz) >> tt) == 0u) ? Dz : Bz;
+    }
+    uint32_t reads = 1u;
+    if (moved || c.children >= 0) {                   // children >= 0: the first find of a pixel starts on the root
+        Dx = min(max(Dx, 0), 4095); Dy = min(max(Dy, 0), 4095); Dz = min(max(Dz, 0), 4095);
+        const int sh = LM - TG;
+        const uint4 e = reinterpret_cast<const uint4 *>(top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
+        const int lvl = (int)(e.x >> 28);
+        reads = 1u + (uint32_t)k + (uint32_t)(lvl - (c.level - k));
+        c.level = lvl;
+        c.children = -1;
+        c.v0 = e.y;
+        c.v1 = e.z;
+        const int32_t keep = ~((1 << (LM - lvl)) - 1);
+        c.ax = Dx & keep; c.ay = Dy & keep; c.az = Dz & keep;
+    }
+    return reads;
+}
+
 template <bool FULL>
 __device__ __forceinline__ uint32_t find(CursorST<FULL> &c, const NodeRec *__restrict__ nodes, const TopCell *__restrict__ top,
                                          int TG, uint32_t, int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz,
@@ -417,7 +441,9 @@ __device__ __forceinline__ uint32_t find(CursorST<FULL> &c, const NodeRec *__res
     const int32_t Ax = axis_a(px, ux, fx), Ay = axis_a(py, uy, fy), Az = axis_a(pz, uz, fz);
     const bool gx = ux == fx, gy = uy == fy, gz = uz == fz;    // on the 2^-LM grid (false for NaN)
     u.x = ux; u.y = uy; u.z = uz;
-    if (__ballot(gx || gy || gz) == 0ull)
+    if constexpr (FULL)
+        return find_full(c, top, TG, Ax, Ay, Az, gx, gy, gz, __ballot(gx || gy || gz) != 0ull);
+    else if (__ballot(gx || gy || gz) == 0ull)
         return find_s<false, FULL>(c, nodes, top, TG, stack, stride, Ax, Ay, Az, false, false, false);
     return find_s<true, FULL>(c, nodes, top, TG, stack, stride, Ax, Ay, Az, gx, gy, gz);
 }
