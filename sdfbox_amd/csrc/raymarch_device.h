@@ -386,50 +386,103 @@ __device__ __forceinline__ uint32_t find_s(CursorST<FULL> &c, const NodeRec *__r
     return reads;
 }
 
-// find() when the top grid is as deep as the tree: every leaf is a grid cell or a block of cells,
-// so the grid says where the position's leaf is.  What is left of the cursor logic: is the position
-// still in the current cell, and -- on exact cell boundaries (any_on_grid, wave-uniform) -- which of
-// the two adjacent cells does the reference's descent pick (the same A/B rule as find_s).  The ascent
-// count k feeds the algorithmic read count only.  One place updates the cursor, so the two branches
-// join on D and k, not on the cursor.
-__device__ __forceinline__ uint32_t find_full(CursorST<true> &c, const TopCell *__restrict__ top, const int TG,
+// ---- cursor when the top grid is as deep as the tree ---------------------------------------------
+// Every leaf is a grid cell or a block of cells, so the grid says where a position's leaf is and the
+// cursor shrinks to the leaf's anchor, size and values: no children index, no ancestor stack.  It
+// keeps s = LM - level (what the shifts need); such a grid stores s in the top bits of a cell's link
+// (k_top_grid).  After reset the anchor is a mark that no position matches: the first find of a
+// pixel always looks its cell up.
+struct CursorF {
+    typedef Scaled Pos;
+    static constexpr int32_t ROOT_MARK = 0x40000000;
+    int32_t ax, ay, az;      // lower * 2^LM
+    int32_t s;               // LM - level
+    uint32_t v0, v1;
+
+    __device__ __forceinline__ void reset(const NodeRec &)
+    {
+        ax = ay = az = ROOT_MARK; s = LM; v0 = v1 = 0u;
+    }
+    __device__ __forceinline__ Cell cell() const
+    {
+        Cell k;
+        const float q = 1.0f / 4096.0f;
+        k.lx = (float)ax * q; k.ly = (float)ay * q; k.lz = (float)az * q;   // exact
+        k.scale = __int_as_float((127 - LM + s) << 23);                     // 2^-level
+        k.inv = __int_as_float((127 + LM - s) << 23);                       // 2^level
+        k.v0 = v0; k.v1 = v1;
+        return k;
+    }
+};
+
+// find(): is the position still in the current cell, and -- on exact cell boundaries (any_on_grid,
+// wave-uniform) -- which of the two adjacent cells does the reference's descent pick (the same A/B
+// rule as find_s).  The ascent count k feeds the algorithmic read count only.  One place updates the
+// cursor, so the two branches join on D and k, not on the cursor.
+__device__ __forceinline__ uint32_t find_full(CursorF &c, const TopCell *__restrict__ top, const int TG,
                                               int32_t Dx, int32_t Dy, int32_t Dz, bool gx, bool gy, bool gz,
                                               const bool any_on_grid)
 {
-    const int s = LM - c.level;
+    const int s = c.s, level = LM - c.s;
     bool moved;
     int k;
     if (!any_on_grid) {
         const uint32_t diff = (uint32_t)(c.ax ^ Dx) | (uint32_t)(c.ay ^ Dy) | (uint32_t)(c.az ^ Dz);
-        moved = (diff >> s) != 0u;
-        k = min(max(bitlen(diff), s) - s, c.level);
+        moved = (diff >> s) != 0u;                    // on the root: the mark differs from every A in bit 30
+        k = min(max(bitlen(diff), s) - s, level);
     } else {
+        const bool root = s == LM;
+        const int32_t ax = root ? 0 : c.ax, ay = root ? 0 : c.ay, az = root ? 0 : c.az;
         const int32_t Bx = Dx - (gx ? 1 : 0), By = Dy - (gy ? 1 : 0), Bz = Dz - (gz ? 1 : 0);
-        const int tx = min(bitlen((uint32_t)(c.ax ^ Dx)), bitlen((uint32_t)(c.ax ^ Bx)));
-        const int ty = min(bitlen((uint32_t)(c.ay ^ Dy)), bitlen((uint32_t)(c.ay ^ By)));
-        const int tz = min(bitlen((uint32_t)(c.az ^ Dz)), bitlen((uint32_t)(c.az ^ Bz)));
-        k = min(max(max(tx, ty), max(tz, s)) - s, c.level);
-        moved = k > 0;
+        const int tx = min(bitlen((uint32_t)(ax ^ Dx)), bitlen((uint32_t)(ax ^ Bx)));
+        const int ty = min(bitlen((uint32_t)(ay ^ Dy)), bitlen((uint32_t)(ay ^ By)));
+        const int tz = min(bitlen((uint32_t)(az ^ Dz)), bitlen((uint32_t)(az ^ Bz)));
+        k = min(max(max(tx, ty), max(tz, s)) - s, level);
+        moved = k > 0 || root;
         const int tt = s + k;                        // LM - (level the descent restarts at), <= LM
-        Dx = (((uint32_t)(c.ax ^ Dx) >> tt) == 0u) ? Dx : Bx;
-        Dy = (((uint32_t)(c.ay ^ Dy) >> tt) == 0u) ? Dy : By;
-        Dz = (((uint32_t)(c.az ^ Dz) >> tt) == 0u) ? Dz : Bz;
+        Dx = (((uint32_t)(ax ^ Dx) >> tt) == 0u) ? Dx : Bx;
+        Dy = (((uint32_t)(ay ^ Dy) >> tt) == 0u) ? Dy : By;
+        Dz = (((uint32_t)(az ^ Dz) >> tt) == 0u) ? Dz : Bz;
     }
     uint32_t reads = 1u;
-    if (moved || c.children >= 0) {                   // children >= 0: the first find of a pixel starts on the root
+    if (moved) {
         Dx = min(max(Dx, 0), 4095); Dy = min(max(Dy, 0), 4095); Dz = min(max(Dz, 0), 4095);
         const int sh = LM - TG;
         const uint4 e = reinterpret_cast<const uint4 *>(top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
-        const int lvl = (int)(e.x >> 28);
-        reads = 1u + (uint32_t)k + (uint32_t)(lvl - (c.level - k));
-        c.level = lvl;
-        c.children = -1;
+        const int ns = (int)(e.x >> 28);              // LM - level of the leaf
+        reads = 1u + (uint32_t)k + (uint32_t)((LM - ns) - (level - k));
+        c.s = ns;
         c.v0 = e.y;
         c.v1 = e.z;
-        const int32_t keep = ~((1 << (LM - lvl)) - 1);
+        const int32_t keep = (int32_t)(0xFFFFFFFFu << ns);
         c.ax = Dx & keep; c.ay = Dy & keep; c.az = Dz & keep;
     }
     return reads;
+}
+__device__ __forceinline__ uint32_t find(CursorF &c, const NodeRec *__restrict__, const TopCell *__restrict__ top,
+                                         int TG, uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
+                                         Scaled &u)
+{
+    float fx, fy, fz;
+    const int32_t Ax = axis_a(px, u.x, fx), Ay = axis_a(py, u.y, fy), Az = axis_a(pz, u.z, fz);
+    const bool gx = u.x == fx, gy = u.y == fy, gz = u.z == fz;    // on the 2^-LM grid (false for NaN)
+    return find_full(c, top, TG, Ax, Ay, Az, gx, gy, gz, __ballot(gx || gy || gz) != 0ull);
+}
+__device__ __forceinline__ float sample_after_find(const CursorF &c, const Scaled &u, float, float, float)
+{
+    const int32_t scale_bits = (c.s + (127 - LM)) << 23;                       // 2^-level = 2^(s - LM)
+    const float scale = __int_as_float(scale_bits);
+    const bool flat = c.v0 == c.v1 && c.v0 == (c.v0 & 0xFFu) * 0x01010101u;    // see interpol_world
+    if (__ballot(!flat) == 0ull)
+        return (unorm8((float)(c.v0 & 0xFFu)) - 0.25f) * scale * 2.0f;
+    const float inv = __int_as_float(((2 * 127 - LM) << 23) - scale_bits);     // 2^-s = 2^(level - LM)
+    float dx = sat((u.x - (float)c.ax) * inv);
+    float dy = sat((u.y - (float)c.ay) * inv);
+    float dz = sat((u.z - (float)c.az) * inv);
+    Texels t = decode(c.v0, c.v1);
+    float loadL = bilerp(t.v[0], t.v[1], t.v[2], t.v[3], dx, dy);
+    float loadH = bilerp(t.v[4], t.v[5], t.v[6], t.v[7], dx, dy);
+    return (lerp(loadL, loadH, dz) - 0.25f) * scale * 2.0f;
 }
 
 template <bool FULL>
@@ -441,9 +494,7 @@ __device__ __forceinline__ uint32_t find(CursorST<FULL> &c, const NodeRec *__res
     const int32_t Ax = axis_a(px, ux, fx), Ay = axis_a(py, uy, fy), Az = axis_a(pz, uz, fz);
     const bool gx = ux == fx, gy = uy == fy, gz = uz == fz;    // on the 2^-LM grid (false for NaN)
     u.x = ux; u.y = uy; u.z = uz;
-    if constexpr (FULL)
-        return find_full(c, top, TG, Ax, Ay, Az, gx, gy, gz, __ballot(gx || gy || gz) != 0ull);
-    else if (__ballot(gx || gy || gz) == 0ull)
+    if (__ballot(gx || gy || gz) == 0ull)
         return find_s<false, FULL>(c, nodes, top, TG, stack, stride, Ax, Ay, Az, false, false, false);
     return find_s<true, FULL>(c, nodes, top, TG, stack, stride, Ax, Ay, Az, gx, gy, gz);
 }

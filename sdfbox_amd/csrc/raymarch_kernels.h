@@ -37,7 +37,7 @@ constexpr int MAX_STACK = LM;          // the shader's own descent limit (Comput
 enum { CUR_GENERIC = 0, CUR_STACK = 1, CUR_STACK_FULL = 2 };
 template <int CUR> struct CursorOf { typedef CursorG type; };
 template <> struct CursorOf<CUR_STACK> { typedef CursorST<false> type; };
-template <> struct CursorOf<CUR_STACK_FULL> { typedef CursorST<true> type; };
+template <> struct CursorOf<CUR_STACK_FULL> { typedef CursorF type; };
 
 // lane states: marching (primary / shadow), march over and shading pending, no pixel
 enum { PH_PRIMARY = 0, PH_SHADOW = 1, PH_SHADE = 2, PH_IDLE = 3, PH_DONE = 4 };   // DONE: idle, colour waiting in LDS

@@ -35,7 +35,7 @@ __global__ void k_fuse(const int2 *__restrict__ structs, const uint2 *__restrict
 
 // The top grid of the cursor-stack kernels (raymarch_device.h): one thread per level-TG cell walks
 // from the root by the cell's octant bits and stores the record it ends at.
-__global__ void k_top_grid(const NodeRec *__restrict__ nodes, TopCell *__restrict__ top, int TG)
+__global__ void k_top_grid(const NodeRec *__restrict__ nodes, TopCell *__restrict__ top, int TG, int full)
 {
     const uint32_t total = 1u << (3 * TG), mask = (1u << TG) - 1u;
     for (uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x; cell < total; cell += gridDim.x * blockDim.x) {
@@ -48,7 +48,8 @@ __global__ void k_top_grid(const NodeRec *__restrict__ nodes, TopCell *__restric
             level++;
         }
         TopCell t;
-        t.link = top_link((int32_t)r.y, level); t.v0 = r.z; t.v1 = r.w; t.pad = 0;
+        // a grid as deep as the tree serves CursorF, which wants LM - level in the top bits
+        t.link = top_link((int32_t)r.y, full ? (uint32_t)LM - level : level); t.v0 = r.z; t.v1 = r.w; t.pad = 0;
         top[top_index(cx, cy, cz, TG)] = t;
     }
 }
@@ -249,7 +250,8 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
             const size_t ncell = (size_t)1 << (3 * top_level);
             s->top_level = top_level;
             const uint32_t tb = (uint32_t)((ncell + 255) / 256 < 8192 ? (ncell + 255) / 256 : 8192);
-            hipLaunchKernelGGL(k_top_grid, dim3(tb), dim3(256), 0, s->stream, s->nodes, s->d_top, top_level);
+            hipLaunchKernelGGL(k_top_grid, dim3(tb), dim3(256), 0, s->stream, s->nodes, s->d_top, top_level,
+                               (uint32_t)top_level >= depth ? 1 : 0);
             if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_top_grid launch");
         }
     }
