@@ -269,7 +269,10 @@ __device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned l
 template <int CUR, bool COUNT, int BT>
 __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams P)
 {
-    const FrameInfo &I = P.frames[blockIdx.y];       // batched launch: one frame per grid.y
+    FrameInfo I = P.frames[blockIdx.y];              // batched launch: one frame per grid.y
+    // the three scalars every march step reads stay in SGPRs: left alone, the compiler reloads them
+    // from the kernel arguments (s_load + s_waitcnt) in every iteration
+    asm volatile("" : "+s"(I.margin), "+s"(I.margin2), "+s"(I.limit));
     __shared__ int32_t stack_lds[CUR ? MAX_STACK * BT : 1];
     constexpr uint32_t TW = BT >= 128 ? 16 : 8, TH = BT / 8 / (TW / 8);   // tile = TW x TH pixels
     // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give
