@@ -345,7 +345,8 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
     __shared__ int32_t stack_lds[CUR ? MAX_STACK * 64 : 1];
     __shared__ float4 out_lds[64];
     const uint32_t lane = threadIdx.x;
-    const FrameInfo &I = P.frames[0];
+    FrameInfo I = P.frames[0];
+    asm volatile("" : "+s"(I.margin), "+s"(I.margin2), "+s"(I.limit));     // see k_plain
     const NodeRec root = P.nodes[0];
     const LdsSink dst{&out_lds[lane]};
     unsigned long long cn = 0, cs = 0, ct = 0, cr = 0;   // nodes, samples, steps, shadow rays
@@ -480,7 +481,8 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
     if (live) { y = global_row(P, yl); live = y < P.height; }
     if (live) {
         typedef typename CursorOf<CUR>::type CursorT;
-        const FrameInfo &I = P.frames[0];
+        FrameInfo I = P.frames[0];
+        asm volatile("" : "+s"(I.margin), "+s"(I.limit));                      // see k_plain
         const NodeRec root = P.nodes[0];
         const uint32_t p = y * P.width + x;
         const float margin = I.margin;
