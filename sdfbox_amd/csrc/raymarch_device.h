@@ -472,7 +472,7 @@ __device__ __forceinline__ float sample_after_find(const CursorF &c, const Scale
 {
     const int32_t scale_bits = (c.s + (127 - LM)) << 23;                       // 2^-level = 2^(s - LM)
     const float scale = __int_as_float(scale_bits);
-    const bool flat = c.v0 == c.v1 && c.v0 == (c.v0 & 0xFFu) * 0x01010101u;    // see interpol_world
+    const bool flat = c.v0 == c.v1 && c.v0 == __builtin_amdgcn_alignbit(c.v0, c.v0, 8);    // see interpol_world
     if (__ballot(!flat) == 0ull)
         return (unorm8((float)(c.v0 & 0xFFu)) - 0.25f) * scale * 2.0f;
     const float inv = __int_as_float(((2 * 127 - LM) << 23) - scale_bits);     // 2^-s = 2^(level - LM)
@@ -507,7 +507,8 @@ __device__ __forceinline__ float interpol_world(const Cell &c, float px, float p
     // (fma(t, a - a, a) = a for finite t; d is saturated, hence finite), so the
     // trilinear blend of such a cell is unorm8(byte) bit for bit.  When that holds for
     // every active lane of the wave -- whole wavefronts of sky rays -- skip the blend.
-    const bool flat = c.v0 == c.v1 && c.v0 == (c.v0 & 0xFFu) * 0x01010101u;
+    // (Four equal bytes <=> the word equals itself rotated by 8 bits: one full-rate instruction.)
+    const bool flat = c.v0 == c.v1 && c.v0 == __builtin_amdgcn_alignbit(c.v0, c.v0, 8);
     if (__ballot(!flat) == 0ull)
         return (unorm8((float)(c.v0 & 0xFFu)) - 0.25f) * c.scale * 2.0f;
     float dx = sat((px - c.lx) * c.inv);
@@ -531,7 +532,7 @@ template <bool FULL>
 __device__ __forceinline__ float sample_after_find(const CursorST<FULL> &c, const Scaled &u, float, float, float)
 {
     const float scale = __int_as_float((127 - c.level) << 23);                 // 2^-level
-    const bool flat = c.v0 == c.v1 && c.v0 == (c.v0 & 0xFFu) * 0x01010101u;    // see interpol_world
+    const bool flat = c.v0 == c.v1 && c.v0 == __builtin_amdgcn_alignbit(c.v0, c.v0, 8);    // see interpol_world
     if (__ballot(!flat) == 0ull)
         return (unorm8((float)(c.v0 & 0xFFu)) - 0.25f) * scale * 2.0f;
     const float inv = __int_as_float((127 + c.level - LM) << 23);              // 2^(level - LM)
