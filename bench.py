@@ -361,7 +361,7 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
                          G, nbuf):
     """Rank 0 also assembles the frame (de-interleave and wire expansion of all ranks' rows), so an
     even deal makes it the slowest rank.  Before anything is timed, rank 0 tries layouts that give it
-    0.5 .. 1.0 of a peer's share: for each it times its own work (render + assembly) and the largest
+    0.3 .. 1.0 of a peer's share: for each it times its own work (render + assembly) and the largest
     peer share (rank 1's, which it can render itself: the scene is replicated), and every rank then
     receives the weight with the smallest max of the two."""
     import torch
@@ -396,7 +396,7 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
             return best
 
         tried = []
-        for cand in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5):
+        for cand in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3):
             lay = BandLayout(H, world, band_rows, cand)
             local = [torch.zeros((G,) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
             gathered = torch.zeros((world, G) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda")
