@@ -244,7 +244,10 @@ constexpr int LM = 12;
 // every cell of level TG, the record of the deepest node of level <= TG that contains it:
 // {children (28 bits, sign-extended) | level << 28, values}.  A descent that restarts above level
 // TG takes ONE load from the grid instead of up to TG dependent loads, and ends in the same node.
-// TG is chosen per scene at upload (RenderParams::top_level); top == nullptr disables it.
+// TG is chosen per scene at upload (RenderParams::top_level); top == nullptr disables it.  When the
+// grid is as deep as the tree the kernels use CursorF (below) instead of CursorS, and the cells hold
+// LM - level in the top bits.
+//
 // Cell (x, y, z) of the level-TG grid -> index: plain x-y-z order.  Blocked orders (2^B cells per
 // axis contiguous; B = 1 puts the 8 cells of one parent in one 128-byte line) were measured and are
 // slower, 0.183 vs 0.172 ms per 1080p frame for B = 1, 2, 3: the index arithmetic costs more than
@@ -267,12 +270,9 @@ __host__ __device__ __forceinline__ uint32_t top_link(int32_t children, uint32_t
     return ((uint32_t)children & 0x0FFFFFFFu) | (level << 28);
 }
 
-// FULL: the top grid is as deep as the tree (compile-time, so that the kernels for that case carry
-// neither the ascent arithmetic nor the joins with the general path).
-template <bool FULL>
-struct CursorST {
+// ---- cursor-stack cursor: level, integer anchor, children index, values ------------------------
+struct CursorS {
     typedef Scaled Pos;
-    static constexpr bool full = FULL;
     int32_t ax, ay, az;      // lower * 2^LM
     int32_t level;
     int32_t children;
@@ -311,8 +311,8 @@ __device__ __forceinline__ int bitlen(uint32_t x) { return 32 - __clz((int)x); }
 // ON_GRID = false: no lane of the wave has a coordinate exactly on the 2^-LM grid, so
 // B == A on every axis and the B terms drop out (the common case; the wave-uniform
 // branch in find() picks it).
-template <bool ON_GRID, bool FULL>
-__device__ __forceinline__ uint32_t find_s(CursorST<FULL> &c, const NodeRec *__restrict__ nodes,
+template <bool ON_GRID>
+__device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict__ nodes,
                                            const TopCell *__restrict__ top, const int TG,
                                            int32_t *__restrict__ stack, uint32_t stride,
                                            int32_t Ax, int32_t Ay, int32_t Az, bool gx, bool gy, bool gz)
@@ -485,8 +485,7 @@ __device__ __forceinline__ float sample_after_find(const CursorF &c, const Scale
     return (lerp(loadL, loadH, dz) - 0.25f) * scale * 2.0f;
 }
 
-template <bool FULL>
-__device__ __forceinline__ uint32_t find(CursorST<FULL> &c, const NodeRec *__restrict__ nodes, const TopCell *__restrict__ top,
+__device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, const TopCell *__restrict__ top,
                                          int TG, uint32_t, int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz,
                                          Scaled &u)
 {
@@ -495,8 +494,8 @@ __device__ __forceinline__ uint32_t find(CursorST<FULL> &c, const NodeRec *__res
     const bool gx = ux == fx, gy = uy == fy, gz = uz == fz;    // on the 2^-LM grid (false for NaN)
     u.x = ux; u.y = uy; u.z = uz;
     if (__ballot(gx || gy || gz) == 0ull)
-        return find_s<false, FULL>(c, nodes, top, TG, stack, stride, Ax, Ay, Az, false, false, false);
-    return find_s<true, FULL>(c, nodes, top, TG, stack, stride, Ax, Ay, Az, gx, gy, gz);
+        return find_s<false>(c, nodes, top, TG, stack, stride, Ax, Ay, Az, false, false, false);
+    return find_s<true>(c, nodes, top, TG, stack, stride, Ax, Ay, Az, gx, gy, gz);
 }
 
 // Cube::interpol_world -> sample_at, Compute.hlsl:54-58,19-29
@@ -528,8 +527,7 @@ __device__ __forceinline__ float sample_after_find(const CursorG &c, const Unsca
 // Cursor-stack form: with u = 2^LM * pos and a = 2^LM * lower (both exact),
 // (u - a) * 2^(level - LM) == (pos - lower) * 2^level bit for bit -- rounding is invariant under
 // power-of-two scaling -- which saves the conversion of the anchor back to world units.
-template <bool FULL>
-__device__ __forceinline__ float sample_after_find(const CursorST<FULL> &c, const Scaled &u, float, float, float)
+__device__ __forceinline__ float sample_after_find(const CursorS &c, const Scaled &u, float, float, float)
 {
     const float scale = __int_as_float((127 - c.level) << 23);                 // 2^-level
     const bool flat = c.v0 == c.v1 && c.v0 == __builtin_amdgcn_alignbit(c.v0, c.v0, 8);    // see interpol_world

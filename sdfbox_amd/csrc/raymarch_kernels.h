@@ -36,7 +36,7 @@ constexpr int MAX_STACK = LM;          // the shader's own descent limit (Comput
 // cursor kinds of the kernels: generic, cursor stack, cursor stack with a top grid as deep as the tree
 enum { CUR_GENERIC = 0, CUR_STACK = 1, CUR_STACK_FULL = 2 };
 template <int CUR> struct CursorOf { typedef CursorG type; };
-template <> struct CursorOf<CUR_STACK> { typedef CursorST<false> type; };
+template <> struct CursorOf<CUR_STACK> { typedef CursorS type; };
 template <> struct CursorOf<CUR_STACK_FULL> { typedef CursorF type; };
 
 // lane states: marching (primary / shadow), march over and shading pending, no pixel
