@@ -10,7 +10,7 @@ import csv,glob,collections
 agg=collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_path<true, false>" in r["Kernel_Name"]:
+        if "k_path<" in r["Kernel_Name"] and "true>" not in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in sorted(agg.items()): print(k, "%.4g"%(sum(v)/len(v)), len(v))
 PY
