@@ -392,7 +392,11 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
 // keeps s = LM - level (what the shifts need); such a grid stores s in the top bits of a cell's link
 // (k_top_grid).  After reset the anchor is a mark that no position matches: the first find of a
 // pixel always looks its cell up.
-struct CursorF {
+// EXACT: the kernel reports the algorithmic read count, so a NaN coordinate must behave exactly as in
+// find_s (it matches no cell: ascents up to the root).  Without it NaN converts to 0 and the find
+// lands in the same leaf -- the cell at the origin -- without the clamp instructions.
+template <bool EXACT>
+struct CursorFT {
     typedef Scaled Pos;
     static constexpr int32_t ROOT_MARK = 0x40000000;
     int32_t ax, ay, az;      // lower * 2^LM
@@ -419,7 +423,8 @@ struct CursorF {
 // wave-uniform) -- which of the two adjacent cells does the reference's descent pick (the same A/B
 // rule as find_s).  The ascent count k feeds the algorithmic read count only.  One place updates the
 // cursor, so the two branches join on D and k, not on the cursor.
-__device__ __forceinline__ uint32_t find_full(CursorF &c, const TopCell *__restrict__ top, const int TG,
+template <bool EXACT>
+__device__ __forceinline__ uint32_t find_full(CursorFT<EXACT> &c, const TopCell *__restrict__ top, const int TG,
                                               int32_t Dx, int32_t Dy, int32_t Dz, bool gx, bool gy, bool gz,
                                               const bool any_on_grid)
 {
@@ -431,6 +436,8 @@ __device__ __forceinline__ uint32_t find_full(CursorF &c, const TopCell *__restr
         moved = (diff >> s) != 0u;                    // on the root: the mark differs from every A in bit 30
         k = min(max(bitlen(diff), s) - s, level);
     } else {
+        // the A/B arithmetic wants coordinates that do not wrap: far outside the cube is -2 or 2^LM + 1
+        Dx = min(max(Dx, -2), 4097); Dy = min(max(Dy, -2), 4097); Dz = min(max(Dz, -2), 4097);
         const bool root = s == LM;
         const int32_t ax = root ? 0 : c.ax, ay = root ? 0 : c.ay, az = root ? 0 : c.az;
         const int32_t Bx = Dx - (gx ? 1 : 0), By = Dy - (gy ? 1 : 0), Bz = Dz - (gz ? 1 : 0);
@@ -459,16 +466,28 @@ __device__ __forceinline__ uint32_t find_full(CursorF &c, const TopCell *__restr
     }
     return reads;
 }
-__device__ __forceinline__ uint32_t find(CursorF &c, const NodeRec *__restrict__, const TopCell *__restrict__ top,
+// A without the float clamp of axis_a: the conversion saturates (far outside the cube: INT_MIN /
+// INT_MAX, which differ from every anchor in their high bits and clamp to the same D), NaN gives 0.
+__device__ __forceinline__ int32_t axis_a_raw(float p, float &u, float &f)
+{
+    u = p * 4096.0f;
+    f = floorf(u);
+    return (int32_t)f;
+}
+template <bool EXACT>
+__device__ __forceinline__ uint32_t find(CursorFT<EXACT> &c, const NodeRec *__restrict__, const TopCell *__restrict__ top,
                                          int TG, uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
                                          Scaled &u)
 {
     float fx, fy, fz;
-    const int32_t Ax = axis_a(px, u.x, fx), Ay = axis_a(py, u.y, fy), Az = axis_a(pz, u.z, fz);
+    int32_t Ax, Ay, Az;
+    if (EXACT) { Ax = axis_a(px, u.x, fx); Ay = axis_a(py, u.y, fy); Az = axis_a(pz, u.z, fz); }
+    else { Ax = axis_a_raw(px, u.x, fx); Ay = axis_a_raw(py, u.y, fy); Az = axis_a_raw(pz, u.z, fz); }
     const bool gx = u.x == fx, gy = u.y == fy, gz = u.z == fz;    // on the 2^-LM grid (false for NaN)
     return find_full(c, top, TG, Ax, Ay, Az, gx, gy, gz, __ballot(gx || gy || gz) != 0ull);
 }
-__device__ __forceinline__ float sample_after_find(const CursorF &c, const Scaled &u, float, float, float)
+template <bool EXACT>
+__device__ __forceinline__ float sample_after_find(const CursorFT<EXACT> &c, const Scaled &u, float, float, float)
 {
     const int32_t scale_bits = (c.s + (127 - LM)) << 23;                       // 2^-level = 2^(s - LM)
     const float scale = __int_as_float(scale_bits);

@@ -35,9 +35,9 @@ constexpr int MAX_STACK = LM;          // the shader's own descent limit (Comput
 
 // cursor kinds of the kernels: generic, cursor stack, cursor stack with a top grid as deep as the tree
 enum { CUR_GENERIC = 0, CUR_STACK = 1, CUR_STACK_FULL = 2 };
-template <int CUR> struct CursorOf { typedef CursorG type; };
-template <> struct CursorOf<CUR_STACK> { typedef CursorS type; };
-template <> struct CursorOf<CUR_STACK_FULL> { typedef CursorF type; };
+template <int CUR, bool COUNT> struct CursorOf { typedef CursorG type; };
+template <bool COUNT> struct CursorOf<CUR_STACK, COUNT> { typedef CursorS type; };
+template <bool COUNT> struct CursorOf<CUR_STACK_FULL, COUNT> { typedef CursorFT<COUNT> type; };
 
 // lane states: marching (primary / shadow), march over and shading pending, no pixel
 enum { PH_PRIMARY = 0, PH_SHADOW = 1, PH_SHADE = 2, PH_IDLE = 3, PH_DONE = 4 };   // DONE: idle, colour waiting in LDS
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
     if (live) { y = global_row(P, yl); live = y < P.height; }
     if (live) {
         RayState r;
-        typename CursorOf<CUR>::type c;
+        typename CursorOf<CUR, COUNT>::type c;
         const NodeRec root = P.nodes[0];
         start_pixel(I, root, x, y, r, c);
         const size_t npx = (size_t)P.nrows_out * P.width, lidx = (size_t)yl * P.width + x;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
     const LdsSink dst{&out_lds[lane]};
     unsigned long long cn = 0, cs = 0, ct = 0, cr = 0;   // nodes, samples, steps, shadow rays
     RayState r;
-    typename CursorOf<CUR>::type c;
+    typename CursorOf<CUR, COUNT>::type c;
     uint32_t pix = 0;           // x | yl << 16
     uint32_t cur = 0, end = 0;  // wave-uniform: pixel range of the current tile
     uint32_t q = blockIdx.x & 7u, tried = 0;   // wave-uniform: queue in use, queues found empty
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
     uint32_t y = 0;
     if (live) { y = global_row(P, yl); live = y < P.height; }
     if (live) {
-        typedef typename CursorOf<CUR>::type CursorT;
+        typedef typename CursorOf<CUR, COUNT>::type CursorT;
         FrameInfo I = P.frames[0];
         asm volatile("" : "+s"(I.margin), "+s"(I.limit));                      // see k_plain
         const NodeRec root = P.nodes[0];

@@ -101,6 +101,8 @@ def test_camera_edge_cases(sb, oracle_mod, scenes, gpu_scenes):
             img, st = scene.Draw(cam, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
             assert_frames_identical(img, ref, f"{what} / {variant}")
             assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), what
+            # the build that does not count (the one that is timed) is its own set of kernels
+            assert_frames_identical(scene.Draw(cam, W, H, flags_of(sb, variant)), ref, f"{what} / {variant}, not counting")
 
 
 def _chain_tree(depth):
