@@ -43,7 +43,7 @@ struct FrameInfo {
 constexpr int MAX_BATCH = 8;   // frames one k_plain launch can render (grid.y)
 constexpr int MAX_BAND_LIST = 512;   // bands one launch can be handed as an explicit list
 
-struct TopCell { uint32_t link, v0, v1, pad; };   // a cell of the top grid, see below (cursor-stack kernels)
+struct TopCell { uint32_t level, v0, v1; int32_t children; };   // a cell of the top grid, see below (cursor-stack kernels)
 
 // Kernel parameters: scene, frame geometry, and the camera block of every frame of the launch.
 struct RenderParams {
@@ -242,11 +242,11 @@ constexpr int LM = 12;
 // through a face of a shallow ancestor: half of all records a descent loads belong to levels 1-3,
 // 87 % to levels 1-6 (scripts/descent_levels.py), each one a dependent load.  The grid holds, for
 // every cell of level TG, the record of the deepest node of level <= TG that contains it:
-// {children (28 bits, sign-extended) | level << 28, values}.  A descent that restarts above level
+// {level, values, children}.  A descent that restarts above level
 // TG takes ONE load from the grid instead of up to TG dependent loads, and ends in the same node.
 // TG is chosen per scene at upload (RenderParams::top_level); top == nullptr disables it.  When the
 // grid is as deep as the tree the kernels use CursorF (below) instead of CursorS, and the cells hold
-// LM - level in the top bits.
+// LM - level instead of the level (and CursorF loads only the first 12 bytes of a cell).
 //
 // Cell (x, y, z) of the level-TG grid -> index: plain x-y-z order.  Blocked orders (2^B cells per
 // axis contiguous; B = 1 puts the 8 cells of one parent in one 128-byte line) were measured and are
@@ -264,10 +264,6 @@ __host__ __device__ __forceinline__ uint32_t top_index(uint32_t x, uint32_t y, u
     const uint32_t hi = (x >> B) | ((y >> B) << H) | ((z >> B) << (2 * H));
     const uint32_t lo = (x & m) | ((y & m) << B) | ((z & m) << (2 * B));
     return (hi << (3 * B)) | lo;
-}
-__host__ __device__ __forceinline__ uint32_t top_link(int32_t children, uint32_t level)
-{
-    return ((uint32_t)children & 0x0FFFFFFFu) | (level << 28);
 }
 
 // ---- cursor-stack cursor: level, integer anchor, children index, values ------------------------
@@ -353,10 +349,10 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
             const int sh = LM - TG;
             const uint32_t cellidx = top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG);
             const uint4 e = reinterpret_cast<const uint4 *>(top)[cellidx];
-            const int lvl = (int)(e.x >> 28);
+            const int lvl = (int)e.x;
             reads += (uint32_t)(lvl - c.level);
             c.level = lvl;
-            c.children = (int32_t)(e.x << 4) >> 4;
+            c.children = (int32_t)e.w;
             c.v0 = e.y;
             c.v1 = e.z;
         }
@@ -389,8 +385,7 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
 // ---- cursor when the top grid is as deep as the tree ---------------------------------------------
 // Every leaf is a grid cell or a block of cells, so the grid says where a position's leaf is and the
 // cursor shrinks to the leaf's anchor, size and values: no children index, no ancestor stack.  It
-// keeps s = LM - level (what the shifts need); such a grid stores s in the top bits of a cell's link
-// (k_top_grid).  After reset the anchor is a mark that no position matches: the first find of a
+// keeps s = LM - level (what the shifts need); such a grid stores s instead of the level (k_top_grid).  After reset the anchor is a mark that no position matches: the first find of a
 // pixel always looks its cell up.
 // EXACT: the kernel reports the algorithmic read count, so a NaN coordinate must behave exactly as in
 // find_s (it matches no cell: ascents up to the root).  Without it NaN converts to 0 and the find
@@ -456,7 +451,7 @@ __device__ __forceinline__ uint32_t find_full(CursorFT<EXACT> &c, const TopCell 
         Dx = min(max(Dx, 0), 4095); Dy = min(max(Dy, 0), 4095); Dz = min(max(Dz, 0), 4095);
         const int sh = LM - TG;
         const uint4 e = reinterpret_cast<const uint4 *>(top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
-        const int ns = (int)(e.x >> 28);              // LM - level of the leaf
+        const int ns = (int)e.x;                      // LM - level of the leaf
         reads = 1u + (uint32_t)k + (uint32_t)((LM - ns) - (level - k));
         c.s = ns;
         c.v0 = e.y;

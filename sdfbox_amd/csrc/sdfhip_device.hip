@@ -49,7 +49,7 @@ __global__ void k_top_grid(const NodeRec *__restrict__ nodes, TopCell *__restric
         }
         TopCell t;
         // a grid as deep as the tree serves CursorF, which wants LM - level in the top bits
-        t.link = top_link((int32_t)r.y, full ? (uint32_t)LM - level : level); t.v0 = r.z; t.v1 = r.w; t.pad = 0;
+        t.level = full ? (uint32_t)LM - level : level; t.v0 = r.z; t.v1 = r.w; t.children = (int32_t)r.y;
         top[top_index(cx, cy, cz, TG)] = t;
     }
 }
@@ -93,6 +93,9 @@ __global__ void k_unorm_table(float *out)
 }
 
 constexpr int MAX_TOP_LEVEL = 8;
+#ifndef FULL_GRID_SHARE
+#define FULL_GRID_SHARE 64          // a grid as deep as the tree may take 1/FULL_GRID_SHARE of the device's memory
+#endif
 
 }  // namespace sdfhip
 
@@ -225,9 +228,9 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     // Top grid.  As deep as the tree when that fits 1/64 of the device's memory (4.5 GB of 288: trees up
     // to depth 9, 2.1 GB) -- then every leaf is in the grid and a find is one load.  Otherwise at most
     // MAX_TOP_LEVEL and no larger than the tree's own records (16 bytes per cell and per node; at least
-    // 64 KB).  SDFHIP_TOP_GRID_LEVEL overrides (0 = none).  A cell packs a children index into 27 bits + sign.
+    // 64 KB).  SDFHIP_TOP_GRID_LEVEL overrides (0 = none).
     int top_level = 0;
-    if (depth >= 1 && depth <= 9 && (sizeof(TopCell) << (3 * depth)) <= prop.totalGlobalMem / 64) {
+    if (depth >= 1 && depth <= 10 && (sizeof(TopCell) << (3 * depth)) <= prop.totalGlobalMem / FULL_GRID_SHARE) {
         top_level = (int)depth;
     } else {
         const size_t budget = (size_t)n * 16 > ((size_t)1 << 16) ? (size_t)n * 16 : ((size_t)1 << 16);
@@ -237,9 +240,9 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     }
     if (const char *env = getenv("SDFHIP_TOP_GRID_LEVEL")) {
         const int v = atoi(env);
-        if (v >= 0 && v <= 9) top_level = v < (int)depth ? v : (int)depth;
+        if (v >= 0 && v <= 10) top_level = v < (int)depth ? v : (int)depth;
     }
-    if (s->stack_ok && top_level > 0 && n < (1u << 27)) {
+    if (s->stack_ok && top_level > 0) {
         // the grid is an accelerator, not part of the scene: without memory for it, shrink it
         while (top_level > 0 && hipMalloc((void **)&s->d_top, sizeof(TopCell) << (3 * top_level)) != hipSuccess) {
             (void)hipGetLastError();
