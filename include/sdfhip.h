@@ -201,8 +201,8 @@ SDFHIP_API int sdfhip_scene_info(const sdfhip_scene *scene, uint32_t *n, uint32_
  * and algorithmic counts are unchanged).  level = 0, bytes = 0: none (inconsistent or deeper than
  * 12 levels: generic kernel).  The level is the tree's depth when such a grid (16 bytes per cell, 8^level
  * cells) fits 1/64 of the device's memory -- every leaf is then in the grid and a find is one load --
- * and otherwise at most 8 and no larger than the tree's own records; the environment variable
- * SDFHIP_TOP_GRID_LEVEL (0..9) overrides it at upload, and it shrinks by itself when memory is short. */
+ * (trees up to depth 10) -- and otherwise at most 8 and no larger than the tree's own records; the environment variable
+ * SDFHIP_TOP_GRID_LEVEL (0..10) overrides it at upload, and it shrinks by itself when memory is short. */
 SDFHIP_API int sdfhip_scene_top_grid(const sdfhip_scene *scene, int32_t *level, uint64_t *bytes);
 
 /* Replaces: Program.Draw's UpdateBuffer(info) + DispatchSized(W, H, 1),
