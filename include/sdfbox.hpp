@@ -108,6 +108,21 @@ public:
     // Logic.Position, Logic.cs:60-78 (also refreshes State.limit)
     void SetPosition(float x, float y, float z) { sdfhip_info_set_position(&State, x, y, z); }
     void Resize(int width, int height) { State.screen_size[0] = (float)width; State.screen_size[1] = (float)height; }
+    // the camera part of Logic.Update (Logic.cs:239-272): keys is a mask of SDFHIP_KEY_*
+    void Update(float seconds, uint32_t keys)
+    {
+        float h[2] = { headingX, headingY };
+        sdfhip_camera_update(&State, h, mSpeed, keys, seconds);
+        headingX = h[0]; headingY = h[1];
+    }
+    void MouseMove(float dx, float dy)                                // Logic.cs:290-293
+    {
+        float h[2] = { headingX, headingY };
+        sdfhip_camera_mouse_move(&State, h, dx, dy);
+        headingX = h[0]; headingY = h[1];
+    }
+    void MouseWheel(float delta) { mSpeed = sdfhip_camera_mouse_wheel(mSpeed, delta); }   // Logic.cs:202-205
+    float mSpeed = 0.5f;                                              // Logic.cs:28
 
     static FileFormat FormatOf(const std::string &filename)          // Logic.cs:126-138
     {

@@ -182,6 +182,30 @@ SDFHIP_API void sdfhip_info_set_heading(sdfhip_info *info, float heading_x, floa
 /* Replaces: Logic.Position setter, SdfBox/Logic.cs:60-78 (position + limit). */
 SDFHIP_API void sdfhip_info_set_position(sdfhip_info *info, float x, float y, float z);
 
+/* Movement keys of Logic.Update (SdfBox/Logic.cs:252-271), as a bit mask. */
+enum {
+    SDFHIP_KEY_RIGHT = 1, SDFHIP_KEY_LEFT = 2, SDFHIP_KEY_UP = 4, SDFHIP_KEY_DOWN = 8,   /* arrow keys: turn   */
+    SDFHIP_KEY_FORWARD = 16,        /* W / numpad 8 */
+    SDFHIP_KEY_BACK = 32,           /* S / numpad 2 */
+    SDFHIP_KEY_STRAFE_RIGHT = 64,   /* D / numpad 6 */
+    SDFHIP_KEY_STRAFE_LEFT = 128,   /* A / numpad 4 */
+    SDFHIP_KEY_SHIFT = 256,         /* left shift / numpad 9: position.y -= step */
+    SDFHIP_KEY_CONTROL = 512        /* left control / numpad 3: position.y += step */
+};
+
+/* Replaces: the camera part of Logic.Update, SdfBox/Logic.cs:239-272, for one time step of
+ * `seconds`: the arrow keys turn the heading by tSpeed * seconds, the movement keys move the
+ * position by mSpeed^2 * seconds in the yaw plane (yawMat, Logic.cs:79-83) or along y, in the
+ * reference's order; heading_xy (in/out: X = pitch, Y = yaw) and `info` (heading, position,
+ * limit) are updated.  m_speed: Logic.mSpeed, 0.5 at start (Logic.cs:28). */
+SDFHIP_API void sdfhip_camera_update(sdfhip_info *info, float *heading_xy, float m_speed, uint32_t keys, float seconds);
+
+/* Replaces: Logic.MouseMove, SdfBox/Logic.cs:290-293: heading += (-dy, dx) / 512 * 4. */
+SDFHIP_API void sdfhip_camera_mouse_move(sdfhip_info *info, float *heading_xy, float dx, float dy);
+
+/* Replaces: the MouseWheel handler, SdfBox/Logic.cs:202-205: the new mSpeed. */
+SDFHIP_API float sdfhip_camera_mouse_wheel(float m_speed, float wheel_delta);
+
 /* ---- device ------------------------------------------------------------ */
 
 SDFHIP_API int sdfhip_device_count(int *count);

@@ -147,6 +147,9 @@ _SIG = {
                                          _c.c_int, _vp, _c.POINTER(Stats)]),
     "sdfhip_deinterleave_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32,
                                               _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+    "sdfhip_camera_update": (None, [_c.POINTER(Info), _c.POINTER(_c.c_float), _c.c_float, _c.c_uint32, _c.c_float]),
+    "sdfhip_camera_mouse_move": (None, [_c.POINTER(Info), _c.POINTER(_c.c_float), _c.c_float, _c.c_float]),
+    "sdfhip_camera_mouse_wheel": (_c.c_float, [_c.c_float, _c.c_float]),
     "sdfhip_scene_top_grid": (_c.c_int, [_vp, _c.POINTER(_c.c_int32), _c.POINTER(_c.c_uint64)]),
     "sdfhip_render_bands_device": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.POINTER(PathTrace), _c.c_uint32,
                                               _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_uint16), _c.c_uint32,

@@ -6,6 +6,11 @@
 //   sdfhip_info_set_heading   Logic.Heading setter, Logic.cs:46-55, through
 //                             Float3x3(Matrix4x4), Logic.cs:445-462.
 //   sdfhip_info_set_position  Logic.Position setter, Logic.cs:60-78.
+//   sdfhip_camera_update      the camera part of Logic.Update, Logic.cs:239-272 (arrow keys
+//                             turn, WASD / numpad move in the yaw plane, shift / control
+//                             move along y), with yawMat of Logic.cs:79-83.
+//   sdfhip_camera_mouse_move  Logic.MouseMove, Logic.cs:290-293.
+//   sdfhip_camera_mouse_wheel the MouseWheel handler, Logic.cs:202-205.
 //
 // Matrix4x4.CreateFromYawPitchRoll is .NET BCL code that is not in the
 // reference tree; it is restated here from its published definition
@@ -73,4 +78,51 @@ extern "C" void sdfhip_info_default(sdfhip_info *info, float width, float height
     info->hidef = 0;
     sdfhip_info_set_heading(info, 0.0f, 0.0f);
     sdfhip_info_set_position(info, 0.5f, 0.5f, 0.1f);
+}
+
+extern "C" void sdfhip_camera_update(sdfhip_info *info, float *heading_xy, float m_speed, uint32_t keys, float seconds)
+{
+    if (!info || !heading_xy) return;
+    const float t_speed = 0.1f;                      // tSpeed, Logic.cs:29
+    const float transform = m_speed * m_speed * seconds;
+    const float rotate = t_speed * seconds;
+    float hx = heading_xy[0], hy = heading_xy[1];
+    if (keys & SDFHIP_KEY_RIGHT) hy += rotate;       // Heading += (0, rotate)
+    if (keys & SDFHIP_KEY_LEFT) hy -= rotate;
+    if (keys & SDFHIP_KEY_UP) hx += rotate;          // Heading += (rotate, 0)
+    if (keys & SDFHIP_KEY_DOWN) hx -= rotate;
+    heading_xy[0] = hx; heading_xy[1] = hy;
+    sdfhip_info_set_heading(info, hx, hy);
+    float Y[3][3];
+    yaw_pitch_roll(hy, 0.0f, 0.0f, Y);               // yawMat, Logic.cs:79-83
+    float p[3] = { info->position[0], info->position[1], info->position[2] };
+    // Position += Vector3.Transform(v, yawMat) * transform: row vector times matrix, then the scale, then the sum
+    auto move = [&](float vx, float vy, float vz) {
+        for (int j = 0; j < 3; j++) {
+            float d = vx * Y[0][j] + vy * Y[1][j] + vz * Y[2][j];
+            p[j] = p[j] + d * transform;
+        }
+    };
+    if (keys & SDFHIP_KEY_FORWARD) move(0.0f, 0.0f, 1.0f);
+    if (keys & SDFHIP_KEY_BACK) move(0.0f, 0.0f, -1.0f);
+    if (keys & SDFHIP_KEY_STRAFE_RIGHT) move(1.0f, 0.0f, 0.0f);
+    if (keys & SDFHIP_KEY_STRAFE_LEFT) move(-1.0f, 0.0f, 0.0f);
+    if (keys & SDFHIP_KEY_SHIFT) p[1] = p[1] + -1.0f * transform;     // Position += (0, -1, 0) * transform
+    if (keys & SDFHIP_KEY_CONTROL) p[1] = p[1] + 1.0f * transform;
+    sdfhip_info_set_position(info, p[0], p[1], p[2]);
+}
+
+extern "C" void sdfhip_camera_mouse_move(sdfhip_info *info, float *heading_xy, float dx, float dy)
+{
+    if (!info || !heading_xy) return;
+    heading_xy[0] += -dy / 512.0f * 4.0f;             // Heading += new Vector2(-diff.Y, diff.X) / 512 * 4
+    heading_xy[1] += dx / 512.0f * 4.0f;
+    sdfhip_info_set_heading(info, heading_xy[0], heading_xy[1]);
+}
+
+extern "C" float sdfhip_camera_mouse_wheel(float m_speed, float wheel_delta)
+{
+    if ((wheel_delta > 0 && m_speed < 1) || (wheel_delta < 0 && m_speed > 0.05))
+        m_speed += wheel_delta * 0.05f;
+    return m_speed;
 }

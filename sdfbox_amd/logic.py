@@ -22,6 +22,7 @@ class Logic:
         self.State = Info()
         lib.sdfhip_info_default(ctypes.byref(self.State), w, h)
         self._heading = (0.0, 0.0)
+        self.mSpeed = 0.5        # Logic.cs:28
 
     # Logic.Heading, Logic.cs:46-55: (X = pitch, Y = yaw)
     @property
@@ -43,6 +44,26 @@ class Logic:
     def Position(self, value):
         lib.sdfhip_info_set_position(ctypes.byref(self.State), float(value[0]), float(value[1]),
                                      float(value[2]))
+
+    # the camera part of Logic.Update, Logic.cs:239-272
+    KEY_RIGHT, KEY_LEFT, KEY_UP, KEY_DOWN = 1, 2, 4, 8
+    KEY_FORWARD, KEY_BACK, KEY_STRAFE_RIGHT, KEY_STRAFE_LEFT, KEY_SHIFT, KEY_CONTROL = 16, 32, 64, 128, 256, 512
+
+    def Update(self, seconds, keys):
+        """One time step with the pressed movement keys (a KEY_* bit mask)."""
+        h = (ctypes.c_float * 2)(*self._heading)
+        lib.sdfhip_camera_update(ctypes.byref(self.State), h, float(self.mSpeed), int(keys), float(seconds))
+        self._heading = (h[0], h[1])
+
+    def MouseMove(self, dx, dy):
+        """Logic.MouseMove, Logic.cs:290-293."""
+        h = (ctypes.c_float * 2)(*self._heading)
+        lib.sdfhip_camera_mouse_move(ctypes.byref(self.State), h, float(dx), float(dy))
+        self._heading = (h[0], h[1])
+
+    def MouseWheel(self, delta):
+        """The MouseWheel handler, Logic.cs:202-205."""
+        self.mSpeed = lib.sdfhip_camera_mouse_wheel(float(self.mSpeed), float(delta))
 
     def Resize(self, width, height):
         """Program.Resize, Program.cs:282-292: screen_size follows the window."""

@@ -47,6 +47,15 @@ int main(int argc, char **argv)
             if (!f || fwrite(disp.data(), 1, disp.size(), f) != disp.size()) return 13;
             fclose(f);
         }
+        {   // Logic.Update / MouseMove through the mirror: a step forward and back again returns the camera
+            Logic walk;
+            walk.Update(2.0f, SDFHIP_KEY_FORWARD);
+            if (walk.State.position[2] <= 0.1f) return 16;
+            walk.Update(2.0f, SDFHIP_KEY_BACK);
+            if (walk.State.position[2] < 0.0999f || walk.State.position[2] > 0.1001f) return 17;
+            walk.MouseMove(128.0f, 0.0f);
+            if (walk.HeadingY() != 1.0f) return 18;
+        }
         program.Load(model);                       // reload swaps the scene (Program.cs:59-65)
         program.Draw(logic.State, W, H, frame);
         try {                                      // errors are exceptions of one type, never a crash

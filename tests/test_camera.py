@@ -78,3 +78,48 @@ def test_info_blocks_match_golden(sb):
     g = np.load(os.path.join(GOLDEN, "info_blocks.npz"))
     for name in CAMERAS:
         assert bytes(make_camera(name, 64, 64).State) == g[name].tobytes(), name
+
+
+def test_update_moves_as_logic_update_does(sb):
+    # Logic.Update, Logic.cs:239-272: transform = mSpeed^2 * sec, rotate = tSpeed * sec (0.1)
+    cam = sb.Logic(64, 64)
+    assert cam.mSpeed == 0.5
+    p0 = np.array(cam.Position, dtype=np.float64)
+    cam.Update(2.0, cam.KEY_FORWARD)                      # W: +z by 0.25 * 2
+    assert np.allclose(cam.Position, p0 + [0, 0, 0.5], atol=1e-7)
+    cam.Update(2.0, cam.KEY_BACK | cam.KEY_STRAFE_RIGHT)  # S and D: back where it was in z, +x by 0.5
+    assert np.allclose(cam.Position, p0 + [0.5, 0, 0], atol=1e-7)
+    cam.Update(1.0, cam.KEY_SHIFT)                        # LShift: Position += (0, -1, 0) * 0.25
+    assert np.allclose(cam.Position, p0 + [0.5, -0.25, 0], atol=1e-7)
+    cam.Update(1.0, cam.KEY_CONTROL | cam.KEY_STRAFE_LEFT)
+    assert np.allclose(cam.Position, p0 + [0.25, 0, 0], atol=1e-7)
+    # the Position setter ran: limit follows
+    x, y, z = cam.Position
+    assert abs(cam.State.limit - max((cx - x) ** 2 + (cy - y) ** 2 + (cz - z) ** 2
+                                     for cx in (0, 1) for cy in (0, 1) for cz in (0, 1))) < 1e-6
+    # arrow keys turn: Right = yaw += 0.1 * sec, Up = pitch += 0.1 * sec; movement uses the NEW yaw, never the pitch
+    cam = sb.Logic(64, 64)
+    cam.Update(float(np.pi / 2 / 0.1), cam.KEY_RIGHT)     # yaw = 90 degrees
+    assert np.allclose(cam.Heading, (0.0, np.pi / 2), atol=1e-6)
+    assert np.allclose(transform([0, 0, 1], cam.State), [1, 0, 0], atol=1e-6)
+    q0 = np.array(cam.Position, dtype=np.float64)
+    cam.Update(4.0, cam.KEY_FORWARD | cam.KEY_UP)         # forward is now +x; pitching does not tilt the walk
+    assert np.allclose(cam.Position, q0 + [1.0, 0, 0], atol=1e-6)
+    assert np.allclose(cam.Heading, (0.4, np.pi / 2), atol=1e-6)
+    cam.Update(1.0, cam.KEY_LEFT | cam.KEY_DOWN)
+    assert np.allclose(cam.Heading, (0.3, np.pi / 2 - 0.1), atol=1e-6)
+
+
+def test_mouse_move_and_wheel(sb):
+    cam = sb.Logic(64, 64)
+    cam.MouseMove(128.0, -64.0)                            # Heading += (-dy, dx) / 512 * 4
+    assert np.allclose(cam.Heading, (0.5, 1.0), atol=1e-7)
+    ref = sb.Logic(64, 64); ref.Heading = (0.5, 1.0)
+    assert bytes(cam.State) == bytes(ref.State)
+    cam.MouseWheel(1.0); assert abs(cam.mSpeed - 0.55) < 1e-7
+    for _ in range(20):
+        cam.MouseWheel(1.0)
+    assert 1.0 <= cam.mSpeed < 1.05                        # grows only while mSpeed < 1
+    for _ in range(40):
+        cam.MouseWheel(-1.0)
+    assert 0.0 < cam.mSpeed <= 0.05 + 1e-6                 # shrinks only while mSpeed > 0.05
