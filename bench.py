@@ -469,6 +469,12 @@ def cpu_baseline(od, cam, W, H, target_seconds):
     oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=nrows, row_step=step, nthreads=nthreads)
     dt = time.perf_counter() - t0
     pix = nrows * W
+    # one thread beside it, on a sparser sample of the same frame: about 2 s
+    step1 = max(1, int(H * per_row * nthreads / 2.0))
+    nrows1 = (H + step1 - 1) // step1
+    t0 = time.perf_counter()
+    oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=nrows1, row_step=step1, nthreads=1)
+    dt1 = time.perf_counter() - t0
     return {
         "value": round(pix / dt / 1e6, 3),
         "unit": "Mray/s",
@@ -477,6 +483,8 @@ def cpu_baseline(od, cam, W, H, target_seconds):
         "sample": f"every {step}th row of the same {W}x{H} frame = {pix} pixels in {dt:.2f} s wall "
                   f"({dt * nthreads:.0f} core-seconds); oracle/sdf_oracle.c, gcc -O2 -ffp-contract=off, "
                   f"{nthreads} pthreads, rows interleaved",
+        "one_thread": {"value": round(nrows1 * W / dt1 / 1e6, 3), "unit": "Mray/s",
+                       "sample": f"every {step1}th row = {nrows1 * W} pixels in {dt1:.2f} s"},
     }
 
 
