@@ -11,7 +11,7 @@ W, H = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1920x1080").spli
 od = sb.dragon_standin(9); sc = sb.Scene(od)
 cam = sb.Logic(W, H); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
 pb, fl = 5, sb.FLAG_WIRE
-for world, weights in ((2, (1.0, 0.9)), (4, (1.0, 0.8)), (8, (1.0, 0.7, 0.6, 0.5))):
+for world, weights in ((2, (1.0, 0.9, 0.8)), (4, (1.0, 0.8, 0.6, 0.5)), (8, (1.0, 0.5, 0.4, 0.3, 0.2))):
     G, S = 4, 4                      # bench.py's defaults: 4 frames per launch, 4 launches in flight
     for band_rows in (16,):
         for w0 in weights:

@@ -286,7 +286,11 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
     } else if (P.tile_order == 1) {   // dispatch order = row-major tile order
         tile = bid;
     } else {                          // default: XCD k renders tile rows k, k+8, ... (grid padded to 8*ceil(tiles_y/8) rows)
-        const uint32_t xcd = bid & 7u, j = bid >> 3;           // j-th block of this XCD
+        // tiles_y is rarely a multiple of 8: the first tiles_y % 8 labels get one tile row more.  A rank's
+        // share of a sharded frame has few tile rows (17 at 8 ranks: 3 for label 0, 2 for the others), so
+        // in a batched launch frame f shifts the labels by f * (tiles_y % 8): the extra rows go to
+        // different XCDs frame after frame
+        const uint32_t xcd = (bid + blockIdx.y * (P.tiles_y & 7u)) & 7u, j = bid >> 3;   // j-th block of this label
         const uint32_t r = j / P.tiles_x, cx = j - r * P.tiles_x;
         const uint32_t row = r * 8 + xcd;
         tile = row < P.tiles_y ? row * P.tiles_x + cx : 0xFFFFFFFFu;
