@@ -337,6 +337,27 @@ SDFHIP_API int sdfhip_deinterleave_bands_device(int device, const void *d_gather
                                                 uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
                                                 uint32_t pixel_bytes, uint32_t frames, void *stream);
 
+/* Sparse wire format: what the ranks put on xGMI when most of a frame is sky.  A frame-share in the
+ * wire format of SDFHIP_FLAG_WIRE (rows x width pixels, rows a multiple of 8) is compacted on its own
+ * GPU -- the code bytes stay; of the float plane only the values with any bit set, packed in tile
+ * order behind a 64-bit mask and a slot index per 8x8 tile -- gathered, and expanded by rank 0 while it
+ * restores row order.  `capacity` = float slots per frame-share; a share with more lit pixels sets the
+ * overflow word (then the frame is not complete: choose the capacity from a measured maximum, or
+ * rows * width to be safe).  Lossless within the capacity; 1.2 bytes per pixel + 4 per lit pixel.
+ *   sdfhip_wire_sparse_bytes            bytes of one sparse frame-share
+ *   sdfhip_wire_compact_device          d_wire [frames] dense wire shares -> d_sparse [frames] sparse shares
+ *   sdfhip_deinterleave_sparse_device   like sdfhip_deinterleave[_bands]_device (owner may be NULL: round
+ *                                       robin) for [world][frames] sparse shares; *d_overflow (device word,
+ *                                       may be NULL) is OR-ed with 1 when a share overflowed */
+SDFHIP_API uint64_t sdfhip_wire_sparse_bytes(uint32_t width, uint32_t rows, uint32_t capacity);
+SDFHIP_API int sdfhip_wire_compact_device(int device, const void *d_wire, void *d_sparse, uint32_t width,
+                                          uint32_t rows, uint32_t frames, uint32_t capacity, void *stream);
+SDFHIP_API int sdfhip_deinterleave_sparse_device(int device, const void *d_gathered, void *d_frame,
+                                                 uint32_t width, uint32_t height, uint32_t band_rows,
+                                                 uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
+                                                 uint32_t capacity, uint32_t frames, uint32_t *d_overflow,
+                                                 void *stream);
+
 /* Test hook: the kernel's R8_UNorm decode of bytes 0..255 (256 floats to the
  * host), checked exhaustively against byte/255.0f. */
 SDFHIP_API int sdfhip_debug_unorm_table(int device, float *out256);

@@ -157,6 +157,10 @@ _SIG = {
     "sdfhip_deinterleave_bands_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                     _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_uint8), _c.c_uint32,
                                                     _c.c_uint32, _vp]),
+    "sdfhip_wire_sparse_bytes": (_c.c_uint64, [_c.c_uint32, _c.c_uint32, _c.c_uint32]),
+    "sdfhip_wire_compact_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+    "sdfhip_deinterleave_sparse_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                                     _c.c_uint32, _c.POINTER(_c.c_uint8), _c.c_uint32, _c.c_uint32, _vp, _vp]),
     "sdfhip_debug_unorm_table": (_c.c_int, [_c.c_int, _vp]),
 }
 # every symbol include/sdfhip.h declares must be exported: fail at import otherwise

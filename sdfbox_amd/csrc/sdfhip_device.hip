@@ -87,6 +87,123 @@ __global__ void k_deinterleave(const In *__restrict__ gathered, Out *__restrict_
     }
 }
 
+// ---- sparse wire format of the tile gather ------------------------------------------------------
+// A frame-share in the dense wire format (SDFHIP_FLAG_WIRE: rows*width floats, then rows*width code
+// bytes) is mostly zeros in its float plane: sky and unlit pixels carry a = +0.  The sparse form keeps
+// the code bytes, and per 8x8 tile a 64-bit mask of the pixels whose a has any bit set plus the index
+// of the tile's first slot in a packed array of those floats (capacity slots; more are dropped and
+// flagged).  Lossless within the capacity; about 1.2 bytes + 4 bytes per lit pixel instead of 5.
+struct SparseLayout {
+    uint32_t width, rows, tiles_x, tiles_y, tiles, capacity;
+    size_t off_masks, off_bases, off_head, off_floats, bytes;
+};
+__host__ __device__ inline SparseLayout sparse_layout(uint32_t width, uint32_t rows, uint32_t capacity)
+{
+    SparseLayout L;
+    L.width = width; L.rows = rows; L.capacity = capacity;
+    L.tiles_x = (width + 7) / 8; L.tiles_y = (rows + 7) / 8; L.tiles = L.tiles_x * L.tiles_y;
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    L.off_masks = up((size_t)rows * width);
+    L.off_bases = up(L.off_masks + (size_t)L.tiles * 8);
+    L.off_head = up(L.off_bases + (size_t)L.tiles * 4);
+    L.off_floats = L.off_head + 16;
+    L.bytes = up(L.off_floats + (size_t)capacity * 4);
+    return L;
+}
+
+// one wavefront per tile: the mask of pixels with a != +0 (bitwise), its popcount; the code bytes are copied
+__global__ __launch_bounds__(256) void k_sparse_masks(const uint8_t *__restrict__ wire, uint8_t *__restrict__ sparse, SparseLayout L)
+{
+    const uint32_t f = blockIdx.y, tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (tile >= L.tiles) return;
+    const size_t npx = (size_t)L.rows * L.width;
+    const uint8_t *src = wire + (size_t)f * npx * 5;
+    uint8_t *dst = sparse + (size_t)f * L.bytes;
+    const uint32_t x = (tile % L.tiles_x) * 8 + (lane & 7u), y = (tile / L.tiles_x) * 8 + (lane >> 3);
+    const bool in = x < L.width && y < L.rows;
+    uint32_t bits = 0;
+    if (in) {
+        const size_t l = (size_t)y * L.width + x;
+        bits = reinterpret_cast<const uint32_t *>(src)[l];
+        dst[l] = src[4 * npx + l];
+    }
+    const unsigned long long m = __ballot(bits != 0u);
+    if (lane == 0) {
+        reinterpret_cast<unsigned long long *>(dst + L.off_masks)[tile] = m;
+        reinterpret_cast<uint32_t *>(dst + L.off_bases)[tile] = (uint32_t)__popcll(m);
+    }
+}
+// one workgroup per frame: exclusive scan of the tile counts in place, total and overflow flag to the header
+__global__ __launch_bounds__(1024) void k_sparse_scan(uint8_t *__restrict__ sparse, SparseLayout L)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    uint8_t *dst = sparse + (size_t)blockIdx.x * L.bytes;
+    uint32_t *bases = reinterpret_cast<uint32_t *>(dst + L.off_bases);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < L.tiles; b += 1024) {
+        const uint32_t i = b + tid;
+        uint32_t v = i < L.tiles ? bases[i] : 0u, x = v;
+        for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if ((int)lane >= o) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
+        const uint32_t c = carry;
+        if (i < L.tiles) bases[i] = c + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) carry = c + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint32_t *head = reinterpret_cast<uint32_t *>(dst + L.off_head);
+        head[0] = carry; head[1] = carry > L.capacity ? 1u : 0u; head[2] = 0; head[3] = 0;
+    }
+}
+// one wavefront per tile: the floats of its lit pixels to their slots
+__global__ __launch_bounds__(256) void k_sparse_scatter(const uint8_t *__restrict__ wire, uint8_t *__restrict__ sparse, SparseLayout L)
+{
+    const uint32_t f = blockIdx.y, tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (tile >= L.tiles) return;
+    const size_t npx = (size_t)L.rows * L.width;
+    const uint8_t *src = wire + (size_t)f * npx * 5;
+    uint8_t *dst = sparse + (size_t)f * L.bytes;
+    const unsigned long long m = reinterpret_cast<const unsigned long long *>(dst + L.off_masks)[tile];
+    if (!((m >> lane) & 1ull)) return;
+    const uint32_t slot = reinterpret_cast<const uint32_t *>(dst + L.off_bases)[tile] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (slot >= L.capacity) return;
+    const uint32_t x = (tile % L.tiles_x) * 8 + (lane & 7u), y = (tile / L.tiles_x) * 8 + (lane >> 3);
+    reinterpret_cast<uint32_t *>(dst + L.off_floats)[slot] = reinterpret_cast<const uint32_t *>(src)[(size_t)y * L.width + x];
+}
+// rank 0: gathered sparse frame-shares -> RGBA32F frames in row order
+__global__ void k_deinterleave_sparse(const uint8_t *__restrict__ gathered, float4 *__restrict__ frame, uint32_t width, uint32_t height,
+                                      uint32_t band_rows, uint32_t world, uint32_t frames, SparseLayout L, const BandMap M,
+                                      uint32_t *overflow)
+{
+    size_t per_frame = (size_t)width * height, total = per_frame * frames;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t f = (uint32_t)(i / per_frame);
+        size_t r = i - (size_t)f * per_frame;
+        uint32_t y = (uint32_t)(r / width), x = (uint32_t)(r - (size_t)y * width);
+        uint32_t band = y / band_rows, rank = band % world, lband = band / world;
+        if (M.n) { const uint32_t e = M.src[band]; rank = e >> 10; lband = e & 1023u; }
+        const uint32_t yl = lband * band_rows + (y - band * band_rows);
+        const uint8_t *src = gathered + ((size_t)rank * frames + f) * L.bytes;
+        const uint32_t code = src[(size_t)yl * width + x];
+        const uint32_t tile = (yl >> 3) * L.tiles_x + (x >> 3), bit = (yl & 7u) * 8 + (x & 7u);
+        const unsigned long long m = reinterpret_cast<const unsigned long long *>(src + L.off_masks)[tile];
+        float a = 0.0f;
+        if ((m >> bit) & 1ull) {
+            const uint32_t slot = reinterpret_cast<const uint32_t *>(src + L.off_bases)[tile] + (uint32_t)__popcll(m & ((1ull << bit) - 1ull));
+            if (slot < L.capacity) a = __uint_as_float(reinterpret_cast<const uint32_t *>(src + L.off_floats)[slot]);
+        }
+        if (x == 0 && yl == 0 && overflow && reinterpret_cast<const uint32_t *>(src + L.off_head)[1]) atomicOr(overflow, 1u);
+        frame[i] = wire_expand(a, code);
+    }
+}
+
 __global__ void k_unorm_table(float *out)
 {
     out[threadIdx.x] = unorm8((float)threadIdx.x);
@@ -611,6 +728,67 @@ extern "C" int sdfhip_deinterleave_bands_device(int device, const void *d_gather
     if (!owner) return fail(SDFHIP_ERR_ARG, "deinterleave_bands: null owner table");
     return deinterleave_impl(device, d_gathered, d_frame, width, height, band_rows, world, rows_per_rank, owner,
                              pixel_bytes, frames, stream);
+}
+
+extern "C" uint64_t sdfhip_wire_sparse_bytes(uint32_t width, uint32_t rows, uint32_t capacity)
+{
+    return (uint64_t)sparse_layout(width, rows, capacity).bytes;
+}
+
+extern "C" int sdfhip_wire_compact_device(int device, const void *d_wire, void *d_sparse, uint32_t width, uint32_t rows,
+                                          uint32_t frames, uint32_t capacity, void *stream)
+{
+    if (!d_wire || !d_sparse || width == 0 || rows == 0 || frames == 0)
+        return fail(SDFHIP_ERR_ARG, "wire_compact: null or zero argument");
+    if (((size_t)rows * width) % 4 != 0) return fail(SDFHIP_ERR_ARG, "wire_compact: rows * width must be a multiple of 4");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "wire_compact: hipSetDevice(%d) failed", device);
+    const SparseLayout L = sparse_layout(width, rows, capacity);
+    const dim3 grid((L.tiles + 3) / 4, frames);
+    hipLaunchKernelGGL(k_sparse_masks, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_wire, (uint8_t *)d_sparse, L);
+    hipLaunchKernelGGL(k_sparse_scan, dim3(frames), dim3(1024), 0, (hipStream_t)stream, (uint8_t *)d_sparse, L);
+    hipLaunchKernelGGL(k_sparse_scatter, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_wire, (uint8_t *)d_sparse, L);
+    HIP_TRY(hipGetLastError());
+    return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_deinterleave_sparse_device(int device, const void *d_gathered, void *d_frame, uint32_t width,
+                                                 uint32_t height, uint32_t band_rows, uint32_t world,
+                                                 uint32_t rows_per_rank, const uint8_t *owner, uint32_t capacity,
+                                                 uint32_t frames, uint32_t *d_overflow, void *stream)
+{
+    if (frames == 0 || !d_gathered || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
+        return fail(SDFHIP_ERR_ARG, "deinterleave_sparse: null or zero argument");
+    if (band_rows % 8 != 0 || rows_per_rank % 8 != 0)
+        return fail(SDFHIP_ERR_ARG, "deinterleave_sparse: bands must be whole 8x8 tiles (band_rows %u, rows_per_rank %u)", band_rows, rows_per_rank);
+    const uint32_t nbands = (height + band_rows - 1) / band_rows;
+    BandMap M;
+    M.n = 0;
+    memset(M.src, 0, sizeof M.src);
+    uint32_t need_rows = ((nbands + world - 1) / world) * band_rows;
+    if (owner) {
+        if (nbands > (uint32_t)MAX_BAND_LIST || world > 64)
+            return fail(SDFHIP_ERR_ARG, "deinterleave_sparse: %u bands (max %d) over %u ranks (max 64)", nbands, MAX_BAND_LIST, world);
+        uint32_t have[64] = { 0 };
+        for (uint32_t b = 0; b < nbands; b++) {
+            if (owner[b] >= world) return fail(SDFHIP_ERR_ARG, "deinterleave_sparse: band %u belongs to rank %u of %u", b, (unsigned)owner[b], world);
+            M.src[b] = (uint16_t)((uint32_t)owner[b] << 10 | have[owner[b]]++);
+        }
+        M.n = nbands;
+        need_rows = 0;
+        for (uint32_t r = 0; r < world; r++) need_rows = have[r] * band_rows > need_rows ? have[r] * band_rows : need_rows;
+    }
+    if (rows_per_rank < need_rows)
+        return fail(SDFHIP_ERR_ARG, "deinterleave_sparse: rows_per_rank %u < %u needed", rows_per_rank, need_rows);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "deinterleave_sparse: hipSetDevice(%d) failed", device);
+    const SparseLayout L = sparse_layout(width, rows_per_rank, capacity);
+    size_t total = (size_t)width * height * frames;
+    uint32_t blocks = (uint32_t)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(k_deinterleave_sparse, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_gathered,
+                       (float4 *)d_frame, width, height, band_rows, world, frames, L, M, d_overflow);
+    HIP_TRY(hipGetLastError());
+    return SDFHIP_OK;
 }
 
 extern "C" int sdfhip_debug_unorm_table(int device, float *out256)

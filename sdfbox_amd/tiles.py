@@ -16,6 +16,13 @@ sky constant, so ranks render 5-byte *wire pixels* (FLAG_WIRE: per frame a plane
 of floats -- the bits of a -- followed by a plane of bytes -- the step count, or
 255 minus it for a sky pixel; `wire_shape`) and rank 0 expands them while restoring
 row order -- the assembled RGBA32F frame is bit for bit the single-GPU frame.
+
+Most of a wire float plane is zeros (sky and unlit pixels), so before the gather a
+rank may compact its shares into the *sparse* wire format (`wire_compact`: code
+bytes, per 8x8 tile a mask and a slot index, the non-zero floats packed; about
+1.2 bytes per pixel + 4 per lit pixel) and rank 0 expands that instead
+(`deinterleave_sparse`).  The capacity of the float array is fixed per run: choose
+it from a measured maximum (`sparse_count`), or rows * width to be safe.
 """
 import ctypes
 
@@ -137,3 +144,41 @@ def deinterleave(device, gathered_ptr, frame_ptr, width, layout, stream=None, pi
                                          ctypes.c_void_p(int(frame_ptr)), int(width),
                                          layout.height, layout.band_rows, layout.world,
                                          layout.rows_per_rank, int(pixel_bytes), int(frames), st))
+
+
+def sparse_share_bytes(rows, width, capacity):
+    """Bytes of one frame-share in the sparse wire format."""
+    return int(lib.sdfhip_wire_sparse_bytes(int(width), int(rows), int(capacity)))
+
+
+def wire_compact(device, wire_ptr, sparse_ptr, width, rows, frames, capacity, stream=None):
+    """[frames] dense wire shares (FLAG_WIRE renders) -> [frames] sparse shares, on `stream`."""
+    check(lib.sdfhip_wire_compact_device(int(device), ctypes.c_void_p(int(wire_ptr)), ctypes.c_void_p(int(sparse_ptr)),
+                                         int(width), int(rows), int(frames), int(capacity),
+                                         ctypes.c_void_p(int(stream)) if stream else None))
+
+
+def sparse_count(sparse_tensor, rows, width, capacity):
+    """Lit pixels (float slots needed) and overflow flag of every sparse share in a uint8 tensor
+    [..., sparse_share_bytes]: -> (counts, overflowed) as flat lists.  Synchronises."""
+    import torch
+    nbytes = sparse_share_bytes(rows, width, capacity)
+    tiles = ((width + 7) // 8) * ((rows + 7) // 8)
+    up = lambda v: (v + 15) & ~15
+    off_head = up(up(up(rows * width) + tiles * 8) + tiles * 4)
+    flat = sparse_tensor.reshape(-1, nbytes)
+    head = flat[:, off_head:off_head + 8].contiguous().cpu().view(torch.int32)
+    return head[:, 0].tolist(), head[:, 1].tolist()
+
+
+def deinterleave_sparse(device, gathered_ptr, frame_ptr, width, layout, capacity, stream=None, frames=1, overflow_ptr=None):
+    """Rank 0: gathered sparse shares (world x frames x sparse_share_bytes) -> frames x height x width
+    RGBA32F.  overflow_ptr: a device int32 that is OR-ed with 1 if a share had more lit pixels than
+    `capacity` (the frame is then incomplete)."""
+    owner = (ctypes.c_uint8 * layout.n_bands)(*layout.owner) if layout.weighted else None
+    check(lib.sdfhip_deinterleave_sparse_device(int(device), ctypes.c_void_p(int(gathered_ptr)),
+                                                ctypes.c_void_p(int(frame_ptr)), int(width), layout.height,
+                                                layout.band_rows, layout.world, layout.rows_per_rank, owner,
+                                                int(capacity), int(frames),
+                                                ctypes.c_void_p(int(overflow_ptr)) if overflow_ptr else None,
+                                                ctypes.c_void_p(int(stream)) if stream else None))

@@ -500,6 +500,62 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
             os.environ["SDFHIP_TOP_GRID_LEVEL"] = prev
 
 
+def test_sparse_wire_format_is_lossless_within_its_capacity(sb, gpu_scenes):
+    # dense wire shares compacted on the rendering side (codes + per-tile mask and slot index + packed
+    # non-zero floats), expanded by the rank-0 kernel: the same frame bit for bit; too small a
+    # capacity is reported, never silent
+    import torch
+    from sdfbox_amd.tiles import (BandLayout, deinterleave_sparse, render_bands_batch, sparse_count, sparse_share_bytes,
+                                  wire_compact, wire_shape)
+    stream = torch.cuda.current_stream().cuda_stream
+    scene = gpu_scenes["torus_d6"]
+    for (W, H, world, band_rows, w0) in [(160, 96, 1, 96, 1.0), (150, 90, 3, 16, 1.0), (97, 61, 4, 8, 0.6), (64, 200, 8, 8, 0.5)]:
+        lay = BandLayout(H, world, band_rows, w0)
+        R = lay.rows_per_rank
+        cams = [make_camera(n, W, H) for n in ("default", "rotated", "closeup")]
+        for i, v in enumerate((0.9, 0.1, 0.2)):
+            cams[1].State.light[i] = v
+        full = [torch.from_numpy(scene.Draw(c, W, H)).cuda() for c in cams]
+        dense = torch.zeros((world, 3) + wire_shape(R, W), dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            render_bands_batch(scene, cams, W, lay, r, dense[r].data_ptr(), flags=sb.FLAG_WIRE, stream=stream)
+        # generous capacity: every pixel could be lit
+        cap = R * W
+        nb = sparse_share_bytes(R, W, cap)
+        sparse = torch.zeros((world, 3, nb), dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            wire_compact(0, dense[r].data_ptr(), sparse[r].data_ptr(), W, R, 3, cap, stream=stream)
+        frames = torch.full((3, H, W, 4), -1.0, dtype=torch.float32, device="cuda")
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        deinterleave_sparse(0, sparse.data_ptr(), frames.data_ptr(), W, lay, cap, stream=stream, frames=3, overflow_ptr=flag.data_ptr())
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        for f in range(3):
+            assert torch.equal(frames[f].view(torch.int32), full[f].view(torch.int32)), (W, H, world, f)
+        counts, over = sparse_count(sparse, R, W, cap)
+        assert not any(over)
+        # the counts are the pixels whose grey level has any bit set
+        lit = sum(int((fr[..., 0].view(torch.int32) != 0).logical_and(fr[..., 0].view(torch.int32) == fr[..., 1].view(torch.int32)).sum())
+                  for fr in full)      # bitwise: a NaN grey is a lit pixel too
+        assert sum(counts) == lit, (sum(counts), lit)
+        # exactly enough capacity works, one slot less is flagged
+        tight = max(counts)
+        if tight > 1:
+            for capn, expect in ((tight, 0), (tight - 1, 1)):
+                nb2 = sparse_share_bytes(R, W, capn)
+                sp2 = torch.zeros((world, 3, nb2), dtype=torch.uint8, device="cuda")
+                for r in range(world):
+                    wire_compact(0, dense[r].data_ptr(), sp2[r].data_ptr(), W, R, 3, capn, stream=stream)
+                flag.zero_()
+                deinterleave_sparse(0, sp2.data_ptr(), frames.data_ptr(), W, lay, capn, stream=stream, frames=3, overflow_ptr=flag.data_ptr())
+                torch.cuda.synchronize()
+                assert int(flag.item()) == expect, (capn, tight)
+                if not expect:
+                    for f in range(3):
+                        assert torch.equal(frames[f].view(torch.int32), full[f].view(torch.int32))
+                    assert sparse_share_bytes(R, W, capn) < 5 * R * W or tight > R * W * 0.9
+
+
 def test_two_handles_render_concurrently(sb, oracle_mod, scenes):
     # upload / render are callable from several threads on different handles
     cam = make_camera("default", 128, 128)
