@@ -62,9 +62,10 @@ def parse():
     ap.add_argument("--rank0-weight", type=float, default=0.0,
                     help="sharded runs: rank 0's share of the frame as a fraction of a peer's share "
                          "(0 = measure at start-up so that render + assembly on rank 0 takes as long as a peer's render)")
-    ap.add_argument("--wire", type=int, default=1,
-                    help="sharded runs: 1 = ranks send 5-byte wire pixels and rank 0 expands them to the RGBA32F "
-                         "frame (lossless, 5/16 of the xGMI bytes); 0 = ranks send RGBA32F pixels")
+    ap.add_argument("--wire", type=int, default=2,
+                    help="sharded runs: what the ranks send.  2 = sparse wire shares (code bytes + the non-zero grey "
+                         "levels packed per 8x8 tile; capacity measured before the timed region), 1 = 5-byte wire "
+                         "pixels, 0 = RGBA32F pixels.  Rank 0 expands 1 and 2 to the same RGBA32F frame, bit for bit")
     return ap.parse_args()
 
 
@@ -87,7 +88,8 @@ def main():
     import torch.distributed as dist
 
     import sdfbox_amd as sb
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch, wire_shape
+    from sdfbox_amd.tiles import (BandLayout, deinterleave, deinterleave_sparse, render_bands, render_bands_batch, sparse_count,
+                                  sparse_share_bytes, wire_compact, wire_shape)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
@@ -129,7 +131,8 @@ def main():
     pt = sb.PathTrace(spp=args.spp) if args.spp > 0 else None
     # what travels in the gather: the frame's own pixels, or 5-byte wire pixels that rank 0 expands
     # to the RGBA32F frame while it restores row order (lossless; sdfbox_amd/tiles.py)
-    wire = sharded and args.wire == 1 and not args.display and pt is None and not compact
+    wire = sharded and args.wire >= 1 and not args.display and pt is None and not compact
+    sparse = wire and args.wire == 2       # ... compacted before the gather: most of the float plane is zeros (sky)
     wpx_dtype, wpx_bytes = (torch.uint8, 5) if wire else (px_dtype, px_bytes)
 
     def share_shape(rows):                 # one frame-share of `rows` rows as it is rendered and gathered
@@ -142,7 +145,8 @@ def main():
     # sharded: G frames share one launch (grid.y = frame) and one gather; nbuf groups are in
     # flight (so G*nbuf frames).  A rank's share is mostly the serial tail of its longest
     # pixels: G frames in one grid share that tail
-    G = (args.gather_every if args.gather_every > 0 else 4) if sharded else 1
+    # (8 at 8 ranks: the shares are small there, and a group costs ~60 us of host time: launch, collective, wait)
+    G = (args.gather_every if args.gather_every > 0 else (8 if world >= 8 else 4)) if sharded else 1
     if pt is not None or compact:
         G = 1 if not sharded else G            # those kernels render one frame per launch
     # in flight: 2 frames on one GPU; 4 groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4
@@ -163,10 +167,34 @@ def main():
     rows_local = layout.rows_per_rank if sharded else H
     local = [torch.zeros((G,) + share_shape(rows_local), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
     gathered = frame = None
+    send = local                                    # what the gather carries
+    cap = 0
+    overflow = torch.zeros(1, dtype=torch.int32, device="cuda")
+    if sparse:
+        # capacity of the packed float array: this rank's lit pixels per frame-share, the maximum over the
+        # ranks (a control-plane all-reduce before anything is timed), plus a quarter
+        full_cap = rows_local * W
+        probe = torch.zeros((G, sparse_share_bytes(rows_local, W, full_cap)), dtype=torch.uint8, device="cuda")
+        render_bands_batch(scene, [cam] * G, W, layout, rank, local[0].data_ptr(), flags=flags, stream=main)
+        wire_compact(device, local[0].data_ptr(), probe.data_ptr(), W, rows_local, G, full_cap, stream=main)
+        counts, _ = sparse_count(probe, rows_local, W, full_cap)
+        need = torch.tensor([max(counts)], dtype=torch.int64, device="cuda" if nccl else "cpu")
+        if world > 1:
+            dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        cap = min(full_cap, (int(need.item()) * 5 // 4 + 1023) // 1024 * 1024)
+        del probe
+        send = [torch.zeros((G, sparse_share_bytes(rows_local, W, cap)), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     if sharded and rank == 0:
-        gathered = [torch.zeros((world, G) + share_shape(layout.rows_per_rank), dtype=wpx_dtype, device="cuda")
-                    for _ in range(nbuf)]
+        gathered = [torch.zeros((world,) + tuple(send[0].shape), dtype=send[0].dtype, device="cuda") for _ in range(nbuf)]
         frame = [torch.zeros((G, H, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
+
+    def assemble(slot, st):
+        if sparse:
+            deinterleave_sparse(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, cap, stream=st,
+                                frames=G, overflow_ptr=overflow.data_ptr())
+        else:
+            deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=st,
+                         pixel_bytes=wpx_bytes, frames=G)
 
     def render(buf, st, stats=None, fl=None):
         f = flags if fl is None else fl
@@ -192,12 +220,10 @@ def main():
             with torch.cuda.stream(streams[slot]):
                 w.wait()                              # the group's stream waits for its gather
                 if rank == 0:
-                    deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout,
-                                 stream=streams[slot].cuda_stream, pixel_bytes=wpx_bytes, frames=G)
+                    assemble(slot, streams[slot].cuda_stream)
         elif rank == 0:                               # gloo rehearsal: through host buffers
             gathered[slot].copy_(torch.stack(w).cuda())
-            deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=main,
-                         pixel_bytes=wpx_bytes, frames=G)
+            assemble(slot, main)
 
     def step(k, timed=False, last=False):
         group, within = divmod(k, G)
@@ -227,14 +253,16 @@ def main():
                 ev.append((e0, e1, 1))
         if not sharded or not group_ends:
             return
+        if sparse:                                    # three small launches behind the render, on its stream
+            wire_compact(device, local[slot].data_ptr(), send[slot].data_ptr(), W, rows_local, G, cap, stream=s.cuda_stream)
         # one collective for the whole group (a partial last group is gathered whole, too)
         if nccl:
             glist = list(gathered[slot].unbind(0)) if rank == 0 else None
             with torch.cuda.stream(s):                # the collective orders itself behind this stream's renders
-                pending[slot] = dist.gather(local[slot], glist, dst=0, async_op=True)
+                pending[slot] = dist.gather(send[slot], glist, dst=0, async_op=True)
         else:
             s.synchronize()
-            host = local[slot].cpu()
+            host = send[slot].cpu()
             glist = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
             dist.gather(host, glist, dst=0)
             pending[slot] = glist if rank == 0 else True
@@ -294,6 +322,8 @@ def main():
                   for w in range(G) if g * G + w < args.steps]
         check_ok = all(bool(torch.equal(frame[sl][w].view(torch.int32), ref.view(torch.int32))) for sl, w in filled)
 
+    if rank == 0 and sparse and int(overflow.item()):
+        raise SystemExit("bench.py: a sparse wire share overflowed its capacity: the assembled frames are incomplete")
     if rank == 0:
         sec_per_step = elapsed / args.steps
         peak = 8000.0                                  # GB/s, HBM3E spec (MI355X_MICROARCH.md)
@@ -325,7 +355,8 @@ def main():
                                f" + gather to rank 0 ({args.backend})",
                 "frames_in_flight": nbuf * G,
                 "frames_per_gather": G if sharded else None,
-                "gather_pixel_bytes": wpx_bytes if sharded else None,
+                "gather_pixel_bytes": (round(send[0].shape[1] / (rows_local * W), 3) if sparse else wpx_bytes) if sharded else None,
+                "gather_format": ("sparse wire" if sparse else "wire" if wire else "frame pixels") if sharded else None,
                 "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
                 "gstep_per_s": round(float(counters[2]) / sec_per_step / 1e9, 3),
                 "shadow_rays_per_frame": int(counters[3]),
