@@ -158,7 +158,7 @@ def main():
     w0 = args.rank0_weight if world > 1 else 1.0
     if sharded and world > 1 and w0 <= 0:
         w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, share_shape, wpx_dtype, wpx_bytes,
-                                  rank, nccl, pt, compact, G, nbuf)
+                                  rank, nccl, pt, compact, G, nbuf, sparse)
     if (H + args.band_rows - 1) // args.band_rows > 512 or w0 > 0.98:
         w0 = 1.0
     layout = BandLayout(H, world, args.band_rows, w0)
@@ -389,7 +389,7 @@ def main():
 
 
 def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_shape, wpx_dtype, wpx_bytes, rank, nccl, pt, compact,
-                         G, nbuf):
+                         G, nbuf, sparse):
     """Rank 0 also assembles the frame (de-interleave and wire expansion of all ranks' rows), so an
     even deal makes it the slowest rank.  Before anything is timed, rank 0 tries layouts that give it
     0.3 .. 1.0 of a peer's share: for each it times its own work (render + assembly) and the largest
@@ -397,7 +397,7 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
     receives the weight with the smallest max of the two."""
     import torch
     import torch.distributed as dist
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch
+    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch, sparse_share_bytes, wire_compact
     w = torch.ones(1, dtype=torch.float64)
     if rank == 0:
         streams = [torch.cuda.Stream() for _ in range(nbuf)]
@@ -405,7 +405,7 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
         frame = torch.zeros((G, H, W) + full_shape, dtype=full_dtype, device="cuda")
         n = 3 if pt is not None else 16
 
-        def work(lay, r, local, gathered):
+        def work(lay, r, local, gathered, packed):
             def one(k):
                 s = streams[k % nbuf].cuda_stream
                 if pt is None and not compact:
@@ -413,7 +413,10 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
                 else:
                     for f in range(G):
                         render_bands(scene, cam, W, lay, r, local[k % nbuf][f].data_ptr(), flags=flags, stream=s, pt=pt)
-                if r == 0:
+                if sparse:           # every rank compacts its shares (the capacity does not change the cost)
+                    wire_compact(torch.cuda.current_device(), local[k % nbuf].data_ptr(), packed.data_ptr(), W, lay.rows_per_rank, G,
+                                 lay.rows_per_rank * W // 4, stream=s)
+                if r == 0:           # (assembling dense wire shares costs the same as assembling sparse ones)
                     deinterleave(torch.cuda.current_device(), gathered.data_ptr(), frame.data_ptr(), W, lay,
                                  stream=s, pixel_bytes=wpx_bytes, frames=G)
             best = 1e9
@@ -431,9 +434,11 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
             lay = BandLayout(H, world, band_rows, cand)
             local = [torch.zeros((G,) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
             gathered = torch.zeros((world, G) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda")
-            t0, t1 = work(lay, 0, local, gathered), work(lay, 1, local, gathered)
+            packed = torch.zeros(G * sparse_share_bytes(lay.rows_per_rank, W, lay.rows_per_rank * W // 4) if sparse else 1,
+                                 dtype=torch.uint8, device="cuda")
+            t0, t1 = work(lay, 0, local, gathered, packed), work(lay, 1, local, gathered, packed)
             tried.append((max(t0, t1), cand, t0, t1))
-            del local, gathered
+            del local, gathered, packed
             if t0 <= t1:                               # rank 0 is no longer the slowest: a smaller share only loads the peers
                 break
         _, best, t0, t1 = min(tried)
