@@ -556,6 +556,43 @@ def test_sparse_wire_format_is_lossless_within_its_capacity(sb, gpu_scenes):
                     assert sparse_share_bytes(R, W, capn) < 5 * R * W or tight > R * W * 0.9
 
 
+def test_sparse_wire_format_on_random_shares(sb):
+    # the format itself, fed with arbitrary wire shares (any float bit pattern: NaNs, -0.0, denormals;
+    # any legal code byte; ragged widths): expanding the sparse form equals expanding the dense form
+    import torch
+    from sdfbox_amd.tiles import BandLayout, deinterleave, deinterleave_sparse, sparse_count, sparse_share_bytes, wire_compact, wire_shape
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for (W, H, world, band_rows, frames, p_lit) in [(61, 40, 1, 8, 2, 0.3), (200, 64, 2, 16, 3, 0.05), (33, 96, 4, 8, 1, 0.9), (128, 24, 3, 8, 2, 0.0)]:
+        lay = BandLayout(H, world, band_rows)
+        R = lay.rows_per_rank
+        n = world * frames * R * W
+        bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64).to(torch.int32)
+        bits[torch.rand(n, generator=g) >= p_lit] = 0
+        bits[:7] = torch.tensor([0x7FC00000, -0x400000, -2 ** 31, 1, 0x7F800000, 0, 0x00800000][:7], dtype=torch.int64).to(torch.int32)[:min(7, n)]
+        codes = torch.randint(0, 141, (n,), generator=g, dtype=torch.int64)
+        sky = torch.rand(n, generator=g) < 0.4
+        codes[sky] = 255 - torch.randint(0, 101, (int(sky.sum()),), generator=g, dtype=torch.int64)
+        dense = torch.zeros((world, frames) + wire_shape(R, W), dtype=torch.uint8)
+        dense[:, :, :4] = bits.view(world, frames, R * W).view(torch.uint8).reshape(world, frames, 4, R, W)
+        dense[:, :, 4] = codes.to(torch.uint8).view(world, frames, R, W)
+        dense = dense.cuda()
+        want = torch.zeros((frames, H, W, 4), dtype=torch.float32, device="cuda")
+        deinterleave(0, dense.data_ptr(), want.data_ptr(), W, lay, stream=stream, pixel_bytes=5, frames=frames)
+        cap = R * W
+        sparse = torch.zeros((world, frames, sparse_share_bytes(R, W, cap)), dtype=torch.uint8, device="cuda")
+        for r in range(world):
+            wire_compact(0, dense[r].data_ptr(), sparse[r].data_ptr(), W, R, frames, cap, stream=stream)
+        got = torch.full((frames, H, W, 4), -1.0, dtype=torch.float32, device="cuda")
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        deinterleave_sparse(0, sparse.data_ptr(), got.data_ptr(), W, lay, cap, stream=stream, frames=frames, overflow_ptr=flag.data_ptr())
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (W, H, world)
+        counts, _ = sparse_count(sparse, R, W, cap)
+        assert sum(counts) == int((bits != 0).sum())
+
+
 def test_two_handles_render_concurrently(sb, oracle_mod, scenes):
     # upload / render are callable from several threads on different handles
     cam = make_camera("default", 128, 128)
