@@ -1,4 +1,5 @@
 #!/bin/bash
+# PMC passes of the path-traced kernel (1080p, 4 spp): HBM traffic, cache hit rates, waits, lane utilisation
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/pmc_path; mkdir -p $OUT; export TMPDIR=/tmp; cd $ROOT
 A="--spp 4 --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/p1 -- python3 bench.py $A > $OUT/p1.json 2> $OUT/p1.err

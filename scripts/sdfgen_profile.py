@@ -1,3 +1,4 @@
+"""Dev script: one GPU SdfGen build of the 200 k-point sphere at depth 8, for rocprofv3 (profiles/r01_sdfgen_d8_kernel_stats.csv)."""
 import sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import sdfbox_amd as sb
