@@ -746,3 +746,10 @@ def test_fuzz_random_trees_and_on_grid_cameras(sb, oracle_mod, seed):
                 assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), (seed, ci, variant)
                 # the kernels that do not count are separate instances (and the timed ones)
                 assert_frames_identical(sc.Draw(cam, W, H, flags_of(sb, variant)), ref, f"seed {seed} cam {ci} {variant}, not counting")
+            if ci == 0:      # the path-traced mode on the same tree (both find() forms)
+                pref, pcnt = oracle_mod.render_pt(s, v, cam.State, W, H, spp=2, nthreads=8)
+                for kern in (sb.KERNEL_STACK, sb.KERNEL_GENERIC):
+                    pimg, pst = sc.DrawPath(cam, W, H, pt=sb.PathTrace(spp=2), flags=kern | sb.FLAG_COUNT, want_stats=True)
+                    assert_frames_identical(pimg, pref, f"seed {seed} path-traced, kernel {kern}")
+                    assert (pst.n_nodes, pst.n_samples, pst.n_steps, pst.n_shadow_rays) == tuple(int(c) for c in pcnt), (seed, kern)
+                    assert_frames_identical(sc.DrawPath(cam, W, H, pt=sb.PathTrace(spp=2), flags=kern), pref, f"seed {seed} path-traced, not counting")
