@@ -156,3 +156,19 @@ def test_two_rank_gather_reassembles_the_frame(world, H, band_rows, rank0_weight
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_sparse_share_size_arithmetic():
+    # the byte layout of a sparse wire share (codes, per-tile masks and slot indices, header, floats), from the
+    # host side of the library: sizes are 16-byte multiples, grow by 4 bytes per slot, and beat the dense 5 bytes
+    # per pixel whenever at most ~90 % of the pixels are lit
+    from sdfbox_amd.tiles import sparse_share_bytes
+    for rows, W in [(8, 8), (16, 61), (144, 1920), (1088, 3840)]:
+        tiles = ((W + 7) // 8) * (rows // 8)
+        up = lambda v: (v + 15) & ~15
+        for cap in (0, 1, 1000, rows * W // 4, rows * W):
+            nb = sparse_share_bytes(rows, W, cap)
+            want = up(up(up(up(rows * W) + tiles * 8) + tiles * 4) + 16 + cap * 4)
+            assert nb == want and nb % 16 == 0, (rows, W, cap, nb, want)
+        assert sparse_share_bytes(rows, W, rows * W // 4) < 5 * rows * W / 2 or rows * W < 1024
+        assert sparse_share_bytes(rows, W, int(rows * W * 0.9)) < 5 * rows * W + 64
