@@ -44,6 +44,8 @@ constexpr int MAX_BATCH = 8;   // frames one k_plain launch can render (grid.y)
 constexpr int MAX_BAND_LIST = 512;   // bands one launch can be handed as an explicit list
 
 struct TopCell { uint32_t level, v0, v1; int32_t children; };   // a cell of the top grid, see below (cursor-stack kernels)
+// the grid as find() sees it: dense cells of level `level`; for a split grid, blocks of 8^fine_bits finer cells
+struct GridRef { const TopCell *top; const TopCell *fine; int level; int fine_bits; };
 
 // Kernel parameters: scene, frame geometry, and the camera block of every frame of the launch.
 struct RenderParams {
@@ -51,6 +53,10 @@ struct RenderParams {
     uint32_t n_nodes;
     const TopCell *top;        // top grid (cursor-stack kernels) of level top_level, or null
     int32_t top_level;
+    // split grid (CUR_STACK_SPLIT kernels): a cell of `top` whose node is internal has level 15 and names,
+    // in `children`, a block of `fine`: the 8^fine_bits cells of the next fine_bits levels below it
+    int32_t fine_bits;
+    const TopCell *fine;
     float4 *out;               // compact rows: nrows_out x width
     uint32_t width, height;    // full frame
     uint32_t band_rows, band_first, band_stride, nrows_out;
@@ -182,7 +188,7 @@ __device__ __forceinline__ int descend_box(CursorG &c, float px, float py, float
 // through memory exactly as the shader does (the entry read of data[index] is
 // served from the registers that already hold that record).  Returns the number
 // of node records the *reference* reads in this call.
-__device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__ nodes, const void *, int,
+__device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__ nodes, const GridRef &,
                                          uint32_t n_nodes, int32_t *, uint32_t, float px, float py, float pz, Unscaled &)
 {
     uint32_t reads = 1;
@@ -390,7 +396,10 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
 // EXACT: the kernel reports the algorithmic read count, so a NaN coordinate must behave exactly as in
 // find_s (it matches no cell: ascents up to the root).  Without it NaN converts to 0 and the find
 // lands in the same leaf -- the cell at the origin -- without the clamp instructions.
-template <bool EXACT>
+// SPLIT: the grid is a coarse dense level whose internal cells point at blocks of finer cells (one more
+// dependent load for the positions near the surface, a fraction of the memory of a dense grid of the
+// tree's depth: the form for trees of depth 10-12).
+template <bool EXACT, bool SPLIT>
 struct CursorFT {
     typedef Scaled Pos;
     static constexpr int32_t ROOT_MARK = 0x40000000;
@@ -418,8 +427,8 @@ struct CursorFT {
 // wave-uniform) -- which of the two adjacent cells does the reference's descent pick (the same A/B
 // rule as find_s).  The ascent count k feeds the algorithmic read count only.  One place updates the
 // cursor, so the two branches join on D and k, not on the cursor.
-template <bool EXACT>
-__device__ __forceinline__ uint32_t find_full(CursorFT<EXACT> &c, const TopCell *__restrict__ top, const int TG,
+template <bool EXACT, bool SPLIT>
+__device__ __forceinline__ uint32_t find_full(CursorFT<EXACT, SPLIT> &c, const GridRef &g,
                                               int32_t Dx, int32_t Dy, int32_t Dz, bool gx, bool gy, bool gz,
                                               const bool any_on_grid)
 {
@@ -449,8 +458,19 @@ __device__ __forceinline__ uint32_t find_full(CursorFT<EXACT> &c, const TopCell 
     uint32_t reads = 1u;
     if (moved) {
         Dx = min(max(Dx, 0), 4095); Dy = min(max(Dy, 0), 4095); Dz = min(max(Dz, 0), 4095);
-        const int sh = LM - TG;
-        const uint4 e = reinterpret_cast<const uint4 *>(top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
+        const int TG = g.level, sh = LM - TG;
+        uint4 e = reinterpret_cast<const uint4 *>(g.top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
+        if (SPLIT) {
+            // one 16-byte load for the whole cell (left alone, the compiler fetches level and children first
+            // and the values in a second, dependent load)
+            asm volatile("" : "+v"(e.y), "+v"(e.z), "+v"(e.w));
+            if (e.x == 15u) {                         // internal at the coarse level: its block of fine cells
+                const int FB = g.fine_bits, sh2 = sh - FB;
+                const uint32_t m = (1u << FB) - 1u;
+                const uint32_t local = (((uint32_t)Dx >> sh2) & m) | ((((uint32_t)Dy >> sh2) & m) << FB) | ((((uint32_t)Dz >> sh2) & m) << (2 * FB));
+                e = reinterpret_cast<const uint4 *>(g.fine)[((size_t)e.w << (3 * FB)) + local];
+            }
+        }
         const int ns = (int)e.x;                      // LM - level of the leaf
         reads = 1u + (uint32_t)k + (uint32_t)((LM - ns) - (level - k));
         c.s = ns;
@@ -469,9 +489,9 @@ __device__ __forceinline__ int32_t axis_a_raw(float p, float &u, float &f)
     f = floorf(u);
     return (int32_t)f;
 }
-template <bool EXACT>
-__device__ __forceinline__ uint32_t find(CursorFT<EXACT> &c, const NodeRec *__restrict__, const TopCell *__restrict__ top,
-                                         int TG, uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
+template <bool EXACT, bool SPLIT>
+__device__ __forceinline__ uint32_t find(CursorFT<EXACT, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
+                                         uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
                                          Scaled &u)
 {
     float fx, fy, fz;
@@ -479,10 +499,10 @@ __device__ __forceinline__ uint32_t find(CursorFT<EXACT> &c, const NodeRec *__re
     if (EXACT) { Ax = axis_a(px, u.x, fx); Ay = axis_a(py, u.y, fy); Az = axis_a(pz, u.z, fz); }
     else { Ax = axis_a_raw(px, u.x, fx); Ay = axis_a_raw(py, u.y, fy); Az = axis_a_raw(pz, u.z, fz); }
     const bool gx = u.x == fx, gy = u.y == fy, gz = u.z == fz;    // on the 2^-LM grid (false for NaN)
-    return find_full(c, top, TG, Ax, Ay, Az, gx, gy, gz, __ballot(gx || gy || gz) != 0ull);
+    return find_full(c, g, Ax, Ay, Az, gx, gy, gz, __ballot(gx || gy || gz) != 0ull);
 }
-template <bool EXACT>
-__device__ __forceinline__ float sample_after_find(const CursorFT<EXACT> &c, const Scaled &u, float, float, float)
+template <bool EXACT, bool SPLIT>
+__device__ __forceinline__ float sample_after_find(const CursorFT<EXACT, SPLIT> &c, const Scaled &u, float, float, float)
 {
     const int32_t scale_bits = (c.s + (127 - LM)) << 23;                       // 2^-level = 2^(s - LM)
     const float scale = __int_as_float(scale_bits);
@@ -499,10 +519,12 @@ __device__ __forceinline__ float sample_after_find(const CursorFT<EXACT> &c, con
     return (lerp(loadL, loadH, dz) - 0.25f) * scale * 2.0f;
 }
 
-__device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, const TopCell *__restrict__ top,
-                                         int TG, uint32_t, int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz,
+__device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, const GridRef &g,
+                                         uint32_t, int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz,
                                          Scaled &u)
 {
+    const TopCell *__restrict__ top = g.top;
+    const int TG = g.level;
     float ux, uy, uz, fx, fy, fz;
     const int32_t Ax = axis_a(px, ux, fx), Ay = axis_a(py, uy, fy), Az = axis_a(pz, uz, fz);
     const bool gx = ux == fx, gy = uy == fy, gz = uz == fz;    // on the 2^-LM grid (false for NaN)

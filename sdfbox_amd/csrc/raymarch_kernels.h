@@ -34,10 +34,11 @@ constexpr int MAX_STACK = LM;          // the shader's own descent limit (Comput
 #endif
 
 // cursor kinds of the kernels: generic, cursor stack, cursor stack with a top grid as deep as the tree
-enum { CUR_GENERIC = 0, CUR_STACK = 1, CUR_STACK_FULL = 2 };
+enum { CUR_GENERIC = 0, CUR_STACK = 1, CUR_STACK_FULL = 2, CUR_STACK_SPLIT = 3 };
 template <int CUR, bool COUNT> struct CursorOf { typedef CursorG type; };
 template <bool COUNT> struct CursorOf<CUR_STACK, COUNT> { typedef CursorS type; };
-template <bool COUNT> struct CursorOf<CUR_STACK_FULL, COUNT> { typedef CursorFT<COUNT> type; };
+template <bool COUNT> struct CursorOf<CUR_STACK_FULL, COUNT> { typedef CursorFT<COUNT, false> type; };
+template <bool COUNT> struct CursorOf<CUR_STACK_SPLIT, COUNT> { typedef CursorFT<COUNT, true> type; };
 
 // lane states: marching (primary / shadow), march over and shading pending, no pixel
 enum { PH_PRIMARY = 0, PH_SHADOW = 1, PH_SHADE = 2, PH_IDLE = 3, PH_DONE = 4 };   // DONE: idle, colour waiting in LDS
@@ -236,7 +237,7 @@ __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const Fram
                                                int32_t *stack, uint32_t stride)
 {
     typename CursorT::Pos u;
-    uint32_t reads = find(c, P.nodes, P.top, P.top_level, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
+    uint32_t reads = find(c, P.nodes, GridRef{P.top, P.fine, P.top_level, P.fine_bits}, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
     r.prox = sample_after_find(c, u, r.px, r.py, r.pz);
     float step = r.phase ? r.prox + I.margin : r.prox;
     r.px = __builtin_fmaf(r.dx, step, r.px);
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
             }
             // ---- one march step of the segment or of the shadow ray -----------------------
             typename CursorT::Pos u;
-            uint32_t reads = find(c, P.nodes, P.top, P.top_level, P.n_nodes, stack, 64, mx, my, mz, u);
+            uint32_t reads = find(c, P.nodes, GridRef{P.top, P.fine, P.top_level, P.fine_bits}, P.n_nodes, stack, 64, mx, my, mz, u);
             prox = sample_after_find(c, u, mx, my, mz);
             if (COUNT) { cn += reads; cs += 1; }
             const float st = shadow ? prox + margin : prox;

@@ -35,22 +35,49 @@ __global__ void k_fuse(const int2 *__restrict__ structs, const uint2 *__restrict
 
 // The top grid of the cursor-stack kernels (raymarch_device.h): one thread per level-TG cell walks
 // from the root by the cell's octant bits and stores the record it ends at.
+// full = 0: cells hold the level (CursorS); 1: LM - level (CursorF, grid as deep as the tree); 2: like 1, but a
+// cell whose node is still internal holds level 15 and the node's index: the coarse half of a split grid
 __global__ void k_top_grid(const NodeRec *__restrict__ nodes, TopCell *__restrict__ top, int TG, int full)
 {
     const uint32_t total = 1u << (3 * TG), mask = (1u << TG) - 1u;
     for (uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x; cell < total; cell += gridDim.x * blockDim.x) {
         const uint32_t cx = cell & mask, cy = (cell >> TG) & mask, cz = cell >> (2 * TG);
         NodeRec r = nodes[0];
-        uint32_t level = 0;
+        uint32_t level = 0, index = 0;
         while (level < (uint32_t)TG && (int32_t)r.y >= 0) {
             const uint32_t sb = (uint32_t)TG - 1u - level;
-            r = nodes[r.y + ((cx >> sb & 1u) | ((cy >> sb & 1u) << 1) | ((cz >> sb & 1u) << 2))];
+            index = r.y + ((cx >> sb & 1u) | ((cy >> sb & 1u) << 1) | ((cz >> sb & 1u) << 2));
+            r = nodes[index];
             level++;
         }
         TopCell t;
-        // a grid as deep as the tree serves CursorF, which wants LM - level in the top bits
+        // a grid as deep as the tree serves CursorF, which wants LM - level
         t.level = full ? (uint32_t)LM - level : level; t.v0 = r.z; t.v1 = r.w; t.children = (int32_t)r.y;
+        if (full == 2 && (int32_t)r.y >= 0) { t.level = 15u; t.children = (int32_t)index; }
         top[top_index(cx, cy, cz, TG)] = t;
+    }
+}
+
+// The fine half of a split grid: block b holds the 8^FB cells below the internal node block_node[b] of level TG,
+// each the leaf that contains it (LM - level, values), in x-y-z order.
+__global__ void k_fine_blocks(const NodeRec *__restrict__ nodes, const uint32_t *__restrict__ block_node,
+                              TopCell *__restrict__ fine, uint32_t n_blocks, int TG, int FB)
+{
+    const size_t total = (size_t)n_blocks << (3 * FB);
+    const uint32_t mask = (1u << FB) - 1u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)(i >> (3 * FB)), local = (uint32_t)i & ((1u << (3 * FB)) - 1u);
+        const uint32_t cx = local & mask, cy = (local >> FB) & mask, cz = local >> (2 * FB);
+        NodeRec r = nodes[block_node[b]];
+        uint32_t level = (uint32_t)TG, down = 0;
+        while (down < (uint32_t)FB && (int32_t)r.y >= 0) {
+            const uint32_t sb = (uint32_t)FB - 1u - down;
+            r = nodes[r.y + ((cx >> sb & 1u) | ((cy >> sb & 1u) << 1) | ((cz >> sb & 1u) << 2))];
+            down++; level++;
+        }
+        TopCell t;
+        t.level = (uint32_t)LM - level; t.v0 = r.z; t.v1 = r.w; t.children = -1;
+        fine[i] = t;
     }
 }
 
@@ -230,6 +257,9 @@ struct sdfhip_scene {
     hipStream_t stream;
     TopCell *d_top;                  // top grid of the cursor-stack kernels (raymarch_device.h), or null
     int top_level;
+    TopCell *d_fine;                 // split grid: blocks of fine cells below the internal cells of d_top, or null
+    int fine_bits;
+    uint64_t fine_bytes;
     unsigned long long *d_counters;  // 4 x u64: nodes, samples, steps, shadow rays
     uint32_t *d_queue;
     float4 *d_frame;        // grown on demand by sdfhip_render
@@ -277,6 +307,7 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
         if (s->alloc) (void)hipFree(s->alloc);
         if (s->d_counters) (void)hipFree(s->d_counters);
         if (s->d_top) (void)hipFree(s->d_top);
+        if (s->d_fine) (void)hipFree(s->d_fine);
         if (s->d_queue) (void)hipFree(s->d_queue);
         if (s->d_frame) (void)hipFree(s->d_frame);
         if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -313,7 +344,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if (!s) return fail(SDFHIP_ERR_NOMEM, "scene_upload: out of host memory");
     s->device = device; s->n = n; s->depth = depth;
     s->stack_ok = (consistent && depth <= (uint32_t)MAX_STACK) ? 1 : 0;
-    s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr; s->d_top = nullptr; s->top_level = 0;
+    s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0;
     s->d_queue = nullptr; s->d_frame = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
     s->cu_count = prop.multiProcessorCount;
 
@@ -359,7 +390,69 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
         const int v = atoi(env);
         if (v >= 0 && v <= 10) top_level = v < (int)depth ? v : (int)depth;
     }
-    if (s->stack_ok && top_level > 0) {
+    // Split grid for trees too deep for a dense grid of their depth (10-12 levels): a dense coarse level C whose
+    // internal cells point at dense blocks of the remaining FB = depth - C levels.  Every leaf is one or two
+    // loads away (CursorF kernels), the coarse level stays cache-resident, and the blocks exist only where the
+    // tree is deep.  Taken when the blocks fit 1/16 of the device's memory; SDFHIP_TOP_GRID_SPLIT=C forces a
+    // coarse level (0 = never).
+    int split = 0;
+    if ((uint32_t)top_level < depth && depth <= (uint32_t)LM) {
+        // coarse level: as deep as 8, no larger than the tree's own records, leaving at most 4 levels to the blocks
+        const size_t budget = (size_t)n * 16 > ((size_t)1 << 16) ? (size_t)n * 16 : ((size_t)1 << 16);
+        int C = 0;
+        while (C < MAX_TOP_LEVEL && C + 1 < (int)depth && (sizeof(TopCell) << (3 * (C + 1))) <= budget) C++;
+        if (C >= 1 && (int)depth - C <= 4) split = C;
+    }
+    if (const char *env = getenv("SDFHIP_TOP_GRID_SPLIT")) {
+        const int v = atoi(env);
+        split = (v >= 1 && v < (int)depth && (int)depth - v <= 6 && v <= 8) ? v : 0;
+    }
+    if (getenv("SDFHIP_TOP_GRID_LEVEL")) split = getenv("SDFHIP_TOP_GRID_SPLIT") ? split : 0;   // an explicit level means a plain grid
+    bool split_built = false;
+    if (s->stack_ok && split > 0) {
+        const int C = split, FB = (int)depth - split;
+        const size_t ncell = (size_t)1 << (3 * C);
+        std::vector<TopCell> coarse(ncell);
+        uint32_t *d_block_node = nullptr;
+        TopCell *d_coarse = nullptr, *d_fine = nullptr;
+        do {
+            if (hipMalloc((void **)&d_coarse, ncell * sizeof(TopCell)) != hipSuccess) break;
+            const uint32_t tb = (uint32_t)((ncell + 255) / 256 < 8192 ? (ncell + 255) / 256 : 8192);
+            hipLaunchKernelGGL(k_top_grid, dim3(tb), dim3(256), 0, s->stream, s->nodes, d_coarse, C, 2);
+            if (hipMemcpyAsync(coarse.data(), d_coarse, ncell * sizeof(TopCell), hipMemcpyDeviceToHost, s->stream) != hipSuccess) break;
+            if (hipStreamSynchronize(s->stream) != hipSuccess) break;
+            // number the internal cells in cell order on the host (deterministic) and point them at their blocks
+            std::vector<uint32_t> block_node;
+            for (size_t i = 0; i < ncell; i++)
+                if (coarse[i].level == 15u) {
+                    block_node.push_back((uint32_t)coarse[i].children);
+                    coarse[i].children = (int32_t)(block_node.size() - 1);
+                }
+            const size_t nblocks = block_node.size();
+            const uint64_t fine_bytes = (uint64_t)(nblocks << (3 * FB)) * sizeof(TopCell);
+            if (fine_bytes > prop.totalGlobalMem / 16) break;                       // too much: a plain grid below
+            if (nblocks) {
+                if (hipMalloc((void **)&d_fine, fine_bytes) != hipSuccess) break;
+                if (hipMalloc((void **)&d_block_node, nblocks * 4) != hipSuccess) break;
+                if (hipMemcpyAsync(d_block_node, block_node.data(), nblocks * 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) break;
+                if (hipMemcpyAsync(d_coarse, coarse.data(), ncell * sizeof(TopCell), hipMemcpyHostToDevice, s->stream) != hipSuccess) break;
+                const size_t nfine = nblocks << (3 * FB);
+                const uint32_t fb = (uint32_t)((nfine + 255) / 256 < 16384 ? (nfine + 255) / 256 : 16384);
+                hipLaunchKernelGGL(k_fine_blocks, dim3(fb), dim3(256), 0, s->stream, s->nodes, d_block_node, d_fine,
+                                   (uint32_t)nblocks, C, FB);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) break;
+            }
+            s->d_top = d_coarse; d_coarse = nullptr;
+            s->d_fine = d_fine; d_fine = nullptr;
+            s->top_level = C; s->fine_bits = FB; s->fine_bytes = nblocks ? fine_bytes : 0;
+            split_built = true;
+        } while (false);
+        (void)hipGetLastError();
+        if (d_block_node) (void)hipFree(d_block_node);
+        if (d_coarse) (void)hipFree(d_coarse);
+        if (d_fine) (void)hipFree(d_fine);
+    }
+    if (s->stack_ok && top_level > 0 && !split_built) {
         // the grid is an accelerator, not part of the scene: without memory for it, shrink it
         while (top_level > 0 && hipMalloc((void **)&s->d_top, sizeof(TopCell) << (3 * top_level)) != hipSuccess) {
             (void)hipGetLastError();
@@ -386,7 +479,7 @@ extern "C" int sdfhip_scene_top_grid(const sdfhip_scene *s, int32_t *level, uint
 {
     if (!s) return fail(SDFHIP_ERR_ARG, "scene_top_grid: null scene");
     if (level) *level = s->d_top ? s->top_level : 0;
-    if (bytes) *bytes = s->d_top ? (uint64_t)sizeof(TopCell) << (3 * s->top_level) : 0;
+    if (bytes) *bytes = s->d_top ? ((uint64_t)sizeof(TopCell) << (3 * s->top_level)) + s->fine_bytes : 0;
     return SDFHIP_OK;
 }
 
@@ -446,7 +539,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
 
     RenderParams P;
-    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level;
+    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level; P.fine = s->d_fine; P.fine_bits = s->fine_bits;
     P.out = reinterpret_cast<float4 *>(d_out);
     P.width = width; P.height = height;
     P.band_rows = band_rows; P.band_first = band_first; P.band_stride = band_stride;
@@ -513,14 +606,17 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     // cursor kind: generic, cursor stack, or cursor stack with a top grid as deep as the tree
-    const int cur = !use_stack ? CUR_GENERIC : (s->d_top && (uint32_t)s->top_level >= s->depth) ? CUR_STACK_FULL : CUR_STACK;
+    const int cur = !use_stack ? CUR_GENERIC : (s->d_top && s->fine_bits) ? CUR_STACK_SPLIT :
+                    (s->d_top && (uint32_t)s->top_level >= s->depth) ? CUR_STACK_FULL : CUR_STACK;
     if (pt) {
         grid = dim3(8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x);
         auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(64), 0, st, P); };
-        if (cur == CUR_STACK_FULL) { if (count) go(k_path<CUR_STACK_FULL, true>); else go(k_path<CUR_STACK_FULL, false>); }
+        if (cur == CUR_STACK_SPLIT) { if (count) go(k_path<CUR_STACK_SPLIT, true>); else go(k_path<CUR_STACK_SPLIT, false>); }
+        else if (cur == CUR_STACK_FULL) { if (count) go(k_path<CUR_STACK_FULL, true>); else go(k_path<CUR_STACK_FULL, false>); }
         else if (cur == CUR_STACK) { if (count) go(k_path<CUR_STACK, true>); else go(k_path<CUR_STACK, false>); }
         else                       { if (count) go(k_path<CUR_GENERIC, true>); else go(k_path<CUR_GENERIC, false>); }
     }
+    else if (cur == CUR_STACK_SPLIT) { if (count) launch_pair<CUR_STACK_SPLIT, true>(compact, bt, grid, st, P); else launch_pair<CUR_STACK_SPLIT, false>(compact, bt, grid, st, P); }
     else if (cur == CUR_STACK_FULL) { if (count) launch_pair<CUR_STACK_FULL, true>(compact, bt, grid, st, P); else launch_pair<CUR_STACK_FULL, false>(compact, bt, grid, st, P); }
     else if (cur == CUR_STACK)      { if (count) launch_pair<CUR_STACK, true>(compact, bt, grid, st, P); else launch_pair<CUR_STACK, false>(compact, bt, grid, st, P); }
     else                            { if (count) launch_pair<CUR_GENERIC, true>(compact, bt, grid, st, P); else launch_pair<CUR_GENERIC, false>(compact, bt, grid, st, P); }

@@ -493,11 +493,36 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
                         pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
                         assert_frames_identical(pimg, pref, f"top grid {lv}, path-traced")
             assert len(levels_seen) >= 4
+            # split grids: a coarse dense level whose internal cells point at blocks of finer cells
+            os.environ.pop("SDFHIP_TOP_GRID_LEVEL", None)
+            for sp in ("1", "2", "3", "5"):
+                if int(sp) >= od_depth(sb, od):
+                    continue
+                os.environ["SDFHIP_TOP_GRID_SPLIT"] = sp
+                try:
+                    with sb.Scene(od) as scene:
+                        assert scene.top_grid_level == int(sp) and scene.top_grid_bytes >= 16 << (3 * int(sp))
+                        for c, (ref, cnt) in zip((cam, ongrid), refs):
+                            for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT):
+                                img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
+                                assert_frames_identical(img, ref, f"split grid {sp}")
+                                assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), sp
+                                assert_frames_identical(scene.Draw(c, W, H, flags), ref, f"split grid {sp}, not counting")
+                            pimg = scene.DrawPath(c, W, H, pt=sb.PathTrace(spp=2))
+                            pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
+                            assert_frames_identical(pimg, pref, f"split grid {sp}, path-traced")
+                finally:
+                    os.environ.pop("SDFHIP_TOP_GRID_SPLIT", None)
     finally:
         if prev is None:
             os.environ.pop("SDFHIP_TOP_GRID_LEVEL", None)
         else:
             os.environ["SDFHIP_TOP_GRID_LEVEL"] = prev
+
+
+def od_depth(sb, od):
+    with sb.Scene(od) as sc:
+        return sc.depth
 
 
 def test_sparse_wire_format_is_lossless_within_its_capacity(sb, gpu_scenes):
@@ -753,3 +778,20 @@ def test_fuzz_random_trees_and_on_grid_cameras(sb, oracle_mod, seed):
                     assert_frames_identical(pimg, pref, f"seed {seed} path-traced, kernel {kern}")
                     assert (pst.n_nodes, pst.n_samples, pst.n_steps, pst.n_shadow_rays) == tuple(int(c) for c in pcnt), (seed, kern)
                     assert_frames_identical(sc.DrawPath(cam, W, H, pt=sb.PathTrace(spp=2), flags=kern), pref, f"seed {seed} path-traced, not counting")
+    if depth >= 7:           # the same tree behind a split grid (what trees of depth 10-12 get when they are large)
+        prev = os.environ.get("SDFHIP_TOP_GRID_SPLIT")
+        os.environ["SDFHIP_TOP_GRID_SPLIT"] = str(min(8, depth - int(rng.integers(1, 5))))
+        try:
+            with sb.Scene(od) as sc:
+                if sc.depth > int(os.environ["SDFHIP_TOP_GRID_SPLIT"]):     # a random tree may be shallower than asked
+                    for ci, cam in enumerate(cams[:3]):
+                        ref, cnt = oracle_mod.render(s, v, cam.State, W, H, nthreads=8)
+                        img, st = sc.Draw(cam, W, H, sb.FLAG_COUNT, want_stats=True)
+                        assert_frames_identical(img, ref, f"seed {seed} cam {ci} split grid")
+                        assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), (seed, ci)
+                        assert_frames_identical(sc.Draw(cam, W, H), ref, f"seed {seed} cam {ci} split grid, not counting")
+        finally:
+            if prev is None:
+                os.environ.pop("SDFHIP_TOP_GRID_SPLIT", None)
+            else:
+                os.environ["SDFHIP_TOP_GRID_SPLIT"] = prev
