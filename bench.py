@@ -84,6 +84,7 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver supports dmabuf IPC only (RCCL needs it)
     import torch
     import torch.distributed as dist
 
