@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--spp", type=int, default=0,
                     help="path-traced mode (BASELINE config 5: --size 3840x2160 --spp 16): spp jittered camera "
                          "rays per pixel + 3 diffuse bounces; Mray/s then counts W*H*spp camera rays")
+    ap.add_argument("--one-kernel", action="store_true",
+                    help="A/B: the one-kernel form (lane state machine, shading in place) instead of the default "
+                         "two-kernel pipeline k_march -> k_shade")
     ap.add_argument("--check", action="store_true", help="verify the assembled frame against a whole-frame render")
     ap.add_argument("--rank0-weight", type=float, default=0.0,
                     help="sharded runs: rank 0's share of the frame as a fraction of a peer's share "
@@ -127,7 +130,8 @@ def main():
 
     kflag = {"auto": sb.KERNEL_AUTO, "generic": sb.KERNEL_GENERIC, "stack": sb.KERNEL_STACK}[args.kernel]
     compact = (args.compact == 1) if args.compact >= 0 else DEFAULT_COMPACT
-    flags = kflag | (sb.FLAG_COMPACT if compact else 0) | (sb.FLAG_DISPLAY if args.display else 0)
+    flags = kflag | (sb.FLAG_COMPACT if compact else 0) | (sb.FLAG_DISPLAY if args.display else 0) | \
+        (sb.TUNE_ONE_KERNEL if args.one_kernel else 0)
     px_shape, px_dtype, px_bytes = ((), torch.int32, 4) if args.display else ((4,), torch.float32, 16)
     pt = sb.PathTrace(spp=args.spp) if args.spp > 0 else None
     # what travels in the gather: the frame's own pixels, or 5-byte wire pixels that rank 0 expands

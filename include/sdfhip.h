@@ -82,7 +82,11 @@ enum {
      * order of the plain kernel (1 row-major, 2 one slab per XCD), bits 12..15 workgroup
      * size (1 = 64, 2 = 128, 3 = 256 threads).  Results never depend on them. */
     SDFHIP_TUNE_ORDER_SHIFT = 8,
-    SDFHIP_TUNE_BLOCK_SHIFT = 12
+    SDFHIP_TUNE_BLOCK_SHIFT = 12,
+    /* A/B knob: render with the one-kernel form (a lane state machine that shades in place) where the
+     * default is the two-kernel pipeline (primary march -> queue of hits -> shading + shadow march).
+     * Same pixels, same counters. */
+    SDFHIP_TUNE_ONE_KERNEL = 0x20000
 };
 
 /* Per-call statistics (all optional: pass NULL). */

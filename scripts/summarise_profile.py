@@ -1,49 +1,83 @@
-"""gpurun_out/prof_<tag>/ -> profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json
-(per-launch means of every counter for the ray-march kernel) and the HBM traffic
-entry of profiles/hbm_traffic.json that bench.py reports as roofline.traffic.
+"""gpurun_out/prof_<tag>/ -> profiles/<tag>_kernel_stats.csv and profiles/<tag>_pmc.json: per-launch means
+of every PMC counter for each ray-march kernel of the run (k_march, k_shade, k_plain, k_compact, k_path; the
+one counting launch of a bench run is left out), the bench line of the stats pass, and the HBM traffic per
+frame that bench.py reports as roofline.traffic (profiles/hbm_traffic.json, keyed by workload, with the
+profile tag and the hash of the kernel sources it was measured on).
 
-HBM bytes per launch (MI355X_MICROARCH.md "HBM"): FETCH_SIZE and WRITE_SIZE are in KB;
-WRITE_SIZE is exact for 16-B-per-lane stores (ours); FETCH_SIZE = TCC_EA0_RDREQ x 64 B
-under-reports wide coalesced reads by 2x on gfx950 and is uncalibrated for other shapes:
-we report the doubled figure as the (upper) estimate and keep the raw one beside it."""
-import collections, csv, glob, json, os, shutil, sys
+HBM bytes (MI355X_MICROARCH.md "HBM"): FETCH_SIZE and WRITE_SIZE are in KB, collected in separate passes;
+WRITE_SIZE is exact for 16-B-per-lane stores; FETCH_SIZE = TCC_EA0_RDREQ x 64 B reports half the bytes of
+wide reads on gfx950 and is uncalibrated for other shapes: the doubled figure is reported (an upper
+estimate for our 12-byte gathers) and the raw one is kept beside it.
 
-tag = sys.argv[1]
-src = f"gpurun_out/prof_{tag}"
-os.makedirs("profiles", exist_ok=True)
-for f in glob.glob(f"{src}/stats/*/*_kernel_stats.csv"):
-    shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
-bench = None
-try:
-    bench = json.loads([l for l in open(f"{src}/stats_bench.json") if l.startswith("{")][-1])
-except Exception as e:  # noqa: BLE001
-    print("no bench line:", e)
-pmc = {}
-kname = None
-for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if "k_plain" in r["Kernel_Name"] or "k_compact" in r["Kernel_Name"]:
-            if ", true>" in r["Kernel_Name"]:       # the one counting launch
+usage: python scripts/summarise_profile.py <tag> [workload-key]"""
+import collections, csv, glob, hashlib, json, os, re, shutil, sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in ("raymarch_device.h", "raymarch_kernels.h", "sdfhip_device.hip"):
+        h.update(open(os.path.join(REPO, "sdfbox_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def short(name):
+    m = re.match(r"(?:void )?(?:sdfhip::)?(k_\w+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else None
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
+    os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
+    for f in glob.glob(f"{src}/stats/*/*_kernel_stats.csv"):
+        shutil.copy(f, os.path.join(REPO, "profiles", f"{tag}_kernel_stats.csv"))
+    bench = None
+    try:
+        bench = json.loads([l for l in open(f"{src}/stats_bench.json") if l.startswith("{")][-1])
+    except Exception as e:  # noqa: BLE001
+        print("no bench line:", e)
+    kernels = collections.defaultdict(dict)
+    for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if not k or not k.startswith(("k_march", "k_shade", "k_plain", "k_compact", "k_path")):
                 continue
-            kname = r["Kernel_Name"]
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            pmc["VGPR_Count"] = int(r["VGPR_Count"]); pmc["SGPR_Count"] = int(r["SGPR_Count"]); pmc["LDS_Block_Size"] = int(r["LDS_Block_Size"])
-    for k, v in agg.items():
-        pmc[k] = sum(v) / len(v)
-pmc["kernel"] = kname
-if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-    pmc["hbm_read_bytes_raw"] = pmc["FETCH_SIZE"] * 1024
-    pmc["hbm_read_bytes_x2"] = pmc["FETCH_SIZE"] * 2048
-    pmc["hbm_write_bytes"] = pmc["WRITE_SIZE"] * 1024
-    pmc["hbm_bytes_per_launch"] = pmc["hbm_read_bytes_x2"] + pmc["hbm_write_bytes"]
-if bench:
-    pmc["bench_line"] = bench
-json.dump(pmc, open(f"profiles/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
-print(json.dumps({k: v for k, v in pmc.items() if k != "bench_line"}, indent=1, sort_keys=True))
-if bench and "hbm_bytes_per_launch" in pmc and len(sys.argv) > 2:
-    key = sys.argv[2]            # e.g. "1920x1080:dragon_standin_d9"
-    p = "profiles/hbm_traffic.json"
-    t = json.load(open(p)) if os.path.exists(p) else {}
-    t[key] = int(pmc["hbm_bytes_per_launch"])
-    json.dump(t, open(p, "w"), indent=1, sort_keys=True)
+            if re.search(r"<\d+, true", k):             # the one counting launch
+                continue
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            kernels[k]["VGPR_Count"] = int(r["VGPR_Count"]); kernels[k]["SGPR_Count"] = int(r["SGPR_Count"])
+            kernels[k]["LDS_Block_Size"] = int(r["LDS_Block_Size"])
+        for k, cs in agg.items():
+            for c, v in cs.items():
+                kernels[k][c] = sum(v) / len(v)
+                kernels[k]["launches_" + c] = len(v)
+    out = {"tag": tag, "kernel_source_sha": kernel_source_hash(), "kernels": kernels}
+    rd = sum(k.get("FETCH_SIZE", 0.0) for k in kernels.values()) * 1024
+    wr = sum(k.get("WRITE_SIZE", 0.0) for k in kernels.values()) * 1024
+    if rd or wr:
+        # per frame = per launch of each kernel of the frame's pipeline (k_march + k_shade, or k_plain alone)
+        fpl = float(bench["roofline"].get("frames_per_launch", 1.0)) if bench else 1.0
+        out["hbm_read_bytes_raw_per_frame"] = rd / fpl
+        out["hbm_read_bytes_x2_per_frame"] = 2 * rd / fpl
+        out["hbm_write_bytes_per_frame"] = wr / fpl
+        out["hbm_bytes_per_frame"] = (2 * rd + wr) / fpl
+    if bench:
+        out["bench_line"] = bench
+    json.dump(out, open(os.path.join(REPO, "profiles", f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in out.items() if k != "bench_line"}, indent=1, sort_keys=True))
+    if "hbm_bytes_per_frame" in out and len(sys.argv) > 2:
+        p = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        t = json.load(open(p)) if os.path.exists(p) else {}
+        valu = sum(k.get("SQ_INSTS_VALU", 0.0) for k in kernels.values())
+        salu = sum(k.get("SQ_INSTS_SALU", 0.0) for k in kernels.values())
+        t[sys.argv[2]] = {"hbm_bytes_per_frame": int(out["hbm_bytes_per_frame"]), "read_x2": int(out["hbm_read_bytes_x2_per_frame"]),
+                          "write": int(out["hbm_write_bytes_per_frame"]), "valu_insts_per_frame": int(valu), "salu_insts_per_frame": int(salu),
+                          "profile": f"profiles/{tag}_pmc.json", "kernel_source_sha": out["kernel_source_sha"]}
+        json.dump(t, open(p, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -84,7 +84,17 @@ struct RenderParams {
     // path-traced mode (k_path): samples per pixel, diffuse bounces, RNG seed, albedo
     uint32_t pt_spp, pt_bounces, pt_seed;
     float pt_albedo;
+    // two-kernel pipeline (k_march -> k_shade, raymarch_kernels.h): the pixels whose primary march ended on
+    // the surface, as records {position, prox | cursor | pixel, steps, values} in HIT_QUEUES queues per frame
+    // of the launch: arrays [n_frames][HIT_QUEUES][hit_cap]; hit_ctl = two sets of [MAX_BATCH][HIT_QUEUES] fill
+    // counts (a 128-byte line each); this launch pair uses set hit_set and leaves the other one zeroed
+    float4 *hit_a;
+    int4 *hit_b;
+    uint4 *hit_c;
+    uint32_t *hit_ctl;
+    uint32_t hit_cap, hit_set;
 };
+constexpr uint32_t HIT_QUEUES = 64;   // one fill counter (its own 128-byte line) per queue: a wave's append is one atomic, spread over 64 words
 
 __device__ __forceinline__ float sat(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
 __device__ __forceinline__ float lerp(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
@@ -391,37 +401,77 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
 // ---- cursor when the top grid is as deep as the tree ---------------------------------------------
 // Every leaf is a grid cell or a block of cells, so the grid says where a position's leaf is and the
 // cursor shrinks to the leaf's anchor, size and values: no children index, no ancestor stack.  It
-// keeps s = LM - level (what the shifts need); such a grid stores s instead of the level (k_top_grid).  After reset the anchor is a mark that no position matches: the first find of a
-// pixel always looks its cell up.
+// keeps s = LM - level (what the shifts need); such a grid stores s instead of the level (k_top_grid).
+// After reset the anchor is a mark that no position matches -- the first find of a pixel always looks
+// its cell up -- while the values are the root's, and cell() maps the mark back to the root box: a
+// gradient taken before any find (Compute.hlsl:207 with margin >= 0.5) sees node 0 in [0,1]^3, as the
+// shader's cursor does.
+// FLAT cells.  Far from the surface a leaf holds 8 equal bytes (the quantiser clamps at 1.5 s and
+// -0.5 s); its trilinear blend is unorm8(byte) exactly (every lerp of equal operands returns the
+// operand: fma(t, a - a, a) = a for finite t, and d is saturated, hence finite), so the distance such
+// a cell returns depends on the cell alone.  k_top_grid / k_fine_blocks evaluate it once, with the
+// operations of sample_after_find in their order, and store {s | FLAT_BIT, bytes, distance bits}: a
+// march step through empty space -- two thirds of all steps of the bench frame -- is one sign test and
+// a move instead of a decode and seven lerps.  (The shifts that take s use its low five bits, as the
+// hardware does.)
 // EXACT: the kernel reports the algorithmic read count, so a NaN coordinate must behave exactly as in
 // find_s (it matches no cell: ascents up to the root).  Without it NaN converts to 0 and the find
 // lands in the same leaf -- the cell at the origin -- without the clamp instructions.
 // SPLIT: the grid is a coarse dense level whose internal cells point at blocks of finer cells (one more
 // dependent load for the positions near the surface, a fraction of the memory of a dense grid of the
 // tree's depth: the form for trees of depth 10-12).
+constexpr uint32_t FLAT_BIT = 0x80000000u;
 template <bool EXACT, bool SPLIT>
 struct CursorFT {
     typedef Scaled Pos;
     static constexpr int32_t ROOT_MARK = 0x40000000;
     int32_t ax, ay, az;      // lower * 2^LM
-    int32_t s;               // LM - level
-    uint32_t v0, v1;
+    uint32_t s;              // LM - level, | FLAT_BIT
+    uint32_t v0, v1;         // the 8 value bytes; a flat cell: v0 = its byte four times, v1 = its distance (float bits)
 
-    __device__ __forceinline__ void reset(const NodeRec &)
+    __device__ __forceinline__ void reset(const NodeRec &root)
     {
-        ax = ay = az = ROOT_MARK; s = LM; v0 = v1 = 0u;
+        ax = ay = az = ROOT_MARK; s = (uint32_t)LM; v0 = root.z; v1 = root.w;
     }
     __device__ __forceinline__ Cell cell() const
     {
         Cell k;
         const float q = 1.0f / 4096.0f;
-        k.lx = (float)ax * q; k.ly = (float)ay * q; k.lz = (float)az * q;   // exact
-        k.scale = __int_as_float((127 - LM + s) << 23);                     // 2^-level
-        k.inv = __int_as_float((127 + LM - s) << 23);                       // 2^level
-        k.v0 = v0; k.v1 = v1;
+        const bool fresh = ax == ROOT_MARK;                                  // never looked up: the root box
+        k.lx = fresh ? 0.0f : (float)ax * q; k.ly = fresh ? 0.0f : (float)ay * q; k.lz = fresh ? 0.0f : (float)az * q;   // exact
+        const uint32_t sc = s & 15u;
+        k.scale = __uint_as_float((127u - LM + sc) << 23);                  // 2^-level
+        k.inv = __uint_as_float((127u + LM - sc) << 23);                    // 2^level
+        k.v0 = v0; k.v1 = (s & FLAT_BIT) ? v0 : v1;
         return k;
     }
 };
+
+// One lookup in a grid as deep as the tree (dense, or coarse level + fine blocks): the leaf of the clamped
+// cell coordinates D, into the cursor.  Returns s of that leaf.
+template <bool EXACT, bool SPLIT>
+__device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT> &c, const GridRef &g, int32_t Dx, int32_t Dy, int32_t Dz)
+{
+    const int TG = g.level, sh = LM - TG;
+    uint4 e = reinterpret_cast<const uint4 *>(g.top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
+    if (SPLIT) {
+        // one 16-byte load for the whole cell (left alone, the compiler fetches level and children first
+        // and the values in a second, dependent load)
+        asm volatile("" : "+v"(e.y), "+v"(e.z), "+v"(e.w));
+        if (e.x == 15u) {                         // internal at the coarse level: its block of fine cells
+            const int FB = g.fine_bits, sh2 = sh - FB;
+            const uint32_t m = (1u << FB) - 1u;
+            const uint32_t local = (((uint32_t)Dx >> sh2) & m) | ((((uint32_t)Dy >> sh2) & m) << FB) | ((((uint32_t)Dz >> sh2) & m) << (2 * FB));
+            e = reinterpret_cast<const uint4 *>(g.fine)[((size_t)e.w << (3 * FB)) + local];
+        }
+    }
+    c.s = e.x;                                    // LM - level of the leaf, | FLAT_BIT
+    c.v0 = e.y;
+    c.v1 = e.z;
+    const int32_t keep = (int32_t)(0xFFFFFFFFu << (e.x & 31u));
+    c.ax = Dx & keep; c.ay = Dy & keep; c.az = Dz & keep;
+    return (int)(e.x & 15u);
+}
 
 // find(): is the position still in the current cell, and -- on exact cell boundaries (any_on_grid,
 // wave-uniform) -- which of the two adjacent cells does the reference's descent pick (the same A/B
@@ -432,7 +482,7 @@ __device__ __forceinline__ uint32_t find_full(CursorFT<EXACT, SPLIT> &c, const G
                                               int32_t Dx, int32_t Dy, int32_t Dz, bool gx, bool gy, bool gz,
                                               const bool any_on_grid)
 {
-    const int s = c.s, level = LM - c.s;
+    const int s = (int)(c.s & 15u), level = LM - s;
     bool moved;
     int k;
     if (!any_on_grid) {
@@ -442,7 +492,7 @@ __device__ __forceinline__ uint32_t find_full(CursorFT<EXACT, SPLIT> &c, const G
     } else {
         // the A/B arithmetic wants coordinates that do not wrap: far outside the cube is -2 or 2^LM + 1
         Dx = min(max(Dx, -2), 4097); Dy = min(max(Dy, -2), 4097); Dz = min(max(Dz, -2), 4097);
-        const bool root = s == LM;
+        const bool root = c.ax == CursorFT<EXACT, SPLIT>::ROOT_MARK;
         const int32_t ax = root ? 0 : c.ax, ay = root ? 0 : c.ay, az = root ? 0 : c.az;
         const int32_t Bx = Dx - (gx ? 1 : 0), By = Dy - (gy ? 1 : 0), Bz = Dz - (gz ? 1 : 0);
         const int tx = min(bitlen((uint32_t)(ax ^ Dx)), bitlen((uint32_t)(ax ^ Bx)));
@@ -458,58 +508,60 @@ __device__ __forceinline__ uint32_t find_full(CursorFT<EXACT, SPLIT> &c, const G
     uint32_t reads = 1u;
     if (moved) {
         Dx = min(max(Dx, 0), 4095); Dy = min(max(Dy, 0), 4095); Dz = min(max(Dz, 0), 4095);
-        const int TG = g.level, sh = LM - TG;
-        uint4 e = reinterpret_cast<const uint4 *>(g.top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
-        if (SPLIT) {
-            // one 16-byte load for the whole cell (left alone, the compiler fetches level and children first
-            // and the values in a second, dependent load)
-            asm volatile("" : "+v"(e.y), "+v"(e.z), "+v"(e.w));
-            if (e.x == 15u) {                         // internal at the coarse level: its block of fine cells
-                const int FB = g.fine_bits, sh2 = sh - FB;
-                const uint32_t m = (1u << FB) - 1u;
-                const uint32_t local = (((uint32_t)Dx >> sh2) & m) | ((((uint32_t)Dy >> sh2) & m) << FB) | ((((uint32_t)Dz >> sh2) & m) << (2 * FB));
-                e = reinterpret_cast<const uint4 *>(g.fine)[((size_t)e.w << (3 * FB)) + local];
-            }
-        }
-        const int ns = (int)e.x;                      // LM - level of the leaf
+        const int ns = load_cell(c, g, Dx, Dy, Dz);   // LM - level of the leaf
         reads = 1u + (uint32_t)k + (uint32_t)((LM - ns) - (level - k));
-        c.s = ns;
-        c.v0 = e.y;
-        c.v1 = e.z;
-        const int32_t keep = (int32_t)(0xFFFFFFFFu << ns);
-        c.ax = Dx & keep; c.ay = Dy & keep; c.az = Dz & keep;
     }
     return reads;
 }
-// A without the float clamp of axis_a: the conversion saturates (far outside the cube: INT_MIN /
-// INT_MAX, which differ from every anchor in their high bits and clamp to the same D), NaN gives 0.
-__device__ __forceinline__ int32_t axis_a_raw(float p, float &u, float &f)
+// floor(u) as an integer in one instruction.  A float-to-int cast of NaN or of a value outside the
+// int range is undefined in C++; v_cvt_flr_i32_f32 is not: it saturates, and NaN gives 0.
+__device__ __forceinline__ int32_t cvt_floor(float u)
 {
-    u = p * 4096.0f;
-    f = floorf(u);
-    return (int32_t)f;
+    int32_t a;
+    asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(a) : "v"(u));
+    return a;
 }
-template <bool EXACT, bool SPLIT>
-__device__ __forceinline__ uint32_t find(CursorFT<EXACT, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
+// The kernels that do not count: cell coordinates straight from the saturating conversion (far
+// outside the cube: INT_MIN / INT_MAX, NaN: 0) and clamped into the cube BEFORE the "still in my
+// cell?" test -- outside the cube the shader's descent clamps to the boundary leaf at every step
+// (saturate, Compute.hlsl:100), so "the clamped coordinates are still in my cell" selects the cell
+// the shader ends in, and the root mark (bit 30) differs from every clamped coordinate.
+template <bool SPLIT>
+__device__ __forceinline__ uint32_t find(CursorFT<false, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
+                                         uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
+                                         Scaled &u)
+{
+    u.x = px * 4096.0f; u.y = py * 4096.0f; u.z = pz * 4096.0f;
+    const int32_t Ax = cvt_floor(u.x), Ay = cvt_floor(u.y), Az = cvt_floor(u.z);
+    // on the 2^-LM grid on some axis <=> a fractional part is zero (NaN: never; the three are >= 0)
+    const float fx = __builtin_amdgcn_fractf(u.x), fy = __builtin_amdgcn_fractf(u.y), fz = __builtin_amdgcn_fractf(u.z);
+    const float fm = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    if (__ballot(fm == 0.0f) == 0ull) {
+        const int32_t Dx = min(max(Ax, 0), 4095), Dy = min(max(Ay, 0), 4095), Dz = min(max(Az, 0), 4095);
+        const uint32_t diff = (uint32_t)(c.ax ^ Dx) | (uint32_t)(c.ay ^ Dy) | (uint32_t)(c.az ^ Dz);
+        if ((diff >> (c.s & 31u)) != 0u) load_cell(c, g, Dx, Dy, Dz);
+        return 0;
+    }
+    return find_full(c, g, Ax, Ay, Az, fx == 0.0f, fy == 0.0f, fz == 0.0f, true);
+}
+// The counting kernels: NaN must match no cell (ascents up to the root count as reads), see axis_a.
+template <bool SPLIT>
+__device__ __forceinline__ uint32_t find(CursorFT<true, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
                                          uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
                                          Scaled &u)
 {
     float fx, fy, fz;
-    int32_t Ax, Ay, Az;
-    if (EXACT) { Ax = axis_a(px, u.x, fx); Ay = axis_a(py, u.y, fy); Az = axis_a(pz, u.z, fz); }
-    else { Ax = axis_a_raw(px, u.x, fx); Ay = axis_a_raw(py, u.y, fy); Az = axis_a_raw(pz, u.z, fz); }
+    const int32_t Ax = axis_a(px, u.x, fx), Ay = axis_a(py, u.y, fy), Az = axis_a(pz, u.z, fz);
     const bool gx = u.x == fx, gy = u.y == fy, gz = u.z == fz;    // on the 2^-LM grid (false for NaN)
     return find_full(c, g, Ax, Ay, Az, gx, gy, gz, __ballot(gx || gy || gz) != 0ull);
 }
 template <bool EXACT, bool SPLIT>
 __device__ __forceinline__ float sample_after_find(const CursorFT<EXACT, SPLIT> &c, const Scaled &u, float, float, float)
 {
-    const int32_t scale_bits = (c.s + (127 - LM)) << 23;                       // 2^-level = 2^(s - LM)
-    const float scale = __int_as_float(scale_bits);
-    const bool flat = c.v0 == c.v1 && c.v0 == __builtin_amdgcn_alignbit(c.v0, c.v0, 8);    // see interpol_world
-    if (__ballot(!flat) == 0ull)
-        return (unorm8((float)(c.v0 & 0xFFu)) - 0.25f) * scale * 2.0f;
-    const float inv = __int_as_float(((2 * 127 - LM) << 23) - scale_bits);     // 2^-s = 2^(level - LM)
+    if (c.s & FLAT_BIT) return __uint_as_float(c.v1);                            // see CursorFT
+    const uint32_t scale_bits = (c.s + (uint32_t)(127 - LM)) << 23;              // 2^-level = 2^(s - LM)
+    const float scale = __uint_as_float(scale_bits);
+    const float inv = __uint_as_float(((uint32_t)(2 * 127 - LM) << 23) - scale_bits);     // 2^-s = 2^(level - LM)
     float dx = sat((u.x - (float)c.ax) * inv);
     float dy = sat((u.y - (float)c.ay) * inv);
     float dz = sat((u.z - (float)c.az) * inv);
@@ -517,6 +569,12 @@ __device__ __forceinline__ float sample_after_find(const CursorFT<EXACT, SPLIT> 
     float loadL = bilerp(t.v[0], t.v[1], t.v[2], t.v[3], dx, dy);
     float loadH = bilerp(t.v[4], t.v[5], t.v[6], t.v[7], dx, dy);
     return (lerp(loadL, loadH, dz) - 0.25f) * scale * 2.0f;
+}
+// what k_top_grid / k_fine_blocks store in a flat cell: the line above on eight equal texels
+__device__ __forceinline__ uint32_t flat_cell_distance_bits(uint32_t byte, uint32_t s)
+{
+    const float scale = __uint_as_float((s + (uint32_t)(127 - LM)) << 23);
+    return __float_as_uint((unorm8((float)byte) - 0.25f) * scale * 2.0f);
 }
 
 __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, const GridRef &g,

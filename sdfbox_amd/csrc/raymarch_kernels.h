@@ -327,6 +327,224 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
     if (COUNT) flush_counters(P, cn, cs, ct, cr);
 }
 
+// =====================================================================================
+// The default pipeline for trees behind a full-depth or split grid: two kernels per frame.
+//
+//   k_march   one lane per pixel, one 8x8 tile per wave, the plain kernel's XCD-interleaved tile rows.
+//             Runs ONLY the primary march of Compute.hlsl:194-203 -- a loop of loop-header test, escape
+//             test, find, sample, advance with no phase logic, no shading code and no stores in it.
+//             After the loop the wave is converged again: sky pixels store their colour (coalesced),
+//             and the lanes that ended on the surface append their state -- position, prox, step
+//             count, cursor -- to a queue: ballot + mbcnt give the slots, one atomic per wave.
+//   k_shade   one lane per queued hit, 64 consecutive records per wave: the shading step of
+//             Compute.hlsl:205-213 for all 64 lanes at once, then the shadow march :214-230 as its own
+//             tight loop, then the pixel's colour.
+//
+// Why: in the one-kernel form (k_plain) the ~200 instructions of the shading step run whenever ANY
+// lane of a wave finishes its primary march -- for three or four lanes at a time, about 130 000 times
+// per 1080p frame, a quarter of all VALU instructions issued -- and every iteration pays the phase
+// dispatch of a lane state machine.  Here shading runs once per 64 hits with every lane on, and both
+// loops carry only their own exits.  Per-pixel arithmetic, its order and the cursor a pixel carries
+// from the primary into the shadow march are unchanged: images and counters stay bit-identical.
+// The records cost 48 bytes per hit pixel written and read once (20 MB per 1080p bench frame).
+// =====================================================================================
+enum { OUT_RGBA32F = 0, OUT_GAMMA8 = 1, OUT_HEAT8 = 2, OUT_WIRE = 3 };
+
+// Where a finished pixel goes, by output mode (a template parameter: no dispatch at the store, and no
+// display-pass code in the RGBA32F kernels).  idx = pixel index within the launch's frame f.
+template <int MODE>
+struct PixelSink {
+    float4 *out;             // frame f of the launch: RGBA32F pixels / uint32 pixels / the frame's wire planes
+    uint8_t *codes;          // OUT_WIRE: the byte plane behind the float plane
+    uint32_t sky8;
+    __device__ __forceinline__ PixelSink(const RenderParams &P, uint32_t f)
+    {
+        const size_t npx = (size_t)P.nrows_out * P.width;
+        sky8 = P.sky8;
+        if (MODE == OUT_RGBA32F) { out = P.out + f * npx; codes = nullptr; }
+        else if (MODE == OUT_WIRE) {
+            char *base = reinterpret_cast<char *>(P.out) + f * npx * 5;
+            out = reinterpret_cast<float4 *>(base); codes = reinterpret_cast<uint8_t *>(base) + 4 * npx;
+        } else { out = reinterpret_cast<float4 *>(reinterpret_cast<uint32_t *>(P.out) + f * npx); codes = nullptr; }
+    }
+    __device__ __forceinline__ void wire(size_t idx, float a, uint32_t code) const
+    {
+        reinterpret_cast<float *>(out)[idx] = a;
+        codes[idx] = (uint8_t)code;
+    }
+    __device__ __forceinline__ void sky(size_t idx, float steps) const
+    {
+        if (MODE == OUT_RGBA32F) out[idx] = make_float4(0.005f, 0.01f, 0.2f, steps);
+        else if (MODE == OUT_WIRE) wire(idx, 0.0f, 255u - (uint32_t)steps);
+        else reinterpret_cast<uint32_t *>(out)[idx] = MODE == OUT_HEAT8 ? heat8(steps) : (sky8 | alpha8(steps));
+    }
+    __device__ __forceinline__ void grey(size_t idx, float a, float steps) const
+    {
+        if (MODE == OUT_RGBA32F) out[idx] = make_float4(a, a, a, steps);
+        else if (MODE == OUT_WIRE) wire(idx, a, (uint32_t)steps);
+        else if (MODE == OUT_HEAT8) reinterpret_cast<uint32_t *>(out)[idx] = heat8(steps);
+        else { const uint32_t q = gamma8(a); reinterpret_cast<uint32_t *>(out)[idx] = q | (q << 8) | (q << 16) | alpha8(steps); }
+    }
+    __device__ __forceinline__ void black(size_t idx, float steps) const
+    {
+        if (MODE == OUT_RGBA32F) out[idx] = make_float4(0.0f, 0.0f, 0.0f, steps);
+        else if (MODE == OUT_WIRE) wire(idx, 0.0f, (uint32_t)steps);
+        else reinterpret_cast<uint32_t *>(out)[idx] = MODE == OUT_HEAT8 ? heat8(steps) : alpha8(steps);
+    }
+};
+
+// blockIdx -> 8x8 tile of the local rows, XCD-aware (see k_plain): blocks b and b+8 share an XCD and its
+// L2; XCD k renders tile rows k, k+8, ...  Returns 0xFFFFFFFF for the padding blocks.
+__device__ __forceinline__ uint32_t tile_of_block(const RenderParams &P, uint32_t bid, uint32_t frame)
+{
+    const uint32_t xcd = (bid + frame * (P.tiles_y & 7u)) & 7u, j = bid >> 3;   // j-th block of this label
+    const uint32_t r = j / P.tiles_x, cx = j - r * P.tiles_x;
+    const uint32_t row = r * 8 + xcd;
+    return row < P.tiles_y ? row * P.tiles_x + cx : 0xFFFFFFFFu;
+}
+// Fill count of queue q of frame f, one 128-byte line each, in two sets: a launch pair uses set
+// P.hit_set, and its k_shade zeroes the other set for the next pair on this scratch -- nothing else
+// touches that set meanwhile (launches that share a scratch run in stream order), so the queues are
+// emptied without a "last workgroup" counter (8192 atomic adds on one word serialise at ~90 per
+// microsecond: that alone took 90 us per frame in the first version).
+__device__ __forceinline__ uint32_t *hit_count(const RenderParams &P, uint32_t set, uint32_t f, uint32_t q)
+{
+    return P.hit_ctl + (((size_t)set * MAX_BATCH + f) * HIT_QUEUES + q) * 32u;
+}
+
+template <int CUR, bool COUNT, int MODE>
+__global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams P)
+{
+    typedef typename CursorOf<CUR, COUNT>::type CursorT;
+    const uint32_t f = blockIdx.y;
+    FrameInfo I = P.frames[f];
+    // the scalars every march step reads stay in SGPRs: left alone, the compiler reloads them
+    // from the kernel arguments (s_load + s_waitcnt) in every iteration
+    asm volatile("" : "+s"(I.margin2), "+s"(I.limit));
+    const uint32_t tile = tile_of_block(P, blockIdx.x, f);
+    if (tile >= P.n_tiles) return;
+    const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x, lane = threadIdx.x;
+    const uint32_t x = tx * 8 + (lane & 7u), yl = ty * 8 + (lane >> 3);
+    unsigned long long cn = 0, cs = 0, ct = 0;   // nodes, samples, steps (of the pixels that end here)
+    bool live = x < P.width && yl < P.nrows_out;
+    uint32_t y = 0;
+    if (live) { y = global_row(P, yl); live = y < P.height; }
+    RayState r;
+    CursorT c;
+    const NodeRec root = P.nodes[0];
+    start_pixel(I, root, live ? x : 0u, live ? y : 0u, r, c);
+    // Compute.hlsl:194-203.  One exit: the loop-header test and the escape test are evaluated together and
+    // told apart after the loop (a lane that left keeps its state), header first, as the shader orders them.
+    auto marching = [&]() { return (r.prox > I.margin2 || r.prox < 0.0f) && r.n < 100; };
+    if (live) {
+        while (marching() && !(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit)) {
+            uint32_t reads = march_step(P, I, r, c, nullptr, 0);
+            if (COUNT) { cn += reads; cs += 1; }
+        }
+    }
+    const int end = !live ? 3 : marching() ? 2 : 1;   // 1 on the surface (or out of steps), 2 escaped, 3 no pixel
+    // ---- the wave is converged again ----
+    const size_t lidx = (size_t)yl * P.width + x;
+    if (end == 2) {
+        const PixelSink<MODE> dst(P, f);
+        dst.sky(lidx, (float)r.n);
+        if (COUNT) ct = (unsigned long long)r.n;
+    }
+    const unsigned long long hits = __ballot(end == 1);
+    if (hits) {
+        const uint32_t q = blockIdx.x & (HIT_QUEUES - 1u);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(hit_count(P, P.hit_set, f, q), (uint32_t)__popcll(hits));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+        if (end == 1 && base + rank < P.hit_cap) {     // always true while the fill counts start at zero (k_shade leaves them so)
+            const size_t slot = ((size_t)f * HIT_QUEUES + q) * P.hit_cap + base + rank;
+            P.hit_a[slot] = make_float4(r.px, r.py, r.pz, r.prox);
+            P.hit_b[slot] = make_int4(c.ax, c.ay, c.az, (int)c.s);
+            P.hit_c[slot] = make_uint4((uint32_t)lidx, (uint32_t)r.n, c.v0, c.v1);
+        }
+    }
+    if (COUNT) flush_counters(P, cn, cs, ct, 0);
+}
+
+// One lane per hit record; a wave takes 64 consecutive records of one queue at a time (chunks are
+// numbered over the frame's queues: a wave-wide scan of the 64 fill counts, once per wave).
+template <int CUR, bool COUNT, int MODE>
+__global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shade(RenderParams P)
+{
+    typedef typename CursorOf<CUR, COUNT>::type CursorT;
+    const uint32_t f = blockIdx.y, lane = threadIdx.x;
+    FrameInfo I = P.frames[f];
+    asm volatile("" : "+s"(I.margin));
+    const PixelSink<MODE> dst(P, f);
+    // chunks of queue `lane`, and their running sum over the queues (inclusive scan across the wave)
+    const uint32_t fill = min(*hit_count(P, P.hit_set, f, lane), P.hit_cap);
+    if (blockIdx.x == 0 && f == 0)                       // empty the other set -- every frame of it -- for the next launch pair
+        for (uint32_t ff = 0; ff < (uint32_t)MAX_BATCH; ff++) *hit_count(P, P.hit_set ^ 1u, ff, lane) = 0u;
+    const uint32_t chunks = (fill + 63u) >> 6;
+    uint32_t incl = chunks;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0;
+    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+        // queue of chunk t = the number of queues whose inclusive sum is <= t
+        const uint32_t q = (uint32_t)__popcll(__ballot(incl <= t));
+        const uint32_t q_incl = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)q), q_chunks = (uint32_t)__builtin_amdgcn_readlane((int)chunks, (int)q);
+        const uint32_t q_fill = (uint32_t)__builtin_amdgcn_readlane((int)fill, (int)q);
+        const uint32_t i = (t - (q_incl - q_chunks)) * 64u + lane;
+        if (i < q_fill) {
+            const size_t slot = ((size_t)f * HIT_QUEUES + q) * P.hit_cap + i;
+            const float4 a = P.hit_a[slot];
+            const int4 b = P.hit_b[slot];
+            const uint4 e = P.hit_c[slot];
+            RayState r;
+            CursorT c;
+            r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w;
+            r.n = (int)e.y; r.base = 0; r.phase = PH_PRIMARY;
+            c.ax = b.x; c.ay = b.y; c.az = b.z; c.s = (uint32_t)b.w; c.v0 = e.z; c.v1 = e.w;
+            const size_t lidx = e.x;
+            // Compute.hlsl:205-213
+            float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;
+            float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+            r.dx = lx * rl; r.dy = ly * rl; r.dz = lz * rl;
+            r.px = __builtin_fmaf(r.dx, I.margin, r.px);
+            r.py = __builtin_fmaf(r.dy, I.margin, r.py);
+            r.pz = __builtin_fmaf(r.dz, I.margin, r.pz);
+            float gx, gy, gz;
+            gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
+            const float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
+            r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
+            if (r.angle < 0.0f) {
+                dst.black(lidx, (float)r.n);
+                if (COUNT) ct += (unsigned long long)r.n;
+            } else {
+                lx = I.lightx - r.px; ly = I.lighty - r.py; lz = I.lightz - r.pz;
+                r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+                r.phase = PH_SHADOW;
+                r.base = r.n;                 // i stays, j starts
+                r.n = 0;
+                if (COUNT) cr += 1;
+                // Compute.hlsl:214-230: every exit is black (:223, :229) except the one that reaches the light (:215-219)
+                bool lit = false;
+                while (r.n < 40 && r.prox > -I.margin) {
+                    if (r.prox > r.dist || (r.px < 0.0f || r.py < 0.0f || r.pz < 0.0f) ||
+                        (r.px > 1.0f || r.py > 1.0f || r.pz > 1.0f)) { lit = true; break; }
+                    if (r.prox < I.margin) {
+                        gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
+                        if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) break;
+                    }
+                    uint32_t reads = march_step(P, I, r, c, nullptr, 0);
+                    if (COUNT) { cn += reads; cs += 1; }
+                }
+                if (lit) dst.grey(lidx, r.angle / (r.dist * r.dist) * I.k_strength, (float)(r.base + r.n));
+                else dst.black(lidx, (float)(r.base + r.n));
+                if (COUNT) ct += (unsigned long long)(r.base + r.n);
+            }
+        }
+    }
+    if (COUNT) flush_counters(P, cn, cs, ct, cr);
+}
+
 // ---- persistent waves with lane refill and state batching (wavefront ray compaction) --
 // One wave per workgroup, as many workgroups as the chip holds.  Lane states:
 // PRIMARY / SHADOW (marching), SHADE (march over, shading pending), IDLE (no pixel).

@@ -33,6 +33,16 @@ __global__ void k_fuse(const int2 *__restrict__ structs, const uint2 *__restrict
     }
 }
 
+// A leaf cell of a grid that serves CursorFT (t.level = LM - level): when its 8 bytes are equal, mark it flat and
+// replace v1 by the distance it returns (raymarch_device.h, CursorFT)
+__device__ __forceinline__ void flat_cell(TopCell &t)
+{
+    if (t.v0 == t.v1 && t.v0 == __builtin_amdgcn_alignbit(t.v0, t.v0, 8)) {
+        t.v1 = flat_cell_distance_bits(t.v0 & 0xFFu, t.level);
+        t.level |= FLAT_BIT;
+    }
+}
+
 // The top grid of the cursor-stack kernels (raymarch_device.h): one thread per level-TG cell walks
 // from the root by the cell's octant bits and stores the record it ends at.
 // full = 0: cells hold the level (CursorS); 1: LM - level (CursorF, grid as deep as the tree); 2: like 1, but a
@@ -51,9 +61,10 @@ __global__ void k_top_grid(const NodeRec *__restrict__ nodes, TopCell *__restric
             level++;
         }
         TopCell t;
-        // a grid as deep as the tree serves CursorF, which wants LM - level
+        // a grid as deep as the tree serves CursorFT, which wants LM - level
         t.level = full ? (uint32_t)LM - level : level; t.v0 = r.z; t.v1 = r.w; t.children = (int32_t)r.y;
         if (full == 2 && (int32_t)r.y >= 0) { t.level = 15u; t.children = (int32_t)index; }
+        else if (full) flat_cell(t);
         top[top_index(cx, cy, cz, TG)] = t;
     }
 }
@@ -77,6 +88,7 @@ __global__ void k_fine_blocks(const NodeRec *__restrict__ nodes, const uint32_t 
         }
         TopCell t;
         t.level = (uint32_t)LM - level; t.v0 = r.z; t.v1 = r.w; t.children = -1;
+        flat_cell(t);
         fine[i] = t;
     }
 }
@@ -261,7 +273,21 @@ struct sdfhip_scene {
     int fine_bits;
     uint64_t fine_bytes;
     unsigned long long *d_counters;  // 4 x u64: nodes, samples, steps, shadow rays
-    uint32_t *d_queue;
+    // Per-stream scratch of the render launches: the hit queues of the two-kernel pipeline and their
+    // control words, and the tile-queue heads of the compact kernel.  Launches on one stream run in
+    // order and may share a scratch; launches on different streams overlap (frames in flight) and
+    // must not, so every stream that renders on this handle gets its own.
+    struct Scratch {
+        hipStream_t stream;
+        char *hit_buf;               // hit_a | hit_b | hit_c, `records` each
+        size_t records;
+        uint32_t *ctl;               // hit fill counts (two sets), then the compact kernel's tile queues
+        uint32_t launches;           // two-kernel launch pairs so far: its parity selects the set of fill counts
+    };
+    static constexpr int MAX_SCRATCH = 16;
+    static constexpr size_t CTL_HIT_WORDS = (size_t)2 * MAX_BATCH * HIT_QUEUES * 32, CTL_QUEUE_WORDS = 8 * 32;
+    Scratch scratch[MAX_SCRATCH];
+    int n_scratch;
     float4 *d_frame;        // grown on demand by sdfhip_render
     size_t frame_cap;
     hipEvent_t ev0, ev1;
@@ -308,7 +334,10 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
         if (s->d_counters) (void)hipFree(s->d_counters);
         if (s->d_top) (void)hipFree(s->d_top);
         if (s->d_fine) (void)hipFree(s->d_fine);
-        if (s->d_queue) (void)hipFree(s->d_queue);
+        for (int i = 0; i < s->n_scratch; i++) {
+            if (s->scratch[i].hit_buf) (void)hipFree(s->scratch[i].hit_buf);
+            if (s->scratch[i].ctl) (void)hipFree(s->scratch[i].ctl);
+        }
         if (s->d_frame) (void)hipFree(s->d_frame);
         if (s->ev0) (void)hipEventDestroy(s->ev0);
         if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -345,7 +374,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     s->device = device; s->n = n; s->depth = depth;
     s->stack_ok = (consistent && depth <= (uint32_t)MAX_STACK) ? 1 : 0;
     s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0;
-    s->d_queue = nullptr; s->d_frame = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
+    s->n_scratch = 0; s->d_frame = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
     s->cu_count = prop.multiProcessorCount;
 
     void *d_s = nullptr, *d_v = nullptr;
@@ -363,7 +392,6 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if ((e = hipMalloc(&s->alloc, (size_t)n * 16 + 128)) != hipSuccess) return bail(e, "hipMalloc(records)");
     s->nodes = reinterpret_cast<NodeRec *>(static_cast<char *>(s->alloc) + 112);
     if ((e = hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
-    if ((e = hipMalloc((void **)&s->d_queue, 8 * 32 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(queue)");
     if ((e = hipMalloc(&d_s, bytes)) != hipSuccess) return bail(e, "hipMalloc(structs)");
     if ((e = hipMalloc(&d_v, bytes)) != hipSuccess) return bail(e, "hipMalloc(values)");
     if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
@@ -496,6 +524,47 @@ extern "C" int sdfhip_scene_info(const sdfhip_scene *s, uint32_t *n, uint32_t *d
 
 namespace {
 
+// The scratch of stream `st` on this scene, with room for `records` hit records (0: control words only).
+// Created on a stream's first render; grown (after the stream has drained) when a larger frame comes.
+int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::Scratch **out)
+{
+    sdfhip_scene::Scratch *sc = nullptr;
+    for (int i = 0; i < s->n_scratch; i++)
+        if (s->scratch[i].stream == st) sc = &s->scratch[i];
+    if (!sc) {
+        if (s->n_scratch == sdfhip_scene::MAX_SCRATCH)
+            return fail(SDFHIP_ERR_ARG, "render: more than %d streams render on one scene handle", sdfhip_scene::MAX_SCRATCH);
+        sc = &s->scratch[s->n_scratch];
+        sc->stream = st; sc->hit_buf = nullptr; sc->records = 0; sc->ctl = nullptr; sc->launches = 0;
+        const size_t ctl_bytes = (sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS) * sizeof(uint32_t);
+        HIP_TRY(hipMalloc((void **)&sc->ctl, ctl_bytes));
+        HIP_TRY(hipMemset(sc->ctl, 0, ctl_bytes));
+        s->n_scratch++;
+    }
+    if (records > sc->records) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (sc->hit_buf) { (void)hipFree(sc->hit_buf); sc->hit_buf = nullptr; sc->records = 0; }
+        HIP_TRY(hipMalloc((void **)&sc->hit_buf, records * 48));
+        sc->records = records;
+    }
+    *out = sc;
+    return SDFHIP_OK;
+}
+
+// k_march + k_shade for one cursor kind and counting choice, by output mode
+template <int CUR, bool COUNT>
+void launch_two(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, const RenderParams &P)
+{
+    auto go = [&](auto march, auto shade) {
+        hipLaunchKernelGGL(march, grid, dim3(64), 0, st, P);
+        hipLaunchKernelGGL(shade, shade_grid, dim3(64), 0, st, P);
+    };
+    if (mode == OUT_RGBA32F)     go(k_march<CUR, COUNT, OUT_RGBA32F>, k_shade<CUR, COUNT, OUT_RGBA32F>);
+    else if (mode == OUT_GAMMA8) go(k_march<CUR, COUNT, OUT_GAMMA8>, k_shade<CUR, COUNT, OUT_GAMMA8>);
+    else if (mode == OUT_HEAT8)  go(k_march<CUR, COUNT, OUT_HEAT8>, k_shade<CUR, COUNT, OUT_HEAT8>);
+    else                         go(k_march<CUR, COUNT, OUT_WIRE>, k_shade<CUR, COUNT, OUT_WIRE>);
+}
+
 template <int CUR, bool COUNT>
 void launch_pair(bool compact, int bt, dim3 grid, hipStream_t st, const RenderParams &P)
 {
@@ -584,7 +653,9 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     memset(P.frames, 0, sizeof P.frames);
     for (uint32_t f = 0; f < n_frames; f++) unpack(info + f, P.frames[f]);
     if (n_frames > 1 && (compact || pt || count))
-        return fail(SDFHIP_ERR_ARG, "render_batch: only the plain kernel, without counting, renders several frames per launch");
+        return fail(SDFHIP_ERR_ARG, "render_batch: only the default kernels, without counting, render several frames per launch");
+    if (compact && (width > 65535u || nrows_out > 65535u))
+        return fail(SDFHIP_ERR_ARG, "render: the compact kernel packs a pixel's x and row into 16 bits each (frame %u x %u)", width, nrows_out);
     P.out_mode = out_mode;
     {   // the sky constant of Compute.hlsl:196 through DisplayFrag.hlsl:24, alpha excluded
         auto q = [](float c) { float v = powf(c, 1.0f / 2.2f); v = v > 1.0f ? 1.0f : (v > 0.0f ? v : 0.0f); return (uint32_t)(v * 255.0f + 0.5f); };
@@ -593,22 +664,49 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     P.pt_spp = pt ? pt->spp : 0; P.pt_bounces = pt ? pt->max_bounces : 0; P.pt_seed = pt ? pt->seed : 0;
     P.pt_albedo = pt ? pt->albedo : 0.0f;
     P.counters = s->d_counters;
-    P.queue = s->d_queue;
+    // cursor kind: generic, cursor stack, or cursor stack with a top grid as deep as the tree
+    const int cur = !use_stack ? CUR_GENERIC : (s->d_top && s->fine_bits) ? CUR_STACK_SPLIT :
+                    (s->d_top && (uint32_t)s->top_level >= s->depth) ? CUR_STACK_FULL : CUR_STACK;
+    // the two-kernel pipeline (k_march -> k_shade) is the default wherever a find is a grid lookup
+    const bool two = (cur == CUR_STACK_FULL || cur == CUR_STACK_SPLIT) && !compact && !pt && bt == 64 &&
+                     P.tile_order == 0 && !(flags & SDFHIP_TUNE_ONE_KERNEL);
 
-    if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), st));
-    if (compact) HIP_TRY(hipMemsetAsync(s->d_queue, 0, 8 * 32 * sizeof(uint32_t), st));
-    dim3 grid;
+    dim3 grid, shade_grid;
     if (compact) {
         uint32_t blocks = (uint32_t)s->cu_count * 32u;   // one wave per workgroup, 32 waves per CU
         grid = dim3(blocks < P.n_tiles ? blocks : (P.n_tiles ? P.n_tiles : 1));
     } else {
         grid = dim3(P.tile_order == 0 ? 8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x : P.n_tiles, n_frames);
     }
+    sdfhip_scene::Scratch *sc = nullptr;
+    P.queue = nullptr; P.hit_a = nullptr; P.hit_b = nullptr; P.hit_c = nullptr; P.hit_ctl = nullptr; P.hit_cap = 0; P.hit_set = 0;
+    if (two) {
+        // a queue takes the hits of every 64th workgroup: room for all their pixels
+        P.hit_cap = ((grid.x + HIT_QUEUES - 1u) / HIT_QUEUES) * 64u;
+        const size_t records = (size_t)n_frames * HIT_QUEUES * P.hit_cap;
+        int rcs = get_scratch(s, st, records, &sc);
+        if (rcs != SDFHIP_OK) return rcs;
+        P.hit_a = reinterpret_cast<float4 *>(sc->hit_buf);
+        P.hit_b = reinterpret_cast<int4 *>(sc->hit_buf + sc->records * 16);
+        P.hit_c = reinterpret_cast<uint4 *>(sc->hit_buf + sc->records * 32);
+        P.hit_ctl = sc->ctl;
+        P.hit_set = sc->launches++ & 1u;
+        // every queued hit is shaded by a resident wave: at most one chunk of 64 per k_march workgroup
+        const uint32_t resident = (uint32_t)s->cu_count * 32u;
+        shade_grid = dim3(grid.x < resident ? grid.x : resident, n_frames);
+    } else if (compact) {
+        int rcs = get_scratch(s, st, 0, &sc);
+        if (rcs != SDFHIP_OK) return rcs;
+        P.queue = sc->ctl + sdfhip_scene::CTL_HIT_WORDS;
+        HIP_TRY(hipMemsetAsync(P.queue, 0, sdfhip_scene::CTL_QUEUE_WORDS * sizeof(uint32_t), st));
+    }
+    if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), st));
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
-    // cursor kind: generic, cursor stack, or cursor stack with a top grid as deep as the tree
-    const int cur = !use_stack ? CUR_GENERIC : (s->d_top && s->fine_bits) ? CUR_STACK_SPLIT :
-                    (s->d_top && (uint32_t)s->top_level >= s->depth) ? CUR_STACK_FULL : CUR_STACK;
-    if (pt) {
+    if (two) {
+        if (cur == CUR_STACK_SPLIT) { if (count) launch_two<CUR_STACK_SPLIT, true>(out_mode, grid, shade_grid, st, P); else launch_two<CUR_STACK_SPLIT, false>(out_mode, grid, shade_grid, st, P); }
+        else                        { if (count) launch_two<CUR_STACK_FULL, true>(out_mode, grid, shade_grid, st, P); else launch_two<CUR_STACK_FULL, false>(out_mode, grid, shade_grid, st, P); }
+    }
+    else if (pt) {
         grid = dim3(8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x);
         auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(64), 0, st, P); };
         if (cur == CUR_STACK_SPLIT) { if (count) go(k_path<CUR_STACK_SPLIT, true>); else go(k_path<CUR_STACK_SPLIT, false>); }

@@ -13,12 +13,14 @@ from conftest import CAMERAS, GOLDEN, assert_frames_identical, bits_equal, make_
 
 pytestmark = pytest.mark.gpu
 
-ALL_VARIANTS = ["generic", "stack", "generic+compact", "stack+compact"]
+# "stack" = the default: the two-kernel pipeline k_march -> k_shade wherever the scene has a full-depth or split
+# grid (every test scene of depth <= 12 does); "stack+one" = the one-kernel form of the same traversal
+ALL_VARIANTS = ["generic", "stack", "stack+one", "generic+compact", "stack+compact"]
 
 
 def flags_of(sb, name):
     f = {"generic": sb.KERNEL_GENERIC, "stack": sb.KERNEL_STACK}[name.split("+")[0]]
-    return f | (sb.FLAG_COMPACT if name.endswith("compact") else 0)
+    return f | (sb.FLAG_COMPACT if name.endswith("compact") else 0) | (sb.TUNE_ONE_KERNEL if name.endswith("+one") else 0)
 
 
 @pytest.fixture(scope="module")
