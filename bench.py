@@ -12,10 +12,14 @@ on rank 0.
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          # N > 1 without a launcher: spawns that command itself (see spawn_ranks)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -58,6 +62,10 @@ def parse():
     ap.add_argument("--spp", type=int, default=0,
                     help="path-traced mode (BASELINE config 5: --size 3840x2160 --spp 16): spp jittered camera "
                          "rays per pixel + 3 diffuse bounces; Mray/s then counts W*H*spp camera rays")
+    ap.add_argument("--orbit", type=int, default=0,
+                    help="timed region with a camera that moves every frame: N precomputed Info blocks on a circle "
+                         "around the scene's centre (1 degree apart), used round-robin (0 = the fixed cfg-2 camera; "
+                         "the default line reports an orbit pass beside it in `latency`)")
     ap.add_argument("--one-kernel", action="store_true",
                     help="A/B: the one-kernel form (lane state machine, shading in place) instead of the default "
                          "two-kernel pipeline k_march -> k_shade")
@@ -65,6 +73,9 @@ def parse():
     ap.add_argument("--rank0-weight", type=float, default=0.0,
                     help="sharded runs: rank 0's share of the frame as a fraction of a peer's share "
                          "(0 = measure at start-up so that render + assembly on rank 0 takes as long as a peer's render)")
+    ap.add_argument("--sparse-cap-scale", type=float, default=1.25,
+                    help="sparse wire shares: capacity = this x the lit pixels measured before the timed region (a value "
+                         "below 1 forces overflows, to exercise the dense resend)")
     ap.add_argument("--wire", type=int, default=2,
                     help="sharded runs: what the ranks send.  2 = sparse wire shares (code bytes + the non-zero grey "
                          "levels packed per 8x8 tile; capacity measured before the timed region), 1 = 5-byte wire "
@@ -83,8 +94,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            os.dup2(json_fd, 1)
+            raise SystemExit(spawn_ranks(args.gpus))   # nothing has touched the GPU yet in this process
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver supports dmabuf IPC only (RCCL needs it)
@@ -92,8 +104,8 @@ def main():
     import torch.distributed as dist
 
     import sdfbox_amd as sb
-    from sdfbox_amd.tiles import (BandLayout, deinterleave, deinterleave_sparse, render_bands, render_bands_batch, sparse_count,
-                                  sparse_share_bytes, wire_compact, wire_shape)
+    from sdfbox_amd.tiles import (BandLayout, deinterleave, deinterleave_share, deinterleave_sparse, render_bands,
+                                  render_bands_batch, sparse_count, sparse_headers, sparse_share_bytes, wire_compact, wire_shape)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
@@ -127,6 +139,15 @@ def main():
     cam = sb.Logic(W, H)
     cam.Position = (0.5, 0.5, -0.35)
     cam.Heading = (-0.2, 0.35)            # (X = pitch, Y = yaw), Logic.cs:53
+    # --orbit N: the camera of frame k is orbit[k % N] -- the cfg-2 camera carried round the scene's centre in
+    # steps of one degree (position on the circle through (0.5, 0.5, -0.35) about the vertical axis, yaw turned
+    # by the same angle, so the object stays in view as it does when a user walks round it, Logic.cs:252-271)
+    n_orbit_default = 90
+    orbit = orbit_cameras(sb, W, H, args.orbit if args.orbit > 0 else n_orbit_default)
+    cams = orbit if args.orbit > 0 else [cam]
+
+    def cam_of(k):
+        return cams[k % len(cams)]
 
     kflag = {"auto": sb.KERNEL_AUTO, "generic": sb.KERNEL_GENERIC, "stack": sb.KERNEL_STACK}[args.kernel]
     compact = (args.compact == 1) if args.compact >= 0 else DEFAULT_COMPACT
@@ -186,9 +207,20 @@ def main():
         need = torch.tensor([max(counts)], dtype=torch.int64, device="cuda" if nccl else "cpu")
         if world > 1:
             dist.all_reduce(need, op=dist.ReduceOp.MAX)
-        cap = min(full_cap, (int(need.item()) * 5 // 4 + 1023) // 1024 * 1024)
+        cap = min(full_cap, max(1024, (int(int(need.item()) * args.sparse_cap_scale) + 1023) // 1024 * 1024))
         del probe
         send = [torch.zeros((G, sparse_share_bytes(rows_local, W, cap)), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+    # A share that overflows that capacity says so in its header.  Every rank copies the headers of its own shares
+    # to pinned memory behind the compaction (rank 0 also those of the gathered shares, behind the gather), and when
+    # a group's buffers are about to be reused -- groups later, so nothing waits -- a rank whose share overflowed
+    # sends the dense wire share as well, point to point, and rank 0 writes it over that rank's rows.
+    resent = 0
+    hdr_own = hdr_all = hdr_ev = dense_rx = None
+    if sparse:
+        hdr_own = [torch.zeros((G, 8), dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
+        hdr_ev = [torch.cuda.Event() for _ in range(nbuf)]
+        if rank == 0:
+            hdr_all = [torch.zeros((world, G, 8), dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
     if sharded and rank == 0:
         gathered = [torch.zeros((world,) + tuple(send[0].shape), dtype=send[0].dtype, device="cuda") for _ in range(nbuf)]
         frame = [torch.zeros((G, H, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
@@ -201,14 +233,15 @@ def main():
             deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=st,
                          pixel_bytes=wpx_bytes, frames=G)
 
-    def render(buf, st, stats=None, fl=None):
+    def render(buf, st, stats=None, fl=None, c=None):
         f = flags if fl is None else fl
+        c = cam if c is None else c
         if sharded:
-            render_bands(scene, cam, W, layout, rank, buf.data_ptr(), flags=f, stream=st, stats=stats, pt=pt)
+            render_bands(scene, c, W, layout, rank, buf.data_ptr(), flags=f, stream=st, stats=stats, pt=pt)
         elif pt is not None:
-            scene.DrawPathDevice(cam, W, H, buf.data_ptr(), pt=pt, flags=f, stream=st, stats=stats)
+            scene.DrawPathDevice(c, W, H, buf.data_ptr(), pt=pt, flags=f, stream=st, stats=stats)
         else:
-            scene.DrawDevice(cam, W, H, buf.data_ptr(), flags=f, stream=st, stats=stats)
+            scene.DrawDevice(c, W, H, buf.data_ptr(), flags=f, stream=st, stats=stats)
 
     pending = [None] * nbuf
     ev = []                               # (start, end) HIP events around each timed launch
@@ -218,17 +251,59 @@ def main():
     def finish(slot):
         """Complete the gather issued from group buffer `slot`; rank 0 puts the rows of its G frames
         back in order."""
+        nonlocal resent, dense_rx
         w, pending[slot] = pending[slot], None
         if w is None:
             return
+        st = streams[slot]
         if nccl:
-            with torch.cuda.stream(streams[slot]):
+            with torch.cuda.stream(st):
                 w.wait()                              # the group's stream waits for its gather
                 if rank == 0:
-                    assemble(slot, streams[slot].cuda_stream)
+                    if sparse:
+                        hdr_all[slot].copy_(sparse_headers(gathered[slot], rows_local, W, cap), non_blocking=True)
+                        hdr_ev[slot].record(st)
+                    assemble(slot, st.cuda_stream)
         elif rank == 0:                               # gloo rehearsal: through host buffers
             gathered[slot].copy_(torch.stack(w).cuda())
+            if sparse:
+                hdr_all[slot].copy_(sparse_headers(gathered[slot], rows_local, W, cap))
             assemble(slot, main)
+        if not sparse:
+            return
+        # dense resend of overflowed shares (normally none)
+        if rank == 0:
+            if nccl:
+                hdr_ev[slot].synchronize()
+            over = hdr_all[slot].view(torch.int32)[:, :, 1].any(dim=1).tolist()
+            for r in range(world):
+                if not over[r]:
+                    continue
+                resent += 1
+                if r == 0:
+                    src = local[slot]
+                else:
+                    if dense_rx is None:
+                        dense_rx = torch.zeros_like(local[slot])
+                    src = dense_rx
+                    if nccl:
+                        with torch.cuda.stream(st):
+                            dist.recv(src, src=r)
+                    else:
+                        host = torch.empty(local[slot].shape, dtype=local[slot].dtype)
+                        dist.recv(host, src=r)
+                        src.copy_(host)
+                with torch.cuda.stream(st):
+                    deinterleave_share(device, src.data_ptr(), frame[slot].data_ptr(), W, layout, r,
+                                       stream=(st.cuda_stream if nccl else main), pixel_bytes=5, frames=G)
+        else:
+            hdr_ev[slot].synchronize()
+            if bool(hdr_own[slot].view(torch.int32)[:, 1].any()):
+                if nccl:
+                    with torch.cuda.stream(st):
+                        dist.send(local[slot], dst=0)
+                else:
+                    dist.send(local[slot].cpu(), dst=0)
 
     def step(k, timed=False, last=False):
         group, within = divmod(k, G)
@@ -243,8 +318,8 @@ def main():
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(s)
-            render_bands_batch(scene, [cam] * (within + 1), W, layout, rank, local[slot].data_ptr(), flags=flags,
-                               stream=s.cuda_stream)
+            render_bands_batch(scene, [cam_of(k - within + i) for i in range(within + 1)], W, layout, rank,
+                               local[slot].data_ptr(), flags=flags, stream=s.cuda_stream)
             if timed:
                 e1.record(s)
                 ev.append((e0, e1, within + 1))
@@ -252,7 +327,7 @@ def main():
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(s)
-            render(local[slot][within], s.cuda_stream)
+            render(local[slot][within], s.cuda_stream, c=cam_of(k))
             if timed:
                 e1.record(s)
                 ev.append((e0, e1, 1))
@@ -260,6 +335,10 @@ def main():
             return
         if sparse:                                    # three small launches behind the render, on its stream
             wire_compact(device, local[slot].data_ptr(), send[slot].data_ptr(), W, rows_local, G, cap, stream=s.cuda_stream)
+            if rank != 0:                             # this rank's own overflow flags, for finish()
+                with torch.cuda.stream(s):
+                    hdr_own[slot].copy_(sparse_headers(send[slot], rows_local, W, cap), non_blocking=True)
+                    hdr_ev[slot].record(s)
         # one collective for the whole group (a partial last group is gathered whole, too)
         if nccl:
             glist = list(gathered[slot].unbind(0)) if rank == 0 else None
@@ -287,8 +366,13 @@ def main():
     render(local[0], main, stats=st, fl=flags | sb.FLAG_COUNT)
     torch.cuda.synchronize()
     my_pixels = len(layout.rows_of(rank)) * W if sharded else W * H
-    alg_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + wpx_bytes * my_pixels   # SURVEY.md 8d (bytes this rank's kernel stores)
-    counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays], dtype=torch.float64)
+    # the bytes the REFERENCE algorithm reads and writes for these pixels (Compute.hlsl:88-108: entry +
+    # ascents + descents, 8 B of topology each; 8 B of values per sample; the pixel store)
+    ref_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + wpx_bytes * my_pixels
+    # the bytes THIS kernel's own algorithm moves: 16 B per grid cell / node record a lane loads, 48 B written and
+    # 48 B read per hit pixel queued between the two kernels, the pixel store
+    own_bytes_rank = 16 * st.n_loads + 96 * st.n_hits + wpx_bytes * my_pixels
+    counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays, st.n_loads, st.n_hits], dtype=torch.float64)
     kernel_used = st.kernel_used
 
     # ---- warm-up, then the timed region ---------------------------------------------------
@@ -316,24 +400,83 @@ def main():
 
     check_ok = None
     if args.check and sharded and rank == 0:
-        ref = torch.zeros((H, W) + px_shape, dtype=px_dtype, device="cuda")
-        if pt is not None:
-            scene.DrawPathDevice(cam, W, H, ref.data_ptr(), pt=pt, flags=flags, stream=main)
-        else:
-            scene.DrawDevice(cam, W, H, ref.data_ptr(), flags=flags & ~sb.FLAG_WIRE, stream=main)
-        torch.cuda.synchronize()
-        # every frame of every group buffer that the timed steps filled
-        filled = [(g % nbuf, w) for g in range(max(0, (args.steps - 1) // G + 1 - nbuf), (args.steps - 1) // G + 1)
-                  for w in range(G) if g * G + w < args.steps]
-        check_ok = all(bool(torch.equal(frame[sl][w].view(torch.int32), ref.view(torch.int32))) for sl, w in filled)
+        refs = {}
 
-    if rank == 0 and sparse and int(overflow.item()):
-        raise SystemExit("bench.py: a sparse wire share overflowed its capacity: the assembled frames are incomplete")
+        def ref_of(k):                     # the whole-frame render of frame k's camera
+            c = k % len(cams)
+            if c not in refs:
+                ref = torch.zeros((H, W) + px_shape, dtype=px_dtype, device="cuda")
+                if pt is not None:
+                    scene.DrawPathDevice(cams[c], W, H, ref.data_ptr(), pt=pt, flags=flags, stream=main)
+                else:
+                    scene.DrawDevice(cams[c], W, H, ref.data_ptr(), flags=flags & ~sb.FLAG_WIRE, stream=main)
+                torch.cuda.synchronize()
+                refs[c] = ref
+            return refs[c]
+        # every frame of every group buffer that the timed steps filled
+        filled = [(g % nbuf, w, g * G + w) for g in range(max(0, (args.steps - 1) // G + 1 - nbuf), (args.steps - 1) // G + 1)
+                  for w in range(G) if g * G + w < args.steps]
+        check_ok = all(bool(torch.equal(frame[sl][w].view(torch.int32), ref_of(k).view(torch.int32))) for sl, w, k in filled)
+
+    # ---- latency: one frame (sharded: one gather group) at a time, nothing else in flight, host clock around
+    # launch + completion; and the same with the camera moving every frame -----------------------------------
+    def latency_pass(camlist, n):
+        nonlocal cams
+        saved, cams = cams, camlist
+        times = []
+        try:
+            for j in range(n + 3):
+                barrier()
+                t0 = time.perf_counter()
+                for w in range(G):
+                    step(j * G + w, last=(w == G - 1))
+                drain()
+                barrier()
+                if j >= 3:
+                    times.append(time.perf_counter() - t0)
+        finally:
+            cams = saved
+        t = torch.tensor([float(np.median(times))], dtype=torch.float64, device="cuda" if (nccl and world > 1) else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e3
+
+    def throughput_pass(camlist, n):
+        nonlocal cams
+        saved, cams = cams, camlist
+        try:
+            for k in range(min(n, 2 * G * nbuf)):
+                step(k, last=(k == min(n, 2 * G * nbuf) - 1))
+            drain()
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(n):
+                step(k, last=(k == n - 1))
+            drain()
+            barrier()
+            dt = time.perf_counter() - t0
+        finally:
+            cams = saved
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if (nccl and world > 1) else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / n * 1e3
+
+    n_lat = 5 if pt is not None else 40
+    latency = {"frames": G, "ms": round(latency_pass(cams, n_lat), 4)}
+    if pt is None and not args.check:
+        latency["orbit_cameras"] = len(orbit)
+        latency["orbit_ms"] = round(latency_pass(orbit, n_lat), 4)
+        latency["orbit_ms_per_step"] = round(throughput_pass(orbit, max(args.steps, 2 * len(orbit))), 4)
+
     if rank == 0:
         sec_per_step = elapsed / args.steps
-        peak = 8000.0                                  # GB/s, HBM3E spec (MI355X_MICROARCH.md)
         copy_gbs = measured_copy_bandwidth()           # the box's own figure beside the nameplate
-        achieved = alg_bytes_rank * frames_per_launch / (kernel_ms * 1e-3) / 1e9
+        mode = "spp%d" % args.spp if pt is not None else "display" if args.display else "compact" if compact else \
+               "one-kernel" if args.one_kernel else "default"
+        pmc = load_pmc(f"{W}x{H}:{scene_name}:{mode}") if world == 1 else None
+        roof = roofline(sec_per_step, own_bytes_rank, ref_bytes_rank, pmc, copy_gbs)
+        roof.update({"kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch})
         out = {
             "metric": "Mray/s (primary rays; frame W*H / time per frame)",
             "value": round(W * H * max(1, args.spp) / sec_per_step / 1e6, 2),
@@ -342,6 +485,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 4),
+            "latency_ms": latency["ms"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -350,9 +494,12 @@ def main():
             "config": {
                 "workload": (f"{W}x{H} path trace, {args.spp} spp, 3 diffuse bounces, seed 0x5DFB0C5, " if pt is not None else
                              f"{W}x{H} primary-ray sphere trace + shadow march, ") + f"{scene_name} "
-                            f"(N={od.Length} nodes, {od.nbytes / 1e6:.1f} MB), camera (0.5,0.5,-0.35) yaw 0.35 pitch -0.2",
+                            f"(N={od.Length} nodes, {od.nbytes / 1e6:.1f} MB), camera (0.5,0.5,-0.35) yaw 0.35 pitch -0.2" +
+                            (f", moving 1 degree per frame round the scene ({len(cams)} cameras)" if args.orbit > 0 else ""),
                 "kernel": ("path/" if pt is not None else "") +
-                          ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else ""),
+                          ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else "") +
+                          ("" if (pt is not None or compact) else ", one kernel" if args.one_kernel else ", k_march -> k_shade where the scene has a full grid"),
+                "top_grid": {"level": scene.top_grid_level, "bytes": scene.top_grid_bytes},
                 "parallelism": "1 GPU" if not sharded else
                                f"{world} GPU(s), {args.band_rows}-row bands " +
                                ("round-robin" if not layout.weighted else
@@ -362,24 +509,17 @@ def main():
                 "frames_per_gather": G if sharded else None,
                 "gather_pixel_bytes": (round(send[0].shape[1] / (rows_local * W), 3) if sparse else wpx_bytes) if sharded else None,
                 "gather_format": ("sparse wire" if sparse else "wire" if wire else "frame pixels") if sharded else None,
+                "sparse_shares_resent_dense": resent if sparse else None,
                 "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
                 "gstep_per_s": round(float(counters[2]) / sec_per_step / 1e9, 3),
                 "shadow_rays_per_frame": int(counters[3]),
                 "scene_build_s": round(t_gen, 2),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": peak,
-                "unit": "GB/s",
-                "frac": round(achieved / peak, 4),
-                "traffic": None if (args.display or pt is not None) else load_traffic(W, H, scene_name, world),
-                "kernel_ms": round(kernel_ms, 4),
-                "algorithmic_bytes_per_launch": int(alg_bytes_rank * frames_per_launch),
-                "frames_per_launch": frames_per_launch,
-                "measured_copy_gbs": copy_gbs,
-                "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
-            },
+            # latency: host clock around launch + completion of ONE frame (sharded: one gather group of `frames`
+            # frames) with nothing else in flight -- what an interactive viewer waits for; orbit_*: the same, and the
+            # pipelined time per frame, with the camera moving every frame (caches see a new access pattern each time)
+            "latency": latency,
+            "roofline": roof,
         }
         if check_ok is not None:
             out["config"]["assembled_frame_equals_whole_frame_render"] = check_ok
@@ -457,6 +597,105 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
     return float(w.item())
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run and relay
+    its JSON line and exit code.  This process has not touched the GPU (no torch import yet) and never will."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in child.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return child.returncode if child.returncode or lines else 1
+
+
+def orbit_cameras(sb, W, H, n):
+    """n cameras, one degree apart, on the horizontal circle through the cfg-2 camera position about the scene's
+    centre, each turned by its angle (yaw convention of Matrix4x4.CreateFromYawPitchRoll: forward = (sin yaw, ., cos yaw))."""
+    import math
+    out = []
+    r = 0.5 + 0.35
+    for k in range(n):
+        phi = math.radians(k)
+        c = sb.Logic(W, H)
+        c.Position = (0.5 - r * math.sin(phi), 0.5, 0.5 - r * math.cos(phi))
+        c.Heading = (-0.2, 0.35 + phi)
+        out.append(c)
+    return out
+
+
+def kernel_source_hash():
+    """What the PMC figures in profiles/hbm_traffic.json were measured on (scripts/summarise_profile.py)."""
+    h = hashlib.sha256()
+    for f in ("raymarch_device.h", "raymarch_kernels.h", "sdfhip_device.hip"):
+        with open(os.path.join(REPO, "sdfbox_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(key):
+    """rocprofv3 PMC figures of this workload (HBM bytes and issued VALU / SALU wave instructions per frame), or
+    None.  bench.py cannot run rocprofv3 on itself: scripts/profile.sh collects the separate --pmc passes of this
+    very command and scripts/summarise_profile.py writes profiles/hbm_traffic.json together with the hash of the
+    kernel sources they were measured on; figures of another build are not reported."""
+    try:
+        with open(os.path.join(REPO, "profiles", "hbm_traffic.json")) as f:
+            e = json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+    if not isinstance(e, dict) or e.get("kernel_source_sha") != kernel_source_hash():
+        return None
+    return e
+
+
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles (16 lanes wide), 2.4 GHz
+HBM_PEAK_GBS = 8000.0                    # HBM3E spec (MI355X_MICROARCH.md)
+
+
+def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
+    """Which roof does the frame sit under?  Three candidates, each achieved / peak over the steady-state time per
+    frame (the driver-verifiable ms_per_step; with frames in flight the per-launch durations overlap):
+      hbm-algorithmic  the bytes this kernel's own algorithm moves (16 B per cell / record a lane loads, 96 B per
+                       queued hit, the pixel store; counted by the counting build), against 8 TB/s;
+      hbm-traffic      HBM bytes from the rocprofv3 counters (2 x FETCH_SIZE + WRITE_SIZE, separate passes), against 8 TB/s;
+      valu             issued VALU wave instructions (SQ_INSTS_VALU), against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
+                       (scripts/micro/valu_rate.hip measures 603 G/s of that 614 on the box).
+    `frac` is the largest of them -- the binding roof -- and `bound` names it.  The reference algorithm's bytes
+    (8 B per node visit of find(), Compute.hlsl:88-108) are kept as a work-equivalent rate without a
+    fraction: the kernel does not perform those loads (one grid lookup replaces up to nine node visits)."""
+    cands = {"hbm-algorithmic": {"achieved": own_bytes / sec_per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": int(own_bytes)}}
+    traffic = None
+    if pmc:
+        traffic = int(pmc["hbm_bytes_per_frame"])
+        cands["hbm-traffic"] = {"achieved": traffic / sec_per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": traffic}
+        if pmc.get("valu_insts_per_frame"):
+            cands["valu"] = {"achieved": pmc["valu_insts_per_frame"] / sec_per_frame / 1e9, "peak": VALU_PEAK_GINSTR,
+                             "unit": "G wave-instr/s", "per_frame": int(pmc["valu_insts_per_frame"])}
+    for c in cands.values():
+        c["frac"] = round(c["achieved"] / c["peak"], 4)
+        c["achieved"] = round(c["achieved"], 1)
+    name = max(cands, key=lambda k: cands[k]["frac"])
+    b = cands[name]
+    return {
+        "bound": "hbm" if name.startswith("hbm") else "valu",
+        "binding": name,
+        "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"],
+        "traffic": traffic,
+        "traffic_source": ({"profile": pmc.get("profile"), "kernel_source_sha": pmc.get("kernel_source_sha")} if pmc else
+                           "no PMC pass of this build and workload under profiles/ (scripts/profile.sh)"),
+        "candidates": cands,
+        "reference_algorithm_bytes_per_frame": int(ref_bytes),
+        "reference_algorithm_gbs": round(ref_bytes / sec_per_frame / 1e9, 1),
+        "measured_copy_gbs": copy_gbs,
+    }
+
+
 def measured_copy_bandwidth(nbytes=1 << 30, reps=10):
     """Device-to-device copy of 1 GiB, read + written bytes per second in GB/s: what this
     box's HBM delivers to a streaming kernel, reported next to the 8 TB/s nameplate."""
@@ -476,57 +715,83 @@ def measured_copy_bandwidth(nbytes=1 << 30, reps=10):
         return None
 
 
-def load_traffic(W, H, scene_name, world):
-    """HBM bytes per launch from the committed PMC passes, or None.  bench.py cannot run
-    rocprofv3 on itself; scripts/profile.sh collects the separate --pmc FETCH_SIZE /
-    WRITE_SIZE passes of this command and scripts/summarise_profile.py writes
-    profiles/hbm_traffic.json (method and gfx950 corrections: DESIGN.md section 6)."""
-    if world != 1:
-        return None
-    try:
-        with open(os.path.join(REPO, "profiles", "hbm_traffic.json")) as f:
-            return json.load(f).get(f"{W}x{H}:{scene_name}")
-    except (OSError, ValueError):
-        return None
-
-
 def cpu_baseline(od, cam, W, H, target_seconds):
-    """The CPU oracle (the build's C restatement of Compute.hlsl: the reference has
-    no CPU path) timed on this host over a bounded sample of the
-    same frame: every `step`-th row, rows interleaved over all hardware threads."""
+    """The CPU oracle (the build's C restatement of Compute.hlsl: the reference has no CPU path)
+    timed on this host over a bounded sample of the same frame: every `step`-th row, rows interleaved over ALL
+    hardware threads, built here with -O3 -march=native -- same source, same -ffp-contract=off, and
+    its rows are compared bit for bit with the portable build the parity tests use."""
     import oracle
     oracle.build()
-    nthreads = min(os.cpu_count() or 1, 64)
+    native = oracle.build_native()                     # None when the host has no compiler: then the portable build is timed
+    nthreads = os.cpu_count() or 1
+    kw = {"native": native is not None}
     # calibrate on 2*nthreads rows spread over the frame, then size the sample
     ncal = min(H, 2 * nthreads)
     t0 = time.perf_counter()
     oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=ncal, row_step=max(1, H // ncal),
-                  nthreads=nthreads)
+                  nthreads=nthreads, **kw)
     per_row = (time.perf_counter() - t0) / ncal
     rows = int(min(H, max(nthreads, target_seconds / max(per_row, 1e-9))))
     step = max(1, H // rows)
     nrows = (H + step - 1) // step
     t0 = time.perf_counter()
-    oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=nrows, row_step=step, nthreads=nthreads)
+    img, _ = oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=nrows, row_step=step, nthreads=nthreads, **kw)
     dt = time.perf_counter() - t0
     pix = nrows * W
+    same = None
+    if native is not None:                             # a few rows through the portable build: identical bits
+        k = max(1, nrows // 8)
+        ref, _ = oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=(nrows + k - 1) // k, row_step=step * k,
+                               nthreads=nthreads)
+        a, b = img[::k].view(np.uint32), ref.view(np.uint32)
+        same = bool(((a == b) | (np.isnan(img[::k]) & np.isnan(ref))).all())
     # one thread beside it (SURVEY.md 8d), on a sparser sample of the same frame: about 2 s
     step1 = max(1, int(H * per_row * nthreads / 2.0))
     nrows1 = (H + step1 - 1) // step1
     t0 = time.perf_counter()
-    oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=nrows1, row_step=step1, nthreads=1)
+    oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=nrows1, row_step=step1, nthreads=1, **kw)
     dt1 = time.perf_counter() - t0
+    model, physical = host_cpu()
     return {
         "value": round(pix / dt / 1e6, 3),
         "unit": "Mray/s",
         "cores": nthreads,
         "kind": "port",
+        "cpu_model": model,
+        "physical_cores": physical,
+        "build": ("gcc -O3 -march=native -ffp-contract=off, built on this host" if native is not None else
+                  "gcc -O2 -march=x86-64-v2 -ffp-contract=off (no compiler on this host: the portable build)"),
+        "native_build_equals_portable_build": same,
         "sample": f"every {step}th row of the same {W}x{H} frame = {pix} pixels in {dt:.2f} s wall "
-                  f"({dt * nthreads:.0f} core-seconds); oracle/sdf_oracle.c, gcc -O2 -ffp-contract=off, "
-                  f"{nthreads} pthreads, rows interleaved",
+                  f"({dt * nthreads:.0f} thread-seconds); oracle/sdf_oracle.c, {nthreads} pthreads (all hardware threads), "
+                  f"rows interleaved",
         "one_thread": {"value": round(nrows1 * W / dt1 / 1e6, 3), "unit": "Mray/s",
                        "sample": f"every {step1}th row = {nrows1 * W} pixels in {dt1:.2f} s"},
     }
+
+
+def host_cpu():
+    """(model name, physical cores) from /proc/cpuinfo; (None, None) when it cannot be read."""
+    try:
+        model, cores = None, set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model is None:
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None and core is not None:
+                    cores.add((phys, core)); phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        return model, (len(cores) or None)
+    except OSError:
+        return None, None
 
 
 if __name__ == "__main__":

@@ -101,6 +101,12 @@ typedef struct sdfhip_stats {
     uint32_t pad_;
     uint64_t n_shadow_rays; /* with SDFHIP_FLAG_COUNT: pixels (path vertices) */
                             /* that cast a shadow ray, Compute.hlsl:213       */
+    uint64_t n_loads;       /* with SDFHIP_FLAG_COUNT: 16-byte node records / */
+                            /* grid cells the kernels themselves loaded (one  */
+                            /* per lane and load): their own algorithmic reads */
+    uint64_t n_hits;        /* with SDFHIP_FLAG_COUNT: pixels queued from the */
+                            /* primary-march kernel to the shading kernel     */
+                            /* (48-byte records written and read once)        */
 } sdfhip_stats;
 
 /* ---- errors ------------------------------------------------------------ */
@@ -358,6 +364,18 @@ SDFHIP_API int sdfhip_deinterleave_bands_device(int device, const void *d_gather
  *                                       robin) for [world][frames] sparse shares; *d_overflow (device word,
  *                                       may be NULL) is OR-ed with 1 when a share overflowed */
 SDFHIP_API uint64_t sdfhip_wire_sparse_bytes(uint32_t width, uint32_t rows, uint32_t capacity);
+/* Recovery when a sparse share overflowed its capacity: byte offset, within a sparse share, of its 16-byte
+ * header {uint32 lit pixels, uint32 overflowed, 0, 0} -- the sender reads word 1 of its own shares and rank 0
+ * that of the gathered ones, and the rank concerned sends the share again in the dense wire format
+ * (point to point: no other rank takes part), which rank 0 writes over that rank's rows with
+ *   sdfhip_deinterleave_share_device   like sdfhip_deinterleave[_bands]_device, but d_share holds the
+ *                                      [frames] buffers of ONE rank (`rank`) and only its rows are written
+ * (owner may be NULL: round robin). */
+SDFHIP_API uint64_t sdfhip_wire_sparse_head_offset(uint32_t width, uint32_t rows, uint32_t capacity);
+SDFHIP_API int sdfhip_deinterleave_share_device(int device, const void *d_share, void *d_frame,
+                                                uint32_t width, uint32_t height, uint32_t band_rows,
+                                                uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
+                                                uint32_t rank, uint32_t pixel_bytes, uint32_t frames, void *stream);
 SDFHIP_API int sdfhip_wire_compact_device(int device, const void *d_wire, void *d_sparse, uint32_t width,
                                           uint32_t rows, uint32_t frames, uint32_t capacity, void *stream);
 SDFHIP_API int sdfhip_deinterleave_sparse_device(int device, const void *d_gathered, void *d_frame,

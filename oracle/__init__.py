@@ -20,36 +20,60 @@ def build(force=False):
     return LIB_PATH
 
 
+NATIVE_PATH = os.path.join(_HERE, "liboracle_native.so")
+
+
+def build_native():
+    """The same sources with -O3 -march=native, built on THIS host (bench.py's cpu_baseline leg on the GPU box;
+    never shipped from another machine: -march=native code is not portable).  -> path, or None without a compiler."""
+    srcs = [os.path.join(_HERE, f) for f in ("sdf_oracle.c", "sdfgen_oracle.c")]
+    try:
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c11",
+                               "-shared", "-o", NATIVE_PATH] + srcs + ["-lm", "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return NATIVE_PATH
+
+
 _lib = None
+_native = None
 
 
-def lib():
-    global _lib
+def lib(native=False):
+    global _lib, _native
+    if native:
+        if _native is None:
+            _native = _bind(ctypes.CDLL(NATIVE_PATH))
+        return _native
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
-        L = ctypes.CDLL(LIB_PATH)
-        vp, u32, c = ctypes.c_void_p, ctypes.c_uint32, ctypes
-        L.oracle_render_rows.restype = c.c_int
-        L.oracle_render_rows.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, vp, vp, vp, c.c_int]
-        L.oracle_render_rows_pt.restype = c.c_int
-        L.oracle_render_rows_pt.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, u32, u32, u32, c.c_float, vp, vp, c.c_int]
-        L.oracle_pixel.restype = None
-        L.oracle_pixel.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp]
-        L.oracle_distance_at.restype = c.c_float
-        L.oracle_distance_at.argtypes = [vp, vp, u32, c.c_float, c.c_float, c.c_float,
-                                         c.POINTER(u32), c.POINTER(c.c_float)]
-        L.oracle_unorm_table.restype = None
-        L.oracle_unorm_table.argtypes = [vp]
-        L.oracle_sdfgen.restype = c.c_int
-        L.oracle_sdfgen.argtypes = [vp, u32, c.c_int32, c.POINTER(vp), c.POINTER(vp), c.POINTER(vp), c.POINTER(u32),
-                                    c.POINTER(c.c_float), c.POINTER(c.c_float * 3)]
-        L.oracle_sdfgen_free.restype = None
-        L.oracle_sdfgen_free.argtypes = [vp]
-        L.oracle_display.restype = None
-        L.oracle_display.argtypes = [vp, c.c_uint64, c.c_int, vp]
-        _lib = L
+        _lib = _bind(ctypes.CDLL(LIB_PATH))
     return _lib
+
+
+def _bind(L):
+    vp, u32, c = ctypes.c_void_p, ctypes.c_uint32, ctypes
+    L.oracle_render_rows.restype = c.c_int
+    L.oracle_render_rows.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, vp, vp, vp, c.c_int]
+    L.oracle_render_rows_pt.restype = c.c_int
+    L.oracle_render_rows_pt.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, u32, u32, u32, c.c_float, vp, vp, c.c_int]
+    L.oracle_pixel.restype = None
+    L.oracle_pixel.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp]
+    L.oracle_distance_at.restype = c.c_float
+    L.oracle_distance_at.argtypes = [vp, vp, u32, c.c_float, c.c_float, c.c_float,
+                                     c.POINTER(u32), c.POINTER(c.c_float)]
+    L.oracle_unorm_table.restype = None
+    L.oracle_unorm_table.argtypes = [vp]
+    L.oracle_sdfgen.restype = c.c_int
+    L.oracle_sdfgen.argtypes = [vp, u32, c.c_int32, c.POINTER(vp), c.POINTER(vp), c.POINTER(vp), c.POINTER(u32),
+                                c.POINTER(c.c_float), c.POINTER(c.c_float * 3)]
+    L.oracle_sdfgen_free.restype = None
+    L.oracle_sdfgen_free.argtypes = [vp]
+    L.oracle_display.restype = None
+    L.oracle_display.argtypes = [vp, c.c_uint64, c.c_int, vp]
+    return L
 
 
 def _info_buf(info):
@@ -59,7 +83,7 @@ def _info_buf(info):
 
 
 def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1, per_pixel_nodes=False,
-           row_step=1):
+           row_step=1, native=False):
     """-> (rgba[nrows, W, 4] f32, counters[4] u64 (nodes, samples, steps, shadow rays)[, nodes per pixel])."""
     structs = np.ascontiguousarray(structs, dtype=np.int32)
     values = np.ascontiguousarray(values, dtype=np.uint8)
@@ -70,7 +94,7 @@ def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1,
     cnt = np.zeros(4, dtype=np.uint64)
     pix = np.zeros((nrows, width), dtype=np.uint32) if per_pixel_nodes else None
     ib = _info_buf(info)
-    rc = lib().oracle_render_rows(structs.ctypes.data, values.ctypes.data, n, ctypes.addressof(ib),
+    rc = lib(native).oracle_render_rows(structs.ctypes.data, values.ctypes.data, n, ctypes.addressof(ib),
                                   width, row0, nrows, row_step, out.ctypes.data, cnt.ctypes.data,
                                   pix.ctypes.data if pix is not None else None, int(nthreads))
     if rc != 0:

@@ -72,6 +72,8 @@ class Stats(ctypes.Structure):
         ("kernel_used", ctypes.c_uint32),
         ("pad_", ctypes.c_uint32),
         ("n_shadow_rays", ctypes.c_uint64),
+        ("n_loads", ctypes.c_uint64),
+        ("n_hits", ctypes.c_uint64),
     ]
 
 
@@ -159,6 +161,9 @@ _SIG = {
                                                     _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_uint8), _c.c_uint32,
                                                     _c.c_uint32, _vp]),
     "sdfhip_wire_sparse_bytes": (_c.c_uint64, [_c.c_uint32, _c.c_uint32, _c.c_uint32]),
+    "sdfhip_wire_sparse_head_offset": (_c.c_uint64, [_c.c_uint32, _c.c_uint32, _c.c_uint32]),
+    "sdfhip_deinterleave_share_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                                    _c.c_uint32, _c.POINTER(_c.c_uint8), _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "sdfhip_wire_compact_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "sdfhip_deinterleave_sparse_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                      _c.c_uint32, _c.POINTER(_c.c_uint8), _c.c_uint32, _c.c_uint32, _vp, _vp]),

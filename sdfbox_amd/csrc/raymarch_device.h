@@ -73,7 +73,7 @@ struct RenderParams {
     // kernel-argument segment (scalar loads), never through a modified copy.
     uint32_t n_frames;
     FrameInfo frames[MAX_BATCH];
-    unsigned long long *counters;  // [0] nodes [1] samples [2] steps [3] shadow rays (COUNT builds)
+    unsigned long long *counters;  // [0] nodes [1] samples [2] steps [3] shadow rays [4] records / cells loaded [5] queued hits (COUNT builds)
     uint32_t *queue;           // tile queue head (compact kernels)
     uint32_t tile_order;       // k_plain: blockIdx -> tile mapping (tuning knob, flags bits 8..11)
     // fused display pass (DisplayFrag.hlsl): out_mode 0 = RGBA32F frame, 1 = gamma RGBA8,
@@ -155,6 +155,7 @@ struct CursorG {
     int32_t parent, children;
     uint32_t v0, v1;
     uint32_t index;
+    uint32_t loads;          // 16-byte records this lane has loaded (the kernels zero it; only the counting ones read it)
 
     __device__ __forceinline__ void reset(const NodeRec &root)
     {
@@ -207,7 +208,7 @@ __device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__
         NodeRec r = nodes[c.index];
         c.parent = (int32_t)r.x; c.children = (int32_t)r.y; c.v0 = r.z; c.v1 = r.w;
         scale_up(c);
-        reads++;
+        reads++; c.loads++;
     }
     int iterations = 0;
     while (c.index < n_nodes && iterations < 12 && c.children >= 0) {
@@ -216,7 +217,7 @@ __device__ __forceinline__ uint32_t find(CursorG &c, const NodeRec *__restrict__
         NodeRec r = nodes[c.index];
         c.parent = (int32_t)r.x; c.children = (int32_t)r.y; c.v0 = r.z; c.v1 = r.w;
         iterations++;
-        reads++;
+        reads++; c.loads++;
     }
     return reads;
 }
@@ -289,6 +290,7 @@ struct CursorS {
     int32_t level;
     int32_t children;
     uint32_t v0, v1;
+    uint32_t loads;          // 16-byte records / grid cells this lane has loaded (the kernels zero it; only the counting ones read it)
 
     __device__ __forceinline__ void reset(const NodeRec &root)
     {
@@ -366,6 +368,7 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
             const uint32_t cellidx = top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG);
             const uint4 e = reinterpret_cast<const uint4 *>(top)[cellidx];
             const int lvl = (int)e.x;
+            c.loads++;
             reads += (uint32_t)(lvl - c.level);
             c.level = lvl;
             c.children = (int32_t)e.w;
@@ -385,7 +388,7 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
             // round trip after it
             asm volatile("" : "+v"(c.v0), "+v"(c.v1));
             c.level++;
-            reads++;
+            reads++; c.loads++;
         }
         const int32_t keep = ~((1 << (LM - c.level)) - 1);
         c.ax = Dx & keep; c.ay = Dy & keep; c.az = Dz & keep;
@@ -428,6 +431,7 @@ struct CursorFT {
     int32_t ax, ay, az;      // lower * 2^LM
     uint32_t s;              // LM - level, | FLAT_BIT
     uint32_t v0, v1;         // the 8 value bytes; a flat cell: v0 = its byte four times, v1 = its distance (float bits)
+    uint32_t loads;          // grid cells this lane has loaded (the kernels zero it; only the counting ones read it)
 
     __device__ __forceinline__ void reset(const NodeRec &root)
     {
@@ -454,11 +458,13 @@ __device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT> &c, const GridRe
 {
     const int TG = g.level, sh = LM - TG;
     uint4 e = reinterpret_cast<const uint4 *>(g.top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
+    c.loads++;
     if (SPLIT) {
         // one 16-byte load for the whole cell (left alone, the compiler fetches level and children first
         // and the values in a second, dependent load)
         asm volatile("" : "+v"(e.y), "+v"(e.z), "+v"(e.w));
         if (e.x == 15u) {                         // internal at the coarse level: its block of fine cells
+            c.loads++;
             const int FB = g.fine_bits, sh2 = sh - FB;
             const uint32_t m = (1u << FB) - 1u;
             const uint32_t local = (((uint32_t)Dx >> sh2) & m) | ((((uint32_t)Dy >> sh2) & m) << FB) | ((((uint32_t)Dz >> sh2) & m) << (2 * FB));

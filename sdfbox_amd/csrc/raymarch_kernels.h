@@ -247,21 +247,27 @@ __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const Fram
     return reads;
 }
 
+// loads: 16-byte node records / grid cells the kernel itself loaded (the cursor counts them); hits: pixels queued for k_shade
 __device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned long long nodes,
                                                unsigned long long samples, unsigned long long steps,
-                                               unsigned long long shadow_rays)
+                                               unsigned long long shadow_rays, unsigned long long loads,
+                                               unsigned long long hits = 0)
 {
     for (int off = 32; off > 0; off >>= 1) {
         nodes += __shfl_down(nodes, off);
         samples += __shfl_down(samples, off);
         steps += __shfl_down(steps, off);
         shadow_rays += __shfl_down(shadow_rays, off);
+        loads += __shfl_down(loads, off);
+        hits += __shfl_down(hits, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&P.counters[0], nodes);
         atomicAdd(&P.counters[1], samples);
         atomicAdd(&P.counters[2], steps);
         atomicAdd(&P.counters[3], shadow_rays);
+        atomicAdd(&P.counters[4], loads);
+        if (hits) atomicAdd(&P.counters[5], hits);
     }
 }
 
@@ -302,13 +308,14 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
     constexpr uint32_t WX = TW / 8;                        // waves side by side in a tile
     const uint32_t x = tx * TW + (wave % WX) * 8 + (lane & 7u);
     const uint32_t yl = ty * TH + (wave / WX) * 8 + (lane >> 3);
-    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0;   // nodes, samples, steps, shadow rays
+    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0, cl = 0;   // nodes, samples, steps, shadow rays, loads
     bool live = x < P.width && yl < P.nrows_out;
     uint32_t y = 0;
     if (live) { y = global_row(P, yl); live = y < P.height; }
     if (live) {
         RayState r;
         typename CursorOf<CUR, COUNT>::type c;
+        c.loads = 0;
         const NodeRec root = P.nodes[0];
         start_pixel(I, root, x, y, r, c);
         const size_t npx = (size_t)P.nrows_out * P.width, lidx = (size_t)yl * P.width + x;
@@ -322,9 +329,9 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
             uint32_t reads = march_step(P, I, r, c, stack_lds + tid, BT);
             if (COUNT) { cn += reads; cs += 1; }
         }
-        if (COUNT) { ct = (unsigned long long)(r.base + r.n); cr = r.phase == PH_SHADOW ? 1u : 0u; }   // shade() left the lane in PH_SHADOW
+        if (COUNT) { ct = (unsigned long long)(r.base + r.n); cr = r.phase == PH_SHADOW ? 1u : 0u; cl = c.loads; }   // shade() left the lane in PH_SHADOW
     }
-    if (COUNT) flush_counters(P, cn, cs, ct, cr);
+    if (COUNT) flush_counters(P, cn, cs, ct, cr, cl);
 }
 
 // =====================================================================================
@@ -431,6 +438,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     if (live) { y = global_row(P, yl); live = y < P.height; }
     RayState r;
     CursorT c;
+    c.loads = 0;
     const NodeRec root = P.nodes[0];
     start_pixel(I, root, live ? x : 0u, live ? y : 0u, r, c);
     // Compute.hlsl:194-203.  One exit: the loop-header test and the escape test are evaluated together and
@@ -464,7 +472,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
             P.hit_c[slot] = make_uint4((uint32_t)lidx, (uint32_t)r.n, c.v0, c.v1);
         }
     }
-    if (COUNT) flush_counters(P, cn, cs, ct, 0);
+    if (COUNT) flush_counters(P, cn, cs, ct, 0, c.loads, end == 1 ? 1u : 0u);
 }
 
 // One lane per hit record; a wave takes 64 consecutive records of one queue at a time (chunks are
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shade(RenderParams
     uint32_t incl = chunks;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0;
+    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0, cl = 0;
     for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
         // queue of chunk t = the number of queues whose inclusive sum is <= t
         const uint32_t q = (uint32_t)__popcll(__ballot(incl <= t));
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shade(RenderParams
             CursorT c;
             r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w;
             r.n = (int)e.y; r.base = 0; r.phase = PH_PRIMARY;
-            c.ax = b.x; c.ay = b.y; c.az = b.z; c.s = (uint32_t)b.w; c.v0 = e.z; c.v1 = e.w;
+            c.ax = b.x; c.ay = b.y; c.az = b.z; c.s = (uint32_t)b.w; c.v0 = e.z; c.v1 = e.w; c.loads = 0;
             const size_t lidx = e.x;
             // Compute.hlsl:205-213
             float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;
@@ -540,9 +548,10 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shade(RenderParams
                 else dst.black(lidx, (float)(r.base + r.n));
                 if (COUNT) ct += (unsigned long long)(r.base + r.n);
             }
+            if (COUNT) cl += c.loads;
         }
     }
-    if (COUNT) flush_counters(P, cn, cs, ct, cr);
+    if (COUNT) flush_counters(P, cn, cs, ct, cr, cl);
 }
 
 // ---- persistent waves with lane refill and state batching (wavefront ray compaction) --
@@ -582,6 +591,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
     r.px = r.py = r.pz = r.dx = r.dy = r.dz = r.prox = r.angle = r.dist = 0.0f;
     r.n = r.base = 0;
     r.phase = PH_IDLE;
+    c.loads = 0;
     c.reset(root);
     const uint32_t rows_q = (P.tiles_y + 7u) >> 3;         // tile rows per queue (upper bound)
 
@@ -674,7 +684,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
             }
         }
     }
-    if (COUNT) flush_counters(P, cn, cs, ct, cr);
+    if (COUNT) flush_counters(P, cn, cs, ct, cr, c.loads);
 }
 
 // ---- path-traced mode (BASELINE config 5) -----------------------------------------------
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
     if (row >= P.tiles_y) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t x = cxx * 8 + (lane & 7u), yl = row * 8 + (lane >> 3);
-    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0;   // nodes, samples, steps, shadow rays
+    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0, cl = 0;   // nodes, samples, steps, shadow rays, loads
     bool live = x < P.width && yl < P.nrows_out;
     uint32_t y = 0;
     if (live) { y = global_row(P, yl); live = y < P.height; }
@@ -714,6 +724,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
         uint32_t steps = 0;
         // lane state
         CursorT c;
+        c.loads = 0;
         float mx, my, mz;        // the position being marched (segment, then shadow ray)
         float ux, uy, uz;        // its direction (segment direction, then direction to the light)
         float hx = 0, hy = 0, hz = 0;   // the hit point, kept while the shadow ray marches
@@ -836,9 +847,9 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
         }
         const float inv = (float)P.pt_spp;
         P.out[(size_t)yl * P.width + x] = make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps);
-        if (COUNT) ct = steps;
+        if (COUNT) { ct = steps; cl = c.loads; }
     }
-    if (COUNT) flush_counters(P, cn, cs, ct, cr);
+    if (COUNT) flush_counters(P, cn, cs, ct, cr, cl);
 }
 
 }  // namespace sdfhip

@@ -104,8 +104,10 @@ struct WirePlanes {};   // In = WirePlanes: a rank's frame is the two planes SDF
 template <class In, class Out>
 __global__ void k_deinterleave(const In *__restrict__ gathered, Out *__restrict__ frame,
                                uint32_t width, uint32_t height, uint32_t band_rows, uint32_t world,
-                               uint32_t rows_per_rank, uint32_t frames, const BandMap M)
+                               uint32_t rows_per_rank, uint32_t frames, const BandMap M, uint32_t only_rank)
 {
+    // only_rank != ~0: `gathered` is that one rank's buffer, and only its rows are written (the dense resend of a
+    // rank whose sparse share overflowed)
     // gathered: [world][frames][rows_per_rank][width]  ->  frame: [frames][height][width]
     size_t per_frame = (size_t)width * height, total = per_frame * frames;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -115,6 +117,7 @@ __global__ void k_deinterleave(const In *__restrict__ gathered, Out *__restrict_
         uint32_t y = (uint32_t)(r / width), x = (uint32_t)(r - (size_t)y * width);
         uint32_t band = y / band_rows, rank = band % world, lband = band / world;
         if (M.n) { const uint32_t e = M.src[band]; rank = e >> 10; lband = e & 1023u; }
+        if (only_rank != 0xFFFFFFFFu) { if (rank != only_rank) continue; rank = 0; }
         uint32_t yl = lband * band_rows + (y - band * band_rows);
         if constexpr (std::is_same<In, WirePlanes>::value) {
             const size_t npx = (size_t)rows_per_rank * width, l = (size_t)yl * width + x;
@@ -272,7 +275,7 @@ struct sdfhip_scene {
     TopCell *d_fine;                 // split grid: blocks of fine cells below the internal cells of d_top, or null
     int fine_bits;
     uint64_t fine_bytes;
-    unsigned long long *d_counters;  // 4 x u64: nodes, samples, steps, shadow rays
+    unsigned long long *d_counters;  // 6 x u64: nodes, samples, steps, shadow rays, loads, hits
     // Per-stream scratch of the render launches: the hit queues of the two-kernel pipeline and their
     // control words, and the tile-queue heads of the compact kernel.  Launches on one stream run in
     // order and may share a scratch; launches on different streams overlap (frames in flight) and
@@ -391,7 +394,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if ((e = hipEventCreate(&s->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(&s->alloc, (size_t)n * 16 + 128)) != hipSuccess) return bail(e, "hipMalloc(records)");
     s->nodes = reinterpret_cast<NodeRec *>(static_cast<char *>(s->alloc) + 112);
-    if ((e = hipMalloc((void **)&s->d_counters, 4 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMalloc((void **)&s->d_counters, 6 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMalloc(&d_s, bytes)) != hipSuccess) return bail(e, "hipMalloc(structs)");
     if ((e = hipMalloc(&d_v, bytes)) != hipSuccess) return bail(e, "hipMalloc(values)");
     if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
@@ -700,7 +703,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         P.queue = sc->ctl + sdfhip_scene::CTL_HIT_WORDS;
         HIP_TRY(hipMemsetAsync(P.queue, 0, sdfhip_scene::CTL_QUEUE_WORDS * sizeof(uint32_t), st));
     }
-    if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), st));
+    if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 6 * sizeof(unsigned long long), st));
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     if (two) {
         if (cur == CUR_STACK_SPLIT) { if (count) launch_two<CUR_STACK_SPLIT, true>(out_mode, grid, shade_grid, st, P); else launch_two<CUR_STACK_SPLIT, false>(out_mode, grid, shade_grid, st, P); }
@@ -727,10 +730,11 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         stats->kernel_used = (use_stack ? SDFHIP_KERNEL_STACK : SDFHIP_KERNEL_GENERIC) |
                              (compact ? SDFHIP_FLAG_COMPACT : 0u);
         if (count) {
-            unsigned long long h[4];
+            unsigned long long h[6];
             HIP_TRY(hipMemcpyAsync(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             stats->n_nodes = h[0]; stats->n_samples = h[1]; stats->n_steps = h[2]; stats->n_shadow_rays = h[3];
+            stats->n_loads = h[4]; stats->n_hits = h[5];
         }
     }
     return SDFHIP_OK;
@@ -857,8 +861,10 @@ extern "C" int sdfhip_render_display(sdfhip_scene *s, const sdfhip_info *info, u
 
 static int deinterleave_impl(int device, const void *d_gathered, void *d_frame, uint32_t width, uint32_t height,
                             uint32_t band_rows, uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
-                            uint32_t pixel_bytes, uint32_t frames, void *stream)
+                            uint32_t pixel_bytes, uint32_t frames, void *stream, uint32_t only_rank = 0xFFFFFFFFu)
 {
+    if (only_rank != 0xFFFFFFFFu && only_rank >= world)
+        return fail(SDFHIP_ERR_ARG, "deinterleave_share: rank %u of %u", only_rank, world);
     if (frames == 0) return fail(SDFHIP_ERR_ARG, "deinterleave: frames must be >= 1");
     if (!d_gathered || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
         return fail(SDFHIP_ERR_ARG, "deinterleave: null or zero argument");
@@ -892,15 +898,15 @@ static int deinterleave_impl(int device, const void *d_gathered, void *d_frame, 
     if (pixel_bytes == 16)
         hipLaunchKernelGGL((k_deinterleave<float4, float4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const float4 *)d_gathered, (float4 *)d_frame, width, height, band_rows,
-                           world, rows_per_rank, frames, M);
+                           world, rows_per_rank, frames, M, only_rank);
     else if (pixel_bytes == 5)
         hipLaunchKernelGGL((k_deinterleave<WirePlanes, float4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const WirePlanes *)d_gathered, (float4 *)d_frame, width, height, band_rows,
-                           world, rows_per_rank, frames, M);
+                           world, rows_per_rank, frames, M, only_rank);
     else
         hipLaunchKernelGGL((k_deinterleave<uint32_t, uint32_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const uint32_t *)d_gathered, (uint32_t *)d_frame, width, height, band_rows,
-                           world, rows_per_rank, frames, M);
+                           world, rows_per_rank, frames, M, only_rank);
     HIP_TRY(hipGetLastError());
     return SDFHIP_OK;
 }
@@ -924,9 +930,23 @@ extern "C" int sdfhip_deinterleave_bands_device(int device, const void *d_gather
                              pixel_bytes, frames, stream);
 }
 
+extern "C" int sdfhip_deinterleave_share_device(int device, const void *d_share, void *d_frame,
+                                                uint32_t width, uint32_t height, uint32_t band_rows,
+                                                uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
+                                                uint32_t rank, uint32_t pixel_bytes, uint32_t frames, void *stream)
+{
+    return deinterleave_impl(device, d_share, d_frame, width, height, band_rows, world, rows_per_rank, owner,
+                             pixel_bytes, frames, stream, rank);
+}
+
 extern "C" uint64_t sdfhip_wire_sparse_bytes(uint32_t width, uint32_t rows, uint32_t capacity)
 {
     return (uint64_t)sparse_layout(width, rows, capacity).bytes;
+}
+
+extern "C" uint64_t sdfhip_wire_sparse_head_offset(uint32_t width, uint32_t rows, uint32_t capacity)
+{
+    return (uint64_t)sparse_layout(width, rows, capacity).off_head;
 }
 
 extern "C" int sdfhip_wire_compact_device(int device, const void *d_wire, void *d_sparse, uint32_t width, uint32_t rows,

@@ -22,7 +22,10 @@ rank may compact its shares into the *sparse* wire format (`wire_compact`: code
 bytes, per 8x8 tile a mask and a slot index, the non-zero floats packed; about
 1.2 bytes per pixel + 4 per lit pixel) and rank 0 expands that instead
 (`deinterleave_sparse`).  The capacity of the float array is fixed per run: choose
-it from a measured maximum (`sparse_count`), or rows * width to be safe.
+it from a measured maximum (`sparse_count`).  A share with more lit pixels than that
+says so in its header (`sparse_headers`): its rank then sends the dense wire share
+as well, point to point, and rank 0 writes it over that rank's rows
+(`deinterleave_share`) -- the frame is complete either way.
 """
 import ctypes
 
@@ -158,14 +161,35 @@ def wire_compact(device, wire_ptr, sparse_ptr, width, rows, frames, capacity, st
                                          ctypes.c_void_p(int(stream)) if stream else None))
 
 
+def sparse_head_offset(rows, width, capacity):
+    """Byte offset of a sparse share's header {uint32 lit pixels, uint32 overflowed, 0, 0}."""
+    return int(lib.sdfhip_wire_sparse_head_offset(int(width), int(rows), int(capacity)))
+
+
+def sparse_headers(sparse_tensor, rows, width, capacity):
+    """The headers of the sparse shares in a uint8 tensor [..., sparse_share_bytes], as a strided uint8 view
+    [..., 8] (lit pixels, overflowed) -- to be copied to pinned host memory behind the stream that made them."""
+    off = sparse_head_offset(rows, width, capacity)
+    return sparse_tensor[..., off:off + 8]
+
+
+def deinterleave_share(device, share_ptr, frame_ptr, width, layout, rank, stream=None, pixel_bytes=5, frames=1):
+    """Rank 0: write ONE rank's buffers ([frames] x rows_per_rank x width pixels; pixel_bytes as for
+    `deinterleave`) over that rank's rows of the frames: the dense resend of a share whose sparse form
+    overflowed its capacity."""
+    owner = (ctypes.c_uint8 * layout.n_bands)(*layout.owner) if layout.weighted else None
+    check(lib.sdfhip_deinterleave_share_device(int(device), ctypes.c_void_p(int(share_ptr)), ctypes.c_void_p(int(frame_ptr)),
+                                               int(width), layout.height, layout.band_rows, layout.world,
+                                               layout.rows_per_rank, owner, int(rank), int(pixel_bytes), int(frames),
+                                               ctypes.c_void_p(int(stream)) if stream else None))
+
+
 def sparse_count(sparse_tensor, rows, width, capacity):
     """Lit pixels (float slots needed) and overflow flag of every sparse share in a uint8 tensor
     [..., sparse_share_bytes]: -> (counts, overflowed) as flat lists.  Synchronises."""
     import torch
     nbytes = sparse_share_bytes(rows, width, capacity)
-    tiles = ((width + 7) // 8) * ((rows + 7) // 8)
-    up = lambda v: (v + 15) & ~15
-    off_head = up(up(up(rows * width) + tiles * 8) + tiles * 4)
+    off_head = sparse_head_offset(rows, width, capacity)
     flat = sparse_tensor.reshape(-1, nbytes)
     head = flat[:, off_head:off_head + 8].contiguous().cpu().view(torch.int32)
     return head[:, 0].tolist(), head[:, 1].tolist()
