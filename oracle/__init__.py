@@ -36,12 +36,30 @@ def build_native():
     return NATIVE_PATH
 
 
+VARIANTS = {"unfused": "-DO_UNFUSED", "lerp_mathcs": "-DO_LERP_MATHCS", "sampler8": "-DO_SAMPLER8"}
+
+
+def build_variant(name):
+    """A contract variant of sdf_oracle.c (see its header): measurement only, for tests/test_oracle_variants.py."""
+    path = os.path.join(_HERE, f"liboracle_{name}.so")
+    src = os.path.join(_HERE, "sdf_oracle.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-march=x86-64-v2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c11",
+                               VARIANTS[name], "-shared", "-o", path, src, os.path.join(_HERE, "sdfgen_oracle.c"), "-lm", "-lpthread"])
+    return path
+
+
 _lib = None
 _native = None
+_variants = {}
 
 
 def lib(native=False):
     global _lib, _native
+    if isinstance(native, str):                    # a contract variant
+        if native not in _variants:
+            _variants[native] = _bind(ctypes.CDLL(build_variant(native)))
+        return _variants[native]
     if native:
         if _native is None:
             _native = _bind(ctypes.CDLL(NATIVE_PATH))
@@ -84,7 +102,8 @@ def _info_buf(info):
 
 def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1, per_pixel_nodes=False,
            row_step=1, native=False):
-    """-> (rgba[nrows, W, 4] f32, counters[4] u64 (nodes, samples, steps, shadow rays)[, nodes per pixel])."""
+    """-> (rgba[nrows, W, 4] f32, counters[4] u64 (nodes, samples, steps, shadow rays)[, nodes per pixel]).
+    native: True = the -march=native build (bench.py), a name from VARIANTS = that contract variant."""
     structs = np.ascontiguousarray(structs, dtype=np.int32)
     values = np.ascontiguousarray(values, dtype=np.uint8)
     n = structs.size // 2

@@ -38,6 +38,20 @@
  *   - length(v)     = sqrtf(dot(v,v))
  *   - R8_UNorm texel = (float)byte / 255.0f, bilinear = x-lerp then y-lerp
  *   - exp2(strength) is evaluated once per frame on the host (exp2f).
+ *
+ * CONTRACT VARIANTS (measurement only; DESIGN.md section 2 "how far is the contract from other
+ * readings of the shader").  The contract above is one legal reading of D3D11's `mad` and of its
+ * texture sampler; nothing in the reference pins it.  Three build-time variants restate the other
+ * readings so that tests/test_oracle_variants.py can put a number on the distance between them (the
+ * parity statement of SURVEY.md 8d: RGB within 1e-5 and equal step count, fraction of pixels):
+ *   -DO_UNFUSED       SURVEY.md 8c's literal text: lerp = a + t*(b-a), dot and pos += dir*s with
+ *                     separately rounded multiplies and adds (no fused operation anywhere);
+ *   -DO_LERP_MATHCS   lerp as the reference's own (uncalled) CPU helper writes it, SdfBox/Math.cs:25-28:
+ *                     a*(1-p) + b*p, unfused;
+ *   -DO_SAMPLER8      the bilinear weights of the two texture taps (Compute.hlsl:15-29, sampler
+ *                     Program.cs:147) reduced to 8 fractional bits, as D3D11 hardware filtering
+ *                     does at its minimum precision (the z-lerp stays in shader arithmetic).
+ * The default build (none of them) is the oracle; the variants are never compared with the kernels.
  */
 #include <math.h>
 #include <pthread.h>
@@ -85,11 +99,32 @@ typedef struct {
 #define O_CLONES __attribute__((target_clones("default", "fma")))
 
 O_INLINE float o_sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+#if defined(O_UNFUSED) || defined(O_LERP_MATHCS)
+/* contract variants (see the header): every multiply and add rounded on its own */
+O_INLINE float o_mad(float a, float b, float c) { return a * b + c; }      /* -ffp-contract=off: two roundings */
+#if defined(O_LERP_MATHCS)
+O_INLINE float o_lerp(float a, float b, float t) { return a * (1.0f - t) + b * t; }    /* Math.cs:25-28 */
+#else
+O_INLINE float o_lerp(float a, float b, float t) { return a + t * (b - a); }
+#endif
+O_INLINE float o_dot(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx + ay * by) + az * bz;
+}
+#else
+O_INLINE float o_mad(float a, float b, float c) { return fmaf(a, b, c); }
 O_INLINE float o_lerp(float a, float b, float t) { return fmaf(t, b - a, a); }
 O_INLINE float o_dot(float ax, float ay, float az, float bx, float by, float bz)
 {
     return fmaf(az, bz, fmaf(ay, by, ax * bx));
 }
+#endif
+#if defined(O_SAMPLER8)
+/* a bilinear weight as the texture unit sees it at D3D11's minimum filtering precision: 8 fractional bits */
+O_INLINE float o_weight(float w) { return floorf(w * 256.0f + 0.5f) / 256.0f; }
+#else
+O_INLINE float o_weight(float w) { return w; }
+#endif
 
 /* Cube::scale_up, Compute.hlsl:36-40 */
 O_INLINE void o_scale_up(o_cube *b)
@@ -163,6 +198,7 @@ O_INLINE void o_texels(const o_ctx *t, float v[8])
 }
 O_INLINE float o_bilerp(float t00, float t10, float t01, float t11, float wx, float wy)
 {
+    wx = o_weight(wx); wy = o_weight(wy);          /* identity in the oracle; see O_SAMPLER8 */
     float top = o_lerp(t00, t10, wx);
     float bot = o_lerp(t01, t11, wx);
     return o_lerp(top, bot, wy);
@@ -198,11 +234,12 @@ O_INLINE void o_gradient(const o_ctx *t, float px, float py, float pz, float g[3
     float v[8];
     o_texels(t, v);
 
-    float xl = o_lerp(o_lerp(v[0], v[2], dy), o_lerp(v[4], v[6], dy), dz);
-    float xh = o_lerp(o_lerp(v[1], v[3], dy), o_lerp(v[5], v[7], dy), dz);
+    const float wx = o_weight(dx), wy = o_weight(dy);   /* texture weights (identity in the oracle) */
+    float xl = o_lerp(o_lerp(v[0], v[2], wy), o_lerp(v[4], v[6], wy), dz);
+    float xh = o_lerp(o_lerp(v[1], v[3], wy), o_lerp(v[5], v[7], wy), dz);
 
-    float yl = o_lerp(o_lerp(v[0], v[1], dx), o_lerp(v[4], v[5], dx), dz);
-    float yh = o_lerp(o_lerp(v[2], v[3], dx), o_lerp(v[6], v[7], dx), dz);
+    float yl = o_lerp(o_lerp(v[0], v[1], wx), o_lerp(v[4], v[5], wx), dz);
+    float yh = o_lerp(o_lerp(v[2], v[3], wx), o_lerp(v[6], v[7], wx), dz);
 
     float zl = o_bilerp(v[0], v[1], v[2], v[3], dx, dy);
     float zh = o_bilerp(v[4], v[5], v[6], v[7], dx, dy);
@@ -254,18 +291,18 @@ O_INLINE void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_
         }
         o_find(&t, px, py, pz);
         prox = o_interpol_world(&t, px, py, pz);
-        px = fmaf(dir[0], prox, px);
-        py = fmaf(dir[1], prox, py);
-        pz = fmaf(dir[2], prox, pz);
+        px = o_mad(dir[0], prox, px);
+        py = o_mad(dir[1], prox, py);
+        pz = o_mad(dir[2], prox, pz);
     }
     {
         /* dir = normalize(inf.light - pos); pos += dir * inf.margin; */
         float lx = inf->light[0] - px, ly = inf->light[1] - py, lz = inf->light[2] - pz;
         float rl = 1.0f / sqrtf(o_dot(lx, ly, lz, lx, ly, lz));
         dir[0] = lx * rl; dir[1] = ly * rl; dir[2] = lz * rl;
-        px = fmaf(dir[0], margin, px);
-        py = fmaf(dir[1], margin, py);
-        pz = fmaf(dir[2], margin, pz);
+        px = o_mad(dir[0], margin, px);
+        py = o_mad(dir[1], margin, py);
+        pz = o_mad(dir[2], margin, pz);
         /* angle = dot(dir, normalize(gradient(pos))) */
         float g[3];
         o_gradient(&t, px, py, pz, g);
@@ -294,9 +331,9 @@ O_INLINE void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_
             o_find(&t, px, py, pz);
             prox = o_interpol_world(&t, px, py, pz);
             float step = prox + margin;
-            px = fmaf(dir[0], step, px);
-            py = fmaf(dir[1], step, py);
-            pz = fmaf(dir[2], step, pz);
+            px = o_mad(dir[0], step, px);
+            py = o_mad(dir[1], step, py);
+            pz = o_mad(dir[2], step, pz);
         }
         out[0] = out[1] = out[2] = 0.0f; out[3] = (float)(i + j);
     }

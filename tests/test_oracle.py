@@ -25,6 +25,39 @@ def test_c_oracle_equals_python_restatement(sb, oracle_mod, scenes):
                 assert (sh.nodes, sh.samples) == (int(c[0]), int(c[1])), (sname, cname, x, y)
 
 
+def test_c_oracle_equals_vectorised_restatement_on_whole_frames(sb, oracle_mod, scenes):
+    # The same independent restatement, vectorised over pixels (tests/py_restatement_vec.py): EVERY pixel of every
+    # 64x64 scene/camera frame (4 096 each: silhouettes, shadowed and back-facing pixels, 100-140-step pixels, a NaN
+    # grey) and of a 320x180 frame of the bench scene's shape (gyroid shell, depth 7) under the bench camera --
+    # colours, step counts and the per-pixel algorithmic read counts, bit for bit.
+    from py_restatement import Shader
+    from py_restatement_vec import ShaderV
+    seen = {"steps>=100": 0, "nan": 0, "shadowed": 0, "lit": 0, "sky": 0, "backfacing": 0}
+    cases = [(sname, od, make_camera(cname, 64, 64), 64, 64) for sname, od in scenes.items() for cname in CAMERAS]
+    gy = sb.dragon_standin(7, nthreads=4)
+    cam = sb.Logic(320, 180); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
+    cases.append(("gyroid_d7", gy, cam, 320, 180))
+    for sname, od, cam, W, H in cases:
+        ys, xs = np.mgrid[0:H, 0:W]
+        sh = ShaderV(od.Structs, od.Values, cam.State)
+        out, nodes, samples = sh.main(xs.ravel(), ys.ravel())
+        ref, cnt, pix = oracle_mod.render(od.Structs, od.Values, cam.State, W, H, nthreads=4, per_pixel_nodes=True)
+        assert_frames_identical(out.reshape(H, W, 4), ref, f"vectorised restatement, {sname}")
+        assert (nodes.reshape(H, W) == pix).all() and int(samples.sum()) == int(cnt[1]) and sh.shadow_rays == int(cnt[3])
+        sky = (ref[..., 2] == np.float32(0.2)) & (ref[..., 0] == np.float32(0.005))
+        seen["steps>=100"] += int((ref[..., 3] >= 100).sum()); seen["nan"] += int(np.isnan(ref[..., 0]).sum())
+        seen["sky"] += int(sky.sum()); seen["lit"] += int((~sky & (ref[..., 0] > 0)).sum())
+        seen["shadowed"] += int((~sky & (ref[..., 0] == 0)).sum())
+    assert all(v > 0 for v in seen.values() if v is not seen["backfacing"]), seen
+    # and the scalar twin (exact rational fma) agrees with the vectorised one on its handful of pixels
+    od = scenes["sphere_d4"]; cam = make_camera("closeup", 64, 64)
+    px = [(0, 0), (32, 32), (63, 63), (10, 50)]
+    v, _, _ = ShaderV(od.Structs, od.Values, cam.State).main([p[0] for p in px], [p[1] for p in px])
+    s1 = Shader(od.Structs, od.Values, cam.State)
+    for k, (x, y) in enumerate(px):
+        assert bits_equal(v[k], np.array(s1.main(x, y), dtype=np.float32)).all()
+
+
 def test_oracle_reproduces_golden_frames(oracle_mod, scenes):
     g = np.load(os.path.join(GOLDEN, "frames.npz"))
     for sname, od in scenes.items():
