@@ -86,7 +86,10 @@ enum {
     /* A/B knob: render with the one-kernel form (a lane state machine that shades in place) where the
      * default is the two-kernel pipeline (primary march -> queue of hits -> shading + shadow march).
      * Same pixels, same counters. */
-    SDFHIP_TUNE_ONE_KERNEL = 0x20000
+    SDFHIP_TUNE_ONE_KERNEL = 0x20000,
+    /* measurement variant of the cursor-stack kernel when the scene's top grid has level <= 3
+     * (SDFHIP_TOP_GRID_LEVEL=3 at upload): every workgroup stages the grid in LDS */
+    SDFHIP_TUNE_LDS_TOP = 0x40000
 };
 
 /* Per-call statistics (all optional: pass NULL). */

@@ -234,10 +234,11 @@ __device__ __forceinline__ bool pre_step(const FrameInfo &I, RayState &r, const 
 // find + interpol_world + advance: Compute.hlsl:200-202 / :225-227
 template <class CursorT>
 __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const FrameInfo &I, RayState &r, CursorT &c,
-                                               int32_t *stack, uint32_t stride)
+                                               int32_t *stack, uint32_t stride, const TopCell *top = nullptr)
 {
     typename CursorT::Pos u;
-    uint32_t reads = find(c, P.nodes, GridRef{P.top, P.fine, P.top_level, P.fine_bits}, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
+    // top: the top grid somewhere else than P.top (the workgroup's LDS copy, k_plain<..., LDSTOP>)
+    uint32_t reads = find(c, P.nodes, GridRef{top ? top : P.top, P.fine, P.top_level, P.fine_bits}, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
     r.prox = sample_after_find(c, u, r.px, r.py, r.pz);
     float step = r.phase ? r.prox + I.margin : r.prox;
     r.px = __builtin_fmaf(r.dx, step, r.px);
@@ -273,10 +274,14 @@ __device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned l
 
 // ---- one lane per pixel; a workgroup of BT threads renders a 16 x (BT/16) tile (BT >= 128)
 // or one 8x8 wave tile (BT = 64) ------------------------------------------------
-template <int CUR, bool COUNT, int BT>
+// LDSTOP (measurement variant, cursor-stack kernels with a top grid of level <= 3): every workgroup first copies the
+// top grid -- the hot inner nodes: 8^3 cells x 16 B = 8 KB -- into LDS and find() reads it from there
+// (north_star's "LDS caching of the hot inner nodes per workgroup"; DESIGN.md section 4.2 has the timing)
+template <int CUR, bool COUNT, int BT, bool LDSTOP = false>
 __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams P)
 {
     FrameInfo I = P.frames[blockIdx.y];              // batched launch: one frame per grid.y
+    __shared__ TopCell top_lds[LDSTOP ? 512 : 1];
     // the three scalars every march step reads stay in SGPRs: left alone, the compiler reloads them
     // from the kernel arguments (s_load + s_waitcnt) in every iteration
     asm volatile("" : "+s"(I.margin), "+s"(I.margin2), "+s"(I.limit));
@@ -309,6 +314,11 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
     const uint32_t x = tx * TW + (wave % WX) * 8 + (lane & 7u);
     const uint32_t yl = ty * TH + (wave / WX) * 8 + (lane >> 3);
     unsigned long long cn = 0, cs = 0, ct = 0, cr = 0, cl = 0;   // nodes, samples, steps, shadow rays, loads
+    if (LDSTOP) {
+        const uint32_t ncell = 1u << (3 * P.top_level);        // <= 512 (checked by the host)
+        for (uint32_t i = tid; i < ncell; i += BT) top_lds[i] = P.top[i];
+        __syncthreads();
+    }
     bool live = x < P.width && yl < P.nrows_out;
     uint32_t y = 0;
     if (live) { y = global_row(P, yl); live = y < P.height; }
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
                                                reinterpret_cast<float4 *>(reinterpret_cast<uint32_t *>(P.out) + pidx),
                             P.out_mode, P.sky8, wire_base, reinterpret_cast<uint8_t *>(wire_base) + 4 * npx};
         while (!pre_step(I, r, c, dst)) {
-            uint32_t reads = march_step(P, I, r, c, stack_lds + tid, BT);
+            uint32_t reads = march_step(P, I, r, c, stack_lds + tid, BT, LDSTOP ? top_lds : nullptr);
             if (COUNT) { cn += reads; cs += 1; }
         }
         if (COUNT) { ct = (unsigned long long)(r.base + r.n); cr = r.phase == PH_SHADOW ? 1u : 0u; cl = c.loads; }   // shade() left the lane in PH_SHADOW

@@ -717,6 +717,11 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         else if (cur == CUR_STACK) { if (count) go(k_path<CUR_STACK, true>); else go(k_path<CUR_STACK, false>); }
         else                       { if (count) go(k_path<CUR_GENERIC, true>); else go(k_path<CUR_GENERIC, false>); }
     }
+    else if ((flags & SDFHIP_TUNE_LDS_TOP) && cur == CUR_STACK && s->d_top && s->top_level <= 3 && !compact && !count) {
+        // measurement variant: the top grid staged in LDS per workgroup (64- or 256-thread workgroups)
+        if (bt == 256) hipLaunchKernelGGL((k_plain<CUR_STACK, false, 256, true>), grid, dim3(256), 0, st, P);
+        else           hipLaunchKernelGGL((k_plain<CUR_STACK, false, 64, true>), grid, dim3(64), 0, st, P);
+    }
     else if (cur == CUR_STACK_SPLIT) { if (count) launch_pair<CUR_STACK_SPLIT, true>(compact, bt, grid, st, P); else launch_pair<CUR_STACK_SPLIT, false>(compact, bt, grid, st, P); }
     else if (cur == CUR_STACK_FULL) { if (count) launch_pair<CUR_STACK_FULL, true>(compact, bt, grid, st, P); else launch_pair<CUR_STACK_FULL, false>(compact, bt, grid, st, P); }
     else if (cur == CUR_STACK)      { if (count) launch_pair<CUR_STACK, true>(compact, bt, grid, st, P); else launch_pair<CUR_STACK, false>(compact, bt, grid, st, P); }

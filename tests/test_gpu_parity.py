@@ -91,6 +91,10 @@ def test_camera_edge_cases(sb, oracle_mod, scenes, gpu_scenes):
     c = sb.Logic(W, H); c.Position = (3.0, -2.0, -4.0); c.Heading = (0.4, -0.6); cams.append(("far outside the cube", c))
     c = sb.Logic(W, H); c.Position = (0.0, 0.0, 0.0); cams.append(("camera on the light: normalize(0)", c))
     c = sb.Logic(W, H); c.State.margin = 0.05; cams.append(("huge margin", c))
+    # 2 * margin >= 1 = the initial prox: the primary march takes no step and the gradient is taken before any
+    # find(), in the root box with node 0's values (Compute.hlsl:194,207)
+    c = sb.Logic(W, H); c.State.margin = 0.5; cams.append(("margin 0.5: shading before any find", c))
+    c = sb.Logic(W, H); c.State.margin = 0.75; c.Position = (0.4, 0.6, 0.3); cams.append(("margin 0.75 from inside the cube", c))
     c = sb.Logic(W, H); c.State.margin = 0.0; cams.append(("zero margin: 100-step grazing", c))
     c = sb.Logic(W, H); c.State.fov = 6.0; c.State.strength = 3.0; cams.append(("wide fov, strong light", c))
     c = sb.Logic(W, H); c.State.light[0] = 0.5; c.State.light[1] = 0.5; c.State.light[2] = 0.5; cams.append(("light inside the object", c))
@@ -487,10 +491,15 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
                     if lv is None:       # the default for shallow trees: as deep as the tree (every leaf in the grid)
                         assert scene.top_grid_level == scene.depth
                     for c, (ref, cnt) in zip((cam, ongrid), refs):
-                        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT):
+                        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL, sb.KERNEL_STACK | sb.FLAG_COMPACT):
                             img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
                             assert_frames_identical(img, ref, f"top grid {lv}")
                             assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), lv
+                        if 0 < scene.top_grid_level <= 3 and scene.top_grid_level < scene.depth:
+                            # the measurement variant that stages the top grid in LDS (64- and 256-thread workgroups)
+                            for block in (0, 3):
+                                img = scene.Draw(c, W, H, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL | sb._lib.TUNE_LDS_TOP | (block << 12))
+                                assert_frames_identical(img, ref, f"top grid {lv} staged in LDS, block knob {block}")
                         pimg = scene.DrawPath(c, W, H, pt=sb.PathTrace(spp=2))
                         pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
                         assert_frames_identical(pimg, pref, f"top grid {lv}, path-traced")
@@ -505,7 +514,7 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
                     with sb.Scene(od) as scene:
                         assert scene.top_grid_level == int(sp) and scene.top_grid_bytes >= 16 << (3 * int(sp))
                         for c, (ref, cnt) in zip((cam, ongrid), refs):
-                            for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT):
+                            for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL, sb.KERNEL_STACK | sb.FLAG_COMPACT):
                                 img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
                                 assert_frames_identical(img, ref, f"split grid {sp}")
                                 assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), sp
@@ -640,6 +649,30 @@ def test_two_handles_render_concurrently(sb, oracle_mod, scenes):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_frames_in_flight_on_one_handle_do_not_share_scratch(sb, oracle_mod, scenes, gpu_scenes):
+    # Several streams render on ONE scene handle at once, each its own camera (frames in flight): the hit
+    # queues of the two-kernel pipeline and the tile queues of the compact kernel are per-stream scratch, so
+    # no launch may see another's.  (The compact kernel once kept its queue heads in the scene: a second
+    # stream's launch reset them under the first one's feet.)
+    import torch
+    od, scene = scenes["torus_d6"], gpu_scenes["torus_d6"]
+    W, H = 320, 200
+    cams = []
+    for k in range(6):
+        c = sb.Logic(W, H); c.Position = (0.2 + 0.1 * k, 0.3 + 0.05 * k, -0.3 + 0.05 * k); c.Heading = (-0.1 * k, 0.15 * k)
+        cams.append(c)
+    refs = [oracle_mod.render(od.Structs, od.Values, c.State, W, H, nthreads=8)[0] for c in cams]
+    streams = [torch.cuda.Stream() for _ in cams]
+    for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL):
+        bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
+        for rep in range(8):                       # keep every stream busy so that the launches really overlap
+            for c, b, st in zip(cams, bufs, streams):
+                scene.DrawDevice(c, W, H, b.data_ptr(), flags=flags, stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        for k, (b, ref) in enumerate(zip(bufs, refs)):
+            assert_frames_identical(b.cpu().numpy(), ref, f"flags {flags:#x}, stream {k}")
 
 
 # ---- BASELINE.json full sizes: size-independent properties + sampled oracle rows ----
