@@ -387,6 +387,12 @@ SDFHIP_API int sdfhip_deinterleave_sparse_device(int device, const void *d_gathe
                                                  uint32_t capacity, uint32_t frames, uint32_t *d_overflow,
                                                  void *stream);
 
+/* Experiment hook (scripts/ab_tile_order.py): the primary-march kernel of the following single-frame renders
+ * on this scene takes workgroup b's tile from d_perm[b] (device array, one entry per workgroup of its grid =
+ * 8 * ceil(tiles_y / 8) * tiles_x with 8x8 tiles; entries >= the tile count idle) and writes the march
+ * iterations of every tile's wave to d_cost[tile] (device array).  NULL switches either off. */
+SDFHIP_API int sdfhip_debug_tile_order(sdfhip_scene *scene, const uint32_t *d_perm, uint16_t *d_cost);
+
 /* Test hook: the kernel's R8_UNorm decode of bytes 0..255 (256 floats to the
  * host), checked exhaustively against byte/255.0f. */
 SDFHIP_API int sdfhip_debug_unorm_table(int device, float *out256);

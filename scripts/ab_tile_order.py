@@ -1,0 +1,68 @@
+"""Dev script (GPU): what does launching a frame's expensive tiles first buy for the latency of ONE frame?
+k_march writes every tile's march iterations; the next frame's workgroups take their tiles from a permutation that
+keeps each XCD's set of tiles (blocks b, b+8, ... share an L2) but sorts it by descending cost of the previous frame.
+    python scripts/ab_tile_order.py [WxH] [orbit step in degrees]"""
+import ctypes, math, sys, time
+sys.path.insert(0, ".")
+import numpy as np, torch
+import sdfbox_amd as sb
+from sdfbox_amd._lib import lib, check
+W, H = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1920x1080").split("x"))
+deg = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+od = sb.dragon_standin(9, nthreads=32); sc = sb.Scene(od)
+def camera(k):
+    phi = math.radians(k * deg); r = 0.85
+    c = sb.Logic(W, H); c.Position = (0.5 - r * math.sin(phi), 0.5, 0.5 - r * math.cos(phi)); c.Heading = (-0.2, 0.35 + phi)
+    return c
+tx, ty = (W + 7) // 8, (H + 7) // 8
+nblk = 8 * ((ty + 7) // 8) * tx
+def default_perm():
+    b = np.arange(nblk); xcd = b & 7; j = b >> 3; r = j // tx; cx = j - r * tx; row = r * 8 + xcd
+    return np.where(row < ty, row * tx + cx, 0xFFFFFFFF).astype(np.uint32)
+base = default_perm()
+buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+cost = torch.zeros(tx * ty, dtype=torch.int16, device="cuda")
+perm = torch.from_numpy(base.astype(np.int64)).to(torch.int32).cuda() if False else torch.from_numpy(base.view(np.int32)).cuda()
+def frame(cam):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    sc.DrawDevice(cam, W, H, buf.data_ptr())
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) * 1e3
+def sorted_perm(c):
+    out = base.copy()
+    for x in range(8):
+        idx = np.nonzero((np.arange(nblk) & 7) == x)[0]
+        tiles = base[idx]; real = tiles != 0xFFFFFFFF
+        t = tiles[real]; order = np.argsort(-c[t].astype(np.int64), kind="stable")
+        out[idx] = np.concatenate([t[order], tiles[~real]])
+    return out
+def row_perm(c, key):
+    # whole tile rows stay together (neighbouring tiles share cells); each XCD's rows k, k+8, ... are launched in
+    # descending order of the previous frame's row cost
+    out = base.copy()
+    rows = c.reshape(ty, tx).astype(np.int64)
+    rc = rows.max(1) if key == "max" else rows.sum(1)
+    for x in range(8):
+        myrows = np.arange(x, ty, 8)
+        order = myrows[np.argsort(-rc[myrows], kind="stable")]
+        idx = np.nonzero((np.arange(nblk) & 7) == x)[0]
+        tiles = np.concatenate([r * tx + np.arange(tx) for r in order]).astype(np.uint32)
+        out[idx] = np.concatenate([tiles, np.full(len(idx) - len(tiles), 0xFFFFFFFF, np.uint32)])
+    return out
+for mode in ("default order", "previous frame's cost, descending per XCD", "same frame's cost (oracle for the idea)",
+             "rows by previous frame's summed cost", "rows by previous frame's max cost"):
+    times = []
+    check(lib.sdfhip_debug_tile_order(sc._h, None, ctypes.c_void_p(cost.data_ptr())))
+    frame(camera(0))
+    for k in range(1, 61):
+        cam = camera(k)
+        if mode != "default order":
+            if mode.startswith("same"):                 # render once to learn this frame's own cost
+                check(lib.sdfhip_debug_tile_order(sc._h, None, ctypes.c_void_p(cost.data_ptr()))); frame(cam)
+            c = cost.cpu().numpy().view(np.uint16)
+            p = row_perm(c, "sum") if "summed" in mode else row_perm(c, "max") if "rows" in mode else sorted_perm(c)
+            perm.copy_(torch.from_numpy(p.view(np.int32)))
+            check(lib.sdfhip_debug_tile_order(sc._h, ctypes.c_void_p(perm.data_ptr()), ctypes.c_void_p(cost.data_ptr())))
+        times.append(frame(cam))
+    ref_ok = True
+    print(f"{W}x{H}, camera moving {deg} deg/frame, {mode:48s}: median {np.median(times[5:]):.4f} ms, min {min(times[5:]):.4f}")
+check(lib.sdfhip_debug_tile_order(sc._h, None, None))

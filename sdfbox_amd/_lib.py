@@ -168,6 +168,7 @@ _SIG = {
     "sdfhip_wire_compact_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "sdfhip_deinterleave_sparse_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                      _c.c_uint32, _c.POINTER(_c.c_uint8), _c.c_uint32, _c.c_uint32, _vp, _vp]),
+    "sdfhip_debug_tile_order": (_c.c_int, [_vp, _vp, _vp]),
     "sdfhip_debug_unorm_table": (_c.c_int, [_c.c_int, _vp]),
 }
 # every symbol include/sdfhip.h declares must be exported: fail at import otherwise

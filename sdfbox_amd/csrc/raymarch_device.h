@@ -93,6 +93,10 @@ struct RenderParams {
     uint4 *hit_c;
     uint32_t *hit_ctl;
     uint32_t hit_cap, hit_set;
+    // k_march, optional: tile_perm[b] = the tile workgroup b renders (a permutation of the default order: the
+    // previous frame's expensive tiles first); tile_cost[tile] = march iterations the tile's wave ran
+    const uint32_t *tile_perm;
+    uint16_t *tile_cost;
 };
 constexpr uint32_t HIT_QUEUES = 64;   // one fill counter (its own 128-byte line) per queue: a wave's append is one atomic, spread over 64 words
 

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     // the scalars every march step reads stay in SGPRs: left alone, the compiler reloads them
     // from the kernel arguments (s_load + s_waitcnt) in every iteration
     asm volatile("" : "+s"(I.margin2), "+s"(I.limit));
-    const uint32_t tile = tile_of_block(P, blockIdx.x, f);
+    const uint32_t tile = P.tile_perm ? P.tile_perm[blockIdx.x] : tile_of_block(P, blockIdx.x, f);
     if (tile >= P.n_tiles) return;
     const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x, lane = threadIdx.x;
     const uint32_t x = tx * 8 + (lane & 7u), yl = ty * 8 + (lane >> 3);
@@ -461,6 +461,11 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
         }
     }
     const int end = !live ? 3 : marching() ? 2 : 1;   // 1 on the surface (or out of steps), 2 escaped, 3 no pixel
+    if (P.tile_cost) {                                  // iterations this wave ran = its longest lane
+        int m = live ? r.n : 0;
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+        if (lane == 0) P.tile_cost[(size_t)f * P.n_tiles + tile] = (uint16_t)m;
+    }
     // ---- the wave is converged again ----
     const size_t lidx = (size_t)yl * P.width + x;
     if (end == 2) {

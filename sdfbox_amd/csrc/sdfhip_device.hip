@@ -295,6 +295,8 @@ struct sdfhip_scene {
     size_t frame_cap;
     hipEvent_t ev0, ev1;
     int cu_count;
+    const uint32_t *dbg_tile_perm;   // sdfhip_debug_tile_order: experiment hooks for k_march
+    uint16_t *dbg_tile_cost;
     std::mutex lock;        // render on one handle is single-caller; this makes misuse safe
 };
 
@@ -377,7 +379,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     s->device = device; s->n = n; s->depth = depth;
     s->stack_ok = (consistent && depth <= (uint32_t)MAX_STACK) ? 1 : 0;
     s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0;
-    s->n_scratch = 0; s->d_frame = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
+    s->n_scratch = 0; s->d_frame = nullptr; s->dbg_tile_perm = nullptr; s->dbg_tile_cost = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
     s->cu_count = prop.multiProcessorCount;
 
     void *d_s = nullptr, *d_v = nullptr;
@@ -683,6 +685,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
     sdfhip_scene::Scratch *sc = nullptr;
     P.queue = nullptr; P.hit_a = nullptr; P.hit_b = nullptr; P.hit_c = nullptr; P.hit_ctl = nullptr; P.hit_cap = 0; P.hit_set = 0;
+    P.tile_perm = s->dbg_tile_perm; P.tile_cost = s->dbg_tile_cost;
     if (two) {
         // a queue takes the hits of every 64th workgroup: room for all their pixels
         P.hit_cap = ((grid.x + HIT_QUEUES - 1u) / HIT_QUEUES) * 64u;
@@ -1007,6 +1010,14 @@ extern "C" int sdfhip_deinterleave_sparse_device(int device, const void *d_gathe
     hipLaunchKernelGGL(k_deinterleave_sparse, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_gathered,
                        (float4 *)d_frame, width, height, band_rows, world, frames, L, M, d_overflow);
     HIP_TRY(hipGetLastError());
+    return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_debug_tile_order(sdfhip_scene *s, const uint32_t *d_perm, uint16_t *d_cost)
+{
+    if (!s) return fail(SDFHIP_ERR_ARG, "debug_tile_order: null scene");
+    std::lock_guard<std::mutex> lk(s->lock);
+    s->dbg_tile_perm = d_perm; s->dbg_tile_cost = d_cost;
     return SDFHIP_OK;
 }
 
