@@ -93,6 +93,17 @@ struct RenderParams {
     uint4 *hit_c;
     uint32_t *hit_ctl;
     uint32_t hit_cap, hit_set;
+    // path-traced mode as a pipeline of kernels (k_pt_primary -> k_pt_bounce x (bounces + 1) -> k_pt_resolve):
+    // two hit queues used alternately (a level's kernel reads one and fills the other), HIT_QUEUES sub-queues of
+    // pt_cap entries each, an entry = four 16-byte records; per-path results [sample][pixel] that k_pt_resolve sums
+    // in the oracle's order: pt_e[bounce] = the light a path's vertex of that bounce received (0 when unlit), pt_t =
+    // the throughput it escaped to the sky with (0 when it did not), pt_n = its march steps | vertices << 16
+    float4 *pt_q[2];
+    uint32_t *pt_ctl;               // [2 queues][HIT_QUEUES] fill counts, a 128-byte line each
+    uint32_t pt_cap, pt_level;      // entries per sub-queue; the bounce level this launch shades
+    float *pt_e;                    // [bounces + 1][spp][pixels]
+    float *pt_t;                    // [spp][pixels]
+    uint32_t *pt_n;                 // [spp][pixels]
     // k_march, optional: tile_perm[b] = the tile workgroup b renders (a permutation of the default order: the
     // previous frame's expensive tiles first); tile_cost[tile] = march iterations the tile's wave ran
     const uint32_t *tile_perm;

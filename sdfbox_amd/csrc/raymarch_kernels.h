@@ -867,4 +867,248 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
     if (COUNT) flush_counters(P, cn, cs, ct, cr, cl);
 }
 
+// =====================================================================================
+// Path-traced mode as a pipeline of kernels -- the default wherever a find is a grid lookup.
+//
+// k_path (above) gives a lane a pixel and walks its 16 samples x up to 4 segments: on a silhouette tile the
+// sky lanes (80 % of the frame) finish their 16 one-segment samples in a fifth of the time the surface lanes
+// need, and whoever bounces marches alone: lanes were busy in 31 % of the VALU thread-cycles.  Here a lane is
+// a PATH (pixel, sample), and a kernel is one level of it:
+//   k_pt_primary   the camera segment of every path: 8x8 pixels per wave, the samples one after another (all
+//                  64 lanes march sample s together: neighbouring, nearly parallel rays).  A path that escapes
+//                  is finished: its sky throughput and steps go to the path results.  A path that hits appends
+//                  its state to hit queue 0.
+//   k_pt_bounce    level b = 0 .. bounces: one lane per queued hit, 64 consecutive entries per wave: the shading
+//                  step and the shadow march (the light the vertex receives -> pt_e[b]), then -- unless b is the last
+//                  level -- the diffuse bounce and the march of the next segment, which ends in the sky (-> pt_t)
+//                  or in hit queue b + 1.
+//   k_pt_resolve   per pixel, the oracle's accumulation replayed in its order: for every sample, the vertices'
+//                  light in bounce order, then the sky term; the mean and the step total.
+// Float addition is not associative, so the paths do not add into a shared pixel: they leave their addends
+// (adding the +0 of an unlit vertex, or fma(0, sky, acc), changes no bit of a non-negative or NaN sum) and
+// k_pt_resolve adds them as o_pixel_pt does.  Per path the arithmetic, the RNG draws and the cursor carried
+// from segment to shadow ray to next segment are the oracle's: images and counters stay bit-identical.
+// =====================================================================================
+__device__ __forceinline__ uint32_t *pt_count(const RenderParams &P, uint32_t queue, uint32_t q) { return P.pt_ctl + ((size_t)queue * HIT_QUEUES + q) * 32u; }
+
+// a path's state at a surface hit, four 16-byte records (SoA over the queue: record r of entry i at [r * total + i])
+struct PtHit {
+    float px, py, pz, prox;          // where the march ended, its last sample
+    int32_t ax, ay, az; uint32_t s;  // cursor
+    uint32_t v0, v1, pid, steps;     // cursor values; path = pixel * spp + sample (pixel = row * width + x of the LOCAL rows); the segment's steps
+    float ux, uy, uz, T;             // incoming direction, throughput
+};
+template <class CursorT>
+__device__ __forceinline__ void pt_push(const RenderParams &P, uint32_t queue, uint32_t q, bool hit, uint32_t lane,
+                                        float px, float py, float pz, float prox, const CursorT &c, uint32_t pid, uint32_t steps,
+                                        float ux, float uy, float uz, float T)
+{
+    const unsigned long long hits = __ballot(hit);
+    if (!hits) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(pt_count(P, queue, q), (uint32_t)__popcll(hits));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+    if (hit && base + rank < P.pt_cap) {
+        const size_t total = (size_t)HIT_QUEUES * P.pt_cap, i = (size_t)q * P.pt_cap + base + rank;
+        float4 *Q = P.pt_q[queue];
+        Q[i] = make_float4(px, py, pz, prox);
+        Q[total + i] = make_float4(__int_as_float(c.ax), __int_as_float(c.ay), __int_as_float(c.az), __uint_as_float(c.s));
+        Q[2 * total + i] = make_float4(__uint_as_float(c.v0), __uint_as_float(c.v1), __uint_as_float(pid), __uint_as_float(steps));
+        Q[3 * total + i] = make_float4(ux, uy, uz, T);
+    }
+}
+
+// the march of one path segment (o_pixel_pt's inner loop, Compute.hlsl:194-203): true = escaped to the sky
+template <bool COUNT, class CursorT>
+__device__ __forceinline__ bool pt_march(const RenderParams &P, const FrameInfo &I, RayState &r, CursorT &c,
+                                         unsigned long long &cn, unsigned long long &cs)
+{
+    auto marching = [&]() { return (r.prox > I.margin2 || r.prox < 0.0f) && r.n < 100; };
+    while (marching() && !(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit)) {
+        uint32_t reads = march_step(P, I, r, c, nullptr, 0);
+        if (COUNT) { cn += reads; cs += 1; }
+    }
+    return marching();
+}
+
+template <int CUR, bool COUNT>
+__global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_pt_primary(RenderParams P)
+{
+    typedef typename CursorOf<CUR, COUNT>::type CursorT;
+    FrameInfo I = P.frames[0];
+    asm volatile("" : "+s"(I.margin2), "+s"(I.limit));
+    const uint32_t tile = tile_of_block(P, blockIdx.x, 0);
+    if (tile >= P.n_tiles) return;
+    const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x, lane = threadIdx.x;
+    const uint32_t x = tx * 8 + (lane & 7u), yl = ty * 8 + (lane >> 3);
+    unsigned long long cn = 0, cs = 0, cl = 0;
+    bool live = x < P.width && yl < P.nrows_out;
+    uint32_t y = 0;
+    if (live) { y = global_row(P, yl); live = y < P.height; }
+    const NodeRec root = P.nodes[0];
+    const size_t npx = (size_t)P.nrows_out * P.width, lidx = (size_t)yl * P.width + x;
+    const uint32_t p = y * P.width + x;                       // the pixel index that seeds the RNG: of the FRAME
+    const uint32_t q = blockIdx.x & (HIT_QUEUES - 1u);
+    for (uint32_t s = 0; s < P.pt_spp; s++) {
+        RayState r;
+        CursorT c;
+        c.loads = 0;
+        c.reset(root);
+        r.px = I.posx; r.py = I.posy; r.pz = I.posz;
+        ray_f(I, (float)x + rnd(P.pt_seed, p, s, 0, 0), (float)y + rnd(P.pt_seed, p, s, 0, 1), r.dx, r.dy, r.dz);
+        r.prox = 1.0f; r.n = 0; r.base = 0; r.phase = PH_PRIMARY; r.angle = 0.0f; r.dist = 0.0f;
+        bool escaped = false;
+        if (live) escaped = pt_march<COUNT>(P, I, r, c, cn, cs);
+        if (COUNT) cl += c.loads;
+        if (live) {
+            const size_t o = (size_t)s * npx + lidx;
+            P.pt_t[o] = escaped ? 1.0f : 0.0f;                // the camera ray's throughput is 1
+            P.pt_n[o] = (uint32_t)r.n;                        // no vertex yet
+        }
+        pt_push(P, 0, q, live && !escaped, lane, r.px, r.py, r.pz, r.prox, c, (uint32_t)lidx * P.pt_spp + s, (uint32_t)r.n,
+                r.dx, r.dy, r.dz, 1.0f);
+    }
+    if (COUNT) flush_counters(P, cn, cs, 0, 0, cl);
+}
+
+template <int CUR, bool COUNT>
+__global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderParams P)
+{
+    typedef typename CursorOf<CUR, COUNT>::type CursorT;
+    const uint32_t lane = threadIdx.x, b = P.pt_level, qin = b & 1u, qout = qin ^ 1u;
+    FrameInfo I = P.frames[0];
+    asm volatile("" : "+s"(I.margin), "+s"(I.margin2), "+s"(I.limit));
+    const float margin = I.margin;
+    const size_t npx = (size_t)P.nrows_out * P.width, total = (size_t)HIT_QUEUES * P.pt_cap;
+    const uint32_t fill = min(*pt_count(P, qin, lane), P.pt_cap);
+    const uint32_t chunks = (fill + 63u) >> 6;
+    uint32_t incl = chunks;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+    const uint32_t nchunks = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    unsigned long long cn = 0, cs = 0, cr = 0, cl = 0;
+    const float4 *Q = P.pt_q[qin];
+    for (uint32_t t = blockIdx.x; t < nchunks; t += gridDim.x) {
+        const uint32_t q = (uint32_t)__popcll(__ballot(incl <= t));
+        const uint32_t q_incl = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)q), q_chunks = (uint32_t)__builtin_amdgcn_readlane((int)chunks, (int)q);
+        const uint32_t q_fill = (uint32_t)__builtin_amdgcn_readlane((int)fill, (int)q);
+        const uint32_t i = (t - (q_incl - q_chunks)) * 64u + lane;
+        const bool have = i < q_fill;
+        RayState r;
+        CursorT c;
+        c.loads = 0;
+        uint32_t pid = 0;
+        float ux = 0, uy = 0, uz = 1, T = 0;
+        bool next = false, escaped = false;       // a next segment was marched; it escaped
+        if (have) {
+            const size_t e = (size_t)q * P.pt_cap + i;
+            const float4 a = Q[e], k = Q[total + e], v = Q[2 * total + e], d = Q[3 * total + e];
+            r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w;
+            c.ax = __float_as_int(k.x); c.ay = __float_as_int(k.y); c.az = __float_as_int(k.z); c.s = __float_as_uint(k.w);
+            c.v0 = __float_as_uint(v.x); c.v1 = __float_as_uint(v.y); pid = __float_as_uint(v.z);
+            ux = d.x; uy = d.y; uz = d.z; T = d.w;
+            const uint32_t pix = pid / P.pt_spp, s = pid - pix * P.pt_spp;
+            const size_t o = (size_t)s * npx + pix;
+            // shade (Compute.hlsl:205-213)
+            float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;
+            const float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+            const float L0 = lx * rl, L1 = ly * rl, L2 = lz * rl;
+            r.px = __builtin_fmaf(L0, margin, r.px); r.py = __builtin_fmaf(L1, margin, r.py); r.pz = __builtin_fmaf(L2, margin, r.pz);
+            float g0, g1, g2;
+            gradient(c.cell(), r.px, r.py, r.pz, g0, g1, g2);
+            const float rg = 1.0f / sqrtf(dot3(g0, g1, g2, g0, g1, g2));
+            float n0 = g0 * rg, n1 = g1 * rg, n2 = g2 * rg;
+            const float angle = dot3(L0, L1, L2, n0, n1, n2);
+            const float hx = r.px, hy = r.py, hz = r.pz;      // the hit point: the bounce leaves from here
+            float e_light = 0.0f;
+            uint32_t shadow_steps = 0;
+            if (!(angle < 0.0f)) {
+                // shadow march (Compute.hlsl:213-230)
+                lx = I.lightx - r.px; ly = I.lighty - r.py; lz = I.lightz - r.pz;
+                const float dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+                r.dx = L0; r.dy = L1; r.dz = L2; r.n = 0; r.phase = PH_SHADOW;
+                if (COUNT) cr += 1;
+                bool lit = false;
+                while (r.n < 40 && r.prox > -margin) {
+                    if (r.prox > dist || (r.px < 0.0f || r.py < 0.0f || r.pz < 0.0f) ||
+                        (r.px > 1.0f || r.py > 1.0f || r.pz > 1.0f)) { lit = true; break; }
+                    if (r.prox < margin) {
+                        float q0, q1, q2;
+                        gradient(c.cell(), r.px, r.py, r.pz, q0, q1, q2);
+                        if (dot3(q0, q1, q2, L0, L1, L2) < 0.0f) break;
+                    }
+                    uint32_t reads = march_step(P, I, r, c, nullptr, 0);
+                    if (COUNT) { cn += reads; cs += 1; }
+                }
+                shadow_steps = (uint32_t)r.n;
+                if (lit) e_light = T * (P.pt_albedo * (angle / (dist * dist) * I.k_strength));
+            }
+            P.pt_e[(size_t)b * P.pt_spp * npx + o] = e_light;
+            uint32_t nsteps = (P.pt_n[o] & 0xFFFFu) + shadow_steps;
+            if (b < P.pt_bounces) {
+                // diffuse bounce (o_pixel_pt): the normal facing the incoming ray, a direction by rejection in the cube
+                if (dot3(n0, n1, n2, ux, uy, uz) > 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
+                const uint32_t y_l = pix / P.width, x_l = pix - y_l * P.width;
+                const uint32_t p = global_row(P, y_l) * P.width + x_l;          // the frame's pixel index seeds the RNG
+                float u0 = n0, u1 = n1, u2 = n2, qq1 = 1.0f;
+                for (uint32_t a2 = 0; a2 < 8; a2++) {
+                    const float c0 = rnd(P.pt_seed, p, s, b + 1, 3 * a2) * 2.0f - 1.0f;
+                    const float c1 = rnd(P.pt_seed, p, s, b + 1, 3 * a2 + 1) * 2.0f - 1.0f;
+                    const float c2 = rnd(P.pt_seed, p, s, b + 1, 3 * a2 + 2) * 2.0f - 1.0f;
+                    const float qq = dot3(c0, c1, c2, c0, c1, c2);
+                    if (qq <= 1.0f && qq > 1e-12f) { u0 = c0; u1 = c1; u2 = c2; qq1 = qq; break; }
+                }
+                const float ru = 1.0f / sqrtf(qq1);
+                float d0 = __builtin_fmaf(u0, ru, n0), d1 = __builtin_fmaf(u1, ru, n1), d2 = __builtin_fmaf(u2, ru, n2);
+                float qd = dot3(d0, d1, d2, d0, d1, d2);
+                if (!(qd > 1e-12f)) { d0 = n0; d1 = n1; d2 = n2; qd = dot3(n0, n1, n2, n0, n1, n2); }
+                const float rd = 1.0f / sqrtf(qd);
+                ux = d0 * rd; uy = d1 * rd; uz = d2 * rd;
+                const float off = margin * 4.0f;
+                r.px = __builtin_fmaf(n0, off, hx); r.py = __builtin_fmaf(n1, off, hy); r.pz = __builtin_fmaf(n2, off, hz);
+                T *= P.pt_albedo;
+                // the next segment
+                r.dx = ux; r.dy = uy; r.dz = uz; r.prox = 1.0f; r.n = 0; r.phase = PH_PRIMARY;
+                next = true;
+                escaped = pt_march<COUNT>(P, I, r, c, cn, cs);
+                nsteps += (uint32_t)r.n;
+                if (escaped) P.pt_t[o] = T;
+            }
+            P.pt_n[o] = nsteps | ((b + 1u) << 16);
+            if (COUNT) cl += c.loads;
+        }
+        pt_push(P, qout, blockIdx.x & (HIT_QUEUES - 1u), have && next && !escaped, lane, r.px, r.py, r.pz, r.prox, c, pid, 0u, ux, uy, uz, T);
+    }
+    if (COUNT) flush_counters(P, cn, cs, 0, cr, cl);
+}
+
+// Per pixel: o_pixel_pt's accumulation over samples and bounces, in its order; alpha = the march steps of all paths.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_pt_resolve(RenderParams P)
+{
+    const size_t npx = (size_t)P.nrows_out * P.width;
+    unsigned long long ct = 0;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npx; pix += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t yl = (uint32_t)(pix / P.width);
+        if (global_row(P, yl) >= P.height) continue;          // a padding row of the last band: not a pixel
+        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+        uint32_t steps = 0;
+        for (uint32_t s = 0; s < P.pt_spp; s++) {
+            const size_t o = (size_t)s * npx + pix;
+            const uint32_t n = P.pt_n[o], nv = n >> 16;
+            steps += n & 0xFFFFu;
+            for (uint32_t b = 0; b < nv; b++) {
+                const float e = P.pt_e[(size_t)b * P.pt_spp * npx + o];
+                acc0 += e; acc1 += e; acc2 += e;
+            }
+            const float T = P.pt_t[o];
+            acc0 = __builtin_fmaf(T, 0.005f, acc0); acc1 = __builtin_fmaf(T, 0.01f, acc1); acc2 = __builtin_fmaf(T, 0.2f, acc2);
+        }
+        const float inv = (float)P.pt_spp;
+        P.out[pix] = make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps);
+        if (COUNT) ct += steps;
+    }
+    if (COUNT) flush_counters(P, 0, 0, ct, 0, 0);
+}
+
 }  // namespace sdfhip

@@ -286,9 +286,12 @@ struct sdfhip_scene {
         size_t records;
         uint32_t *ctl;               // hit fill counts (two sets), then the compact kernel's tile queues
         uint32_t launches;           // two-kernel launch pairs so far: its parity selects the set of fill counts
+        char *pt_buf;                // path-traced pipeline: two hit queues, then the per-path results
+        size_t pt_bytes;
     };
     static constexpr int MAX_SCRATCH = 16;
-    static constexpr size_t CTL_HIT_WORDS = (size_t)2 * MAX_BATCH * HIT_QUEUES * 32, CTL_QUEUE_WORDS = 8 * 32;
+    static constexpr size_t CTL_HIT_WORDS = (size_t)2 * MAX_BATCH * HIT_QUEUES * 32, CTL_QUEUE_WORDS = 8 * 32,
+                            CTL_PT_WORDS = (size_t)2 * HIT_QUEUES * 32;
     Scratch scratch[MAX_SCRATCH];
     int n_scratch;
     float4 *d_frame;        // grown on demand by sdfhip_render
@@ -341,6 +344,7 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
         if (s->d_fine) (void)hipFree(s->d_fine);
         for (int i = 0; i < s->n_scratch; i++) {
             if (s->scratch[i].hit_buf) (void)hipFree(s->scratch[i].hit_buf);
+            if (s->scratch[i].pt_buf) (void)hipFree(s->scratch[i].pt_buf);
             if (s->scratch[i].ctl) (void)hipFree(s->scratch[i].ctl);
         }
         if (s->d_frame) (void)hipFree(s->d_frame);
@@ -540,8 +544,8 @@ int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::S
         if (s->n_scratch == sdfhip_scene::MAX_SCRATCH)
             return fail(SDFHIP_ERR_ARG, "render: more than %d streams render on one scene handle", sdfhip_scene::MAX_SCRATCH);
         sc = &s->scratch[s->n_scratch];
-        sc->stream = st; sc->hit_buf = nullptr; sc->records = 0; sc->ctl = nullptr; sc->launches = 0;
-        const size_t ctl_bytes = (sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS) * sizeof(uint32_t);
+        sc->stream = st; sc->hit_buf = nullptr; sc->records = 0; sc->ctl = nullptr; sc->launches = 0; sc->pt_buf = nullptr; sc->pt_bytes = 0;
+        const size_t ctl_bytes = (sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS + sdfhip_scene::CTL_PT_WORDS) * sizeof(uint32_t);
         HIP_TRY(hipMalloc((void **)&sc->ctl, ctl_bytes));
         HIP_TRY(hipMemset(sc->ctl, 0, ctl_bytes));
         s->n_scratch++;
@@ -553,6 +557,44 @@ int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::S
         sc->records = records;
     }
     *out = sc;
+    return SDFHIP_OK;
+}
+
+// the path-traced pipeline's buffers on a stream's scratch
+int get_pt_scratch(sdfhip_scene *s, hipStream_t st, size_t bytes, sdfhip_scene::Scratch **out)
+{
+    int rc = get_scratch(s, st, 0, out);
+    if (rc != SDFHIP_OK) return rc;
+    sdfhip_scene::Scratch *sc = *out;
+    if (bytes > sc->pt_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (sc->pt_buf) { (void)hipFree(sc->pt_buf); sc->pt_buf = nullptr; sc->pt_bytes = 0; }
+        HIP_TRY(hipMalloc((void **)&sc->pt_buf, bytes));
+        sc->pt_bytes = bytes;
+    }
+    return SDFHIP_OK;
+}
+
+// path-traced mode as a pipeline: camera segments, one kernel per bounce level, the ordered sum
+template <int CUR, bool COUNT>
+int launch_pt(sdfhip_scene *s, sdfhip_scene::Scratch *sc, dim3 grid, hipStream_t st, RenderParams &P)
+{
+    const uint32_t resident = (uint32_t)s->cu_count * 32u;
+    hipError_t e;
+    if ((e = hipMemsetAsync(P.pt_ctl, 0, sdfhip_scene::CTL_PT_WORDS * sizeof(uint32_t), st)) != hipSuccess)
+        return fail(SDFHIP_ERR_DEVICE, "render_path: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((k_pt_primary<CUR, COUNT>), grid, dim3(64), 0, st, P);
+    for (uint32_t b = 0; b <= P.pt_bounces; b++) {
+        P.pt_level = b;
+        // the queue this level fills was drained by the level before it
+        if (b > 0 && (e = hipMemsetAsync(P.pt_ctl + (size_t)((b & 1u) ^ 1u) * HIT_QUEUES * 32, 0, HIT_QUEUES * 32 * sizeof(uint32_t), st)) != hipSuccess)
+            return fail(SDFHIP_ERR_DEVICE, "render_path: hipMemsetAsync failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((k_pt_bounce<CUR, COUNT>), dim3(resident), dim3(64), 0, st, P);
+    }
+    const size_t npx = (size_t)P.nrows_out * P.width;
+    const uint32_t rb = (uint32_t)((npx + 255) / 256 < 4096 ? (npx + 255) / 256 : 4096);
+    hipLaunchKernelGGL((k_pt_resolve<COUNT>), dim3(rb), dim3(256), 0, st, P);
+    (void)sc;
     return SDFHIP_OK;
 }
 
@@ -686,6 +728,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     sdfhip_scene::Scratch *sc = nullptr;
     P.queue = nullptr; P.hit_a = nullptr; P.hit_b = nullptr; P.hit_c = nullptr; P.hit_ctl = nullptr; P.hit_cap = 0; P.hit_set = 0;
     P.tile_perm = s->dbg_tile_perm; P.tile_cost = s->dbg_tile_cost;
+    P.pt_q[0] = P.pt_q[1] = nullptr; P.pt_ctl = nullptr; P.pt_cap = 0; P.pt_level = 0; P.pt_e = nullptr; P.pt_t = nullptr; P.pt_n = nullptr;
     if (two) {
         // a queue takes the hits of every 64th workgroup: room for all their pixels
         P.hit_cap = ((grid.x + HIT_QUEUES - 1u) / HIT_QUEUES) * 64u;
@@ -711,6 +754,28 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     if (two) {
         if (cur == CUR_STACK_SPLIT) { if (count) launch_two<CUR_STACK_SPLIT, true>(out_mode, grid, shade_grid, st, P); else launch_two<CUR_STACK_SPLIT, false>(out_mode, grid, shade_grid, st, P); }
         else                        { if (count) launch_two<CUR_STACK_FULL, true>(out_mode, grid, shade_grid, st, P); else launch_two<CUR_STACK_FULL, false>(out_mode, grid, shade_grid, st, P); }
+    }
+    else if (pt && (cur == CUR_STACK_FULL || cur == CUR_STACK_SPLIT) && !(flags & SDFHIP_TUNE_ONE_KERNEL)) {
+        // the pipeline of kernels (k_pt_primary -> k_pt_bounce per level -> k_pt_resolve)
+        grid = dim3(8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x);
+        const size_t npx = (size_t)nrows_out * width, npaths = npx * pt->spp;
+        if (npaths >= ((size_t)1 << 32))
+            return fail(SDFHIP_ERR_ARG, "render_path: %zu paths (pixels x spp) exceed the 32-bit path index", npaths);
+        P.pt_cap = (uint32_t)((((size_t)grid.x + HIT_QUEUES - 1) / HIT_QUEUES) * 64 * pt->spp + 8192);
+        const size_t qbytes = (size_t)4 * 16 * HIT_QUEUES * P.pt_cap;                 // one hit queue
+        const size_t ebytes = (size_t)(pt->max_bounces + 1) * npaths * 4, tbytes = npaths * 4;
+        int rcs = get_pt_scratch(s, st, 2 * qbytes + ebytes + 2 * tbytes, &sc);
+        if (rcs != SDFHIP_OK) return rcs;
+        P.pt_q[0] = reinterpret_cast<float4 *>(sc->pt_buf);
+        P.pt_q[1] = reinterpret_cast<float4 *>(sc->pt_buf + qbytes);
+        P.pt_e = reinterpret_cast<float *>(sc->pt_buf + 2 * qbytes);
+        P.pt_t = reinterpret_cast<float *>(sc->pt_buf + 2 * qbytes + ebytes);
+        P.pt_n = reinterpret_cast<uint32_t *>(sc->pt_buf + 2 * qbytes + ebytes + tbytes);
+        P.pt_ctl = sc->ctl + sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS;
+        int rcl;
+        if (cur == CUR_STACK_SPLIT) rcl = count ? launch_pt<CUR_STACK_SPLIT, true>(s, sc, grid, st, P) : launch_pt<CUR_STACK_SPLIT, false>(s, sc, grid, st, P);
+        else                        rcl = count ? launch_pt<CUR_STACK_FULL, true>(s, sc, grid, st, P) : launch_pt<CUR_STACK_FULL, false>(s, sc, grid, st, P);
+        if (rcl != SDFHIP_OK) return rcl;
     }
     else if (pt) {
         grid = dim3(8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x);
