@@ -888,6 +888,10 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
 // (adding the +0 of an unlit vertex, or fma(0, sky, acc), changes no bit of a non-negative or NaN sum) and
 // k_pt_resolve adds them as o_pixel_pt does.  Per path the arithmetic, the RNG draws and the cursor carried
 // from segment to shadow ray to next segment are the oracle's: images and counters stay bit-identical.
+// (Measured and dropped: k_pt_bounce with lane refill -- a wave owning a share of the level's hits, lanes as
+// SHADOW / MARCH / parked state machines around one shared march step, hits loaded, shaded and bounced in batches
+// once 16 / 32 / 48 lanes are free.  Bit-identical, 30.8 / 29.1 / 28.6 ms per cfg-5 frame against 26.3 ms for the
+// plain form below: every batch stalls the marching lanes behind the queue loads and the shading of the new ones.)
 // =====================================================================================
 __device__ __forceinline__ uint32_t *pt_count(const RenderParams &P, uint32_t queue, uint32_t q) { return P.pt_ctl + ((size_t)queue * HIT_QUEUES + q) * 32u; }
 
