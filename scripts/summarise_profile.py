@@ -39,26 +39,33 @@ def main():
     except Exception as e:  # noqa: BLE001
         print("no bench line:", e)
     kernels = collections.defaultdict(dict)
+    per_frame = collections.defaultdict(float)        # counter -> sum over the frame's kernels, per frame
+    FIRST = ("k_march", "k_pt_primary", "k_plain", "k_compact", "k_path")   # one launch of these per frame (or per batch of frames)
     for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if not k or not k.startswith(("k_march", "k_shade", "k_plain", "k_compact", "k_path")):
+            if not k or not k.startswith(("k_march", "k_shade", "k_plain", "k_compact", "k_path", "k_pt_")):
                 continue
-            if re.search(r"<\d+, true", k):             # the one counting launch
+            if re.search(r"<\d+, true", k) or k.endswith("<true>"):     # the one counting launch
                 continue
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             kernels[k]["VGPR_Count"] = int(r["VGPR_Count"]); kernels[k]["SGPR_Count"] = int(r["SGPR_Count"])
             kernels[k]["LDS_Block_Size"] = int(r["LDS_Block_Size"])
+        counters = {c for cs in agg.values() for c in cs}
+        for c in counters:
+            frames = sum(len(cs[c]) for k, cs in agg.items() if k.startswith(FIRST) and c in cs)
+            if frames:
+                per_frame[c] = sum(sum(cs[c]) for cs in agg.values() if c in cs) / frames
         for k, cs in agg.items():
             for c, v in cs.items():
-                kernels[k][c] = sum(v) / len(v)
+                kernels[k][c] = sum(v) / len(v)          # mean per launch of this kernel
                 kernels[k]["launches_" + c] = len(v)
-    out = {"tag": tag, "kernel_source_sha": kernel_source_hash(), "kernels": kernels}
-    rd = sum(k.get("FETCH_SIZE", 0.0) for k in kernels.values()) * 1024
-    wr = sum(k.get("WRITE_SIZE", 0.0) for k in kernels.values()) * 1024
+    out = {"tag": tag, "kernel_source_sha": kernel_source_hash(), "kernels": kernels, "per_frame": dict(per_frame)}
+    rd = per_frame.get("FETCH_SIZE", 0.0) * 1024
+    wr = per_frame.get("WRITE_SIZE", 0.0) * 1024
     if rd or wr:
-        # per frame = per launch of each kernel of the frame's pipeline (k_march + k_shade, or k_plain alone)
+        # per frame = the frame's whole pipeline (k_march + k_shade; k_pt_primary + every k_pt_bounce level + k_pt_resolve; ...)
         fpl = float(bench["roofline"].get("frames_per_launch", 1.0)) if bench else 1.0
         out["hbm_read_bytes_raw_per_frame"] = rd / fpl
         out["hbm_read_bytes_x2_per_frame"] = 2 * rd / fpl
@@ -71,8 +78,9 @@ def main():
     if "hbm_bytes_per_frame" in out and len(sys.argv) > 2:
         p = os.path.join(REPO, "profiles", "hbm_traffic.json")
         t = json.load(open(p)) if os.path.exists(p) else {}
-        valu = sum(k.get("SQ_INSTS_VALU", 0.0) for k in kernels.values())
-        salu = sum(k.get("SQ_INSTS_SALU", 0.0) for k in kernels.values())
+        fpl = float(bench["roofline"].get("frames_per_launch", 1.0)) if bench else 1.0
+        valu = per_frame.get("SQ_INSTS_VALU", 0.0) / fpl
+        salu = per_frame.get("SQ_INSTS_SALU", 0.0) / fpl
         t[sys.argv[2]] = {"hbm_bytes_per_frame": int(out["hbm_bytes_per_frame"]), "read_x2": int(out["hbm_read_bytes_x2_per_frame"]),
                           "write": int(out["hbm_write_bytes_per_frame"]), "valu_insts_per_frame": int(valu), "salu_insts_per_frame": int(salu),
                           "profile": f"profiles/{tag}_pmc.json", "kernel_source_sha": out["kernel_source_sha"]}

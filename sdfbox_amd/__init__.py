@@ -8,11 +8,11 @@ from . import _lib
 from ._lib import (FLAG_COMPACT, FLAG_COUNT, FLAG_DISPLAY, FLAG_DISPLAY_DEBUG, FLAG_WIRE, KERNEL_AUTO, KERNEL_GENERIC, KERNEL_STACK, TUNE_ONE_KERNEL, Info,
                    PathTrace, SdfHipError, Stats)
 from .logic import Logic
-from .octdata import OctData, dragon_standin, sphere_d4, torus_d6
+from .octdata import OctData, dragon_standin, knot_point_cloud, sphere_d4, torus_d6, write_ply
 from .renderer import Scene, device_count, unorm_table
 
 __all__ = [
     "FLAG_COMPACT", "FLAG_COUNT", "FLAG_DISPLAY", "FLAG_DISPLAY_DEBUG", "FLAG_WIRE", "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_STACK", "TUNE_ONE_KERNEL", "Info",
-    "PathTrace", "SdfHipError", "Stats", "Logic", "OctData", "dragon_standin", "sphere_d4", "torus_d6",
+    "PathTrace", "SdfHipError", "Stats", "Logic", "OctData", "dragon_standin", "knot_point_cloud", "write_ply", "sphere_d4", "torus_d6",
     "Scene", "device_count", "unorm_table",
 ]

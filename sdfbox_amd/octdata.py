@@ -134,3 +134,32 @@ def dragon_standin(depth=9, nthreads=None):
     which does not ship and cannot be fetched."""
     return OctData.Generate(_lib.SHAPE_GYROID, [0.5, 0.5, 0.5, 0.42, 12.0 * np.pi, 0.004], depth,
                             nthreads)
+
+
+def knot_point_cloud(n=1_000_000, seed=1):
+    """A mesh-like workload for the .ply -> SdfGen -> .asdf -> render flow (Program.cs:613-650): `n` surface points
+    with normals on the tube of a (2,3) torus knot, (n, 6) float32 {position, normal}.  Deterministic; stands in for
+    the point cloud of a scanned mesh (the Stanford dragon's .ply does not ship and cannot be fetched)."""
+    rng = np.random.default_rng(seed)
+    t = rng.uniform(0, 2 * np.pi, n); a = rng.uniform(0, 2 * np.pi, n)
+    p, q, R, r, tube = 2, 3, 0.28, 0.11, 0.035
+    c = np.stack([(R + r * np.cos(q * t)) * np.cos(p * t), (R + r * np.cos(q * t)) * np.sin(p * t), r * np.sin(q * t)], 1)
+    d = np.stack([-(R + r * np.cos(q * t)) * p * np.sin(p * t) - r * q * np.sin(q * t) * np.cos(p * t),
+                  (R + r * np.cos(q * t)) * p * np.cos(p * t) - r * q * np.sin(q * t) * np.sin(p * t),
+                  r * q * np.cos(q * t)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    u = np.cross(d, [0, 0, 1.0]); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = np.cross(d, u)
+    nrm = np.cos(a)[:, None] * u + np.sin(a)[:, None] * v
+    pos = c + tube * nrm + 0.5
+    return np.concatenate([pos, nrm], 1).astype(np.float32)
+
+
+def write_ply(path, vertices):
+    """Binary little-endian .ply with 6 floats per vertex, vertex element first: what LoadPly reads (ply_reader.cpp:35-71)."""
+    v = np.ascontiguousarray(vertices, dtype="<f4").reshape(-1, 6)
+    with open(path, "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\ncomment sdfbox_amd.write_ply\nelement vertex {len(v)}\n"
+                 "property float x\nproperty float y\nproperty float z\n"
+                 "property float nx\nproperty float ny\nproperty float nz\nend_header\n").encode())
+        f.write(v.tobytes())
