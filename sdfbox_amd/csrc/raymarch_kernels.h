@@ -455,11 +455,15 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     // told apart after the loop (a lane that left keeps its state), header first, as the shader orders them.
     auto marching = [&]() { return (r.prox > I.margin2 || r.prox < 0.0f) && r.n < 100; };
     if (live) {
-        while (marching() && !(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit)) {
+        // (both tests every time, combined without a branch: the escape test is three instructions)
+        while ((int)marching() & (int)!(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit)) {
             uint32_t reads = march_step(P, I, r, c, nullptr, 0);
             if (COUNT) { cn += reads; cs += 1; }
         }
     }
+    // (the lane's own registers say why it left; hiding them from the optimiser here keeps the loop from carrying
+    // one more exec-mask per exit reason through every iteration)
+    asm volatile("" : "+v"(r.prox), "+v"(r.n));
     const int end = !live ? 3 : marching() ? 2 : 1;   // 1 on the surface (or out of steps), 2 escaped, 3 no pixel
     if (P.tile_cost) {                                  // iterations this wave ran = its longest lane
         int m = live ? r.n : 0;
