@@ -654,29 +654,39 @@ def load_pmc(key):
     return e
 
 
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles (16 lanes wide), 2.4 GHz
+# VALU issue: 256 CUs x 4 SIMDs at 2.4 GHz, and 2.35 cycles for the cheapest wave64 VALU instruction (v_mov_b32; simple
+# two-operand ops take 2.4-2.6, three-operand and conversion ops 4.1-4.4: scripts/micro/valu_mix.hip,
+# profiles/r02_micro_valu_mix.txt) -- a ceiling for ANY instruction mix
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.35
 HBM_PEAK_GBS = 8000.0                    # HBM3E spec (MI355X_MICROARCH.md)
 
 
 def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
-    """Which roof does the frame sit under?  Three candidates, each achieved / peak over the steady-state time per
-    frame (the driver-verifiable ms_per_step; with frames in flight the per-launch durations overlap):
-      hbm-algorithmic  the bytes this kernel's own algorithm moves (16 B per cell / record a lane loads, 96 B per
-                       queued hit, the pixel store; counted by the counting build), against 8 TB/s;
-      hbm-traffic      HBM bytes from the rocprofv3 counters (2 x FETCH_SIZE + WRITE_SIZE, separate passes), against 8 TB/s;
-      valu             issued VALU wave instructions (SQ_INSTS_VALU), against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
-                       (scripts/micro/valu_rate.hip measures 603 G/s of that 614 on the box).
-    `frac` is the largest of them -- the binding roof -- and `bound` names it.  The reference algorithm's bytes
-    (8 B per node visit of find(), Compute.hlsl:88-108) are kept as a work-equivalent rate without a
-    fraction: the kernel does not perform those loads (one grid lookup replaces up to nine node visits)."""
-    cands = {"hbm-algorithmic": {"achieved": own_bytes / sec_per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": int(own_bytes)}}
+    """Which roof does the frame sit under?  Candidates, each achieved / peak over the steady-state time per frame
+    (the driver-verifiable ms_per_step; with frames in flight the per-launch durations overlap):
+      hbm-traffic      HBM bytes per frame from the rocprofv3 counters (2 x FETCH_SIZE + WRITE_SIZE, separate passes, the
+                       guide's gfx950 correction), against 8 TB/s;
+      valu             issued VALU wave instructions per frame (SQ_INSTS_VALU), against the chip's ceiling for the
+                       cheapest instruction.
+    Both are measured quantities against a hard ceiling, so frac <= 1; `frac` is the larger -- the binding roof -- and
+    `bound` names it.  They need a PMC pass of this build and workload (profiles/hbm_traffic.json); without one the only
+    figure left is `algorithmic`: the bytes this kernel's own algorithm asks for per frame (16 B per grid cell / node
+    record a LANE loads, 96 B per queued hit, the pixel store; counted by the counting build) -- a demand on the memory
+    system, not on HBM: the lanes of a wave mostly ask for the same few cells, which L1 serves once, so it is not
+    bounded by 8 TB/s (at 4K it reads 9 TB/s).  The reference algorithm's bytes (8 B per node visit of
+    find(), Compute.hlsl:88-108) are the work-equivalent rate: the kernel does not perform those loads (one grid lookup
+    replaces up to nine node visits)."""
+    cands = {}
     traffic = None
     if pmc:
         traffic = int(pmc["hbm_bytes_per_frame"])
         cands["hbm-traffic"] = {"achieved": traffic / sec_per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": traffic}
         if pmc.get("valu_insts_per_frame"):
-            cands["valu"] = {"achieved": pmc["valu_insts_per_frame"] / sec_per_frame / 1e9, "peak": VALU_PEAK_GINSTR,
+            cands["valu"] = {"achieved": pmc["valu_insts_per_frame"] / sec_per_frame / 1e9, "peak": round(VALU_PEAK_GINSTR, 1),
                              "unit": "G wave-instr/s", "per_frame": int(pmc["valu_insts_per_frame"])}
+    measured = bool(cands)
+    if not measured:
+        cands["hbm-algorithmic"] = {"achieved": own_bytes / sec_per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": int(own_bytes)}
     for c in cands.values():
         c["frac"] = round(c["achieved"] / c["peak"], 4)
         c["achieved"] = round(c["achieved"], 1)
@@ -686,12 +696,13 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
         "bound": "hbm" if name.startswith("hbm") else "valu",
         "binding": name,
         "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"],
+        "frac_is_measured_against_a_ceiling": measured,
         "traffic": traffic,
         "traffic_source": ({"profile": pmc.get("profile"), "kernel_source_sha": pmc.get("kernel_source_sha")} if pmc else
                            "no PMC pass of this build and workload under profiles/ (scripts/profile.sh)"),
         "candidates": cands,
-        "reference_algorithm_bytes_per_frame": int(ref_bytes),
-        "reference_algorithm_gbs": round(ref_bytes / sec_per_frame / 1e9, 1),
+        "algorithmic": {"own_bytes_per_frame": int(own_bytes), "own_gbs": round(own_bytes / sec_per_frame / 1e9, 1),
+                        "reference_bytes_per_frame": int(ref_bytes), "reference_gbs": round(ref_bytes / sec_per_frame / 1e9, 1)},
         "measured_copy_gbs": copy_gbs,
     }
 
