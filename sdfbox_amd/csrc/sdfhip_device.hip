@@ -275,6 +275,14 @@ struct sdfhip_scene {
     TopCell *d_fine;                 // split grid: blocks of fine cells below the internal cells of d_top, or null
     int fine_bits;
     uint64_t fine_bytes;
+    // A second, split grid beside a dense full-depth one, for the kernels whose rays are incoherent (the bounce levels of
+    // the path-traced pipeline are HBM-bound: every lookup in the 8^depth-cell dense grid is a cache miss, while a ray
+    // that stays near the surface stays inside one block of fine cells).  Same cells, same cursor; built on the first
+    // path-traced render.
+    TopCell *d_top2, *d_fine2;
+    int top2_level, fine2_bits, scatter_tried;
+    uint64_t top2_bytes;
+    size_t total_mem;
     unsigned long long *d_counters;  // 6 x u64: nodes, samples, steps, shadow rays, loads, hits
     // Per-stream scratch of the render launches: the hit queues of the two-kernel pipeline and their
     // control words, and the tile-queue heads of the compact kernel.  Launches on one stream run in
@@ -342,6 +350,8 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
         if (s->d_counters) (void)hipFree(s->d_counters);
         if (s->d_top) (void)hipFree(s->d_top);
         if (s->d_fine) (void)hipFree(s->d_fine);
+        if (s->d_top2) (void)hipFree(s->d_top2);
+        if (s->d_fine2) (void)hipFree(s->d_fine2);
         for (int i = 0; i < s->n_scratch; i++) {
             if (s->scratch[i].hit_buf) (void)hipFree(s->scratch[i].hit_buf);
             if (s->scratch[i].pt_buf) (void)hipFree(s->scratch[i].pt_buf);
@@ -354,6 +364,55 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
     }
     delete s;
     return SDFHIP_OK;
+}
+
+// A split grid over the scene's records: dense cells of level C whose internal cells (level word 15) name, in `children`,
+// a block of 8^FB fine cells; built on s->stream.  false (nothing allocated) when memory or the byte limit say no.
+static bool build_split_grid(sdfhip_scene *s, int C, int FB, uint64_t max_fine_bytes, TopCell **coarse_out, TopCell **fine_out,
+                             uint64_t *fine_bytes_out)
+{
+    const size_t ncell = (size_t)1 << (3 * C);
+    std::vector<TopCell> coarse(ncell);
+    uint32_t *d_block_node = nullptr;
+    TopCell *d_coarse = nullptr, *d_fine = nullptr;
+    bool ok = false;
+    do {
+        if (hipMalloc((void **)&d_coarse, ncell * sizeof(TopCell)) != hipSuccess) break;
+        const uint32_t tb = (uint32_t)((ncell + 255) / 256 < 8192 ? (ncell + 255) / 256 : 8192);
+        hipLaunchKernelGGL(k_top_grid, dim3(tb), dim3(256), 0, s->stream, s->nodes, d_coarse, C, 2);
+        if (hipMemcpyAsync(coarse.data(), d_coarse, ncell * sizeof(TopCell), hipMemcpyDeviceToHost, s->stream) != hipSuccess) break;
+        if (hipStreamSynchronize(s->stream) != hipSuccess) break;
+        // number the internal cells in cell order on the host (deterministic) and point them at their blocks
+        std::vector<uint32_t> block_node;
+        for (size_t i = 0; i < ncell; i++)
+            if (coarse[i].level == 15u) {
+                block_node.push_back((uint32_t)coarse[i].children);
+                coarse[i].children = (int32_t)(block_node.size() - 1);
+            }
+        const size_t nblocks = block_node.size();
+        const uint64_t fine_bytes = (uint64_t)(nblocks << (3 * FB)) * sizeof(TopCell);
+        if (fine_bytes > max_fine_bytes) break;
+        if (nblocks) {
+            if (hipMalloc((void **)&d_fine, fine_bytes) != hipSuccess) break;
+            if (hipMalloc((void **)&d_block_node, nblocks * 4) != hipSuccess) break;
+            if (hipMemcpyAsync(d_block_node, block_node.data(), nblocks * 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) break;
+            if (hipMemcpyAsync(d_coarse, coarse.data(), ncell * sizeof(TopCell), hipMemcpyHostToDevice, s->stream) != hipSuccess) break;
+            const size_t nfine = nblocks << (3 * FB);
+            const uint32_t fb = (uint32_t)((nfine + 255) / 256 < 16384 ? (nfine + 255) / 256 : 16384);
+            hipLaunchKernelGGL(k_fine_blocks, dim3(fb), dim3(256), 0, s->stream, s->nodes, d_block_node, d_fine,
+                               (uint32_t)nblocks, C, FB);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) break;
+        }
+        *coarse_out = d_coarse; d_coarse = nullptr;
+        *fine_out = d_fine; d_fine = nullptr;
+        *fine_bytes_out = nblocks ? fine_bytes : 0;
+        ok = true;
+    } while (false);
+    (void)hipGetLastError();
+    if (d_block_node) (void)hipFree(d_block_node);
+    if (d_coarse) (void)hipFree(d_coarse);
+    if (d_fine) (void)hipFree(d_fine);
+    return ok;
 }
 
 extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uint8_t *values,
@@ -383,6 +442,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     s->device = device; s->n = n; s->depth = depth;
     s->stack_ok = (consistent && depth <= (uint32_t)MAX_STACK) ? 1 : 0;
     s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0;
+    s->d_top2 = s->d_fine2 = nullptr; s->top2_level = s->fine2_bits = s->scatter_tried = 0; s->top2_bytes = 0; s->total_mem = prop.totalGlobalMem;
     s->n_scratch = 0; s->d_frame = nullptr; s->dbg_tile_perm = nullptr; s->dbg_tile_cost = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
     s->cu_count = prop.multiProcessorCount;
 
@@ -447,47 +507,13 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if (getenv("SDFHIP_TOP_GRID_LEVEL")) split = getenv("SDFHIP_TOP_GRID_SPLIT") ? split : 0;   // an explicit level means a plain grid
     bool split_built = false;
     if (s->stack_ok && split > 0) {
-        const int C = split, FB = (int)depth - split;
-        const size_t ncell = (size_t)1 << (3 * C);
-        std::vector<TopCell> coarse(ncell);
-        uint32_t *d_block_node = nullptr;
-        TopCell *d_coarse = nullptr, *d_fine = nullptr;
-        do {
-            if (hipMalloc((void **)&d_coarse, ncell * sizeof(TopCell)) != hipSuccess) break;
-            const uint32_t tb = (uint32_t)((ncell + 255) / 256 < 8192 ? (ncell + 255) / 256 : 8192);
-            hipLaunchKernelGGL(k_top_grid, dim3(tb), dim3(256), 0, s->stream, s->nodes, d_coarse, C, 2);
-            if (hipMemcpyAsync(coarse.data(), d_coarse, ncell * sizeof(TopCell), hipMemcpyDeviceToHost, s->stream) != hipSuccess) break;
-            if (hipStreamSynchronize(s->stream) != hipSuccess) break;
-            // number the internal cells in cell order on the host (deterministic) and point them at their blocks
-            std::vector<uint32_t> block_node;
-            for (size_t i = 0; i < ncell; i++)
-                if (coarse[i].level == 15u) {
-                    block_node.push_back((uint32_t)coarse[i].children);
-                    coarse[i].children = (int32_t)(block_node.size() - 1);
-                }
-            const size_t nblocks = block_node.size();
-            const uint64_t fine_bytes = (uint64_t)(nblocks << (3 * FB)) * sizeof(TopCell);
-            if (fine_bytes > prop.totalGlobalMem / 16) break;                       // too much: a plain grid below
-            if (nblocks) {
-                if (hipMalloc((void **)&d_fine, fine_bytes) != hipSuccess) break;
-                if (hipMalloc((void **)&d_block_node, nblocks * 4) != hipSuccess) break;
-                if (hipMemcpyAsync(d_block_node, block_node.data(), nblocks * 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) break;
-                if (hipMemcpyAsync(d_coarse, coarse.data(), ncell * sizeof(TopCell), hipMemcpyHostToDevice, s->stream) != hipSuccess) break;
-                const size_t nfine = nblocks << (3 * FB);
-                const uint32_t fb = (uint32_t)((nfine + 255) / 256 < 16384 ? (nfine + 255) / 256 : 16384);
-                hipLaunchKernelGGL(k_fine_blocks, dim3(fb), dim3(256), 0, s->stream, s->nodes, d_block_node, d_fine,
-                                   (uint32_t)nblocks, C, FB);
-                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) break;
-            }
-            s->d_top = d_coarse; d_coarse = nullptr;
-            s->d_fine = d_fine; d_fine = nullptr;
-            s->top_level = C; s->fine_bits = FB; s->fine_bytes = nblocks ? fine_bytes : 0;
+        TopCell *coarse = nullptr, *fine = nullptr;
+        uint64_t fbytes = 0;
+        if (build_split_grid(s, split, (int)depth - split, prop.totalGlobalMem / 16, &coarse, &fine, &fbytes)) {
+            s->d_top = coarse; s->d_fine = fine;
+            s->top_level = split; s->fine_bits = (int)depth - split; s->fine_bytes = fbytes;
             split_built = true;
-        } while (false);
-        (void)hipGetLastError();
-        if (d_block_node) (void)hipFree(d_block_node);
-        if (d_coarse) (void)hipFree(d_coarse);
-        if (d_fine) (void)hipFree(d_fine);
+        }
     }
     if (s->stack_ok && top_level > 0 && !split_built) {
         // the grid is an accelerator, not part of the scene: without memory for it, shrink it
@@ -516,7 +542,7 @@ extern "C" int sdfhip_scene_top_grid(const sdfhip_scene *s, int32_t *level, uint
 {
     if (!s) return fail(SDFHIP_ERR_ARG, "scene_top_grid: null scene");
     if (level) *level = s->d_top ? s->top_level : 0;
-    if (bytes) *bytes = s->d_top ? ((uint64_t)sizeof(TopCell) << (3 * s->top_level)) + s->fine_bytes : 0;
+    if (bytes) *bytes = s->d_top ? ((uint64_t)sizeof(TopCell) << (3 * s->top_level)) + s->fine_bytes + s->top2_bytes : 0;
     return SDFHIP_OK;
 }
 
@@ -589,7 +615,14 @@ int launch_pt(sdfhip_scene *s, sdfhip_scene::Scratch *sc, dim3 grid, hipStream_t
         // the queue this level fills was drained by the level before it
         if (b > 0 && (e = hipMemsetAsync(P.pt_ctl + (size_t)((b & 1u) ^ 1u) * HIT_QUEUES * 32, 0, HIT_QUEUES * 32 * sizeof(uint32_t), st)) != hipSuccess)
             return fail(SDFHIP_ERR_DEVICE, "render_path: hipMemsetAsync failed: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL((k_pt_bounce<CUR, COUNT>), dim3(resident), dim3(64), 0, st, P);
+        if (CUR == CUR_STACK_FULL && s->d_top2) {
+            // incoherent rays: the same cells through the split grid (the cursor does not depend on the grid it was filled from)
+            RenderParams P2 = P;
+            P2.top = s->d_top2; P2.top_level = s->top2_level; P2.fine = s->d_fine2; P2.fine_bits = s->fine2_bits;
+            hipLaunchKernelGGL((k_pt_bounce<CUR_STACK_SPLIT, COUNT>), dim3(resident), dim3(64), 0, st, P2);
+        } else {
+            hipLaunchKernelGGL((k_pt_bounce<CUR, COUNT>), dim3(resident), dim3(64), 0, st, P);
+        }
     }
     const size_t npx = (size_t)P.nrows_out * P.width;
     const uint32_t rb = (uint32_t)((npx + 255) / 256 < 4096 ? (npx + 255) / 256 : 4096);
@@ -772,6 +805,19 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         P.pt_t = reinterpret_cast<float *>(sc->pt_buf + 2 * qbytes + ebytes);
         P.pt_n = reinterpret_cast<uint32_t *>(sc->pt_buf + 2 * qbytes + ebytes + tbytes);
         P.pt_ctl = sc->ctl + sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS;
+        // beside a dense full-depth grid, the bounce levels read a split grid of the same cells (built now, once)
+        if (cur == CUR_STACK_FULL && !s->scatter_tried) {
+            s->scatter_tried = 1;
+            const char *env = getenv("SDFHIP_SCATTER_GRID");
+            const int FB = env ? atoi(env) : 3;                                     // blocks of 8^FB fine cells; 0 = off
+            if (FB >= 1 && FB <= 4 && (int)s->depth - FB >= 1 && (int)s->depth - FB <= MAX_TOP_LEVEL) {
+                uint64_t fbytes = 0;
+                if (build_split_grid(s, (int)s->depth - FB, FB, s->total_mem / 32, &s->d_top2, &s->d_fine2, &fbytes)) {
+                    s->top2_level = (int)s->depth - FB; s->fine2_bits = FB;
+                    s->top2_bytes = ((uint64_t)sizeof(TopCell) << (3 * s->top2_level)) + fbytes;
+                }
+            }
+        }
         int rcl;
         if (cur == CUR_STACK_SPLIT) rcl = count ? launch_pt<CUR_STACK_SPLIT, true>(s, sc, grid, st, P) : launch_pt<CUR_STACK_SPLIT, false>(s, sc, grid, st, P);
         else                        rcl = count ? launch_pt<CUR_STACK_FULL, true>(s, sc, grid, st, P) : launch_pt<CUR_STACK_FULL, false>(s, sc, grid, st, P);
