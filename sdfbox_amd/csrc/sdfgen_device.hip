@@ -222,6 +222,147 @@ __global__ __launch_bounds__(BT) void k_corners(GenParams P, LevelArrays L, cons
     if (tid == 0) L.split[node] = (center_value < P.scale * 2 && P.depth < P.max_depth) ? 1u : 0u;
 }
 
+// ---- several nodes per wavefront --------------------------------------------------------------------
+// On the deepest levels a node's candidate list is short (tens of entries): with one wavefront per node most lanes
+// of k_center / k_corners idle through the list, and the eight 6-step butterfly reductions of k_corners cost more
+// than the list itself.  Here G = 16 lanes work on a node and a wavefront takes 64 / G nodes: the same arithmetic
+// per candidate and the same tie-breaking (earliest list position), so the same bytes.
+template <int G> __device__ __forceinline__ Best sub_min(Best b)
+{
+    for (int off = G / 2; off > 0; off >>= 1) {
+        Best o;
+        o.d = __shfl_xor(b.d, off);
+        o.k = (uint32_t)__shfl_xor((int)b.k, off);
+        if (better(o, b)) b = o;
+    }
+    return b;
+}
+
+template <int G>
+__global__ __launch_bounds__(64) void k_center_sub(GenParams P, LevelArrays L, const uint32_t *__restrict__ cand,
+                                                   uint32_t n_nodes, uint32_t *err)
+{
+    const uint32_t tid = threadIdx.x, sub = tid % G, node = blockIdx.x * (64 / G) + tid / G;
+    const bool have = node < n_nodes;
+    const float h = 0.5f * P.scale;
+    float cx = 0, cy = 0, cz = 0;
+    uint32_t off = 0, cnt = 0;
+    if (have) {
+        transform(P, L.px[node] + h, L.py[node] + h, L.pz[node] + h, cx, cy, cz);
+        off = L.cand_off[node]; cnt = L.cand_cnt[node];
+    }
+    Best b{INFINITY, 0xFFFFFFFFu};
+    for (uint32_t k = sub; k < cnt; k += G) {
+        const float *v = P.verts + 6 * (size_t)cand[off + k];
+        float d = lensq(v[0] - cx, v[1] - cy, v[2] - cz);
+        if (d < b.d) { b.d = d; b.k = k; }
+    }
+    b = sub_min<G>(b);
+    const bool bad = b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d);      // "Did not find" / "NaN distance"
+    const float center_value = bad ? 0.0f : sqrtf(b.d) / P.gs;
+    float r = center_value + 0.866025404f * P.scale;     // GetPossible, dllmain.cpp:151-162
+    r *= P.gs;
+    r *= r;
+    uint32_t count = 0;
+    if (!bad)
+        for (uint32_t k = sub; k < cnt; k += G) {
+            const float *v = P.verts + 6 * (size_t)cand[off + k];
+            if (lensq(v[0] - cx, v[1] - cy, v[2] - cz) < r) count++;
+        }
+    for (int o = G / 2; o > 0; o >>= 1) count += __shfl_xor(count, o);
+    if (have && sub == 0) {
+        if (bad) atomicExch(err, 2u);
+        L.center_value[node] = center_value; L.pcount[node] = bad ? 0u : count;
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(64) void k_corners_sub(GenParams P, LevelArrays L, const uint32_t *__restrict__ cand,
+                                                    const uint32_t *__restrict__ poff, uint32_t *__restrict__ possible,
+                                                    uint32_t n_nodes, uint32_t *err)
+{
+    const uint32_t tid = threadIdx.x, sub = tid % G, grp = tid / G, node = blockIdx.x * (64 / G) + grp;
+    const bool have = node < n_nodes;
+    float px = 0, py = 0, pz = 0, center_value = 0;
+    uint32_t off = 0, cnt = 0, out = 0;
+    int slot = -1;
+    if (have) {
+        px = L.px[node]; py = L.py[node]; pz = L.pz[node]; center_value = L.center_value[node];
+        off = L.cand_off[node]; cnt = L.cand_cnt[node]; out = poff[node]; slot = L.slot[node];
+    }
+    const float h = 0.5f * P.scale;
+    float cx, cy, cz;
+    transform(P, px + h, py + h, pz + h, cx, cy, cz);
+    float r = center_value + 0.866025404f * P.scale;
+    r *= P.gs;
+    r *= r;
+    float qx[8], qy[8], qz[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        transform(P, px + (float)(i % 2) * P.scale, py + (float)((i / 2) % 2) * P.scale,
+                  pz + (float)((i / 2 / 2) % 2) * P.scale, qx[i], qy[i], qz[i]);
+    Best best[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) best[i] = Best{INFINITY, 0xFFFFFFFFu};
+    // the groups of a wavefront walk their lists together, chunk by chunk, until the longest is done
+    uint32_t longest = cnt;
+    for (int o = 32; o >= G; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
+    uint32_t base = 0;
+    for (uint32_t k0 = 0; k0 < longest; k0 += G) {
+        const uint32_t k = k0 + sub;
+        bool keep = false;
+        uint32_t vi = 0;
+        float vx = 0, vy = 0, vz = 0;
+        if (k < cnt) {
+            vi = cand[off + k];
+            const float *v = P.verts + 6 * (size_t)vi;
+            vx = v[0]; vy = v[1]; vz = v[2];
+            keep = lensq(vx - cx, vy - cy, vz - cz) < r;
+        }
+        const unsigned long long m = __ballot(keep);
+        const uint32_t gm = (uint32_t)(m >> (G * grp)) & ((1u << G) - 1u);            // this group's survivors of the chunk
+        if (keep) {
+            possible[out + base + (uint32_t)__popc(gm & ((1u << sub) - 1u))] = vi;       // stable: list order
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float d = lensq(vx - qx[i], vy - qy[i], vz - qz[i]);
+                if (d < best[i].d) { best[i].d = d; best[i].k = k; }
+            }
+        }
+        base += (uint32_t)__popc(gm);
+    }
+    float myval = 0.0f;                                  // lane i < 8 of the group ends up holding corner i
+    bool bad_any = false;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        Best b = sub_min<G>(best[i]);
+        float val;
+        if (i == slot) {
+            val = have ? L.inherit[node] : 0.0f;         // n[i] = vals[insert][i], dllmain.cpp:181
+        } else if (b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d)) {
+            bad_any = true;
+            val = 0.0f;
+        } else {                                         // DistanceAt, dllmain.cpp:119-149
+            const float *v = P.verts + 6 * (size_t)cand[off + b.k];
+            float md = sqrtf(b.d);
+            const float ex = qx[i] - v[0], ey = qy[i] - v[1], ez = qz[i] - v[2];      // p - closest.Position
+            if ((double)md < 0.015) {
+                const float nl = sqrtf(lensq(v[3], v[4], v[5]));
+                md = (v[3] / nl) * ex + (v[4] / nl) * ey + (v[5] / nl) * ez;
+            } else if (v[3] * (v[0] - qx[i]) + v[4] * (v[1] - qy[i]) + v[5] * (v[2] - qz[i]) > 0) {   // Inside
+                md *= -1;
+            }
+            val = md / P.gs;
+        }
+        if ((int)sub == i) myval = val;
+    }
+    if (have) {
+        if (bad_any && sub == 0) atomicExch(err, 2u);
+        if (sub < 8) L.vals[8 * (size_t)node + sub] = myval;
+        if (sub == 0) L.split[node] = (center_value < P.scale * 2 && P.depth < P.max_depth) ? 1u : 0u;
+    }
+}
+
 // the 8 children of every split node (construct's push_back loop + the arguments of its recursion)
 __global__ void k_children(LevelArrays L, LevelArrays N, const uint32_t *__restrict__ block_of,
                            const uint32_t *__restrict__ poff, float half_scale, uint32_t n_nodes)
@@ -399,6 +540,7 @@ bool scan_u32(Arena &scratch, const uint32_t *in, uint32_t *out, uint32_t n, uns
 }
 
 constexpr uint32_t WIDE_LEVEL = 4096;
+constexpr uint32_t SHORT_LIST = 40;       // average candidates per node below which 16 lanes, not 64, work on a node
 struct KeptLevel { LevelArrays L; uint32_t n; uint32_t *cnt, *rank; int32_t *index; };
 
 }  // namespace
@@ -467,7 +609,7 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
         std::vector<KeptLevel> levels;
         uint32_t n_nodes = 1;
         size_t total_nodes = 0;
-        unsigned long long cand_entries = n;
+        unsigned long long cand_entries = n, prev_possible = n;
         for (int lvl = 0;; lvl++) {
             Arena &mine = scratch[lvl & 1], &other = scratch[(lvl + 1) & 1];
             P.depth = lvl;
@@ -475,7 +617,10 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
             uint32_t *poff = mine.alloc<uint32_t>(n_nodes);
             if (!poff) return GEN_NOMEM();
             const bool wide = n_nodes >= WIDE_LEVEL;      // enough nodes to fill the GPU with one wavefront each
-            if (wide) hipLaunchKernelGGL(k_center<64>, dim3(n_nodes), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
+            // short lists (on average at most SHORT_LIST entries; prev_possible * 8 bounds the level's entries): 16 lanes per node
+            const bool shortl = wide && n_nodes >= 4 * WIDE_LEVEL && 8.0 * (double)prev_possible <= (double)SHORT_LIST * n_nodes;
+            if (shortl) hipLaunchKernelGGL(k_center_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
+            else if (wide) hipLaunchKernelGGL(k_center<64>, dim3(n_nodes), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
             else hipLaunchKernelGGL(k_center<1024>, dim3(n_nodes), dim3(1024), 0, 0, P, L, cand, n_nodes, d_err);
             if (!scan_u32(mine, L.pcount, poff, n_nodes, d_total)) return GEN_NOMEM();
             unsigned long long total = 0;
@@ -485,8 +630,10 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
             uint32_t *possible = lists[(lvl + 1) & 1].alloc<uint32_t>((size_t)total);
             if (!possible) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory for %llu candidate entries", total);
             cand_entries += total;
-            if (wide) hipLaunchKernelGGL(k_corners<64>, dim3(n_nodes), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            if (shortl) hipLaunchKernelGGL(k_corners_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            else if (wide) hipLaunchKernelGGL(k_corners<64>, dim3(n_nodes), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
             else hipLaunchKernelGGL(k_corners<1024>, dim3(n_nodes), dim3(1024), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            prev_possible = total;
             if (!scan_u32(mine, L.split, L.block_of, n_nodes, d_total)) return GEN_NOMEM();
             struct { unsigned long long n_split; uint32_t err; } back;
             GEN_TRY(hipMemcpy(&back.n_split, d_total, sizeof back.n_split, hipMemcpyDeviceToHost));
