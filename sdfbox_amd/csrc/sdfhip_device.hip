@@ -573,7 +573,9 @@ int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::S
         sc->stream = st; sc->hit_buf = nullptr; sc->records = 0; sc->ctl = nullptr; sc->launches = 0; sc->pt_buf = nullptr; sc->pt_bytes = 0;
         const size_t ctl_bytes = (sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS + sdfhip_scene::CTL_PT_WORDS) * sizeof(uint32_t);
         HIP_TRY(hipMalloc((void **)&sc->ctl, ctl_bytes));
-        HIP_TRY(hipMemset(sc->ctl, 0, ctl_bytes));
+        // zeroed IN the stream that will use it: a hipMemset on the null stream is not ordered against a non-blocking
+        // stream (the first frame on a new scratch would, now and then, have met counters that were not zero yet)
+        HIP_TRY(hipMemsetAsync(sc->ctl, 0, ctl_bytes, st));
         s->n_scratch++;
     }
     if (records > sc->records) {

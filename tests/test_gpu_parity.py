@@ -675,6 +675,19 @@ def test_frames_in_flight_on_one_handle_do_not_share_scratch(sb, oracle_mod, sce
             assert_frames_identical(b.cpu().numpy(), ref, f"flags {flags:#x}, stream {k}")
 
 
+def test_first_frame_on_a_fresh_handle(sb, oracle_mod, scenes):
+    # The very first render on a new handle meets freshly allocated scratch (queue fill counts, tile-queue heads): it must
+    # be zeroed in the stream that uses it.  (A hipMemset on the null stream is not ordered against the handle's
+    # non-blocking stream: now and then the first frame met counters that were not zero yet and lost hit pixels.)
+    od = scenes["torus_d6"]
+    cam = make_camera("closeup", 256, 192)
+    ref, _ = oracle_mod.render(od.Structs, od.Values, cam.State, 256, 192, nthreads=8)
+    for rep in range(30):
+        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.FLAG_COUNT):
+            with sb.Scene(od) as sc:
+                assert_frames_identical(sc.Draw(cam, 256, 192, flags), ref, f"first frame, flags {flags:#x}, handle {rep}")
+
+
 # ---- BASELINE.json full sizes: size-independent properties + sampled oracle rows ----
 @pytest.fixture(scope="module")
 def dragon(sb):
