@@ -45,7 +45,15 @@ constexpr int MAX_BAND_LIST = 512;   // bands one launch can be handed as an exp
 
 struct TopCell { uint32_t level, v0, v1; int32_t children; };   // a cell of the top grid, see below (cursor-stack kernels)
 // the grid as find() sees it: dense cells of level `level`; for a split grid, blocks of 8^fine_bits finer cells
-struct GridRef { const TopCell *top; const TopCell *fine; int level; int fine_bits; };
+// fine_order 1: within a block the cells are stored 2x2x2 sub-cube by sub-cube (the 8 cells of a sub-cube share a 128-byte
+// line), not in x-y-z order: for the kernels whose every lookup is a cache miss (fine_cell_index)
+struct GridRef { const TopCell *top; const TopCell *fine; int level; int fine_bits; int fine_order; };
+__host__ __device__ __forceinline__ uint32_t fine_cell_index(uint32_t x, uint32_t y, uint32_t z, int FB, int order)
+{
+    if (order == 0) return x | (y << FB) | (z << (2 * FB));
+    const int H = FB - 1;                                  // sub-cube coordinates have FB - 1 bits
+    return ((((x >> 1) | ((y >> 1) << H) | ((z >> 1) << (2 * H))) << 3) | (x & 1u) | ((y & 1u) << 1) | ((z & 1u) << 2));
+}
 
 // Kernel parameters: scene, frame geometry, and the camera block of every frame of the launch.
 struct RenderParams {
@@ -56,6 +64,7 @@ struct RenderParams {
     // split grid (CUR_STACK_SPLIT kernels): a cell of `top` whose node is internal has level 15 and names,
     // in `children`, a block of `fine`: the 8^fine_bits cells of the next fine_bits levels below it
     int32_t fine_bits;
+    int32_t fine_order;        // see GridRef
     const TopCell *fine;
     float4 *out;               // compact rows: nrows_out x width
     uint32_t width, height;    // full frame
@@ -482,7 +491,7 @@ __device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT> &c, const GridRe
             c.loads++;
             const int FB = g.fine_bits, sh2 = sh - FB;
             const uint32_t m = (1u << FB) - 1u;
-            const uint32_t local = (((uint32_t)Dx >> sh2) & m) | ((((uint32_t)Dy >> sh2) & m) << FB) | ((((uint32_t)Dz >> sh2) & m) << (2 * FB));
+            const uint32_t local = fine_cell_index(((uint32_t)Dx >> sh2) & m, ((uint32_t)Dy >> sh2) & m, ((uint32_t)Dz >> sh2) & m, FB, g.fine_order);
             e = reinterpret_cast<const uint4 *>(g.fine)[((size_t)e.w << (3 * FB)) + local];
         }
     }

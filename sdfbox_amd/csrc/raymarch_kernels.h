@@ -238,7 +238,7 @@ __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const Fram
 {
     typename CursorT::Pos u;
     // top: the top grid somewhere else than P.top (the workgroup's LDS copy, k_plain<..., LDSTOP>)
-    uint32_t reads = find(c, P.nodes, GridRef{top ? top : P.top, P.fine, P.top_level, P.fine_bits}, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
+    uint32_t reads = find(c, P.nodes, GridRef{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order}, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
     r.prox = sample_after_find(c, u, r.px, r.py, r.pz);
     float step = r.phase ? r.prox + I.margin : r.prox;
     r.px = __builtin_fmaf(r.dx, step, r.px);
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
             }
             // ---- one march step of the segment or of the shadow ray -----------------------
             typename CursorT::Pos u;
-            uint32_t reads = find(c, P.nodes, GridRef{P.top, P.fine, P.top_level, P.fine_bits}, P.n_nodes, stack, 64, mx, my, mz, u);
+            uint32_t reads = find(c, P.nodes, GridRef{P.top, P.fine, P.top_level, P.fine_bits, P.fine_order}, P.n_nodes, stack, 64, mx, my, mz, u);
             prox = sample_after_find(c, u, mx, my, mz);
             if (COUNT) { cn += reads; cs += 1; }
             const float st = shadow ? prox + margin : prox;

@@ -72,13 +72,14 @@ __global__ void k_top_grid(const NodeRec *__restrict__ nodes, TopCell *__restric
 // The fine half of a split grid: block b holds the 8^FB cells below the internal node block_node[b] of level TG,
 // each the leaf that contains it (LM - level, values), in x-y-z order.
 __global__ void k_fine_blocks(const NodeRec *__restrict__ nodes, const uint32_t *__restrict__ block_node,
-                              TopCell *__restrict__ fine, uint32_t n_blocks, int TG, int FB)
+                              TopCell *__restrict__ fine, uint32_t n_blocks, int TG, int FB, int order)
 {
     const size_t total = (size_t)n_blocks << (3 * FB);
     const uint32_t mask = (1u << FB) - 1u;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t b = (uint32_t)(i >> (3 * FB)), local = (uint32_t)i & ((1u << (3 * FB)) - 1u);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)(j >> (3 * FB)), local = (uint32_t)j & ((1u << (3 * FB)) - 1u);
         const uint32_t cx = local & mask, cy = (local >> FB) & mask, cz = local >> (2 * FB);
+        const size_t i = ((size_t)b << (3 * FB)) + fine_cell_index(cx, cy, cz, FB, order);    // where the cell is stored
         NodeRec r = nodes[block_node[b]];
         uint32_t level = (uint32_t)TG, down = 0;
         while (down < (uint32_t)FB && (int32_t)r.y >= 0) {
@@ -280,7 +281,7 @@ struct sdfhip_scene {
     // that stays near the surface stays inside one block of fine cells).  Same cells, same cursor; built on the first
     // path-traced render.
     TopCell *d_top2, *d_fine2;
-    int top2_level, fine2_bits, scatter_tried;
+    int top2_level, fine2_bits, fine2_order, scatter_tried;
     uint64_t top2_bytes;
     size_t total_mem;
     unsigned long long *d_counters;  // 6 x u64: nodes, samples, steps, shadow rays, loads, hits
@@ -368,7 +369,7 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
 
 // A split grid over the scene's records: dense cells of level C whose internal cells (level word 15) name, in `children`,
 // a block of 8^FB fine cells; built on s->stream.  false (nothing allocated) when memory or the byte limit say no.
-static bool build_split_grid(sdfhip_scene *s, int C, int FB, uint64_t max_fine_bytes, TopCell **coarse_out, TopCell **fine_out,
+static bool build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_t max_fine_bytes, TopCell **coarse_out, TopCell **fine_out,
                              uint64_t *fine_bytes_out)
 {
     const size_t ncell = (size_t)1 << (3 * C);
@@ -400,7 +401,7 @@ static bool build_split_grid(sdfhip_scene *s, int C, int FB, uint64_t max_fine_b
             const size_t nfine = nblocks << (3 * FB);
             const uint32_t fb = (uint32_t)((nfine + 255) / 256 < 16384 ? (nfine + 255) / 256 : 16384);
             hipLaunchKernelGGL(k_fine_blocks, dim3(fb), dim3(256), 0, s->stream, s->nodes, d_block_node, d_fine,
-                               (uint32_t)nblocks, C, FB);
+                               (uint32_t)nblocks, C, FB, order);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) break;
         }
         *coarse_out = d_coarse; d_coarse = nullptr;
@@ -442,7 +443,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     s->device = device; s->n = n; s->depth = depth;
     s->stack_ok = (consistent && depth <= (uint32_t)MAX_STACK) ? 1 : 0;
     s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0;
-    s->d_top2 = s->d_fine2 = nullptr; s->top2_level = s->fine2_bits = s->scatter_tried = 0; s->top2_bytes = 0; s->total_mem = prop.totalGlobalMem;
+    s->d_top2 = s->d_fine2 = nullptr; s->top2_level = s->fine2_bits = s->fine2_order = s->scatter_tried = 0; s->top2_bytes = 0; s->total_mem = prop.totalGlobalMem;
     s->n_scratch = 0; s->d_frame = nullptr; s->dbg_tile_perm = nullptr; s->dbg_tile_cost = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
     s->cu_count = prop.multiProcessorCount;
 
@@ -509,7 +510,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if (s->stack_ok && split > 0) {
         TopCell *coarse = nullptr, *fine = nullptr;
         uint64_t fbytes = 0;
-        if (build_split_grid(s, split, (int)depth - split, prop.totalGlobalMem / 16, &coarse, &fine, &fbytes)) {
+        if (build_split_grid(s, split, (int)depth - split, 0, prop.totalGlobalMem / 16, &coarse, &fine, &fbytes)) {
             s->d_top = coarse; s->d_fine = fine;
             s->top_level = split; s->fine_bits = (int)depth - split; s->fine_bytes = fbytes;
             split_built = true;
@@ -620,7 +621,7 @@ int launch_pt(sdfhip_scene *s, sdfhip_scene::Scratch *sc, dim3 grid, hipStream_t
         if (CUR == CUR_STACK_FULL && s->d_top2) {
             // incoherent rays: the same cells through the split grid (the cursor does not depend on the grid it was filled from)
             RenderParams P2 = P;
-            P2.top = s->d_top2; P2.top_level = s->top2_level; P2.fine = s->d_fine2; P2.fine_bits = s->fine2_bits;
+            P2.top = s->d_top2; P2.top_level = s->top2_level; P2.fine = s->d_fine2; P2.fine_bits = s->fine2_bits; P2.fine_order = s->fine2_order;
             hipLaunchKernelGGL((k_pt_bounce<CUR_STACK_SPLIT, COUNT>), dim3(resident), dim3(64), 0, st, P2);
         } else {
             hipLaunchKernelGGL((k_pt_bounce<CUR, COUNT>), dim3(resident), dim3(64), 0, st, P);
@@ -690,7 +691,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
 
     RenderParams P;
-    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level; P.fine = s->d_fine; P.fine_bits = s->fine_bits;
+    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level; P.fine = s->d_fine; P.fine_bits = s->fine_bits; P.fine_order = 0;
     P.out = reinterpret_cast<float4 *>(d_out);
     P.width = width; P.height = height;
     P.band_rows = band_rows; P.band_first = band_first; P.band_stride = band_stride;
@@ -814,7 +815,8 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
             const int FB = env ? atoi(env) : 3;                                     // blocks of 8^FB fine cells; 0 = off
             if (FB >= 1 && FB <= 4 && (int)s->depth - FB >= 1 && (int)s->depth - FB <= MAX_TOP_LEVEL) {
                 uint64_t fbytes = 0;
-                if (build_split_grid(s, (int)s->depth - FB, FB, s->total_mem / 32, &s->d_top2, &s->d_fine2, &fbytes)) {
+                s->fine2_order = (FB >= 2 && !(getenv("SDFHIP_SCATTER_ORDER") && atoi(getenv("SDFHIP_SCATTER_ORDER")) == 0)) ? 1 : 0;
+                if (build_split_grid(s, (int)s->depth - FB, FB, s->fine2_order, s->total_mem / 32, &s->d_top2, &s->d_fine2, &fbytes)) {
                     s->top2_level = (int)s->depth - FB; s->fine2_bits = FB;
                     s->top2_bytes = ((uint64_t)sizeof(TopCell) << (3 * s->top2_level)) + fbytes;
                 }
