@@ -474,6 +474,8 @@ def main():
         copy_gbs = measured_copy_bandwidth()           # the box's own figure beside the nameplate
         mode = "spp%d" % args.spp if pt is not None else "display" if args.display else "compact" if compact else \
                "one-kernel" if args.one_kernel else "default"
+        if sharded:
+            mode += ":sharded"                         # other kernels instances (wire pixels, bands): no PMC pass of its own
         pmc = load_pmc(f"{W}x{H}:{scene_name}:{mode}") if world == 1 else None
         roof = roofline(sec_per_step, own_bytes_rank, ref_bytes_rank, pmc, copy_gbs)
         roof.update({"kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch})
