@@ -500,7 +500,8 @@ def main():
                             (f", moving 1 degree per frame round the scene ({len(cams)} cameras)" if args.orbit > 0 else ""),
                 "kernel": ("path/" if pt is not None else "") +
                           ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else "") +
-                          ("" if (pt is not None or compact) else ", one kernel" if args.one_kernel else ", k_march -> k_shade where the scene has a full grid"),
+                          ("" if (pt is not None or compact) else ", one kernel" if args.one_kernel else
+                           ", k_march -> hit queue (wavefront ballot + prefix compaction of the rays that reached the surface) -> k_shade"),
                 "top_grid": {"level": scene.top_grid_level, "bytes": scene.top_grid_bytes},
                 "parallelism": "1 GPU" if not sharded else
                                f"{world} GPU(s), {args.band_rows}-row bands " +
