@@ -478,7 +478,11 @@ def main():
             mode += ":sharded"                         # other kernels instances (wire pixels, bands): no PMC pass of its own
         pmc = load_pmc(f"{W}x{H}:{scene_name}:{mode}") if world == 1 else None
         roof = roofline(sec_per_step, own_bytes_rank, ref_bytes_rank, pmc, copy_gbs)
-        roof.update({"kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch})
+        # what the fraction divides by, so that it can be recomputed from profiles/: per_frame / time_ms / peak.  kernel_ms is
+        # the HIP-event time around one frame's launches on their stream (k_march + k_shade; overlapping the other frame in
+        # flight), and frac_over_kernel_ms the same fraction over that longer time
+        roof.update({"time_ms": round(sec_per_step * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch,
+                     "frac_over_kernel_ms": round(roof["frac"] * sec_per_step * 1e3 * frames_per_launch / kernel_ms, 4) if kernel_ms > 0 else None})
         out = {
             "metric": "Mray/s (primary rays; frame W*H / time per frame)",
             "value": round(W * H * max(1, args.spp) / sec_per_step / 1e6, 2),
