@@ -543,36 +543,40 @@ __device__ __forceinline__ uint32_t find_full(CursorFT<EXACT, SPLIT> &c, const G
     }
     return reads;
 }
-// floor(u) as an integer in one instruction.  A float-to-int cast of NaN or of a value outside the
-// int range is undefined in C++; v_cvt_flr_i32_f32 is not: it saturates, and NaN gives 0.
+// floor(u) as an integer in one instruction.  A float-to-int cast of NaN or of a value outside the int range is
+// undefined in C++; v_cvt_flr_i32_f32 is not: it saturates, and NaN gives INT_MAX (scripts/micro/cvt_check.hip).
 __device__ __forceinline__ int32_t cvt_floor(float u)
 {
     int32_t a;
     asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(a) : "v"(u));
     return a;
 }
-// The kernels that do not count: cell coordinates straight from the saturating conversion (far
-// outside the cube: INT_MIN / INT_MAX, NaN: 0) and clamped into the cube BEFORE the "still in my
-// cell?" test -- outside the cube the shader's descent clamps to the boundary leaf at every step
-// (saturate, Compute.hlsl:100), so "the clamped coordinates are still in my cell" selects the cell
-// the shader ends in, and the root mark (bit 30) differs from every clamped coordinate.
+// The kernels that do not count: the cell coordinates are clamped into the cube BEFORE the "still in my cell?"
+// test -- outside the cube the shader's descent clamps to the boundary leaf at every step (saturate,
+// Compute.hlsl:100), so "the clamped coordinates are still in my cell" selects the cell the shader ends in, and the
+// root mark (bit 30) differs from every clamped coordinate.  The clamp is a float v_med3 in front of the conversion:
+// it returns the smaller bound when its first operand is NaN, so a NaN coordinate selects cell 0 on that axis, as the
+// shader does (every comparison with NaN is false: up to the root; saturate(NaN) = 0: down along the low cells).
 template <bool SPLIT>
 __device__ __forceinline__ uint32_t find(CursorFT<false, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
                                          uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
                                          Scaled &u)
 {
     u.x = px * 4096.0f; u.y = py * 4096.0f; u.z = pz * 4096.0f;
-    const int32_t Ax = cvt_floor(u.x), Ay = cvt_floor(u.y), Az = cvt_floor(u.z);
     // on the 2^-LM grid on some axis <=> a fractional part is zero (NaN: never; the three are >= 0)
     const float fx = __builtin_amdgcn_fractf(u.x), fy = __builtin_amdgcn_fractf(u.y), fz = __builtin_amdgcn_fractf(u.z);
     const float fm = __builtin_fminf(__builtin_fminf(fx, fy), fz);
     if (__ballot(fm == 0.0f) == 0ull) {
-        const int32_t Dx = min(max(Ax, 0), 4095), Dy = min(max(Ay, 0), 4095), Dz = min(max(Az, 0), 4095);
+        const int32_t Dx = cvt_floor(__builtin_amdgcn_fmed3f(u.x, 0.0f, 4095.0f)), Dy = cvt_floor(__builtin_amdgcn_fmed3f(u.y, 0.0f, 4095.0f)),
+                      Dz = cvt_floor(__builtin_amdgcn_fmed3f(u.z, 0.0f, 4095.0f));
         const uint32_t diff = (uint32_t)(c.ax ^ Dx) | (uint32_t)(c.ay ^ Dy) | (uint32_t)(c.az ^ Dz);
         if ((diff >> (c.s & 31u)) != 0u) load_cell(c, g, Dx, Dy, Dz);
         return 0;
     }
-    return find_full(c, g, Ax, Ay, Az, fx == 0.0f, fy == 0.0f, fz == 0.0f, true);
+    // some lane sits on a cell face: the exact rule for the whole wave (coordinates as the counting kernels take them)
+    float tx, ty, tz, qx, qy, qz;
+    const int32_t Ax = axis_a(px, tx, qx), Ay = axis_a(py, ty, qy), Az = axis_a(pz, tz, qz);
+    return find_full(c, g, Ax, Ay, Az, tx == qx, ty == qy, tz == qz, true);
 }
 // The counting kernels: NaN must match no cell (ascents up to the root count as reads), see axis_a.
 template <bool SPLIT>

@@ -779,8 +779,38 @@ def _random_tree(rng, max_depth, p_split, max_nodes=60000):
     return s, v
 
 
+def test_nan_coordinates_select_the_low_cells(sb, oracle_mod):
+    # A NaN coordinate fails every comparison of inside() (up to the root) and saturates to 0 in the descent
+    # (Compute.hlsl:93-106): the shader lands in the cell at the LOW end of that axis.  On a tree whose corners hold
+    # different values the two ends give different distances -- v_cvt_flr_i32_f32 turns NaN into INT_MAX, which a
+    # clamp would send to the HIGH end (found by the fuzz campaign, seed 26, through NaN bounce directions).
+    rng = np.random.default_rng(77)
+    s, v = _random_tree(rng, 5, p_split=0.75)
+    v = rng.integers(0, 256, size=v.shape, dtype=np.uint8)
+    od = sb.OctData(s, v)
+    W, H = 48, 40
+    cams = []
+    for axes in ((0,), (1,), (2,), (0, 2), (0, 1, 2)):
+        c = sb.Logic(W, H); c.Position = (0.3, 0.6, -0.2); c.Heading = (0.2, 0.4)
+        for a in axes:
+            c.State.position[a] = float("nan")
+        cams.append(c)
+    c = sb.Logic(W, H); c.Position = (0.4, 0.5, 0.3); c.State.heading[0][0] = float("nan"); cams.append(c)      # NaN ray directions
+    with sb.Scene(od) as sc:
+        for ci, cam in enumerate(cams):
+            ref, cnt = oracle_mod.render(s, v, cam.State, W, H, nthreads=4)
+            for variant in ALL_VARIANTS:
+                img, st = sc.Draw(cam, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
+                assert_frames_identical(img, ref, f"NaN camera {ci} {variant}")
+                assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(x) for x in cnt), (ci, variant)
+                assert_frames_identical(sc.Draw(cam, W, H, flags_of(sb, variant)), ref, f"NaN camera {ci} {variant}, not counting")
+            pref, _ = oracle_mod.render_pt(s, v, cam.State, W, H, spp=2, nthreads=4)
+            for fl in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL, sb.KERNEL_GENERIC):
+                assert_frames_identical(sc.DrawPath(cam, W, H, pt=sb.PathTrace(spp=2), flags=fl), pref, f"NaN camera {ci} path-traced {fl:#x}")
+
+
 # SDFHIP_FUZZ_SEEDS=n runs n seeds instead of 6 (a one-off campaign; the committed default stays small)
-@pytest.mark.parametrize("seed", range(int(os.environ.get("SDFHIP_FUZZ_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", sorted(set(range(int(os.environ.get("SDFHIP_FUZZ_SEEDS", "6")))) | {26}))
 def test_fuzz_random_trees_and_on_grid_cameras(sb, oracle_mod, seed):
     rng = np.random.default_rng(1000 + seed)
     depth = [3, 5, 7, 9, 11, 12][seed % 6]
