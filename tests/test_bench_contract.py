@@ -72,6 +72,45 @@ def test_cfg4_frame_two_ranks_moving_camera_and_dense_resend():
     assert j["config"]["sparse_shares_resent_dense"] > 0
 
 
+def test_roofline_reports_only_measured_fractions():
+    # bench.py's roofline(): with a PMC entry of this build the fraction is the larger of two measured quantities against
+    # hard ceilings (HBM counter bytes against 8 TB/s, issued VALU instructions against the cheapest instruction's rate);
+    # without one, only the kernel's algorithmic demand is left, flagged as not bounded by a ceiling
+    sys.path.insert(0, REPO)
+    import bench
+    pmc = {"hbm_bytes_per_frame": 580_000_000, "valu_insts_per_frame": 68_000_000, "profile": "profiles/x.json", "kernel_source_sha": "abc"}
+    r = bench.roofline(0.1232e-3, 904e6, 3.92e9, pmc, 5500.0)
+    assert r["binding"] == "hbm-traffic" and r["bound"] == "hbm" and r["traffic"] == 580_000_000
+    assert abs(r["frac"] - 580e6 / 0.1232e-3 / 1e9 / 8000.0) < 1e-3 and r["frac"] <= 1.0 and r["frac_is_measured_against_a_ceiling"]
+    assert abs(r["candidates"]["valu"]["frac"] - 68e6 / 0.1232e-3 / 1e9 / bench.VALU_PEAK_GINSTR) < 1e-3
+    assert "hbm-algorithmic" not in r["candidates"] and r["algorithmic"]["own_bytes_per_frame"] == 904_000_000
+    r4k = bench.roofline(0.388e-3, 3.62e9, 15.7e9, {"hbm_bytes_per_frame": 1_178_000_000, "valu_insts_per_frame": 259_000_000}, None)
+    assert r4k["binding"] == "valu" and r4k["bound"] == "valu" and r4k["frac"] <= 1.0
+    none = bench.roofline(0.388e-3, 3.62e9, 15.7e9, None, None)      # the demand of 64 lanes asking for the same cells is not an HBM figure
+    assert none["binding"] == "hbm-algorithmic" and none["traffic"] is None and not none["frac_is_measured_against_a_ceiling"]
+    # PMC figures are reported only for the build they were measured on
+    assert bench.load_pmc("no such workload") is None
+    import json as _json
+    with open(os.path.join(REPO, "profiles", "hbm_traffic.json")) as f:
+        t = _json.load(f)
+    for key, e in t.items():
+        assert set(e) >= {"hbm_bytes_per_frame", "valu_insts_per_frame", "profile", "kernel_source_sha"}, key
+        assert os.path.exists(os.path.join(REPO, e["profile"])), key
+
+
+def test_orbit_cameras_walk_round_the_scene():
+    sys.path.insert(0, REPO)
+    import bench
+    import sdfbox_amd as sb
+    cams = bench.orbit_cameras(sb, 640, 360, 90)
+    assert len(cams) == 90
+    p0 = list(cams[0].State.position)
+    assert [round(v, 6) for v in p0] == [0.5, 0.5, -0.35]          # camera 0 is the cfg-2 camera
+    for c in cams:                                                  # all on the circle of radius 0.85 about the cube centre, at its height
+        x, y, z = c.State.position
+        assert abs(((x - 0.5) ** 2 + (z - 0.5) ** 2) ** 0.5 - 0.85) < 1e-5 and abs(y - 0.5) < 1e-6
+
+
 def test_bench_refuses_to_run_without_a_gpu():
     import torch
     if torch.cuda.is_available():
