@@ -369,9 +369,9 @@ def main():
     # the bytes the REFERENCE algorithm reads and writes for these pixels (Compute.hlsl:88-108: entry +
     # ascents + descents, 8 B of topology each; 8 B of values per sample; the pixel store)
     ref_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + wpx_bytes * my_pixels
-    # the bytes THIS kernel's own algorithm moves: 16 B per grid cell / node record a lane loads, 48 B written and
-    # 48 B read per hit pixel queued between the two kernels, the pixel store
-    own_bytes_rank = 16 * st.n_loads + 96 * st.n_hits + wpx_bytes * my_pixels
+    # the bytes THIS kernel's own algorithm moves: 16 B per grid cell / node record a lane loads, 64 B written and
+    # 64 B read per shadow ray queued between the two kernels, the pixel store
+    own_bytes_rank = 16 * st.n_loads + 128 * st.n_hits + wpx_bytes * my_pixels
     counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays, st.n_loads, st.n_hits], dtype=torch.float64)
     kernel_used = st.kernel_used
 
@@ -505,7 +505,7 @@ def main():
                 "kernel": ("path/" if pt is not None else "") +
                           ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else "") +
                           ("" if (pt is not None or compact) else ", one kernel" if args.one_kernel else
-                           ", k_march -> hit queue (wavefront ballot + prefix compaction of the rays that reached the surface) -> k_shade"),
+                           ", k_march (primary march, shading) -> queue (wavefront ballot + prefix compaction of the shadow rays) -> k_shadow"),
                 "top_grid": {"level": scene.top_grid_level, "bytes": scene.top_grid_bytes},
                 "parallelism": "1 GPU" if not sharded else
                                f"{world} GPU(s), {args.band_rows}-row bands " +
@@ -678,7 +678,7 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
     Both are measured quantities against a hard ceiling, so frac <= 1; `frac` is the larger -- the binding roof -- and
     `bound` names it.  They need a PMC pass of this build and workload (profiles/hbm_traffic.json); without one the only
     figure left is `algorithmic`: the bytes this kernel's own algorithm asks for per frame (16 B per grid cell / node
-    record a LANE loads, 96 B per queued hit, the pixel store; counted by the counting build) -- a demand on the memory
+    record a LANE loads, 128 B per queued shadow ray, the pixel store; counted by the counting build) -- a demand on the memory
     system, not on HBM: the lanes of a wave mostly ask for the same few cells, which L1 serves once, so it is not
     bounded by 8 TB/s (at 4K it reads 9 TB/s).  The reference algorithm's bytes (8 B per node visit of
     find(), Compute.hlsl:88-108) are the work-equivalent rate: the kernel does not perform those loads (one grid lookup

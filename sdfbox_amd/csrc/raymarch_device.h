@@ -100,6 +100,7 @@ struct RenderParams {
     float4 *hit_a;
     int4 *hit_b;
     uint4 *hit_c;
+    float4 *hit_d;                 // direction to the light, Lambert term
     uint32_t *hit_ctl;
     uint32_t hit_cap, hit_set;
     // path-traced mode as a pipeline of kernels (k_pt_primary -> k_pt_bounce x (bounces + 1) -> k_pt_resolve):

@@ -353,17 +353,18 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
 //             After the loop the wave is converged again: sky pixels store their colour (coalesced),
 //             and the lanes that ended on the surface append their state -- position, prox, step
 //             count, cursor -- to a queue: ballot + mbcnt give the slots, one atomic per wave.
-//   k_shade   one lane per queued hit, 64 consecutive records per wave: the shading step of
-//             Compute.hlsl:205-213 for all 64 lanes at once, then the shadow march :214-230 as its own
-//             tight loop, then the pixel's colour.
+//             (In the same converged epilogue the hit lanes take the shading step of Compute.hlsl:205-213 together; a
+//             pixel that faces away from the light is finished there, black, and only the others are queued.)
+//   k_shadow  one lane per queued shadow ray, 64 consecutive records per wave, every lane live from the first
+//             step: the shadow march of Compute.hlsl:214-230 as its own tight loop, then the pixel's colour.
 //
 // Why: in the one-kernel form (k_plain) the ~200 instructions of the shading step run whenever ANY
 // lane of a wave finishes its primary march -- for three or four lanes at a time, about 130 000 times
 // per 1080p frame, a quarter of all VALU instructions issued -- and every iteration pays the phase
-// dispatch of a lane state machine.  Here shading runs once per 64 hits with every lane on, and both
-// loops carry only their own exits.  Per-pixel arithmetic, its order and the cursor a pixel carries
+// dispatch of a lane state machine.  Here shading runs once per wave, after its march loop, for all its hit
+// lanes together, the shadow rays march 64 to a wave, and both loops carry only their own exits.  Per-pixel arithmetic, its order and the cursor a pixel carries
 // from the primary into the shadow march are unchanged: images and counters stay bit-identical.
-// The records cost 48 bytes per hit pixel written and read once (20 MB per 1080p bench frame).
+// The records cost 64 bytes per shadow ray written and read once (17 MB per 1080p bench frame).
 // =====================================================================================
 enum { OUT_RGBA32F = 0, OUT_GAMMA8 = 1, OUT_HEAT8 = 2, OUT_WIRE = 3 };
 
@@ -477,27 +478,53 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
         dst.sky(lidx, (float)r.n);
         if (COUNT) ct = (unsigned long long)r.n;
     }
-    const unsigned long long hits = __ballot(end == 1);
+    // The shading step (Compute.hlsl:205-213) for the lanes that ended on the surface -- all of them at once, after the
+    // loop, not whenever one of them gets there: a pixel that faces away from the light is finished (black); the others
+    // go to the queue of shadow rays with what the shadow march needs.
+    bool shadow = false;
+    if (__ballot(end == 1)) {
+        if (end == 1) {
+            float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;
+            const float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+            r.dx = lx * rl; r.dy = ly * rl; r.dz = lz * rl;
+            r.px = __builtin_fmaf(r.dx, I.margin, r.px);
+            r.py = __builtin_fmaf(r.dy, I.margin, r.py);
+            r.pz = __builtin_fmaf(r.dz, I.margin, r.pz);
+            float gx, gy, gz;
+            gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
+            const float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
+            r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
+            if (r.angle < 0.0f) {
+                const PixelSink<MODE> dst(P, f);
+                dst.black(lidx, (float)r.n);
+                if (COUNT) ct = (unsigned long long)r.n;
+            } else {
+                shadow = true;
+            }
+        }
+    }
+    const unsigned long long hits = __ballot(shadow);
     if (hits) {
         const uint32_t q = blockIdx.x & (HIT_QUEUES - 1u);
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(hit_count(P, P.hit_set, f, q), (uint32_t)__popcll(hits));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
-        if (end == 1 && base + rank < P.hit_cap) {     // always true while the fill counts start at zero (k_shade leaves them so)
+        if (shadow && base + rank < P.hit_cap) {       // always true while the fill counts start at zero (k_shadow leaves them so)
             const size_t slot = ((size_t)f * HIT_QUEUES + q) * P.hit_cap + base + rank;
             P.hit_a[slot] = make_float4(r.px, r.py, r.pz, r.prox);
             P.hit_b[slot] = make_int4(c.ax, c.ay, c.az, (int)c.s);
             P.hit_c[slot] = make_uint4((uint32_t)lidx, (uint32_t)r.n, c.v0, c.v1);
+            P.hit_d[slot] = make_float4(r.dx, r.dy, r.dz, r.angle);
         }
     }
-    if (COUNT) flush_counters(P, cn, cs, ct, 0, c.loads, end == 1 ? 1u : 0u);
+    if (COUNT) flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, shadow ? 1u : 0u);
 }
 
-// One lane per hit record; a wave takes 64 consecutive records of one queue at a time (chunks are
+// One lane per queued shadow ray; a wave takes 64 consecutive records of one queue at a time (chunks are
 // numbered over the frame's queues: a wave-wide scan of the 64 fill counts, once per wave).
 template <int CUR, bool COUNT, int MODE>
-__global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shade(RenderParams P)
+__global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shadow(RenderParams P)
 {
     typedef typename CursorOf<CUR, COUNT>::type CursorT;
     const uint32_t f = blockIdx.y, lane = threadIdx.x;
@@ -512,7 +539,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shade(RenderParams
     uint32_t incl = chunks;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    unsigned long long cn = 0, cs = 0, ct = 0, cr = 0, cl = 0;
+    unsigned long long cn = 0, cs = 0, ct = 0, cl = 0;
     for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
         // queue of chunk t = the number of queues whose inclusive sum is <= t
         const uint32_t q = (uint32_t)__popcll(__ballot(incl <= t));
@@ -521,56 +548,38 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shade(RenderParams
         const uint32_t i = (t - (q_incl - q_chunks)) * 64u + lane;
         if (i < q_fill) {
             const size_t slot = ((size_t)f * HIT_QUEUES + q) * P.hit_cap + i;
-            const float4 a = P.hit_a[slot];
+            const float4 a = P.hit_a[slot], d = P.hit_d[slot];
             const int4 b = P.hit_b[slot];
             const uint4 e = P.hit_c[slot];
             RayState r;
             CursorT c;
-            r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w;
-            r.n = (int)e.y; r.base = 0; r.phase = PH_PRIMARY;
+            r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w; r.dx = d.x; r.dy = d.y; r.dz = d.z; r.angle = d.w;
+            r.base = (int)e.y; r.n = 0; r.phase = PH_SHADOW;          // i stays, j starts
             c.ax = b.x; c.ay = b.y; c.az = b.z; c.s = (uint32_t)b.w; c.v0 = e.z; c.v1 = e.w; c.loads = 0;
             const size_t lidx = e.x;
-            // Compute.hlsl:205-213
-            float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;
-            float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
-            r.dx = lx * rl; r.dy = ly * rl; r.dz = lz * rl;
-            r.px = __builtin_fmaf(r.dx, I.margin, r.px);
-            r.py = __builtin_fmaf(r.dy, I.margin, r.py);
-            r.pz = __builtin_fmaf(r.dz, I.margin, r.pz);
-            float gx, gy, gz;
-            gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
-            const float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
-            r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
-            if (r.angle < 0.0f) {
-                dst.black(lidx, (float)r.n);
-                if (COUNT) ct += (unsigned long long)r.n;
-            } else {
-                lx = I.lightx - r.px; ly = I.lighty - r.py; lz = I.lightz - r.pz;
-                r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
-                r.phase = PH_SHADOW;
-                r.base = r.n;                 // i stays, j starts
-                r.n = 0;
-                if (COUNT) cr += 1;
-                // Compute.hlsl:214-230: every exit is black (:223, :229) except the one that reaches the light (:215-219)
-                bool lit = false;
-                while (r.n < 40 && r.prox > -I.margin) {
-                    if (r.prox > r.dist || (r.px < 0.0f || r.py < 0.0f || r.pz < 0.0f) ||
-                        (r.px > 1.0f || r.py > 1.0f || r.pz > 1.0f)) { lit = true; break; }
-                    if (r.prox < I.margin) {
-                        gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
-                        if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) break;
-                    }
-                    uint32_t reads = march_step(P, I, r, c, nullptr, 0);
-                    if (COUNT) { cn += reads; cs += 1; }
+            const float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;      // Compute.hlsl:212
+            r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+            // Compute.hlsl:214-230: every exit is black (:223, :229) except the one that reaches the light (:215-219)
+            bool lit = false;
+            while (r.n < 40 && r.prox > -I.margin) {
+                // any(pos < 0) || any(pos > 1) as min3 / max3: v_min3_f32 and v_max3_f32 skip NaN operands, and a
+                // comparison with NaN is false either way, so the two forms agree for every input
+                const float lo = __builtin_fminf(__builtin_fminf(r.px, r.py), r.pz), hi = __builtin_fmaxf(__builtin_fmaxf(r.px, r.py), r.pz);
+                if (r.prox > r.dist || lo < 0.0f || hi > 1.0f) { lit = true; break; }
+                if (r.prox < I.margin) {
+                    float gx, gy, gz;
+                    gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
+                    if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) break;
                 }
-                if (lit) dst.grey(lidx, r.angle / (r.dist * r.dist) * I.k_strength, (float)(r.base + r.n));
-                else dst.black(lidx, (float)(r.base + r.n));
-                if (COUNT) ct += (unsigned long long)(r.base + r.n);
+                uint32_t reads = march_step(P, I, r, c, nullptr, 0);
+                if (COUNT) { cn += reads; cs += 1; }
             }
-            if (COUNT) cl += c.loads;
+            if (lit) dst.grey(lidx, r.angle / (r.dist * r.dist) * I.k_strength, (float)(r.base + r.n));
+            else dst.black(lidx, (float)(r.base + r.n));
+            if (COUNT) { ct += (unsigned long long)(r.base + r.n); cl += c.loads; }
         }
     }
-    if (COUNT) flush_counters(P, cn, cs, ct, cr, cl);
+    if (COUNT) flush_counters(P, cn, cs, ct, 0, cl);
 }
 
 // ---- persistent waves with lane refill and state batching (wavefront ray compaction) --

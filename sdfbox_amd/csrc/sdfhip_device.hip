@@ -582,7 +582,7 @@ int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::S
     if (records > sc->records) {
         HIP_TRY(hipStreamSynchronize(st));
         if (sc->hit_buf) { (void)hipFree(sc->hit_buf); sc->hit_buf = nullptr; sc->records = 0; }
-        HIP_TRY(hipMalloc((void **)&sc->hit_buf, records * 48));
+        HIP_TRY(hipMalloc((void **)&sc->hit_buf, records * 64));
         sc->records = records;
     }
     *out = sc;
@@ -634,7 +634,7 @@ int launch_pt(sdfhip_scene *s, sdfhip_scene::Scratch *sc, dim3 grid, hipStream_t
     return SDFHIP_OK;
 }
 
-// k_march + k_shade for one cursor kind and counting choice, by output mode
+// k_march + k_shadow for one cursor kind and counting choice, by output mode
 template <int CUR, bool COUNT>
 void launch_two(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, const RenderParams &P)
 {
@@ -642,10 +642,10 @@ void launch_two(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, const
         hipLaunchKernelGGL(march, grid, dim3(64), 0, st, P);
         hipLaunchKernelGGL(shade, shade_grid, dim3(64), 0, st, P);
     };
-    if (mode == OUT_RGBA32F)     go(k_march<CUR, COUNT, OUT_RGBA32F>, k_shade<CUR, COUNT, OUT_RGBA32F>);
-    else if (mode == OUT_GAMMA8) go(k_march<CUR, COUNT, OUT_GAMMA8>, k_shade<CUR, COUNT, OUT_GAMMA8>);
-    else if (mode == OUT_HEAT8)  go(k_march<CUR, COUNT, OUT_HEAT8>, k_shade<CUR, COUNT, OUT_HEAT8>);
-    else                         go(k_march<CUR, COUNT, OUT_WIRE>, k_shade<CUR, COUNT, OUT_WIRE>);
+    if (mode == OUT_RGBA32F)     go(k_march<CUR, COUNT, OUT_RGBA32F>, k_shadow<CUR, COUNT, OUT_RGBA32F>);
+    else if (mode == OUT_GAMMA8) go(k_march<CUR, COUNT, OUT_GAMMA8>, k_shadow<CUR, COUNT, OUT_GAMMA8>);
+    else if (mode == OUT_HEAT8)  go(k_march<CUR, COUNT, OUT_HEAT8>, k_shadow<CUR, COUNT, OUT_HEAT8>);
+    else                         go(k_march<CUR, COUNT, OUT_WIRE>, k_shadow<CUR, COUNT, OUT_WIRE>);
 }
 
 template <int CUR, bool COUNT>
@@ -750,7 +750,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     // cursor kind: generic, cursor stack, or cursor stack with a top grid as deep as the tree
     const int cur = !use_stack ? CUR_GENERIC : (s->d_top && s->fine_bits) ? CUR_STACK_SPLIT :
                     (s->d_top && (uint32_t)s->top_level >= s->depth) ? CUR_STACK_FULL : CUR_STACK;
-    // the two-kernel pipeline (k_march -> k_shade) is the default wherever a find is a grid lookup
+    // the two-kernel pipeline (k_march -> k_shadow) is the default wherever a find is a grid lookup
     const bool two = (cur == CUR_STACK_FULL || cur == CUR_STACK_SPLIT) && !compact && !pt && bt == 64 &&
                      P.tile_order == 0 && !(flags & SDFHIP_TUNE_ONE_KERNEL);
 
@@ -762,7 +762,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         grid = dim3(P.tile_order == 0 ? 8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x : P.n_tiles, n_frames);
     }
     sdfhip_scene::Scratch *sc = nullptr;
-    P.queue = nullptr; P.hit_a = nullptr; P.hit_b = nullptr; P.hit_c = nullptr; P.hit_ctl = nullptr; P.hit_cap = 0; P.hit_set = 0;
+    P.queue = nullptr; P.hit_a = nullptr; P.hit_b = nullptr; P.hit_c = nullptr; P.hit_d = nullptr; P.hit_ctl = nullptr; P.hit_cap = 0; P.hit_set = 0;
     P.tile_perm = s->dbg_tile_perm; P.tile_cost = s->dbg_tile_cost;
     P.pt_q[0] = P.pt_q[1] = nullptr; P.pt_ctl = nullptr; P.pt_cap = 0; P.pt_level = 0; P.pt_e = nullptr; P.pt_t = nullptr; P.pt_n = nullptr;
     if (two) {
@@ -774,6 +774,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         P.hit_a = reinterpret_cast<float4 *>(sc->hit_buf);
         P.hit_b = reinterpret_cast<int4 *>(sc->hit_buf + sc->records * 16);
         P.hit_c = reinterpret_cast<uint4 *>(sc->hit_buf + sc->records * 32);
+        P.hit_d = reinterpret_cast<float4 *>(sc->hit_buf + sc->records * 48);
         P.hit_ctl = sc->ctl;
         P.hit_set = sc->launches++ & 1u;
         // every queued hit is shaded by a resident wave: at most one chunk of 64 per k_march workgroup
