@@ -68,7 +68,7 @@ def parse():
                          "the default line reports an orbit pass beside it in `latency`)")
     ap.add_argument("--one-kernel", action="store_true",
                     help="A/B: the one-kernel form (lane state machine, shading in place) instead of the default "
-                         "two-kernel pipeline k_march -> k_shade")
+                         "two-kernel pipeline k_march -> k_shadow")
     ap.add_argument("--check", action="store_true", help="verify the assembled frame against a whole-frame render")
     ap.add_argument("--rank0-weight", type=float, default=0.0,
                     help="sharded runs: rank 0's share of the frame as a fraction of a peer's share "
@@ -479,7 +479,7 @@ def main():
         pmc = load_pmc(f"{W}x{H}:{scene_name}:{mode}") if world == 1 else None
         roof = roofline(sec_per_step, own_bytes_rank, ref_bytes_rank, pmc, copy_gbs)
         # what the fraction divides by, so that it can be recomputed from profiles/: per_frame / time_ms / peak.  kernel_ms is
-        # the HIP-event time around one frame's launches on their stream (k_march + k_shade; overlapping the other frame in
+        # the HIP-event time around one frame's launches on their stream (k_march + k_shadow; overlapping the other frame in
         # flight), and frac_over_kernel_ms the same fraction over that longer time
         roof.update({"time_ms": round(sec_per_step * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch,
                      "frac_over_kernel_ms": round(roof["frac"] * sec_per_step * 1e3 * frames_per_launch / kernel_ms, 4) if kernel_ms > 0 else None})

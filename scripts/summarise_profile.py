@@ -1,5 +1,5 @@
 """gpurun_out/prof_<tag>/ -> profiles/<tag>_kernel_stats.csv and profiles/<tag>_pmc.json: per-launch means
-of every PMC counter for each ray-march kernel of the run (k_march, k_shade, k_plain, k_compact, k_path; the
+of every PMC counter for each ray-march kernel of the run (k_march, k_shadow, k_plain, k_compact, k_path; the
 one counting launch of a bench run is left out), the bench line of the stats pass, and the HBM traffic per
 frame that bench.py reports as roofline.traffic (profiles/hbm_traffic.json, keyed by workload, with the
 profile tag and the hash of the kernel sources it was measured on).
@@ -45,7 +45,7 @@ def main():
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if not k or not k.startswith(("k_march", "k_shade", "k_plain", "k_compact", "k_path", "k_pt_")):
+            if not k or not k.startswith(("k_march", "k_shade", "k_shadow", "k_plain", "k_compact", "k_path", "k_pt_")):
                 continue
             if re.search(r"<\d+, true", k) or k.endswith("<true>"):     # the one counting launch
                 continue
@@ -65,7 +65,7 @@ def main():
     rd = per_frame.get("FETCH_SIZE", 0.0) * 1024
     wr = per_frame.get("WRITE_SIZE", 0.0) * 1024
     if rd or wr:
-        # per frame = the frame's whole pipeline (k_march + k_shade; k_pt_primary + every k_pt_bounce level + k_pt_resolve; ...)
+        # per frame = the frame's whole pipeline (k_march + k_shadow; k_pt_primary + every k_pt_bounce level + k_pt_resolve; ...)
         fpl = float(bench["roofline"].get("frames_per_launch", 1.0)) if bench else 1.0
         out["hbm_read_bytes_raw_per_frame"] = rd / fpl
         out["hbm_read_bytes_x2_per_frame"] = 2 * rd / fpl

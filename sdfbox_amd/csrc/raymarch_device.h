@@ -93,8 +93,9 @@ struct RenderParams {
     // path-traced mode (k_path): samples per pixel, diffuse bounces, RNG seed, albedo
     uint32_t pt_spp, pt_bounces, pt_seed;
     float pt_albedo;
-    // two-kernel pipeline (k_march -> k_shade, raymarch_kernels.h): the pixels whose primary march ended on
-    // the surface, as records {position, prox | cursor | pixel, steps, values} in HIT_QUEUES queues per frame
+    // two-kernel pipeline (k_march -> k_shadow, raymarch_kernels.h): the pixels whose primary march ended on
+    // the surface facing the light, as records {position, prox | cursor | pixel, steps, values | direction to the
+    // light, Lambert term} in HIT_QUEUES queues per frame
     // of the launch: arrays [n_frames][HIT_QUEUES][hit_cap]; hit_ctl = two sets of [MAX_BATCH][HIT_QUEUES] fill
     // counts (a 128-byte line each); this launch pair uses set hit_set and leaves the other one zeroed
     float4 *hit_a;

@@ -248,7 +248,7 @@ __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const Fram
     return reads;
 }
 
-// loads: 16-byte node records / grid cells the kernel itself loaded (the cursor counts them); hits: pixels queued for k_shade
+// loads: 16-byte node records / grid cells the kernel itself loaded (the cursor counts them); hits: shadow rays queued for k_shadow
 __device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned long long nodes,
                                                unsigned long long samples, unsigned long long steps,
                                                unsigned long long shadow_rays, unsigned long long loads,
@@ -421,7 +421,7 @@ __device__ __forceinline__ uint32_t tile_of_block(const RenderParams &P, uint32_
     return row < P.tiles_y ? row * P.tiles_x + cx : 0xFFFFFFFFu;
 }
 // Fill count of queue q of frame f, one 128-byte line each, in two sets: a launch pair uses set
-// P.hit_set, and its k_shade zeroes the other set for the next pair on this scratch -- nothing else
+// P.hit_set, and its k_shadow zeroes the other set for the next pair on this scratch -- nothing else
 // touches that set meanwhile (launches that share a scratch run in stream order), so the queues are
 // emptied without a "last workgroup" counter (8192 atomic adds on one word serialise at ~90 per
 // microsecond: that alone took 90 us per frame in the first version).

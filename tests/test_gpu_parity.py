@@ -13,7 +13,7 @@ from conftest import CAMERAS, GOLDEN, assert_frames_identical, bits_equal, make_
 
 pytestmark = pytest.mark.gpu
 
-# "stack" = the default: the two-kernel pipeline k_march -> k_shade wherever the scene has a full-depth or split
+# "stack" = the default: the two-kernel pipeline k_march -> k_shadow wherever the scene has a full-depth or split
 # grid (every test scene of depth <= 12 does); "stack+one" = the one-kernel form of the same traversal
 ALL_VARIANTS = ["generic", "stack", "stack+one", "generic+compact", "stack+compact"]
 
