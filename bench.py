@@ -472,8 +472,9 @@ def main():
     if rank == 0:
         sec_per_step = elapsed / args.steps
         copy_gbs = measured_copy_bandwidth()           # the box's own figure beside the nameplate
-        mode = "spp%d" % args.spp if pt is not None else "display" if args.display else "compact" if compact else \
-               "one-kernel" if args.one_kernel else "default"
+        mode = "spp%d" % args.spp if pt is not None else "display" if args.display else "compact" if compact else "default"
+        if args.one_kernel and not compact:
+            mode = "one-kernel" if mode == "default" else mode + ":one-kernel"     # k_plain / k_path: other kernels, other counters
         if sharded:
             mode += ":sharded"                         # other kernels instances (wire pixels, bands): no PMC pass of its own
         pmc = load_pmc(f"{W}x{H}:{scene_name}:{mode}") if world == 1 else None
