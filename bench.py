@@ -66,9 +66,11 @@ def parse():
                     help="timed region with a camera that moves every frame: N precomputed Info blocks on a circle "
                          "around the scene's centre (1 degree apart), used round-robin (0 = the fixed cfg-2 camera; "
                          "the default line reports an orbit pass beside it in `latency`)")
+    ap.add_argument("--shadow-queue", action="store_true",
+                    help="A/B knob: k_march queues its shadow rays for a second kernel (k_shadow), 64 to a wave")
     ap.add_argument("--one-kernel", action="store_true",
-                    help="A/B: the one-kernel form (lane state machine, shading in place) instead of the default "
-                         "two-kernel pipeline k_march -> k_shadow")
+                    help="A/B: round 1's one-kernel form (lane state machine, shading in place) instead of the default "
+                         "k_march (wave-converged march / shading / shadow march)")
     ap.add_argument("--check", action="store_true", help="verify the assembled frame against a whole-frame render")
     ap.add_argument("--rank0-weight", type=float, default=0.0,
                     help="sharded runs: rank 0's share of the frame as a fraction of a peer's share "
@@ -152,7 +154,7 @@ def main():
     kflag = {"auto": sb.KERNEL_AUTO, "generic": sb.KERNEL_GENERIC, "stack": sb.KERNEL_STACK}[args.kernel]
     compact = (args.compact == 1) if args.compact >= 0 else DEFAULT_COMPACT
     flags = kflag | (sb.FLAG_COMPACT if compact else 0) | (sb.FLAG_DISPLAY if args.display else 0) | \
-        (sb.TUNE_ONE_KERNEL if args.one_kernel else 0)
+        (sb.TUNE_ONE_KERNEL if args.one_kernel else 0) | (sb._lib.TUNE_SHADOW_QUEUE if args.shadow_queue else 0)
     px_shape, px_dtype, px_bytes = ((), torch.int32, 4) if args.display else ((4,), torch.float32, 16)
     pt = sb.PathTrace(spp=args.spp) if args.spp > 0 else None
     # what travels in the gather: the frame's own pixels, or 5-byte wire pixels that rank 0 expands
@@ -369,8 +371,8 @@ def main():
     # the bytes the REFERENCE algorithm reads and writes for these pixels (Compute.hlsl:88-108: entry +
     # ascents + descents, 8 B of topology each; 8 B of values per sample; the pixel store)
     ref_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + wpx_bytes * my_pixels
-    # the bytes THIS kernel's own algorithm moves: 16 B per grid cell / node record a lane loads, 64 B written and
-    # 64 B read per shadow ray queued between the two kernels, the pixel store
+    # the bytes THIS kernel's own algorithm moves: 16 B per grid cell / node record a lane loads, the pixel store, and
+    # under --shadow-queue 64 B written and 64 B read per shadow ray queued between the two kernels
     own_bytes_rank = 16 * st.n_loads + 128 * st.n_hits + wpx_bytes * my_pixels
     counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays, st.n_loads, st.n_hits], dtype=torch.float64)
     kernel_used = st.kernel_used
@@ -473,6 +475,8 @@ def main():
         sec_per_step = elapsed / args.steps
         copy_gbs = measured_copy_bandwidth()           # the box's own figure beside the nameplate
         mode = "spp%d" % args.spp if pt is not None else "display" if args.display else "compact" if compact else "default"
+        if args.shadow_queue and not compact and pt is None and not args.one_kernel:
+            mode += ":shadow-queue"
         if args.one_kernel and not compact:
             mode = "one-kernel" if mode == "default" else mode + ":one-kernel"     # k_plain / k_path: other kernels, other counters
         if sharded:
@@ -480,7 +484,7 @@ def main():
         pmc = load_pmc(f"{W}x{H}:{scene_name}:{mode}") if world == 1 else None
         roof = roofline(sec_per_step, own_bytes_rank, ref_bytes_rank, pmc, copy_gbs)
         # what the fraction divides by, so that it can be recomputed from profiles/: per_frame / time_ms / peak.  kernel_ms is
-        # the HIP-event time around one frame's launches on their stream (k_march + k_shadow; overlapping the other frame in
+        # the HIP-event time around one frame's launches on their stream (k_march; overlapping the other frame in
         # flight), and frac_over_kernel_ms the same fraction over that longer time
         roof.update({"time_ms": round(sec_per_step * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch,
                      "frac_over_kernel_ms": round(roof["frac"] * sec_per_step * 1e3 * frames_per_launch / kernel_ms, 4) if kernel_ms > 0 else None})
@@ -506,7 +510,9 @@ def main():
                 "kernel": ("path/" if pt is not None else "") +
                           ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else "") +
                           ("" if (pt is not None or compact) else ", one kernel" if args.one_kernel else
-                           ", k_march (primary march, shading) -> queue (wavefront ballot + prefix compaction of the shadow rays) -> k_shadow"),
+                           ", k_march (primary march, shading) -> queue (wavefront ballot + prefix compaction of the shadow rays) -> k_shadow"
+                           if args.shadow_queue else
+                           ", k_march: primary march, shading and shadow march as three wave-converged loops of one kernel"),
                 "top_grid": {"level": scene.top_grid_level, "bytes": scene.top_grid_bytes},
                 "parallelism": "1 GPU" if not sharded else
                                f"{world} GPU(s), {args.band_rows}-row bands " +

@@ -84,12 +84,15 @@ enum {
     SDFHIP_TUNE_ORDER_SHIFT = 8,
     SDFHIP_TUNE_BLOCK_SHIFT = 12,
     /* A/B knob: render with the one-kernel form (a lane state machine that shades in place) where the
-     * default is the two-kernel pipeline (primary march -> queue of hits -> shading + shadow march).
+     * default is k_march (primary march, shading, shadow march as three wave-converged loops).
      * Same pixels, same counters. */
     SDFHIP_TUNE_ONE_KERNEL = 0x20000,
     /* measurement variant of the cursor-stack kernel when the scene's top grid has level <= 3
      * (SDFHIP_TOP_GRID_LEVEL=3 at upload): every workgroup stages the grid in LDS */
-    SDFHIP_TUNE_LDS_TOP = 0x40000
+    SDFHIP_TUNE_LDS_TOP = 0x40000,
+    /* A/B knob: k_march appends its shadow rays to a queue that a second kernel (k_shadow) marches 64 to a
+     * wave, where by default every wave marches its own shadow rays after the shading step */
+    SDFHIP_TUNE_SHADOW_QUEUE = 0x80000
 };
 
 /* Per-call statistics (all optional: pass NULL). */

@@ -30,8 +30,9 @@ OK, ERR_ARG, ERR_IO, ERR_BAD_TREE, ERR_DEVICE, ERR_NOMEM = range(6)
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_STACK = 0, 1, 2
 FLAG_COMPACT, FLAG_COUNT, FLAG_DISPLAY, FLAG_DISPLAY_DEBUG = 0x10, 0x20, 0x40, 0x80
 FLAG_WIRE = 0x10000
-TUNE_ONE_KERNEL = 0x20000     # A/B knob: the one-kernel form where the default is k_march -> k_shadow
+TUNE_ONE_KERNEL = 0x20000     # A/B knob: round 1's one-kernel lane state machine where the default is k_march
 TUNE_LDS_TOP = 0x40000        # measurement variant: top grid (level <= 3) staged in LDS per workgroup
+TUNE_SHADOW_QUEUE = 0x80000   # A/B knob: k_march queues its shadow rays for a second kernel (k_shadow), 64 to a wave
 SHAPE_SPHERE, SHAPE_TORUS, SHAPE_GYROID = 0, 1, 2
 
 

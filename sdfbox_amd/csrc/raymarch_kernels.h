@@ -430,7 +430,31 @@ __device__ __forceinline__ uint32_t *hit_count(const RenderParams &P, uint32_t s
     return P.hit_ctl + (((size_t)set * MAX_BATCH + f) * HIT_QUEUES + q) * 32u;
 }
 
-template <int CUR, bool COUNT, int MODE>
+// The shadow march of Compute.hlsl:214-230 for a lane whose RayState holds the shading step's results (pos, dir, prox,
+// dist; n = 0).  Every exit is black (:223, :229) except the one that reaches the light (:215-219): returns that.
+template <bool COUNT, class CursorT>
+__device__ __forceinline__ bool shadow_march(const RenderParams &P, const FrameInfo &I, RayState &r, CursorT &c,
+                                             unsigned long long &cn, unsigned long long &cs)
+{
+    while (r.n < 40 && r.prox > -I.margin) {
+        // any(pos < 0) || any(pos > 1) as min3 / max3: v_min3_f32 and v_max3_f32 skip NaN operands, and a
+        // comparison with NaN is false either way, so the two forms agree for every input
+        const float lo = __builtin_fminf(__builtin_fminf(r.px, r.py), r.pz), hi = __builtin_fmaxf(__builtin_fmaxf(r.px, r.py), r.pz);
+        if (r.prox > r.dist || lo < 0.0f || hi > 1.0f) return true;
+        if (r.prox < I.margin) {
+            float gx, gy, gz;
+            gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
+            if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) break;
+        }
+        uint32_t reads = march_step(P, I, r, c, nullptr, 0);
+        if (COUNT) { cn += reads; cs += 1; }
+    }
+    return false;
+}
+
+// QUEUE = false (the default): the wave marches its own shadow rays after the shading step.  QUEUE = true
+// (SDFHIP_TUNE_SHADOW_QUEUE, an A/B knob): it appends them to the queue that k_shadow marches 64 to a wave.
+template <int CUR, bool COUNT, int MODE, bool QUEUE = false>
 __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams P)
 {
     typedef typename CursorOf<CUR, COUNT>::type CursorT;
@@ -503,6 +527,20 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
             }
         }
     }
+    if (!QUEUE) {
+        if (shadow) {
+            const PixelSink<MODE> dst(P, f);
+            const float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;      // Compute.hlsl:212
+            r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+            r.base = r.n; r.n = 0; r.phase = PH_SHADOW;           // i stays, j starts; steps are prox + margin from here
+            const bool lit = shadow_march<COUNT>(P, I, r, c, cn, cs);
+            if (lit) dst.grey(lidx, r.angle / (r.dist * r.dist) * I.k_strength, (float)(r.base + r.n));
+            else dst.black(lidx, (float)(r.base + r.n));
+            if (COUNT) ct = (unsigned long long)(r.base + r.n);
+        }
+        if (COUNT) flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, 0u);
+        return;
+    }
     const unsigned long long hits = __ballot(shadow);
     if (hits) {
         const uint32_t q = blockIdx.x & (HIT_QUEUES - 1u);
@@ -559,21 +597,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shadow(RenderParam
             const size_t lidx = e.x;
             const float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;      // Compute.hlsl:212
             r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
-            // Compute.hlsl:214-230: every exit is black (:223, :229) except the one that reaches the light (:215-219)
-            bool lit = false;
-            while (r.n < 40 && r.prox > -I.margin) {
-                // any(pos < 0) || any(pos > 1) as min3 / max3: v_min3_f32 and v_max3_f32 skip NaN operands, and a
-                // comparison with NaN is false either way, so the two forms agree for every input
-                const float lo = __builtin_fminf(__builtin_fminf(r.px, r.py), r.pz), hi = __builtin_fmaxf(__builtin_fmaxf(r.px, r.py), r.pz);
-                if (r.prox > r.dist || lo < 0.0f || hi > 1.0f) { lit = true; break; }
-                if (r.prox < I.margin) {
-                    float gx, gy, gz;
-                    gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
-                    if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) break;
-                }
-                uint32_t reads = march_step(P, I, r, c, nullptr, 0);
-                if (COUNT) { cn += reads; cs += 1; }
-            }
+            const bool lit = shadow_march<COUNT>(P, I, r, c, cn, cs);
             if (lit) dst.grey(lidx, r.angle / (r.dist * r.dist) * I.k_strength, (float)(r.base + r.n));
             else dst.black(lidx, (float)(r.base + r.n));
             if (COUNT) { ct += (unsigned long long)(r.base + r.n); cl += c.loads; }

@@ -636,16 +636,23 @@ int launch_pt(sdfhip_scene *s, sdfhip_scene::Scratch *sc, dim3 grid, hipStream_t
 
 // k_march + k_shadow for one cursor kind and counting choice, by output mode
 template <int CUR, bool COUNT>
-void launch_two(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, const RenderParams &P)
+void launch_two(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, const RenderParams &P, bool queued)
 {
+    if (!queued) {                                      // the default: k_march alone, its waves march their own shadow rays
+        if (mode == OUT_RGBA32F)     hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_RGBA32F, false>), grid, dim3(64), 0, st, P);
+        else if (mode == OUT_GAMMA8) hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_GAMMA8, false>), grid, dim3(64), 0, st, P);
+        else if (mode == OUT_HEAT8)  hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_HEAT8, false>), grid, dim3(64), 0, st, P);
+        else                         hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_WIRE, false>), grid, dim3(64), 0, st, P);
+        return;
+    }
     auto go = [&](auto march, auto shade) {
         hipLaunchKernelGGL(march, grid, dim3(64), 0, st, P);
         hipLaunchKernelGGL(shade, shade_grid, dim3(64), 0, st, P);
     };
-    if (mode == OUT_RGBA32F)     go(k_march<CUR, COUNT, OUT_RGBA32F>, k_shadow<CUR, COUNT, OUT_RGBA32F>);
-    else if (mode == OUT_GAMMA8) go(k_march<CUR, COUNT, OUT_GAMMA8>, k_shadow<CUR, COUNT, OUT_GAMMA8>);
-    else if (mode == OUT_HEAT8)  go(k_march<CUR, COUNT, OUT_HEAT8>, k_shadow<CUR, COUNT, OUT_HEAT8>);
-    else                         go(k_march<CUR, COUNT, OUT_WIRE>, k_shadow<CUR, COUNT, OUT_WIRE>);
+    if (mode == OUT_RGBA32F)     go(k_march<CUR, COUNT, OUT_RGBA32F, true>, k_shadow<CUR, COUNT, OUT_RGBA32F>);
+    else if (mode == OUT_GAMMA8) go(k_march<CUR, COUNT, OUT_GAMMA8, true>, k_shadow<CUR, COUNT, OUT_GAMMA8>);
+    else if (mode == OUT_HEAT8)  go(k_march<CUR, COUNT, OUT_HEAT8, true>, k_shadow<CUR, COUNT, OUT_HEAT8>);
+    else                         go(k_march<CUR, COUNT, OUT_WIRE, true>, k_shadow<CUR, COUNT, OUT_WIRE>);
 }
 
 template <int CUR, bool COUNT>
@@ -765,7 +772,8 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     P.queue = nullptr; P.hit_a = nullptr; P.hit_b = nullptr; P.hit_c = nullptr; P.hit_d = nullptr; P.hit_ctl = nullptr; P.hit_cap = 0; P.hit_set = 0;
     P.tile_perm = s->dbg_tile_perm; P.tile_cost = s->dbg_tile_cost;
     P.pt_q[0] = P.pt_q[1] = nullptr; P.pt_ctl = nullptr; P.pt_cap = 0; P.pt_level = 0; P.pt_e = nullptr; P.pt_t = nullptr; P.pt_n = nullptr;
-    if (two) {
+    const bool queued = two && (flags & SDFHIP_TUNE_SHADOW_QUEUE) != 0;
+    if (queued) {
         // a queue takes the hits of every 64th workgroup: room for all their pixels
         P.hit_cap = ((grid.x + HIT_QUEUES - 1u) / HIT_QUEUES) * 64u;
         const size_t records = (size_t)n_frames * HIT_QUEUES * P.hit_cap;
@@ -789,8 +797,8 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 6 * sizeof(unsigned long long), st));
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     if (two) {
-        if (cur == CUR_STACK_SPLIT) { if (count) launch_two<CUR_STACK_SPLIT, true>(out_mode, grid, shade_grid, st, P); else launch_two<CUR_STACK_SPLIT, false>(out_mode, grid, shade_grid, st, P); }
-        else                        { if (count) launch_two<CUR_STACK_FULL, true>(out_mode, grid, shade_grid, st, P); else launch_two<CUR_STACK_FULL, false>(out_mode, grid, shade_grid, st, P); }
+        if (cur == CUR_STACK_SPLIT) { if (count) launch_two<CUR_STACK_SPLIT, true>(out_mode, grid, shade_grid, st, P, queued); else launch_two<CUR_STACK_SPLIT, false>(out_mode, grid, shade_grid, st, P, queued); }
+        else                        { if (count) launch_two<CUR_STACK_FULL, true>(out_mode, grid, shade_grid, st, P, queued); else launch_two<CUR_STACK_FULL, false>(out_mode, grid, shade_grid, st, P, queued); }
     }
     else if (pt && (cur == CUR_STACK_FULL || cur == CUR_STACK_SPLIT) && !(flags & SDFHIP_TUNE_ONE_KERNEL)) {
         // the pipeline of kernels (k_pt_primary -> k_pt_bounce per level -> k_pt_resolve)

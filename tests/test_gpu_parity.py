@@ -13,14 +13,16 @@ from conftest import CAMERAS, GOLDEN, assert_frames_identical, bits_equal, make_
 
 pytestmark = pytest.mark.gpu
 
-# "stack" = the default: the two-kernel pipeline k_march -> k_shadow wherever the scene has a full-depth or split
-# grid (every test scene of depth <= 12 does); "stack+one" = the one-kernel form of the same traversal
-ALL_VARIANTS = ["generic", "stack", "stack+one", "generic+compact", "stack+compact"]
+# "stack" = the default: k_march (primary march, shading, shadow march as wave-converged loops) wherever the scene has a full-depth or split
+# grid (every test scene of depth <= 12 does); "stack+one" = the one-kernel form of the same traversal;
+# "stack+queue" = k_march queues its shadow rays for k_shadow (the A/B knob SDFHIP_TUNE_SHADOW_QUEUE)
+ALL_VARIANTS = ["generic", "stack", "stack+one", "stack+queue", "generic+compact", "stack+compact"]
 
 
 def flags_of(sb, name):
     f = {"generic": sb.KERNEL_GENERIC, "stack": sb.KERNEL_STACK}[name.split("+")[0]]
-    return f | (sb.FLAG_COMPACT if name.endswith("compact") else 0) | (sb.TUNE_ONE_KERNEL if name.endswith("+one") else 0)
+    return f | (sb.FLAG_COMPACT if name.endswith("compact") else 0) | (sb.TUNE_ONE_KERNEL if name.endswith("+one") else 0) | \
+        (sb._lib.TUNE_SHADOW_QUEUE if name.endswith("+queue") else 0)
 
 
 @pytest.fixture(scope="module")
@@ -653,7 +655,7 @@ def test_two_handles_render_concurrently(sb, oracle_mod, scenes):
 
 def test_frames_in_flight_on_one_handle_do_not_share_scratch(sb, oracle_mod, scenes, gpu_scenes):
     # Several streams render on ONE scene handle at once, each its own camera (frames in flight): the hit
-    # queues of the two-kernel pipeline and the tile queues of the compact kernel are per-stream scratch, so
+    # queues of the queued-shadow pipeline (SDFHIP_TUNE_SHADOW_QUEUE) and the tile queues of the compact kernel are per-stream scratch, so
     # no launch may see another's.  (The compact kernel once kept its queue heads in the scene: a second
     # stream's launch reset them under the first one's feet.)
     import torch
@@ -665,7 +667,7 @@ def test_frames_in_flight_on_one_handle_do_not_share_scratch(sb, oracle_mod, sce
         cams.append(c)
     refs = [oracle_mod.render(od.Structs, od.Values, c.State, W, H, nthreads=8)[0] for c in cams]
     streams = [torch.cuda.Stream() for _ in cams]
-    for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL):
+    for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb._lib.TUNE_SHADOW_QUEUE, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL):
         bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
         for rep in range(8):                       # keep every stream busy so that the launches really overlap
             for c, b, st in zip(cams, bufs, streams):
@@ -683,7 +685,7 @@ def test_first_frame_on_a_fresh_handle(sb, oracle_mod, scenes):
     cam = make_camera("closeup", 256, 192)
     ref, _ = oracle_mod.render(od.Structs, od.Values, cam.State, 256, 192, nthreads=8)
     for rep in range(30):
-        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.FLAG_COUNT):
+        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb._lib.TUNE_SHADOW_QUEUE, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.FLAG_COUNT):
             with sb.Scene(od) as sc:
                 assert_frames_identical(sc.Draw(cam, 256, 192, flags), ref, f"first frame, flags {flags:#x}, handle {rep}")
 

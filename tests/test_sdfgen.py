@@ -168,7 +168,9 @@ def test_mesh_scale_import_and_render(sb, oracle_mod, tmp_path, depth):
         assert sc.stack_kernel_ok and sc.depth == depth and sc.top_grid_level > 0
         img, stt = sc.Draw(cam, W, H, sb.FLAG_COUNT, want_stats=True)
         img2 = sc.Draw(cam, W, H, sb.TUNE_ONE_KERNEL)
+        img3 = sc.Draw(cam, W, H, sb.TUNE_SHADOW_QUEUE)
     assert ((img.view(np.uint32) == img2.view(np.uint32)) | (np.isnan(img) & np.isnan(img2))).all()
+    assert ((img.view(np.uint32) == img3.view(np.uint32)) | (np.isnan(img) & np.isnan(img3))).all()
     assert int(img[..., 3].astype(np.float64).sum()) == stt.n_steps
     hit = img[..., 2] != np.float32(0.2)
     assert 0.05 < hit.mean() < 0.6 and (img[..., 0][hit] > 0).sum() > 10000        # the knot is there and lit
