@@ -454,7 +454,8 @@ template <bool EXACT, bool SPLIT>
 struct CursorFT {
     typedef Scaled Pos;
     static constexpr int32_t ROOT_MARK = 0x40000000;
-    int32_t ax, ay, az;      // lower * 2^LM
+    int32_t ax, ay, az;      // lower * 2^LM in the bits from s up; the bits below s are whatever the last lookup's
+                             // coordinates had there (masking is left to the two readers: anchor())
     uint32_t s;              // LM - level, | FLAT_BIT
     uint32_t v0, v1;         // the 8 value bytes; a flat cell: v0 = its byte four times, v1 = its distance (float bits)
     uint32_t loads;          // grid cells this lane has loaded (the kernels zero it; only the counting ones read it)
@@ -468,7 +469,8 @@ struct CursorFT {
         Cell k;
         const float q = 1.0f / 4096.0f;
         const bool fresh = ax == ROOT_MARK;                                  // never looked up: the root box
-        k.lx = fresh ? 0.0f : (float)ax * q; k.ly = fresh ? 0.0f : (float)ay * q; k.lz = fresh ? 0.0f : (float)az * q;   // exact
+        const int32_t keep = (int32_t)(0xFFFFFFFFu << (s & 31u));
+        k.lx = fresh ? 0.0f : (float)(ax & keep) * q; k.ly = fresh ? 0.0f : (float)(ay & keep) * q; k.lz = fresh ? 0.0f : (float)(az & keep) * q;   // exact
         const uint32_t sc = s & 15u;
         k.scale = __uint_as_float((127u - LM + sc) << 23);                  // 2^-level
         k.inv = __uint_as_float((127u + LM - sc) << 23);                    // 2^level
@@ -500,8 +502,7 @@ __device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT> &c, const GridRe
     c.s = e.x;                                    // LM - level of the leaf, | FLAT_BIT
     c.v0 = e.y;
     c.v1 = e.z;
-    const int32_t keep = (int32_t)(0xFFFFFFFFu << (e.x & 31u));
-    c.ax = Dx & keep; c.ay = Dy & keep; c.az = Dz & keep;
+    c.ax = Dx; c.ay = Dy; c.az = Dz;              // the anchor is these with the low s bits cleared: see CursorFT
     return (int)(e.x & 15u);
 }
 
@@ -571,8 +572,10 @@ __device__ __forceinline__ uint32_t find(CursorFT<false, SPLIT> &c, const NodeRe
     if (__ballot(fm == 0.0f) == 0ull) {
         const int32_t Dx = cvt_floor(__builtin_amdgcn_fmed3f(u.x, 0.0f, 4095.0f)), Dy = cvt_floor(__builtin_amdgcn_fmed3f(u.y, 0.0f, 4095.0f)),
                       Dz = cvt_floor(__builtin_amdgcn_fmed3f(u.z, 0.0f, 4095.0f));
-        const uint32_t diff = (uint32_t)(c.ax ^ Dx) | (uint32_t)(c.ay ^ Dy) | (uint32_t)(c.az ^ Dz);
-        if ((diff >> (c.s & 31u)) != 0u) load_cell(c, g, Dx, Dy, Dz);
+        // no "still in my cell?" test: the march steps are as long as the cells are wide, 98 % of the lane-steps leave
+        // their cell, so the wave's load is issued anyway -- and the lookup of a position in the cell it came from
+        // returns that cell
+        load_cell(c, g, Dx, Dy, Dz);
         return 0;
     }
     // some lane sits on a cell face: the exact rule for the whole wave (coordinates as the counting kernels take them)
@@ -598,9 +601,10 @@ __device__ __forceinline__ float sample_after_find(const CursorFT<EXACT, SPLIT> 
     const uint32_t scale_bits = (c.s + (uint32_t)(127 - LM)) << 23;              // 2^-level = 2^(s - LM)
     const float scale = __uint_as_float(scale_bits);
     const float inv = __uint_as_float(((uint32_t)(2 * 127 - LM) << 23) - scale_bits);     // 2^-s = 2^(level - LM)
-    float dx = sat((u.x - (float)c.ax) * inv);
-    float dy = sat((u.y - (float)c.ay) * inv);
-    float dz = sat((u.z - (float)c.az) * inv);
+    const int32_t keep = (int32_t)(0xFFFFFFFFu << (c.s & 31u));                  // non-flat here: s has no flag bit set
+    float dx = sat((u.x - (float)(c.ax & keep)) * inv);
+    float dy = sat((u.y - (float)(c.ay & keep)) * inv);
+    float dz = sat((u.z - (float)(c.az & keep)) * inv);
     Texels t = decode(c.v0, c.v1);
     float loadL = bilerp(t.v[0], t.v[1], t.v[2], t.v[3], dx, dy);
     float loadH = bilerp(t.v[4], t.v[5], t.v[6], t.v[7], dx, dy);
