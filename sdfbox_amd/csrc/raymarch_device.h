@@ -454,23 +454,42 @@ template <bool EXACT, bool SPLIT>
 struct CursorFT {
     typedef Scaled Pos;
     static constexpr int32_t ROOT_MARK = 0x40000000;
-    int32_t ax, ay, az;      // lower * 2^LM in the bits from s up; the bits below s are whatever the last lookup's
-                             // coordinates had there (masking is left to the two readers: anchor())
+    // The coordinates of the last lookup, in units of 2^-(LM - sh): the cell's lower corner * 2^LM is these shifted left by
+    // sh, with the bits below s cleared (masking is left to the readers: cell(), sample_after_find).  The counting
+    // cursors (EXACT) work in units of 2^-LM, sh = 0; the others in units of the grid's own cells (sh = LM - its full level;
+    // find() sets it), which saves the shifts between the two in every step.
+    int32_t ax, ay, az;
     uint32_t s;              // LM - level, | FLAT_BIT
     uint32_t v0, v1;         // the 8 value bytes; a flat cell: v0 = its byte four times, v1 = its distance (float bits)
+    uint32_t sh;             // wave-uniform: see ax
     uint32_t loads;          // grid cells this lane has loaded (the kernels zero it; only the counting ones read it)
 
     __device__ __forceinline__ void reset(const NodeRec &root)
     {
-        ax = ay = az = ROOT_MARK; s = (uint32_t)LM; v0 = root.z; v1 = root.w;
+        ax = ay = az = ROOT_MARK; s = (uint32_t)LM; v0 = root.z; v1 = root.w; sh = 0;
     }
+    // for the queues between kernels: coordinates in units of 2^-LM whatever the cursor works in, and back
+    __device__ __forceinline__ int4 pack() const
+    {
+        const bool fresh = ax == ROOT_MARK;
+        return make_int4(fresh ? ax : (int32_t)((uint32_t)ax << sh), fresh ? ay : (int32_t)((uint32_t)ay << sh), fresh ? az : (int32_t)((uint32_t)az << sh), (int32_t)s);
+    }
+    __device__ __forceinline__ void unpack(const int4 &b, uint32_t shift)
+    {
+        const bool fresh = b.x == ROOT_MARK;
+        ax = fresh ? b.x : b.x >> shift; ay = fresh ? b.y : b.y >> shift; az = fresh ? b.z : b.z >> shift;
+        s = (uint32_t)b.w; sh = fresh ? 0u : shift;
+    }
+    // the unit shift of a grid as deep as the tree (full level = top_level, + fine_bits for a split grid)
+    __device__ __forceinline__ static uint32_t units_shift(int full_level) { return EXACT ? 0u : (uint32_t)(LM - full_level); }
     __device__ __forceinline__ Cell cell() const
     {
         Cell k;
         const float q = 1.0f / 4096.0f;
         const bool fresh = ax == ROOT_MARK;                                  // never looked up: the root box
         const int32_t keep = (int32_t)(0xFFFFFFFFu << (s & 31u));
-        k.lx = fresh ? 0.0f : (float)(ax & keep) * q; k.ly = fresh ? 0.0f : (float)(ay & keep) * q; k.lz = fresh ? 0.0f : (float)(az & keep) * q;   // exact
+        const int32_t x = (int32_t)((uint32_t)ax << sh) & keep, y = (int32_t)((uint32_t)ay << sh) & keep, z = (int32_t)((uint32_t)az << sh) & keep;
+        k.lx = fresh ? 0.0f : (float)x * q; k.ly = fresh ? 0.0f : (float)y * q; k.lz = fresh ? 0.0f : (float)z * q;   // exact
         const uint32_t sc = s & 15u;
         k.scale = __uint_as_float((127u - LM + sc) << 23);                  // 2^-level
         k.inv = __uint_as_float((127u + LM - sc) << 23);                    // 2^level
@@ -506,6 +525,53 @@ __device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT> &c, const GridRe
     return (int)(e.x & 15u);
 }
 
+// The same lookup with D in units of the grid's full level (level, + fine_bits for a split grid): no shifts.
+template <bool SPLIT>
+__device__ __forceinline__ void load_cell_units(CursorFT<false, SPLIT> &c, const GridRef &g, int32_t Dx, int32_t Dy, int32_t Dz)
+{
+    uint4 e;
+    c.loads++;
+    if (!SPLIT) {
+        e = reinterpret_cast<const uint4 *>(g.top)[top_index((uint32_t)Dx, (uint32_t)Dy, (uint32_t)Dz, g.level)];
+    } else {
+        const int FB = g.fine_bits;
+        e = reinterpret_cast<const uint4 *>(g.top)[top_index((uint32_t)Dx >> FB, (uint32_t)Dy >> FB, (uint32_t)Dz >> FB, g.level)];
+        asm volatile("" : "+v"(e.y), "+v"(e.z), "+v"(e.w));       // one 16-byte load, see load_cell
+        if (e.x == 15u) {
+            c.loads++;
+            const uint32_t m = (1u << FB) - 1u;
+            const uint32_t local = fine_cell_index((uint32_t)Dx & m, (uint32_t)Dy & m, (uint32_t)Dz & m, FB, g.fine_order);
+            e = reinterpret_cast<const uint4 *>(g.fine)[((size_t)e.w << (3 * FB)) + local];
+        }
+    }
+    c.s = e.x; c.v0 = e.y; c.v1 = e.z;
+    c.ax = Dx; c.ay = Dy; c.az = Dz;
+}
+
+// The reference's choice between the two cells that meet in a position exactly on a cell face (the same A/B rule as
+// find_s): (ax, ay, az, s) the cursor in units of 2^-LM (or the root mark), D the floor coordinates, g* "this axis is
+// on the 2^-LM grid".  Replaces D by the coordinates of the cell the descent ends in; k = the ascents.
+__device__ __forceinline__ int on_face_choice(int32_t cax, int32_t cay, int32_t caz, int s, int32_t &Dx, int32_t &Dy, int32_t &Dz,
+                                              bool gx, bool gy, bool gz, bool &moved)
+{
+    const int level = LM - s;
+    // the A/B arithmetic wants coordinates that do not wrap: far outside the cube is -2 or 2^LM + 1
+    Dx = min(max(Dx, -2), 4097); Dy = min(max(Dy, -2), 4097); Dz = min(max(Dz, -2), 4097);
+    const bool root = cax == 0x40000000;
+    const int32_t ax = root ? 0 : cax, ay = root ? 0 : cay, az = root ? 0 : caz;
+    const int32_t Bx = Dx - (gx ? 1 : 0), By = Dy - (gy ? 1 : 0), Bz = Dz - (gz ? 1 : 0);
+    const int tx = min(bitlen((uint32_t)(ax ^ Dx)), bitlen((uint32_t)(ax ^ Bx)));
+    const int ty = min(bitlen((uint32_t)(ay ^ Dy)), bitlen((uint32_t)(ay ^ By)));
+    const int tz = min(bitlen((uint32_t)(az ^ Dz)), bitlen((uint32_t)(az ^ Bz)));
+    const int k = min(max(max(tx, ty), max(tz, s)) - s, level);
+    moved = k > 0 || root;
+    const int tt = s + k;                        // LM - (level the descent restarts at), <= LM
+    Dx = (((uint32_t)(ax ^ Dx) >> tt) == 0u) ? Dx : Bx;
+    Dy = (((uint32_t)(ay ^ Dy) >> tt) == 0u) ? Dy : By;
+    Dz = (((uint32_t)(az ^ Dz) >> tt) == 0u) ? Dz : Bz;
+    return k;
+}
+
 // find(): is the position still in the current cell, and -- on exact cell boundaries (any_on_grid,
 // wave-uniform) -- which of the two adjacent cells does the reference's descent pick (the same A/B
 // rule as find_s).  The ascent count k feeds the algorithmic read count only.  One place updates the
@@ -523,20 +589,7 @@ __device__ __forceinline__ uint32_t find_full(CursorFT<EXACT, SPLIT> &c, const G
         moved = (diff >> s) != 0u;                    // on the root: the mark differs from every A in bit 30
         k = min(max(bitlen(diff), s) - s, level);
     } else {
-        // the A/B arithmetic wants coordinates that do not wrap: far outside the cube is -2 or 2^LM + 1
-        Dx = min(max(Dx, -2), 4097); Dy = min(max(Dy, -2), 4097); Dz = min(max(Dz, -2), 4097);
-        const bool root = c.ax == CursorFT<EXACT, SPLIT>::ROOT_MARK;
-        const int32_t ax = root ? 0 : c.ax, ay = root ? 0 : c.ay, az = root ? 0 : c.az;
-        const int32_t Bx = Dx - (gx ? 1 : 0), By = Dy - (gy ? 1 : 0), Bz = Dz - (gz ? 1 : 0);
-        const int tx = min(bitlen((uint32_t)(ax ^ Dx)), bitlen((uint32_t)(ax ^ Bx)));
-        const int ty = min(bitlen((uint32_t)(ay ^ Dy)), bitlen((uint32_t)(ay ^ By)));
-        const int tz = min(bitlen((uint32_t)(az ^ Dz)), bitlen((uint32_t)(az ^ Bz)));
-        k = min(max(max(tx, ty), max(tz, s)) - s, level);
-        moved = k > 0 || root;
-        const int tt = s + k;                        // LM - (level the descent restarts at), <= LM
-        Dx = (((uint32_t)(ax ^ Dx) >> tt) == 0u) ? Dx : Bx;
-        Dy = (((uint32_t)(ay ^ Dy) >> tt) == 0u) ? Dy : By;
-        Dz = (((uint32_t)(az ^ Dz) >> tt) == 0u) ? Dz : Bz;
+        k = on_face_choice(c.ax, c.ay, c.az, s, Dx, Dy, Dz, gx, gy, gz, moved);
     }
     uint32_t reads = 1u;
     if (moved) {
@@ -554,34 +607,42 @@ __device__ __forceinline__ int32_t cvt_floor(float u)
     asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(a) : "v"(u));
     return a;
 }
-// The kernels that do not count: the cell coordinates are clamped into the cube BEFORE the "still in my cell?"
-// test -- outside the cube the shader's descent clamps to the boundary leaf at every step (saturate,
-// Compute.hlsl:100), so "the clamped coordinates are still in my cell" selects the cell the shader ends in, and the
-// root mark (bit 30) differs from every clamped coordinate.  The clamp is a float v_med3 in front of the conversion:
-// it returns the smaller bound when its first operand is NaN, so a NaN coordinate selects cell 0 on that axis, as the
-// shader does (every comparison with NaN is false: up to the root; saturate(NaN) = 0: down along the low cells).
+// The kernels that do not count work in units of the grid's own cells, 2^-F (F = the grid's full level = the tree's depth):
+//   * every step looks its cell up -- no "still in my cell?" test: the march steps are as long as the cells are wide, 98 %
+//     of the lane-steps leave their cell, so the wave's load is issued anyway, and the lookup of a position in the cell
+//     it came from returns that cell;
+//   * the cell coordinates are floor(clamp(pos * 2^F)): outside the cube the shader's descent clamps to the boundary leaf
+//     at every step (saturate, Compute.hlsl:100).  The clamp is a float v_med3 in front of the conversion: it returns the
+//     smaller bound when its first operand is NaN, so a NaN coordinate selects cell 0 on that axis, as the shader does
+//     (every comparison with NaN is false: up to the root; saturate(NaN) = 0: down along the low cells);
+//   * a position exactly on a cell face needs the reference's choice between the two cells (on_face_choice).  Every face
+//     lies on the 2^-F lattice, so "no coordinate of any lane is on that lattice" (a fractional part of zero) rules it out
+//     for the whole wave; otherwise the wave takes the exact rule, in the 2^-LM coordinates the counting kernels use.
 template <bool SPLIT>
 __device__ __forceinline__ uint32_t find(CursorFT<false, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
                                          uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
                                          Scaled &u)
 {
-    u.x = px * 4096.0f; u.y = py * 4096.0f; u.z = pz * 4096.0f;
-    // on the 2^-LM grid on some axis <=> a fractional part is zero (NaN: never; the three are >= 0)
+    const int F = g.level + (SPLIT ? g.fine_bits : 0), sh = LM - F;
+    const float unit = __uint_as_float((uint32_t)(127 + F) << 23), top = unit - 1.0f;      // 2^F, and the last cell
+    u.x = px * unit; u.y = py * unit; u.z = pz * unit;
     const float fx = __builtin_amdgcn_fractf(u.x), fy = __builtin_amdgcn_fractf(u.y), fz = __builtin_amdgcn_fractf(u.z);
-    const float fm = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+    const float fm = __builtin_fminf(__builtin_fminf(fx, fy), fz);                           // NaN: never zero; the three are >= 0
+    int32_t Dx, Dy, Dz;
     if (__ballot(fm == 0.0f) == 0ull) {
-        const int32_t Dx = cvt_floor(__builtin_amdgcn_fmed3f(u.x, 0.0f, 4095.0f)), Dy = cvt_floor(__builtin_amdgcn_fmed3f(u.y, 0.0f, 4095.0f)),
-                      Dz = cvt_floor(__builtin_amdgcn_fmed3f(u.z, 0.0f, 4095.0f));
-        // no "still in my cell?" test: the march steps are as long as the cells are wide, 98 % of the lane-steps leave
-        // their cell, so the wave's load is issued anyway -- and the lookup of a position in the cell it came from
-        // returns that cell
-        load_cell(c, g, Dx, Dy, Dz);
-        return 0;
+        Dx = cvt_floor(__builtin_amdgcn_fmed3f(u.x, 0.0f, top)); Dy = cvt_floor(__builtin_amdgcn_fmed3f(u.y, 0.0f, top));
+        Dz = cvt_floor(__builtin_amdgcn_fmed3f(u.z, 0.0f, top));
+    } else {
+        float tx, ty, tz, qx, qy, qz;
+        Dx = axis_a(px, tx, qx); Dy = axis_a(py, ty, qy); Dz = axis_a(pz, tz, qz);
+        const int4 k = c.pack();
+        bool moved;
+        on_face_choice(k.x, k.y, k.z, (int)(c.s & 15u), Dx, Dy, Dz, tx == qx, ty == qy, tz == qz, moved);
+        Dx = min(max(Dx, 0), 4095) >> sh; Dy = min(max(Dy, 0), 4095) >> sh; Dz = min(max(Dz, 0), 4095) >> sh;
     }
-    // some lane sits on a cell face: the exact rule for the whole wave (coordinates as the counting kernels take them)
-    float tx, ty, tz, qx, qy, qz;
-    const int32_t Ax = axis_a(px, tx, qx), Ay = axis_a(py, ty, qy), Az = axis_a(pz, tz, qz);
-    return find_full(c, g, Ax, Ay, Az, tx == qx, ty == qy, tz == qz, true);
+    c.sh = (uint32_t)sh;
+    load_cell_units(c, g, Dx, Dy, Dz);
+    return 0;
 }
 // The counting kernels: NaN must match no cell (ascents up to the root count as reads), see axis_a.
 template <bool SPLIT>
@@ -594,14 +655,16 @@ __device__ __forceinline__ uint32_t find(CursorFT<true, SPLIT> &c, const NodeRec
     const bool gx = u.x == fx, gy = u.y == fy, gz = u.z == fz;    // on the 2^-LM grid (false for NaN)
     return find_full(c, g, Ax, Ay, Az, gx, gy, gz, __ballot(gx || gy || gz) != 0ull);
 }
+// u = the position in the cursor's units, 2^-(LM - sh) (find() leaves it so): with a = the anchor in the same units and
+// k = s - sh, (u - a) * 2^-k == (pos - lower) * 2^level bit for bit -- rounding is invariant under power-of-two scaling.
 template <bool EXACT, bool SPLIT>
 __device__ __forceinline__ float sample_after_find(const CursorFT<EXACT, SPLIT> &c, const Scaled &u, float, float, float)
 {
     if (c.s & FLAT_BIT) return __uint_as_float(c.v1);                            // see CursorFT
-    const uint32_t scale_bits = (c.s + (uint32_t)(127 - LM)) << 23;              // 2^-level = 2^(s - LM)
-    const float scale = __uint_as_float(scale_bits);
-    const float inv = __uint_as_float(((uint32_t)(2 * 127 - LM) << 23) - scale_bits);     // 2^-s = 2^(level - LM)
-    const int32_t keep = (int32_t)(0xFFFFFFFFu << (c.s & 31u));                  // non-flat here: s has no flag bit set
+    const float scale = __uint_as_float((c.s + (uint32_t)(127 - LM)) << 23);     // 2^-level = 2^(s - LM)
+    const uint32_t k = c.s - c.sh;                                               // non-flat here: s has no flag bit set
+    const float inv = __uint_as_float((127u - k) << 23);                         // 2^-k
+    const int32_t keep = (int32_t)(0xFFFFFFFFu << (k & 31u));
     float dx = sat((u.x - (float)(c.ax & keep)) * inv);
     float dy = sat((u.y - (float)(c.ay & keep)) * inv);
     float dz = sat((u.z - (float)(c.az & keep)) * inv);

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
         if (shadow && base + rank < P.hit_cap) {       // always true while the fill counts start at zero (k_shadow leaves them so)
             const size_t slot = ((size_t)f * HIT_QUEUES + q) * P.hit_cap + base + rank;
             P.hit_a[slot] = make_float4(r.px, r.py, r.pz, r.prox);
-            P.hit_b[slot] = make_int4(c.ax, c.ay, c.az, (int)c.s);
+            P.hit_b[slot] = c.pack();
             P.hit_c[slot] = make_uint4((uint32_t)lidx, (uint32_t)r.n, c.v0, c.v1);
             P.hit_d[slot] = make_float4(r.dx, r.dy, r.dz, r.angle);
         }
@@ -593,7 +593,8 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shadow(RenderParam
             CursorT c;
             r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w; r.dx = d.x; r.dy = d.y; r.dz = d.z; r.angle = d.w;
             r.base = (int)e.y; r.n = 0; r.phase = PH_SHADOW;          // i stays, j starts
-            c.ax = b.x; c.ay = b.y; c.az = b.z; c.s = (uint32_t)b.w; c.v0 = e.z; c.v1 = e.w; c.loads = 0;
+            c.unpack(b, CursorT::units_shift(P.top_level + (CUR == CUR_STACK_SPLIT ? P.fine_bits : 0)));
+            c.v0 = e.z; c.v1 = e.w; c.loads = 0;
             const size_t lidx = e.x;
             const float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;      // Compute.hlsl:212
             r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
@@ -954,7 +955,8 @@ __device__ __forceinline__ void pt_push(const RenderParams &P, uint32_t queue, u
         const size_t total = (size_t)HIT_QUEUES * P.pt_cap, i = (size_t)q * P.pt_cap + base + rank;
         float4 *Q = P.pt_q[queue];
         Q[i] = make_float4(px, py, pz, prox);
-        Q[total + i] = make_float4(__int_as_float(c.ax), __int_as_float(c.ay), __int_as_float(c.az), __uint_as_float(c.s));
+        const int4 k = c.pack();
+        Q[total + i] = make_float4(__int_as_float(k.x), __int_as_float(k.y), __int_as_float(k.z), __int_as_float(k.w));
         Q[2 * total + i] = make_float4(__uint_as_float(c.v0), __uint_as_float(c.v1), __uint_as_float(pid), __uint_as_float(steps));
         Q[3 * total + i] = make_float4(ux, uy, uz, T);
     }
@@ -1045,7 +1047,8 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
             const size_t e = (size_t)q * P.pt_cap + i;
             const float4 a = Q[e], k = Q[total + e], v = Q[2 * total + e], d = Q[3 * total + e];
             r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w;
-            c.ax = __float_as_int(k.x); c.ay = __float_as_int(k.y); c.az = __float_as_int(k.z); c.s = __float_as_uint(k.w);
+            c.unpack(make_int4(__float_as_int(k.x), __float_as_int(k.y), __float_as_int(k.z), __float_as_int(k.w)),
+                     CursorT::units_shift(P.top_level + (CUR == CUR_STACK_SPLIT ? P.fine_bits : 0)));
             c.v0 = __float_as_uint(v.x); c.v1 = __float_as_uint(v.y); pid = __float_as_uint(v.z);
             ux = d.x; uy = d.y; uz = d.z; T = d.w;
             const uint32_t pix = pid / P.pt_spp, s = pid - pix * P.pt_spp;
