@@ -618,10 +618,13 @@ __device__ __forceinline__ int32_t cvt_floor(float u)
 //   * a position exactly on a cell face needs the reference's choice between the two cells (on_face_choice).  Every face
 //     lies on the 2^-F lattice, so "no coordinate of any lane is on that lattice" (a fractional part of zero) rules it out
 //     for the whole wave; otherwise the wave takes the exact rule, in the 2^-LM coordinates the counting kernels use.
-template <bool SPLIT>
-__device__ __forceinline__ uint32_t find(CursorFT<false, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
-                                         uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
-                                         Scaled &u)
+//   * FRESH: the cursor has not looked anything up yet (the first step of a pixel).  From the root the exact rule picks
+//     the floor cell on every axis whose coordinate is inside the cube and the clamped one otherwise (on_face_choice with
+//     a = 0, s = LM: the descent restarts at level 0 and "same cell above level 0" holds for 0 <= D < 2^LM) -- what the
+//     plain lookup does, so the first step skips the lattice test.  (The reference's default camera sits at x = y = 0.5:
+//     without this every pixel's first step takes the exact rule.)
+template <bool SPLIT, bool FRESH>
+__device__ __forceinline__ uint32_t find_units(CursorFT<false, SPLIT> &c, const GridRef &g, float px, float py, float pz, Scaled &u)
 {
     const int F = g.level + (SPLIT ? g.fine_bits : 0), sh = LM - F;
     const float unit = __uint_as_float((uint32_t)(127 + F) << 23), top = unit - 1.0f;      // 2^F, and the last cell
@@ -629,7 +632,7 @@ __device__ __forceinline__ uint32_t find(CursorFT<false, SPLIT> &c, const NodeRe
     const float fx = __builtin_amdgcn_fractf(u.x), fy = __builtin_amdgcn_fractf(u.y), fz = __builtin_amdgcn_fractf(u.z);
     const float fm = __builtin_fminf(__builtin_fminf(fx, fy), fz);                           // NaN: never zero; the three are >= 0
     int32_t Dx, Dy, Dz;
-    if (__ballot(fm == 0.0f) == 0ull) {
+    if (FRESH || __ballot(fm == 0.0f) == 0ull) {
         Dx = cvt_floor(__builtin_amdgcn_fmed3f(u.x, 0.0f, top)); Dy = cvt_floor(__builtin_amdgcn_fmed3f(u.y, 0.0f, top));
         Dz = cvt_floor(__builtin_amdgcn_fmed3f(u.z, 0.0f, top));
     } else {
@@ -643,6 +646,27 @@ __device__ __forceinline__ uint32_t find(CursorFT<false, SPLIT> &c, const NodeRe
     c.sh = (uint32_t)sh;
     load_cell_units(c, g, Dx, Dy, Dz);
     return 0;
+}
+template <bool SPLIT>
+__device__ __forceinline__ uint32_t find(CursorFT<false, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
+                                         uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
+                                         Scaled &u)
+{
+    return find_units<SPLIT, false>(c, g, px, py, pz, u);
+}
+// find() for a cursor straight from reset(): the same as find() for every cursor kind but the one above
+template <class CursorT, class Pos>
+__device__ __forceinline__ uint32_t find_fresh(CursorT &c, const NodeRec *__restrict__ nodes, const GridRef &g, uint32_t n,
+                                               int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz, Pos &u)
+{
+    return find(c, nodes, g, n, stack, stride, px, py, pz, u);
+}
+template <bool SPLIT>
+__device__ __forceinline__ uint32_t find_fresh(CursorFT<false, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
+                                               uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
+                                               Scaled &u)
+{
+    return find_units<SPLIT, true>(c, g, px, py, pz, u);
 }
 // The counting kernels: NaN must match no cell (ascents up to the root count as reads), see axis_a.
 template <bool SPLIT>

@@ -232,13 +232,16 @@ __device__ __forceinline__ bool pre_step(const FrameInfo &I, RayState &r, const 
 }
 
 // find + interpol_world + advance: Compute.hlsl:200-202 / :225-227
-template <class CursorT>
+// FRESH: the cursor comes straight from reset() (the first step of a pixel), see find_fresh
+template <class CursorT, bool FRESH = false>
 __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const FrameInfo &I, RayState &r, CursorT &c,
                                                int32_t *stack, uint32_t stride, const TopCell *top = nullptr)
 {
     typename CursorT::Pos u;
     // top: the top grid somewhere else than P.top (the workgroup's LDS copy, k_plain<..., LDSTOP>)
-    uint32_t reads = find(c, P.nodes, GridRef{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order}, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
+    const GridRef g{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order};
+    uint32_t reads = FRESH ? find_fresh(c, P.nodes, g, P.n_nodes, stack, stride, r.px, r.py, r.pz, u)
+                           : find(c, P.nodes, g, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
     r.prox = sample_after_find(c, u, r.px, r.py, r.pz);
     float step = r.phase ? r.prox + I.margin : r.prox;
     r.px = __builtin_fmaf(r.dx, step, r.px);
@@ -481,9 +484,14 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     auto marching = [&]() { return (r.prox > I.margin2 || r.prox < 0.0f) && r.n < 100; };
     if (live) {
         // (both tests every time, combined without a branch: the escape test is three instructions)
-        while ((int)marching() & (int)!(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit)) {
-            uint32_t reads = march_step(P, I, r, c, nullptr, 0);
+        auto go_on = [&]() { return ((int)marching() & (int)!(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit)) != 0; };
+        if (go_on()) {                               // the first step, from the root, apart: see find_fresh
+            uint32_t reads = march_step<CursorT, true>(P, I, r, c, nullptr, 0);
             if (COUNT) { cn += reads; cs += 1; }
+            while (go_on()) {
+                reads = march_step(P, I, r, c, nullptr, 0);
+                if (COUNT) { cn += reads; cs += 1; }
+            }
         }
     }
     // (the lane's own registers say why it left; hiding them from the optimiser here keeps the loop from carrying
@@ -963,12 +971,18 @@ __device__ __forceinline__ void pt_push(const RenderParams &P, uint32_t queue, u
 }
 
 // the march of one path segment (o_pixel_pt's inner loop, Compute.hlsl:194-203): true = escaped to the sky
-template <bool COUNT, class CursorT>
+// FRESH: the cursor comes straight from reset() (a camera segment), see find_fresh
+template <bool COUNT, bool FRESH = false, class CursorT>
 __device__ __forceinline__ bool pt_march(const RenderParams &P, const FrameInfo &I, RayState &r, CursorT &c,
                                          unsigned long long &cn, unsigned long long &cs)
 {
     auto marching = [&]() { return (r.prox > I.margin2 || r.prox < 0.0f) && r.n < 100; };
-    while (marching() && !(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit)) {
+    auto go_on = [&]() { return marching() && !(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit); };
+    if (FRESH && go_on()) {
+        uint32_t reads = march_step<CursorT, true>(P, I, r, c, nullptr, 0);
+        if (COUNT) { cn += reads; cs += 1; }
+    }
+    while (go_on()) {
         uint32_t reads = march_step(P, I, r, c, nullptr, 0);
         if (COUNT) { cn += reads; cs += 1; }
     }
@@ -1002,7 +1016,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_pt_primary(RenderP
         ray_f(I, (float)x + rnd(P.pt_seed, p, s, 0, 0), (float)y + rnd(P.pt_seed, p, s, 0, 1), r.dx, r.dy, r.dz);
         r.prox = 1.0f; r.n = 0; r.base = 0; r.phase = PH_PRIMARY; r.angle = 0.0f; r.dist = 0.0f;
         bool escaped = false;
-        if (live) escaped = pt_march<COUNT>(P, I, r, c, cn, cs);
+        if (live) escaped = pt_march<COUNT, true>(P, I, r, c, cn, cs);
         if (COUNT) cl += c.loads;
         if (live) {
             const size_t o = (size_t)s * npx + lidx;
