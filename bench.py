@@ -377,51 +377,10 @@ def main():
     counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays, st.n_loads, st.n_hits], dtype=torch.float64)
     kernel_used = st.kernel_used
 
-    # ---- warm-up, then the timed region ---------------------------------------------------
-    for k in range(args.warmup):
-        step(k, last=(k == args.warmup - 1))
-    drain()
-    barrier()
-    t_start = time.perf_counter()
-    for k in range(args.steps):
-        step(k, timed=True, last=(k == args.steps - 1))
-    drain()
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if nccl else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = counters.cuda() if nccl else counters
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        counters = c.cpu()
-    # average duration of the ray-march launch over the timed region (HIP events on the
-    # stream each launch went to; with frames in flight the launches overlap each other)
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
-    frames_per_launch = float(np.mean([n for _, _, n in ev]))
-
-    check_ok = None
-    if args.check and sharded and rank == 0:
-        refs = {}
-
-        def ref_of(k):                     # the whole-frame render of frame k's camera
-            c = k % len(cams)
-            if c not in refs:
-                ref = torch.zeros((H, W) + px_shape, dtype=px_dtype, device="cuda")
-                if pt is not None:
-                    scene.DrawPathDevice(cams[c], W, H, ref.data_ptr(), pt=pt, flags=flags, stream=main)
-                else:
-                    scene.DrawDevice(cams[c], W, H, ref.data_ptr(), flags=flags & ~sb.FLAG_WIRE, stream=main)
-                torch.cuda.synchronize()
-                refs[c] = ref
-            return refs[c]
-        # every frame of every group buffer that the timed steps filled
-        filled = [(g % nbuf, w, g * G + w) for g in range(max(0, (args.steps - 1) // G + 1 - nbuf), (args.steps - 1) // G + 1)
-                  for w in range(G) if g * G + w < args.steps]
-        check_ok = all(bool(torch.equal(frame[sl][w].view(torch.int32), ref_of(k).view(torch.int32))) for sl, w, k in filled)
-
     # ---- latency: one frame (sharded: one gather group) at a time, nothing else in flight, host clock around
-    # launch + completion; and the same with the camera moving every frame -----------------------------------
+    # launch + completion; and the same with the camera moving every frame.  Measured BEFORE the timed region: a few
+    # hundred frames that also bring the GPU's clocks up, so that a short timed run (--steps 20 --warmup 5 is 2.5 ms of
+    # work) measures the steady state the long ones do ------------------------------------------------------------
     def latency_pass(camlist, n):
         nonlocal cams
         saved, cams = cams, camlist
@@ -470,6 +429,49 @@ def main():
         latency["orbit_cameras"] = len(orbit)
         latency["orbit_ms"] = round(latency_pass(orbit, n_lat), 4)
         latency["orbit_ms_per_step"] = round(throughput_pass(orbit, max(args.steps, 2 * len(orbit))), 4)
+
+    # ---- warm-up, then the timed region ---------------------------------------------------
+    for k in range(args.warmup):
+        step(k, last=(k == args.warmup - 1))
+    drain()
+    barrier()
+    t_start = time.perf_counter()
+    for k in range(args.steps):
+        step(k, timed=True, last=(k == args.steps - 1))
+    drain()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if nccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = counters.cuda() if nccl else counters
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        counters = c.cpu()
+    # average duration of the ray-march launch over the timed region (HIP events on the
+    # stream each launch went to; with frames in flight the launches overlap each other)
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
+    frames_per_launch = float(np.mean([n for _, _, n in ev]))
+
+    check_ok = None
+    if args.check and sharded and rank == 0:
+        refs = {}
+
+        def ref_of(k):                     # the whole-frame render of frame k's camera
+            c = k % len(cams)
+            if c not in refs:
+                ref = torch.zeros((H, W) + px_shape, dtype=px_dtype, device="cuda")
+                if pt is not None:
+                    scene.DrawPathDevice(cams[c], W, H, ref.data_ptr(), pt=pt, flags=flags, stream=main)
+                else:
+                    scene.DrawDevice(cams[c], W, H, ref.data_ptr(), flags=flags & ~sb.FLAG_WIRE, stream=main)
+                torch.cuda.synchronize()
+                refs[c] = ref
+            return refs[c]
+        # every frame of every group buffer that the timed steps filled
+        filled = [(g % nbuf, w, g * G + w) for g in range(max(0, (args.steps - 1) // G + 1 - nbuf), (args.steps - 1) // G + 1)
+                  for w in range(G) if g * G + w < args.steps]
+        check_ok = all(bool(torch.equal(frame[sl][w].view(torch.int32), ref_of(k).view(torch.int32))) for sl, w, k in filled)
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
