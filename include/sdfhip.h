@@ -393,7 +393,8 @@ SDFHIP_API int sdfhip_deinterleave_sparse_device(int device, const void *d_gathe
 /* Experiment hook (scripts/ab_tile_order.py): the primary-march kernel of the following single-frame renders
  * on this scene takes workgroup b's tile from d_perm[b] (device array, one entry per workgroup of its grid =
  * 8 * ceil(tiles_y / 8) * tiles_x with 8x8 tiles; entries >= the tile count idle) and writes the march
- * iterations of every tile's wave to d_cost[tile] (device array).  NULL switches either off. */
+ * iterations of every tile's wave to d_cost[tile] (device array): the primary loop's in the low byte, the
+ * shadow loop's in the high byte.  NULL switches either off. */
 SDFHIP_API int sdfhip_debug_tile_order(sdfhip_scene *scene, const uint32_t *d_perm, uint16_t *d_cost);
 
 /* Test hook: the kernel's R8_UNorm decode of bytes 0..255 (256 floats to the

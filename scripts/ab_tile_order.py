@@ -59,6 +59,7 @@ for mode in ("default order", "previous frame's cost, descending per XCD", "same
             if mode.startswith("same"):                 # render once to learn this frame's own cost
                 check(lib.sdfhip_debug_tile_order(sc._h, None, ctypes.c_void_p(cost.data_ptr()))); frame(cam)
             c = cost.cpu().numpy().view(np.uint16)
+            c = ((c & 0xFF) + (c >> 8)).astype(np.uint16)       # primary + shadow loop iterations of the tile's wave
             p = row_perm(c, "sum") if "summed" in mode else row_perm(c, "max") if "rows" in mode else sorted_perm(c)
             perm.copy_(torch.from_numpy(p.view(np.int32)))
             check(lib.sdfhip_debug_tile_order(sc._h, ctypes.c_void_p(perm.data_ptr()), ctypes.c_void_p(cost.data_ptr())))

@@ -5,6 +5,8 @@ run() { n=$1; shift; python bench.py "$@" > $O/${R}_$n.json 2> $O/${R}_$n.err ||
 run 1080p_default
 run 1080p_driver_style --steps 20 --warmup 5
 run 1080p_one_frame_in_flight --no-cpu-baseline --frames-in-flight 1
+run 1080p_shadow_queue --no-cpu-baseline --shadow-queue
+run 1080p_shadow_queue_single --no-cpu-baseline --shadow-queue --frames-in-flight 1
 run 1080p_one_kernel --no-cpu-baseline --one-kernel
 run 1080p_one_kernel_single --no-cpu-baseline --one-kernel --frames-in-flight 1
 run 1080p_display --no-cpu-baseline --display
@@ -12,6 +14,7 @@ run 1080p_depth10 --no-cpu-baseline --depth 10
 run 1080p_compact --no-cpu-baseline --compact 1
 run 1080p_orbit --no-cpu-baseline --orbit 90
 run 4k_default --no-cpu-baseline --size 3840x2160
+run 4k_shadow_queue --no-cpu-baseline --size 3840x2160 --shadow-queue
 run 4k_one_kernel --no-cpu-baseline --size 3840x2160 --one-kernel
 run 4k_compact --no-cpu-baseline --size 3840x2160 --compact 1
 run cfg5_4k_spp16 --no-cpu-baseline --size 3840x2160 --spp 16 --steps 8 --warmup 2

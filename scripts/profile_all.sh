@@ -4,6 +4,8 @@
 R=${1:-r02}
 bash scripts/profile.sh ${R}_1080p                                  && \
 bash scripts/profile.sh ${R}_1080p_onekernel --one-kernel           && \
+bash scripts/profile.sh ${R}_1080p_queue --shadow-queue             && \
+bash scripts/profile.sh ${R}_4k_queue --size 3840x2160 --shadow-queue && \
 bash scripts/profile.sh ${R}_4k --size 3840x2160                    && \
 bash scripts/profile.sh ${R}_4k_compact --size 3840x2160 --compact 1 && \
 bash scripts/profile.sh ${R}_1080p_display --display                && \

@@ -435,24 +435,32 @@ __device__ __forceinline__ uint32_t *hit_count(const RenderParams &P, uint32_t s
 
 // The shadow march of Compute.hlsl:214-230 for a lane whose RayState holds the shading step's results (pos, dir, prox,
 // dist; n = 0).  Every exit is black (:223, :229) except the one that reaches the light (:215-219): returns that.
+// One loop exit, as in the primary march: the three tests are combined without a branch (the gradient of :221-223 only for
+// the lanes close to the surface), and which one ended the march is read off the lane's final state afterwards.
 template <bool COUNT, class CursorT>
 __device__ __forceinline__ bool shadow_march(const RenderParams &P, const FrameInfo &I, RayState &r, CursorT &c,
                                              unsigned long long &cn, unsigned long long &cs)
 {
-    while (r.n < 40 && r.prox > -I.margin) {
-        // any(pos < 0) || any(pos > 1) as min3 / max3: v_min3_f32 and v_max3_f32 skip NaN operands, and a
-        // comparison with NaN is false either way, so the two forms agree for every input
+    // any(pos < 0) || any(pos > 1) as min3 / max3: v_min3_f32 and v_max3_f32 skip NaN operands, and a
+    // comparison with NaN is false either way, so the two forms agree for every input
+    auto header = [&]() { return r.n < 40 && r.prox > -I.margin; };
+    auto at_light = [&]() {
         const float lo = __builtin_fminf(__builtin_fminf(r.px, r.py), r.pz), hi = __builtin_fmaxf(__builtin_fmaxf(r.px, r.py), r.pz);
-        if (r.prox > r.dist || lo < 0.0f || hi > 1.0f) return true;
-        if (r.prox < I.margin) {
+        return r.prox > r.dist || lo < 0.0f || hi > 1.0f;
+    };
+    for (;;) {
+        bool go = ((int)header() & (int)!at_light()) != 0;
+        if (go && r.prox < I.margin) {
             float gx, gy, gz;
             gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
-            if (dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f) break;
+            go = !(dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f);
         }
+        if (!go) break;
         uint32_t reads = march_step(P, I, r, c, nullptr, 0);
         if (COUNT) { cn += reads; cs += 1; }
     }
-    return false;
+    asm volatile("" : "+v"(r.prox), "+v"(r.n));       // (see k_march: keeps the exit reasons out of the loop)
+    return header() && at_light();
 }
 
 // QUEUE = false (the default): the wave marches its own shadow rays after the shading step.  QUEUE = true
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     // one more exec-mask per exit reason through every iteration)
     asm volatile("" : "+v"(r.prox), "+v"(r.n));
     const int end = !live ? 3 : marching() ? 2 : 1;   // 1 on the surface (or out of steps), 2 escaped, 3 no pixel
-    if (P.tile_cost) {                                  // iterations this wave ran = its longest lane
+    if (P.tile_cost) {                                  // iterations this wave's primary loop ran = its longest lane
         int m = live ? r.n : 0;
         for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
         if (lane == 0) P.tile_cost[(size_t)f * P.n_tiles + tile] = (uint16_t)m;
@@ -545,6 +553,11 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
             if (lit) dst.grey(lidx, r.angle / (r.dist * r.dist) * I.k_strength, (float)(r.base + r.n));
             else dst.black(lidx, (float)(r.base + r.n));
             if (COUNT) ct = (unsigned long long)(r.base + r.n);
+        }
+        if (P.tile_cost) {                              // ... and, in the high byte, the iterations of its shadow loop
+            int m = shadow ? r.n : 0;
+            for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+            if (lane == 0) P.tile_cost[(size_t)f * P.n_tiles + tile] |= (uint16_t)(m << 8);
         }
         if (COUNT) flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, 0u);
         return;
