@@ -1099,18 +1099,8 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
                 const float dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
                 r.dx = L0; r.dy = L1; r.dz = L2; r.n = 0; r.phase = PH_SHADOW;
                 if (COUNT) cr += 1;
-                bool lit = false;
-                while (r.n < 40 && r.prox > -margin) {
-                    if (r.prox > dist || (r.px < 0.0f || r.py < 0.0f || r.pz < 0.0f) ||
-                        (r.px > 1.0f || r.py > 1.0f || r.pz > 1.0f)) { lit = true; break; }
-                    if (r.prox < margin) {
-                        float q0, q1, q2;
-                        gradient(c.cell(), r.px, r.py, r.pz, q0, q1, q2);
-                        if (dot3(q0, q1, q2, L0, L1, L2) < 0.0f) break;
-                    }
-                    uint32_t reads = march_step(P, I, r, c, nullptr, 0);
-                    if (COUNT) { cn += reads; cs += 1; }
-                }
+                r.dist = dist;
+                const bool lit = shadow_march<COUNT>(P, I, r, c, cn, cs);
                 shadow_steps = (uint32_t)r.n;
                 if (lit) e_light = T * (P.pt_albedo * (angle / (dist * dist) * I.k_strength));
             }
