@@ -483,6 +483,9 @@ def main():
             mode = "one-kernel" if mode == "default" else mode + ":one-kernel"     # k_plain / k_path: other kernels, other counters
         if sharded:
             mode += ":sharded"                         # other kernels instances (wire pixels, bands): no PMC pass of its own
+        # ... and of the same grid (SDFHIP_TOP_GRID_LEVEL / _SPLIT change it): "grid9" dense, "grid8+blocks" split
+        lvl, gbytes = scene.top_grid_level, scene.top_grid_bytes
+        mode += f":grid{lvl}" + ("+blocks" if lvl and gbytes > (16 << (3 * lvl)) and pt is None else "")
         pmc = load_pmc(f"{W}x{H}:{scene_name}:{mode}") if world == 1 else None
         roof = roofline(sec_per_step, own_bytes_rank, ref_bytes_rank, pmc, copy_gbs)
         # what the fraction divides by, so that it can be recomputed from profiles/: per_frame / time_ms / peak.  kernel_ms is

@@ -1,10 +1,13 @@
 """python scripts/summarise_all.py r02  -- condense every gpurun_out/prof_<round>_* into profiles/ (see summarise_profile.py)."""
 import subprocess, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r02"
-for tag, key in [("1080p", "1920x1080:dragon_standin_d9:default"), ("1080p_onekernel", "1920x1080:dragon_standin_d9:one-kernel"),
-                 ("1080p_queue", "1920x1080:dragon_standin_d9:default:shadow-queue"), ("4k_queue", "3840x2160:dragon_standin_d9:default:shadow-queue"),
-                 ("4k", "3840x2160:dragon_standin_d9:default"), ("4k_compact", "3840x2160:dragon_standin_d9:compact"),
-                 ("1080p_display", "1920x1080:dragon_standin_d9:display"), ("1080p_d10", "1920x1080:dragon_standin_d10:default"),
-                 ("cfg5", "3840x2160:dragon_standin_d9:spp16")]:
+G = "grid8+blocks"          # the default grid of both stand-in scenes: coarse level 8 + blocks (bench.py's key names it)
+for tag, key in [("1080p", f"1920x1080:dragon_standin_d9:default:{G}"), ("1080p_onekernel", f"1920x1080:dragon_standin_d9:one-kernel:{G}"),
+                 ("1080p_queue", f"1920x1080:dragon_standin_d9:default:shadow-queue:{G}"), ("4k_queue", f"3840x2160:dragon_standin_d9:default:shadow-queue:{G}"),
+                 ("4k", f"3840x2160:dragon_standin_d9:default:{G}"), ("4k_compact", f"3840x2160:dragon_standin_d9:compact:{G}"),
+                 ("1080p_display", f"1920x1080:dragon_standin_d9:display:{G}"), ("1080p_d10", f"1920x1080:dragon_standin_d10:default:{G}"),
+                 ("cfg5", "3840x2160:dragon_standin_d9:spp16:grid8"),
+                 ("1080p_dense", "1920x1080:dragon_standin_d9:default:grid9"), ("4k_dense", "3840x2160:dragon_standin_d9:default:grid9"),
+                 ("1080p_split7", "1920x1080:dragon_standin_d9:default:grid7+blocks"), ("1080p_split6", "1920x1080:dragon_standin_d9:default:grid6+blocks")]:
     subprocess.run([sys.executable, "scripts/summarise_profile.py", f"{R}_{tag}", key], stdout=subprocess.DEVNULL, check=False)
     print(tag, "done")

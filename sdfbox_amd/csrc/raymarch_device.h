@@ -62,7 +62,7 @@ struct RenderParams {
     const TopCell *top;        // top grid (cursor-stack kernels) of level top_level, or null
     int32_t top_level;
     // split grid (CUR_STACK_SPLIT kernels): a cell of `top` whose node is internal has level 15 and names,
-    // in `children`, a block of `fine`: the 8^fine_bits cells of the next fine_bits levels below it
+    // in `children`, the first cell of a block of `fine`: the 8^fine_bits cells of the next fine_bits levels below it
     int32_t fine_bits;
     int32_t fine_order;        // see GridRef
     const TopCell *fine;
@@ -515,7 +515,7 @@ __device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT> &c, const GridRe
             const int FB = g.fine_bits, sh2 = sh - FB;
             const uint32_t m = (1u << FB) - 1u;
             const uint32_t local = fine_cell_index(((uint32_t)Dx >> sh2) & m, ((uint32_t)Dy >> sh2) & m, ((uint32_t)Dz >> sh2) & m, FB, g.fine_order);
-            e = reinterpret_cast<const uint4 *>(g.fine)[((size_t)e.w << (3 * FB)) + local];
+            e = reinterpret_cast<const uint4 *>(g.fine)[e.w + local];      // children = the block's first cell (32-bit: < 2^31 fine cells)
         }
     }
     c.s = e.x;                                    // LM - level of the leaf, | FLAT_BIT
@@ -541,7 +541,7 @@ __device__ __forceinline__ void load_cell_units(CursorFT<false, SPLIT> &c, const
             c.loads++;
             const uint32_t m = (1u << FB) - 1u;
             const uint32_t local = fine_cell_index((uint32_t)Dx & m, (uint32_t)Dy & m, (uint32_t)Dz & m, FB, g.fine_order);
-            e = reinterpret_cast<const uint4 *>(g.fine)[((size_t)e.w << (3 * FB)) + local];
+            e = reinterpret_cast<const uint4 *>(g.fine)[e.w + local];
         }
     }
     c.s = e.x; c.v0 = e.y; c.v1 = e.z;

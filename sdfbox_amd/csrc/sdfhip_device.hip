@@ -256,6 +256,9 @@ constexpr int MAX_TOP_LEVEL = 8;
 #ifndef FULL_GRID_SHARE
 #define FULL_GRID_SHARE 64          // a grid as deep as the tree may take 1/FULL_GRID_SHARE of the device's memory
 #endif
+#ifndef DENSE_GRID_MAX_BYTES
+#define DENSE_GRID_MAX_BYTES (512ull << 20)   // ... and by default no more than this (depth <= 8): deeper trees get a split grid
+#endif
 
 }  // namespace sdfhip
 
@@ -368,7 +371,7 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
 }
 
 // A split grid over the scene's records: dense cells of level C whose internal cells (level word 15) name, in `children`,
-// a block of 8^FB fine cells; built on s->stream.  false (nothing allocated) when memory or the byte limit say no.
+// the first cell of a block of 8^FB fine cells; built on s->stream.  false (nothing allocated) when memory or the byte limit say no.
 static bool build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_t max_fine_bytes, TopCell **coarse_out, TopCell **fine_out,
                              uint64_t *fine_bytes_out)
 {
@@ -392,7 +395,9 @@ static bool build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_t
             }
         const size_t nblocks = block_node.size();
         const uint64_t fine_bytes = (uint64_t)(nblocks << (3 * FB)) * sizeof(TopCell);
-        if (fine_bytes > max_fine_bytes) break;
+        if (fine_bytes > max_fine_bytes || (nblocks << (3 * FB)) >= ((size_t)1 << 31)) break;
+        for (size_t i = 0; i < ncell; i++)               // a cell names its block by the block's first fine cell
+            if (coarse[i].level == 15u) coarse[i].children = (int32_t)((uint32_t)coarse[i].children << (3 * FB));
         if (nblocks) {
             if (hipMalloc((void **)&d_fine, fine_bytes) != hipSuccess) break;
             if (hipMalloc((void **)&d_block_node, nblocks * 4) != hipSuccess) break;
@@ -471,12 +476,19 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     hipLaunchKernelGGL(k_fuse, dim3(blocks), dim3(256), 0, s->stream, (const int2 *)d_s,
                        (const uint2 *)d_v, s->nodes, n);
     if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_fuse launch");
-    // Top grid.  As deep as the tree when that fits 1/64 of the device's memory (4.5 GB of 288: trees up
-    // to depth 9, 2.1 GB) -- then every leaf is in the grid and a find is one load.  Otherwise at most
-    // MAX_TOP_LEVEL and no larger than the tree's own records (16 bytes per cell and per node; at least
-    // 64 KB).  SDFHIP_TOP_GRID_LEVEL overrides (0 = none).
+    // Top grid.  Dense and as deep as the tree -- every leaf in the grid, a find is one load -- for trees of depth
+    // <= 8 (268 MB).  A deeper tree gets a split grid (below): the dense grid of a depth-9 tree is 2.1 GB, a frame
+    // touches a quarter of it, and two 1080p frames in flight are HBM-bound on that traffic; the split grid moves a
+    // third of the bytes for 14 % more instructions -- faster where the dense grid is HBM-bound (1080p pipelined
+    // 0.092 vs 0.097 ms, 0.097 vs 0.106 with a moving camera), 2-3 % slower where it is not (4K, one frame alone),
+    // in a third of the memory.  SDFHIP_TOP_GRID_LEVEL=<depth> asks for the dense grid (it must fit 1/64 of the
+    // device's memory), smaller values for a partial top grid (cursor-stack kernels): at most MAX_TOP_LEVEL and by
+    // default no larger than the tree's own records (16 bytes per cell and per node; at least 64 KB); 0 = none.
     int top_level = 0;
-    if (depth >= 1 && depth <= 10 && (sizeof(TopCell) << (3 * depth)) <= prop.totalGlobalMem / FULL_GRID_SHARE) {
+    const uint64_t dense_bytes = depth <= 10 ? ((uint64_t)sizeof(TopCell) << (3 * depth)) : ~0ull;
+    const char *env_level = getenv("SDFHIP_TOP_GRID_LEVEL");
+    const bool dense_asked = env_level && atoi(env_level) >= (int)depth && dense_bytes <= prop.totalGlobalMem / FULL_GRID_SHARE;
+    if (depth >= 1 && depth <= 10 && (dense_bytes <= DENSE_GRID_MAX_BYTES || dense_asked)) {
         top_level = (int)depth;
     } else {
         const size_t budget = (size_t)n * 16 > ((size_t)1 << 16) ? (size_t)n * 16 : ((size_t)1 << 16);
@@ -618,7 +630,7 @@ int launch_pt(sdfhip_scene *s, sdfhip_scene::Scratch *sc, dim3 grid, hipStream_t
         // the queue this level fills was drained by the level before it
         if (b > 0 && (e = hipMemsetAsync(P.pt_ctl + (size_t)((b & 1u) ^ 1u) * HIT_QUEUES * 32, 0, HIT_QUEUES * 32 * sizeof(uint32_t), st)) != hipSuccess)
             return fail(SDFHIP_ERR_DEVICE, "render_path: hipMemsetAsync failed: %s", hipGetErrorString(e));
-        if (CUR == CUR_STACK_FULL && s->d_top2) {
+        if (s->d_top2) {
             // incoherent rays: the same cells through the split grid (the cursor does not depend on the grid it was filled from)
             RenderParams P2 = P;
             P2.top = s->d_top2; P2.top_level = s->top2_level; P2.fine = s->d_fine2; P2.fine_bits = s->fine2_bits; P2.fine_order = s->fine2_order;
@@ -817,12 +829,14 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         P.pt_t = reinterpret_cast<float *>(sc->pt_buf + 2 * qbytes + ebytes);
         P.pt_n = reinterpret_cast<uint32_t *>(sc->pt_buf + 2 * qbytes + ebytes + tbytes);
         P.pt_ctl = sc->ctl + sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS;
-        // beside a dense full-depth grid, the bounce levels read a split grid of the same cells (built now, once)
-        if (cur == CUR_STACK_FULL && !s->scatter_tried) {
+        // beside the scene's own grid, the bounce levels read a split grid of the same cells with larger, sub-cube-ordered
+        // blocks (built now, once) -- unless the scene's grid already has that coarse level
+        if (!s->scatter_tried) {
             s->scatter_tried = 1;
             const char *env = getenv("SDFHIP_SCATTER_GRID");
             const int FB = env ? atoi(env) : 3;                                     // blocks of 8^FB fine cells; 0 = off
-            if (FB >= 1 && FB <= 4 && (int)s->depth - FB >= 1 && (int)s->depth - FB <= MAX_TOP_LEVEL) {
+            if (FB >= 1 && FB <= 4 && (int)s->depth - FB >= 1 && (int)s->depth - FB <= MAX_TOP_LEVEL &&
+                !(cur == CUR_STACK_SPLIT && s->top_level == (int)s->depth - FB)) {
                 uint64_t fbytes = 0;
                 s->fine2_order = (FB >= 2 && !(getenv("SDFHIP_SCATTER_ORDER") && atoi(getenv("SDFHIP_SCATTER_ORDER")) == 0)) ? 1 : 0;
                 if (build_split_grid(s, (int)s->depth - FB, FB, s->fine2_order, s->total_mem / 32, &s->d_top2, &s->d_fine2, &fbytes)) {
