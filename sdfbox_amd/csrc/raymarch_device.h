@@ -450,7 +450,8 @@ __device__ __forceinline__ uint32_t find_s(CursorS &c, const NodeRec *__restrict
 // dependent load for the positions near the surface, a fraction of the memory of a dense grid of the
 // tree's depth: the form for trees of depth 10-12).
 constexpr uint32_t FLAT_BIT = 0x80000000u;
-template <bool EXACT, bool SPLIT>
+// ORDERED: honour GridRef::fine_order (the path tracer's scatter grid); the other kernels' grids are in x-y-z order
+template <bool EXACT, bool SPLIT, bool ORDERED = false>
 struct CursorFT {
     typedef Scaled Pos;
     static constexpr int32_t ROOT_MARK = 0x40000000;
@@ -500,8 +501,8 @@ struct CursorFT {
 
 // One lookup in a grid as deep as the tree (dense, or coarse level + fine blocks): the leaf of the clamped
 // cell coordinates D, into the cursor.  Returns s of that leaf.
-template <bool EXACT, bool SPLIT>
-__device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT> &c, const GridRef &g, int32_t Dx, int32_t Dy, int32_t Dz)
+template <bool EXACT, bool SPLIT, bool ORDERED>
+__device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT, ORDERED> &c, const GridRef &g, int32_t Dx, int32_t Dy, int32_t Dz)
 {
     const int TG = g.level, sh = LM - TG;
     uint4 e = reinterpret_cast<const uint4 *>(g.top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
@@ -514,7 +515,7 @@ __device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT> &c, const GridRe
             c.loads++;
             const int FB = g.fine_bits, sh2 = sh - FB;
             const uint32_t m = (1u << FB) - 1u;
-            const uint32_t local = fine_cell_index(((uint32_t)Dx >> sh2) & m, ((uint32_t)Dy >> sh2) & m, ((uint32_t)Dz >> sh2) & m, FB, g.fine_order);
+            const uint32_t local = fine_cell_index(((uint32_t)Dx >> sh2) & m, ((uint32_t)Dy >> sh2) & m, ((uint32_t)Dz >> sh2) & m, FB, ORDERED ? g.fine_order : 0);
             e = reinterpret_cast<const uint4 *>(g.fine)[e.w + local];      // children = the block's first cell (32-bit: < 2^31 fine cells)
         }
     }
@@ -526,8 +527,8 @@ __device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT> &c, const GridRe
 }
 
 // The same lookup with D in units of the grid's full level (level, + fine_bits for a split grid): no shifts.
-template <bool SPLIT>
-__device__ __forceinline__ void load_cell_units(CursorFT<false, SPLIT> &c, const GridRef &g, int32_t Dx, int32_t Dy, int32_t Dz)
+template <bool SPLIT, bool ORDERED>
+__device__ __forceinline__ void load_cell_units(CursorFT<false, SPLIT, ORDERED> &c, const GridRef &g, int32_t Dx, int32_t Dy, int32_t Dz)
 {
     uint4 e;
     c.loads++;
@@ -540,8 +541,9 @@ __device__ __forceinline__ void load_cell_units(CursorFT<false, SPLIT> &c, const
         if (e.x == 15u) {
             c.loads++;
             const uint32_t m = (1u << FB) - 1u;
-            const uint32_t local = fine_cell_index((uint32_t)Dx & m, (uint32_t)Dy & m, (uint32_t)Dz & m, FB, g.fine_order);
+            const uint32_t local = fine_cell_index((uint32_t)Dx & m, (uint32_t)Dy & m, (uint32_t)Dz & m, FB, ORDERED ? g.fine_order : 0);
             e = reinterpret_cast<const uint4 *>(g.fine)[e.w + local];
+            asm volatile("" : "+v"(e.y), "+v"(e.z), "+v"(e.w));   // the same shape as the coarse load: one register tuple for both
         }
     }
     c.s = e.x; c.v0 = e.y; c.v1 = e.z;
@@ -576,8 +578,8 @@ __device__ __forceinline__ int on_face_choice(int32_t cax, int32_t cay, int32_t 
 // wave-uniform) -- which of the two adjacent cells does the reference's descent pick (the same A/B
 // rule as find_s).  The ascent count k feeds the algorithmic read count only.  One place updates the
 // cursor, so the two branches join on D and k, not on the cursor.
-template <bool EXACT, bool SPLIT>
-__device__ __forceinline__ uint32_t find_full(CursorFT<EXACT, SPLIT> &c, const GridRef &g,
+template <bool EXACT, bool SPLIT, bool ORDERED>
+__device__ __forceinline__ uint32_t find_full(CursorFT<EXACT, SPLIT, ORDERED> &c, const GridRef &g,
                                               int32_t Dx, int32_t Dy, int32_t Dz, bool gx, bool gy, bool gz,
                                               const bool any_on_grid)
 {
@@ -623,8 +625,8 @@ __device__ __forceinline__ int32_t cvt_floor(float u)
 //     a = 0, s = LM: the descent restarts at level 0 and "same cell above level 0" holds for 0 <= D < 2^LM) -- what the
 //     plain lookup does, so the first step skips the lattice test.  (The reference's default camera sits at x = y = 0.5:
 //     without this every pixel's first step takes the exact rule.)
-template <bool SPLIT, bool FRESH>
-__device__ __forceinline__ uint32_t find_units(CursorFT<false, SPLIT> &c, const GridRef &g, float px, float py, float pz, Scaled &u)
+template <bool SPLIT, bool FRESH, bool ORDERED>
+__device__ __forceinline__ uint32_t find_units(CursorFT<false, SPLIT, ORDERED> &c, const GridRef &g, float px, float py, float pz, Scaled &u)
 {
     const int F = g.level + (SPLIT ? g.fine_bits : 0), sh = LM - F;
     const float unit = __uint_as_float((uint32_t)(127 + F) << 23), top = unit - 1.0f;      // 2^F, and the last cell
@@ -647,12 +649,12 @@ __device__ __forceinline__ uint32_t find_units(CursorFT<false, SPLIT> &c, const 
     load_cell_units(c, g, Dx, Dy, Dz);
     return 0;
 }
-template <bool SPLIT>
-__device__ __forceinline__ uint32_t find(CursorFT<false, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
+template <bool SPLIT, bool ORDERED>
+__device__ __forceinline__ uint32_t find(CursorFT<false, SPLIT, ORDERED> &c, const NodeRec *__restrict__, const GridRef &g,
                                          uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
                                          Scaled &u)
 {
-    return find_units<SPLIT, false>(c, g, px, py, pz, u);
+    return find_units<SPLIT, false, ORDERED>(c, g, px, py, pz, u);
 }
 // find() for a cursor straight from reset(): the same as find() for every cursor kind but the one above
 template <class CursorT, class Pos>
@@ -661,16 +663,16 @@ __device__ __forceinline__ uint32_t find_fresh(CursorT &c, const NodeRec *__rest
 {
     return find(c, nodes, g, n, stack, stride, px, py, pz, u);
 }
-template <bool SPLIT>
-__device__ __forceinline__ uint32_t find_fresh(CursorFT<false, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
+template <bool SPLIT, bool ORDERED>
+__device__ __forceinline__ uint32_t find_fresh(CursorFT<false, SPLIT, ORDERED> &c, const NodeRec *__restrict__, const GridRef &g,
                                                uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
                                                Scaled &u)
 {
-    return find_units<SPLIT, true>(c, g, px, py, pz, u);
+    return find_units<SPLIT, true, ORDERED>(c, g, px, py, pz, u);
 }
 // The counting kernels: NaN must match no cell (ascents up to the root count as reads), see axis_a.
-template <bool SPLIT>
-__device__ __forceinline__ uint32_t find(CursorFT<true, SPLIT> &c, const NodeRec *__restrict__, const GridRef &g,
+template <bool SPLIT, bool ORDERED>
+__device__ __forceinline__ uint32_t find(CursorFT<true, SPLIT, ORDERED> &c, const NodeRec *__restrict__, const GridRef &g,
                                          uint32_t, int32_t *__restrict__, uint32_t, float px, float py, float pz,
                                          Scaled &u)
 {
@@ -681,8 +683,8 @@ __device__ __forceinline__ uint32_t find(CursorFT<true, SPLIT> &c, const NodeRec
 }
 // u = the position in the cursor's units, 2^-(LM - sh) (find() leaves it so): with a = the anchor in the same units and
 // k = s - sh, (u - a) * 2^-k == (pos - lower) * 2^level bit for bit -- rounding is invariant under power-of-two scaling.
-template <bool EXACT, bool SPLIT>
-__device__ __forceinline__ float sample_after_find(const CursorFT<EXACT, SPLIT> &c, const Scaled &u, float, float, float)
+template <bool EXACT, bool SPLIT, bool ORDERED>
+__device__ __forceinline__ float sample_after_find(const CursorFT<EXACT, SPLIT, ORDERED> &c, const Scaled &u, float, float, float)
 {
     if (c.s & FLAT_BIT) return __uint_as_float(c.v1);                            // see CursorFT
     const float scale = __uint_as_float((c.s + (uint32_t)(127 - LM)) << 23);     // 2^-level = 2^(s - LM)

@@ -39,6 +39,9 @@ template <int CUR, bool COUNT> struct CursorOf { typedef CursorG type; };
 template <bool COUNT> struct CursorOf<CUR_STACK, COUNT> { typedef CursorS type; };
 template <bool COUNT> struct CursorOf<CUR_STACK_FULL, COUNT> { typedef CursorFT<COUNT, false> type; };
 template <bool COUNT> struct CursorOf<CUR_STACK_SPLIT, COUNT> { typedef CursorFT<COUNT, true> type; };
+// the bounce kernels of the path tracer may read a split grid whose blocks are stored sub-cube by sub-cube (GridRef::fine_order)
+template <int CUR, bool COUNT> struct ScatterCursorOf { typedef typename CursorOf<CUR, COUNT>::type type; };
+template <bool COUNT> struct ScatterCursorOf<CUR_STACK_SPLIT, COUNT> { typedef CursorFT<COUNT, true, true> type; };
 
 // lane states: marching (primary / shadow), march over and shading pending, no pixel
 enum { PH_PRIMARY = 0, PH_SHADOW = 1, PH_SHADE = 2, PH_IDLE = 3, PH_DONE = 4 };   // DONE: idle, colour waiting in LDS
@@ -1045,7 +1048,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_pt_primary(RenderP
 template <int CUR, bool COUNT>
 __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderParams P)
 {
-    typedef typename CursorOf<CUR, COUNT>::type CursorT;
+    typedef typename ScatterCursorOf<CUR, COUNT>::type CursorT;
     const uint32_t lane = threadIdx.x, b = P.pt_level, qin = b & 1u, qout = qin ^ 1u;
     FrameInfo I = P.frames[0];
     asm volatile("" : "+s"(I.margin), "+s"(I.margin2), "+s"(I.limit));
