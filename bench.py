@@ -492,7 +492,8 @@ def main():
         # the HIP-event time around one frame's launches on their stream (k_march; overlapping the other frame in
         # flight), and frac_over_kernel_ms the same fraction over that longer time
         roof.update({"time_ms": round(sec_per_step * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch,
-                     "frac_over_kernel_ms": round(roof["frac"] * sec_per_step * 1e3 * frames_per_launch / kernel_ms, 4) if kernel_ms > 0 else None})
+                     "frac_over_kernel_ms": round(roof["frac"] * sec_per_step * 1e3 * frames_per_launch / kernel_ms, 4)
+                     if kernel_ms > 0 and roof["frac"] is not None else None})
         out = {
             "metric": "Mray/s (primary rays; frame W*H / time per frame)",
             "value": round(W * H * max(1, args.spp) / sec_per_step / 1e6, 2),
@@ -694,7 +695,7 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
     system, not on HBM: the lanes of a wave mostly ask for the same few cells, which L1 serves once, so it is not
     bounded by 8 TB/s (at 4K it reads 9 TB/s).  The reference algorithm's bytes (8 B per node visit of
     find(), Compute.hlsl:88-108) are the work-equivalent rate: the kernel does not perform those loads (one grid lookup
-    replaces up to nine node visits)."""
+    replaces up to nine node visits).  Where that demand exceeds 8 TB/s, `frac` is null (`demand_over_hbm_peak` holds the ratio)."""
     cands = {}
     traffic = None
     if pmc:
@@ -711,6 +712,10 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
         c["achieved"] = round(c["achieved"], 1)
     name = max(cands, key=lambda k: cands[k]["frac"])
     b = cands[name]
+    if not measured and b["frac"] > 1.0:
+        # a demand above 8 TB/s is served by L1 / L2, not by HBM: it is not a fraction of any roof, so none is reported
+        b["demand_over_hbm_peak"] = b["frac"]
+        b["frac"] = None
     return {
         "bound": "hbm" if name.startswith("hbm") else "valu",
         "binding": name,

@@ -88,6 +88,9 @@ def test_roofline_reports_only_measured_fractions():
     assert r4k["binding"] == "valu" and r4k["bound"] == "valu" and r4k["frac"] <= 1.0
     none = bench.roofline(0.388e-3, 3.62e9, 15.7e9, None, None)      # the demand of 64 lanes asking for the same cells is not an HBM figure
     assert none["binding"] == "hbm-algorithmic" and none["traffic"] is None and not none["frac_is_measured_against_a_ceiling"]
+    assert none["frac"] is None and none["candidates"]["hbm-algorithmic"]["demand_over_hbm_peak"] > 1.0     # 9.3 TB/s of demand is no HBM fraction
+    small = bench.roofline(0.388e-3, 1.0e9, 4.0e9, None, None)
+    assert 0.0 < small["frac"] <= 1.0 and not small["frac_is_measured_against_a_ceiling"]
     # PMC figures are reported only for the build they were measured on
     assert bench.load_pmc("no such workload") is None
     import json as _json
