@@ -1,22 +1,23 @@
-// The ray-march kernels of libsdfhip.so (gfx950): k_plain, k_compact, k_path and the pieces
-// of Compute.hlsl's main() they are built from.  Device building blocks (cursors, find,
+// The ray-march kernels of libsdfhip.so (gfx950): k_march (the default), k_plain, k_compact, the path-traced pipeline
+// and the pieces of Compute.hlsl's main() they are built from.  Device building blocks (cursors, find,
 // sampling): raymarch_device.h.  Host side (launches, C ABI): sdfhip_device.hip.
 //
 // Replaces: SdfBox/Shaders/Compute.hlsl:180-231 main() and, fused into the epilogue,
 // SdfBox/Shaders/DisplayFrag.hlsl:16-24.
 //
 // Kernel structure:
-//   * one lane per pixel, 8x8 pixels per 64-lane wavefront;
-//   * the primary march, the shading step and the shadow march of Compute.hlsl:194-230 run
-//     as ONE per-lane state machine around a single find + sample body, so lanes in
-//     different phases share the instruction stream instead of serialising two loops;
-//   * k_plain: one 8x8 wave tile per workgroup; blockIdx is remapped so that XCD k (own L2)
-//     renders tile rows k, k+8, ...: every XCD sees the same mix of sky and object rows
-//     (balance) while whole rows of neighbouring tiles share an L2;
+//   * one lane per pixel, 8x8 pixels per 64-lane wavefront, one wave per workgroup; blockIdx is remapped so that
+//     XCD k (own L2) renders tile rows k, k+8, ...: every XCD sees the same mix of sky and object rows (balance)
+//     while whole rows of neighbouring tiles share an L2;
+//   * k_march (trees behind a full-depth or split grid): the primary march, the shading step and the shadow march of
+//     Compute.hlsl:194-230 as three wave-converged phases -- two tight loops with one exit each and the shading between
+//     them, once per wave;
+//   * k_plain (other trees; A/B knob): the three phases as ONE per-lane state machine around a single find + sample body;
 //   * k_compact: persistent waves pull 8x8 tiles from per-XCD queues and refill finished
 //     lanes by ballot + prefix count (wavefront ray compaction), with refill and shading
 //     batched;
-//   * k_path: the path-traced mode of BASELINE config 5 (defined by the oracle).
+//   * k_pt_primary / k_pt_bounce / k_pt_resolve (and the one-kernel k_path): the path-traced mode of BASELINE config 5
+//     (defined by the oracle).
 #pragma once
 #include "raymarch_device.h"
 
@@ -351,26 +352,28 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
 }
 
 // =====================================================================================
-// The default pipeline for trees behind a full-depth or split grid: two kernels per frame.
+// The default kernel for trees behind a full-depth or split grid: k_march.
 //
-//   k_march   one lane per pixel, one 8x8 tile per wave, the plain kernel's XCD-interleaved tile rows.
-//             Runs ONLY the primary march of Compute.hlsl:194-203 -- a loop of loop-header test, escape
-//             test, find, sample, advance with no phase logic, no shading code and no stores in it.
-//             After the loop the wave is converged again: sky pixels store their colour (coalesced),
-//             and the lanes that ended on the surface append their state -- position, prox, step
-//             count, cursor -- to a queue: ballot + mbcnt give the slots, one atomic per wave.
-//             (In the same converged epilogue the hit lanes take the shading step of Compute.hlsl:205-213 together; a
-//             pixel that faces away from the light is finished there, black, and only the others are queued.)
-//   k_shadow  one lane per queued shadow ray, 64 consecutive records per wave, every lane live from the first
-//             step: the shadow march of Compute.hlsl:214-230 as its own tight loop, then the pixel's colour.
+//   One lane per pixel, one 8x8 tile per wave, the plain kernel's XCD-interleaved tile rows.  Three phases, the wave
+//   converged between them:
+//     1. the primary march of Compute.hlsl:194-203 -- a loop of loop-header test, escape test, find, sample, advance with no
+//        phase logic, no shading code and no stores in it; one exit, the reason read off the lane's registers afterwards;
+//     2. sky pixels store their colour (coalesced); the lanes that ended on the surface take the shading step of
+//        Compute.hlsl:205-213 together; a pixel that faces away from the light is finished there, black;
+//     3. the others march their shadow rays (Compute.hlsl:214-230), again a tight loop with one exit, and store their colour.
 //
-// Why: in the one-kernel form (k_plain) the ~200 instructions of the shading step run whenever ANY
+// Why: in the one-kernel form of round 1 (k_plain) the ~200 instructions of the shading step run whenever ANY
 // lane of a wave finishes its primary march -- for three or four lanes at a time, about 130 000 times
 // per 1080p frame, a quarter of all VALU instructions issued -- and every iteration pays the phase
-// dispatch of a lane state machine.  Here shading runs once per wave, after its march loop, for all its hit
-// lanes together, the shadow rays march 64 to a wave, and both loops carry only their own exits.  Per-pixel arithmetic, its order and the cursor a pixel carries
-// from the primary into the shadow march are unchanged: images and counters stay bit-identical.
-// The records cost 64 bytes per shadow ray written and read once (17 MB per 1080p bench frame).
+// dispatch of a lane state machine.  Here shading runs once per wave, and both loops carry only their own exits.
+// Per-pixel arithmetic, its order and the cursor a pixel carries from the primary into the shadow march are unchanged:
+// images and counters stay bit-identical.
+//
+// A/B form (QUEUE = true, SDFHIP_TUNE_SHADOW_QUEUE): phase 3 appends the shadow rays -- position, prox, step count,
+// cursor, light direction -- to a queue (ballot + mbcnt give the slots, one atomic per wave) and a second kernel, k_shadow,
+// marches them 64 consecutive records to a wave.  Denser waves in the shadow loop (but a wave marches until its longest
+// ray ends: lanes on 52 % there), 64 bytes per shadow ray written and read once, a second launch: 0.107 ms per 1080p frame
+// against 0.090, 0.346 against 0.311 at 4K.  Measured, kept as a knob.
 // =====================================================================================
 enum { OUT_RGBA32F = 0, OUT_GAMMA8 = 1, OUT_HEAT8 = 2, OUT_WIRE = 3 };
 

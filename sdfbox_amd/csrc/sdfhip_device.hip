@@ -94,6 +94,63 @@ __global__ void k_fine_blocks(const NodeRec *__restrict__ nodes, const uint32_t 
     }
 }
 
+// Numbering the internal cells of a split grid's coarse level in cell order (an exclusive prefix sum of "is internal"),
+// on the device: chunks of 256 cells; count per chunk, scan of the chunk counts by one workgroup, then every internal cell
+// gets its block -- children = the block's first fine cell -- and the block its node.
+__global__ __launch_bounds__(256) void k_split_count(const TopCell *__restrict__ coarse, uint32_t ncell, uint32_t n_chunks,
+                                                     uint32_t *__restrict__ chunk_sums)
+{
+    __shared__ uint32_t part[4];
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const uint32_t i = c * 256u + threadIdx.x;
+        const bool internal = i < ncell && coarse[i].level == 15u;
+        const unsigned long long m = __ballot(internal);
+        if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) chunk_sums[c] = part[0] + part[1] + part[2] + part[3];
+        __syncthreads();
+    }
+}
+// exclusive scan of n values in place by ONE workgroup of 1024 threads; the total goes to v[n]
+__global__ __launch_bounds__(1024) void k_split_scan(uint32_t *__restrict__ v, uint32_t n)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n + 1023u) / 1024u, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += v[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {           // inclusive scan of the 1024 partial sums
+        const uint32_t add = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t x = v[i]; v[i] = run; run += x; }
+    if (threadIdx.x == 1023u) v[n] = part[1023];
+}
+__global__ __launch_bounds__(256) void k_split_assign(TopCell *__restrict__ coarse, uint32_t ncell, uint32_t n_chunks,
+                                                      const uint32_t *__restrict__ chunk_offsets, uint32_t *__restrict__ block_node, int FB)
+{
+    __shared__ uint32_t part[4];
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const uint32_t i = c * 256u + threadIdx.x, w = threadIdx.x >> 6;
+        const bool internal = i < ncell && coarse[i].level == 15u;
+        const unsigned long long m = __ballot(internal);
+        if ((threadIdx.x & 63u) == 0) part[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = chunk_offsets[c];
+        for (uint32_t k = 0; k < w; k++) before += part[k];
+        if (internal) {
+            const uint32_t id = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            block_node[id] = (uint32_t)coarse[i].children;              // the node the block hangs under
+            coarse[i].children = (int32_t)(id << (3 * FB));             // the block's first fine cell
+        }
+        __syncthreads();
+    }
+}
+
 // Gathered compact band buffers -> frame rows (rank-0 side of the tile gather).
 // Which rank rendered a band, and where: round robin (n == 0), or an explicit map with
 // src[band] = rank << 10 | local band (layouts with unequal shares).
@@ -376,33 +433,29 @@ static bool build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_t
                              uint64_t *fine_bytes_out)
 {
     const size_t ncell = (size_t)1 << (3 * C);
-    std::vector<TopCell> coarse(ncell);
-    uint32_t *d_block_node = nullptr;
+    const uint32_t n_chunks = (uint32_t)((ncell + 255) / 256);
+    uint32_t *d_block_node = nullptr, *d_chunks = nullptr;
     TopCell *d_coarse = nullptr, *d_fine = nullptr;
     bool ok = false;
     do {
         if (hipMalloc((void **)&d_coarse, ncell * sizeof(TopCell)) != hipSuccess) break;
+        if (hipMalloc((void **)&d_chunks, ((size_t)n_chunks + 1) * 4) != hipSuccess) break;
         const uint32_t tb = (uint32_t)((ncell + 255) / 256 < 8192 ? (ncell + 255) / 256 : 8192);
         hipLaunchKernelGGL(k_top_grid, dim3(tb), dim3(256), 0, s->stream, s->nodes, d_coarse, C, 2);
-        if (hipMemcpyAsync(coarse.data(), d_coarse, ncell * sizeof(TopCell), hipMemcpyDeviceToHost, s->stream) != hipSuccess) break;
-        if (hipStreamSynchronize(s->stream) != hipSuccess) break;
-        // number the internal cells in cell order on the host (deterministic) and point them at their blocks
-        std::vector<uint32_t> block_node;
-        for (size_t i = 0; i < ncell; i++)
-            if (coarse[i].level == 15u) {
-                block_node.push_back((uint32_t)coarse[i].children);
-                coarse[i].children = (int32_t)(block_node.size() - 1);
-            }
-        const size_t nblocks = block_node.size();
+        // number the internal cells in cell order (deterministic: a prefix sum) and count them
+        const uint32_t cb = n_chunks < 16384u ? n_chunks : 16384u;
+        hipLaunchKernelGGL(k_split_count, dim3(cb), dim3(256), 0, s->stream, d_coarse, (uint32_t)ncell, n_chunks, d_chunks);
+        hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, s->stream, d_chunks, n_chunks);
+        uint32_t nb32 = 0;
+        if (hipMemcpyAsync(&nb32, d_chunks + n_chunks, 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess) break;
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) break;
+        const size_t nblocks = nb32;
         const uint64_t fine_bytes = (uint64_t)(nblocks << (3 * FB)) * sizeof(TopCell);
         if (fine_bytes > max_fine_bytes || (nblocks << (3 * FB)) >= ((size_t)1 << 31)) break;
-        for (size_t i = 0; i < ncell; i++)               // a cell names its block by the block's first fine cell
-            if (coarse[i].level == 15u) coarse[i].children = (int32_t)((uint32_t)coarse[i].children << (3 * FB));
         if (nblocks) {
             if (hipMalloc((void **)&d_fine, fine_bytes) != hipSuccess) break;
             if (hipMalloc((void **)&d_block_node, nblocks * 4) != hipSuccess) break;
-            if (hipMemcpyAsync(d_block_node, block_node.data(), nblocks * 4, hipMemcpyHostToDevice, s->stream) != hipSuccess) break;
-            if (hipMemcpyAsync(d_coarse, coarse.data(), ncell * sizeof(TopCell), hipMemcpyHostToDevice, s->stream) != hipSuccess) break;
+            hipLaunchKernelGGL(k_split_assign, dim3(cb), dim3(256), 0, s->stream, d_coarse, (uint32_t)ncell, n_chunks, d_chunks, d_block_node, FB);
             const size_t nfine = nblocks << (3 * FB);
             const uint32_t fb = (uint32_t)((nfine + 255) / 256 < 16384 ? (nfine + 255) / 256 : 16384);
             hipLaunchKernelGGL(k_fine_blocks, dim3(fb), dim3(256), 0, s->stream, s->nodes, d_block_node, d_fine,
@@ -416,6 +469,7 @@ static bool build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_t
     } while (false);
     (void)hipGetLastError();
     if (d_block_node) (void)hipFree(d_block_node);
+    if (d_chunks) (void)hipFree(d_chunks);
     if (d_coarse) (void)hipFree(d_coarse);
     if (d_fine) (void)hipFree(d_fine);
     return ok;
