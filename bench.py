@@ -512,7 +512,7 @@ def main():
                 "workload": (f"{W}x{H} path trace, {args.spp} spp, 3 diffuse bounces, seed 0x5DFB0C5, " if pt is not None else
                              f"{W}x{H} primary-ray sphere trace + shadow march, ") + f"{scene_name} "
                             f"(N={od.Length} nodes, {od.nbytes / 1e6:.1f} MB), camera (0.5,0.5,-0.35) yaw 0.35 pitch -0.2" +
-                            (f", moving 1 degree per frame round the scene ({len(cams)} cameras)" if args.orbit > 0 else ""),
+                            (f", moving {360.0 / len(cams):g} degrees per frame round the scene ({len(cams)} cameras)" if args.orbit > 0 else ""),
                 "kernel": ("path/" if pt is not None else "") +
                           ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else "") +
                           ("" if (pt is not None or compact) else ", one kernel" if args.one_kernel else
