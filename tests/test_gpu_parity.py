@@ -653,6 +653,48 @@ def test_two_handles_render_concurrently(sb, oracle_mod, scenes):
     assert not errors, errors
 
 
+def test_tile_order_hook_permutes_work_not_results(sb, oracle_mod, scenes):
+    # sdfhip_debug_tile_order (the experiment hook of scripts/ab_tile_order.py and wave_iterations.py): workgroups take their
+    # tiles from a permutation -- the frame must not change -- and the kernel reports every tile's wave-iterations: the longest
+    # primary march of the tile in the low byte, the longest shadow march in the high byte
+    import ctypes
+    import torch
+    from sdfbox_amd._lib import lib, check
+    od = scenes["torus_d6"]
+    W, H = 200, 120                                 # 25 x 15 tiles; the grid has 8 * ceil(15 / 8) * 25 = 400 workgroups
+    cam = make_camera("closeup", W, H)
+    ref, _ = oracle_mod.render(od.Structs, od.Values, cam.State, W, H, nthreads=8)
+    tx, ty = (W + 7) // 8, (H + 7) // 8
+    nblk = 8 * ((ty + 7) // 8) * tx
+    rng = np.random.default_rng(5)
+    with sb.Scene(od) as sc:
+        costs = []
+        for perm in (None, rng.permutation(nblk).astype(np.uint32)):
+            cost = torch.zeros(tx * ty, dtype=torch.int16, device="cuda")
+            buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+            p = None
+            if perm is not None:
+                # a permutation of the workgroups' tiles: entries >= the tile count idle, every tile appears once
+                tiles = np.where(perm < tx * ty, perm, 0xFFFFFFFF).astype(np.uint32)
+                p = torch.from_numpy(tiles.view(np.int32)).cuda()
+            check(lib.sdfhip_debug_tile_order(sc._h, ctypes.c_void_p(p.data_ptr()) if p is not None else None, ctypes.c_void_p(cost.data_ptr())))
+            sc.DrawDevice(cam, W, H, buf.data_ptr())
+            torch.cuda.synchronize()
+            assert_frames_identical(buf.cpu().numpy(), ref, "tile order hook, " + ("permuted" if perm is not None else "default order"))
+            costs.append(cost.cpu().numpy().view(np.uint16).copy())
+        check(lib.sdfhip_debug_tile_order(sc._h, None, None))
+    assert (costs[0] == costs[1]).all()             # a tile's cost does not depend on which workgroup rendered it
+    primary, shadow = costs[0] & 0xFF, costs[0] >> 8
+    assert 1 <= primary.min() and primary.max() <= 100 and shadow.max() <= 40 and (shadow > 0).any()
+    # a tile without a hit pixel casts no shadow ray, and its primary loop ran as long as its longest pixel: alpha = steps
+    steps = ref[..., 3].astype(np.int64)
+    sky = ref[..., 2] == np.float32(0.2)
+    for t_ in range(tx * ty):
+        y0, x0 = (t_ // tx) * 8, (t_ % tx) * 8
+        if sky[y0:y0 + 8, x0:x0 + 8].all():
+            assert shadow[t_] == 0 and primary[t_] == steps[y0:y0 + 8, x0:x0 + 8].max(), t_
+
+
 def test_frames_in_flight_on_one_handle_do_not_share_scratch(sb, oracle_mod, scenes, gpu_scenes):
     # Several streams render on ONE scene handle at once, each its own camera (frames in flight): the hit
     # queues of the queued-shadow pipeline (SDFHIP_TUNE_SHADOW_QUEUE) and the tile queues of the compact kernel are per-stream scratch, so
