@@ -239,14 +239,16 @@ SDFHIP_API int sdfhip_scene_info(const sdfhip_scene *scene, uint32_t *n, uint32_
  * `level`, the record of the deepest node of that level or above that contains it, so that a
  * find() that restarts near the root takes one load instead of `level` dependent ones (results
  * and algorithmic counts are unchanged).  level = 0, bytes = 0: none (inconsistent or deeper than
- * 12 levels: generic kernel).  The level is the tree's depth when such a grid (16 bytes per cell, 8^level
- * cells) fits 1/64 of the device's memory -- every leaf is then in the grid and a find is one load.
- * Deeper trees (up to 12 levels) get a split grid: a coarse dense level (reported as `level`) whose
- * internal cells point at dense blocks of the remaining levels, built only where the tree is deep
- * (`bytes` counts both), if the blocks fit 1/16 of the memory; else a plain grid of at most level 8, no
- * larger than the tree's own records.  Environment, read at upload: SDFHIP_TOP_GRID_LEVEL (0..10) asks
- * for a plain grid of that level (0 = none), SDFHIP_TOP_GRID_SPLIT for a split grid with that coarse
- * level.  The grid shrinks by itself when memory is short. */
+ * 12 levels: generic kernel).  The level is the tree's depth for trees of depth <= 8 (16 bytes per cell,
+ * 8^level cells, <= 268 MB) -- every leaf is then in the grid and a find is one load.
+ * Deeper trees (up to 12 levels) get a split grid: a coarse dense level (reported as `level`; as deep as 8,
+ * no larger than the tree's own records) whose internal cells point at dense blocks of the remaining <= 4
+ * levels, built only where the tree is deep (`bytes` counts both; a find is one or two loads), if the blocks
+ * fit 1/16 of the memory; else a plain grid of at most level 8, no larger than the tree's own records.
+ * Environment, read at upload: SDFHIP_TOP_GRID_LEVEL (0..10) asks for a plain grid of that level (0 = none;
+ * the tree's depth = the dense full-depth grid, if it fits 1/64 of the memory: 2.1 GB at depth 9),
+ * SDFHIP_TOP_GRID_SPLIT for a split grid with that coarse level.  The grid shrinks by itself when memory is
+ * short. */
 SDFHIP_API int sdfhip_scene_top_grid(const sdfhip_scene *scene, int32_t *level, uint64_t *bytes);
 
 /* Replaces: Program.Draw's UpdateBuffer(info) + DispatchSized(W, H, 1),
