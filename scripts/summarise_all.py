@@ -8,6 +8,12 @@ for tag, key in [("1080p", f"1920x1080:dragon_standin_d9:default:{G}"), ("1080p_
                  ("1080p_display", f"1920x1080:dragon_standin_d9:display:{G}"), ("1080p_d10", f"1920x1080:dragon_standin_d10:default:{G}"),
                  ("cfg5", "3840x2160:dragon_standin_d9:spp16:grid8"),
                  ("1080p_dense", "1920x1080:dragon_standin_d9:default:grid9"), ("4k_dense", "3840x2160:dragon_standin_d9:default:grid9"),
-                 ("1080p_split7", "1920x1080:dragon_standin_d9:default:grid7+blocks"), ("1080p_split6", "1920x1080:dragon_standin_d9:default:grid6+blocks")]:
+                 ("1080p_split7", "1920x1080:dragon_standin_d9:default:grid7+blocks"), ("1080p_split6", "1920x1080:dragon_standin_d9:default:grid6+blocks"),
+                 # scripts/profile_mesh.sh: the mesh-derived scenes (both get coarse level 7 + blocks)
+                 ("mesh_d9", "1920x1080:knot_d9.asdf:default:grid7+blocks"), ("mesh_d9_4k", "3840x2160:knot_d9.asdf:default:grid7+blocks"),
+                 ("mesh_d10", "1920x1080:knot_d10.asdf:default:grid7+blocks"), ("mesh_d10_4k", "3840x2160:knot_d10.asdf:default:grid7+blocks")]:
+    import os
+    if not os.path.isdir(f"gpurun_out/prof_{R}_{tag}"):
+        continue
     subprocess.run([sys.executable, "scripts/summarise_profile.py", f"{R}_{tag}", key], stdout=subprocess.DEVNULL, check=False)
     print(tag, "done")
