@@ -381,9 +381,10 @@ def main():
     # launch + completion; and the same with the camera moving every frame.  Measured BEFORE the timed region: a few
     # hundred frames that also bring the GPU's clocks up, so that a short timed run (--steps 20 --warmup 5 is 2.5 ms of
     # work) measures the steady state the long ones do ------------------------------------------------------------
-    def latency_pass(camlist, n):
-        nonlocal cams
+    def latency_pass(camlist, n, extra_flags=0):
+        nonlocal cams, flags
         saved, cams = cams, camlist
+        saved_flags, flags = flags, flags | extra_flags
         times = []
         try:
             for j in range(n + 3):
@@ -397,6 +398,7 @@ def main():
                     times.append(time.perf_counter() - t0)
         finally:
             cams = saved
+            flags = saved_flags
         t = torch.tensor([float(np.median(times))], dtype=torch.float64, device="cuda" if (nccl and world > 1) else "cpu")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -429,6 +431,14 @@ def main():
         latency["orbit_cameras"] = len(orbit)
         latency["orbit_ms"] = round(latency_pass(orbit, n_lat), 4)
         latency["orbit_ms_per_step"] = round(throughput_pass(orbit, max(args.steps, 2 * len(orbit))), 4)
+        if not sharded and not compact and not args.one_kernel:
+            # SDFHIP_FLAG_TILE_ORDER (tiles in descending order of their cost in the stream's last frame): the same passes with it,
+            # and both ways on a slower orbit -- a quarter of a degree per frame is still four turns per second at 0.17 ms per frame
+            slow = orbit_cameras(sb, W, H, 120, 0.25)
+            latency["tile_order"] = {"ms": round(latency_pass(cams, n_lat, sb.FLAG_TILE_ORDER), 4),
+                                     "orbit_ms": round(latency_pass(orbit, n_lat, sb.FLAG_TILE_ORDER), 4),
+                                     "orbit_quarter_degree_ms": round(latency_pass(slow, n_lat, sb.FLAG_TILE_ORDER), 4),
+                                     "orbit_quarter_degree_ms_default_order": round(latency_pass(slow, n_lat), 4)}
 
     # ---- warm-up, then the timed region ---------------------------------------------------
     for k in range(args.warmup):
@@ -512,7 +522,7 @@ def main():
                 "workload": (f"{W}x{H} path trace, {args.spp} spp, 3 diffuse bounces, seed 0x5DFB0C5, " if pt is not None else
                              f"{W}x{H} primary-ray sphere trace + shadow march, ") + f"{scene_name} "
                             f"(N={od.Length} nodes, {od.nbytes / 1e6:.1f} MB), camera (0.5,0.5,-0.35) yaw 0.35 pitch -0.2" +
-                            (f", moving {360.0 / len(cams):g} degrees per frame round the scene ({len(cams)} cameras)" if args.orbit > 0 else ""),
+                            (f", moving 1 degree per frame round the scene ({len(cams)} cameras)" if args.orbit > 0 else ""),
                 "kernel": ("path/" if pt is not None else "") +
                           ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else "") +
                           ("" if (pt is not None or compact) else ", one kernel" if args.one_kernel else
@@ -635,14 +645,14 @@ def spawn_ranks(n):
     return child.returncode if child.returncode or lines else 1
 
 
-def orbit_cameras(sb, W, H, n):
-    """n cameras, one degree apart, on the horizontal circle through the cfg-2 camera position about the scene's
+def orbit_cameras(sb, W, H, n, step_deg=1.0):
+    """n cameras, step_deg (one degree) apart, on the horizontal circle through the cfg-2 camera position about the scene's
     centre, each turned by its angle (yaw convention of Matrix4x4.CreateFromYawPitchRoll: forward = (sin yaw, ., cos yaw))."""
     import math
     out = []
     r = 0.5 + 0.35
     for k in range(n):
-        phi = math.radians(k)
+        phi = math.radians(k * step_deg)
         c = sb.Logic(W, H)
         c.Position = (0.5 - r * math.sin(phi), 0.5, 0.5 - r * math.cos(phi))
         c.Heading = (-0.2, 0.35 + phi)

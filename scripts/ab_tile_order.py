@@ -35,6 +35,16 @@ def sorted_perm(c):
         t = tiles[real]; order = np.argsort(-c[t].astype(np.int64), kind="stable")
         out[idx] = np.concatenate([t[order], tiles[~real]])
     return out
+def long_first_perm(c, threshold):
+    # only the few long tiles move: per XCD, the tiles whose wave ran >= threshold iterations in the previous frame are
+    # launched first (in their old order), all others keep their order behind them
+    out = base.copy()
+    for x in range(8):
+        idx = np.nonzero((np.arange(nblk) & 7) == x)[0]
+        tiles = base[idx]; real = tiles != 0xFFFFFFFF
+        t = tiles[real]; long = c[t] >= threshold
+        out[idx] = np.concatenate([t[long], t[~long], tiles[~real]])
+    return out
 def row_perm(c, key):
     # whole tile rows stay together (neighbouring tiles share cells); each XCD's rows k, k+8, ... are launched in
     # descending order of the previous frame's row cost
@@ -49,7 +59,8 @@ def row_perm(c, key):
         out[idx] = np.concatenate([tiles, np.full(len(idx) - len(tiles), 0xFFFFFFFF, np.uint32)])
     return out
 for mode in ("default order", "previous frame's cost, descending per XCD", "same frame's cost (oracle for the idea)",
-             "rows by previous frame's summed cost", "rows by previous frame's max cost"):
+             "rows by previous frame's summed cost", "rows by previous frame's max cost",
+             "long tiles first, threshold 60", "long tiles first, threshold 90", "long tiles first, threshold 110"):
     times = []
     check(lib.sdfhip_debug_tile_order(sc._h, None, ctypes.c_void_p(cost.data_ptr())))
     frame(camera(0))
@@ -60,10 +71,29 @@ for mode in ("default order", "previous frame's cost, descending per XCD", "same
                 check(lib.sdfhip_debug_tile_order(sc._h, None, ctypes.c_void_p(cost.data_ptr()))); frame(cam)
             c = cost.cpu().numpy().view(np.uint16)
             c = ((c & 0xFF) + (c >> 8)).astype(np.uint16)       # primary + shadow loop iterations of the tile's wave
-            p = row_perm(c, "sum") if "summed" in mode else row_perm(c, "max") if "rows" in mode else sorted_perm(c)
+            p = row_perm(c, "sum") if "summed" in mode else row_perm(c, "max") if "rows" in mode else \
+                long_first_perm(c, int(mode.split()[-1])) if mode.startswith("long") else sorted_perm(c)
             perm.copy_(torch.from_numpy(p.view(np.int32)))
             check(lib.sdfhip_debug_tile_order(sc._h, ctypes.c_void_p(perm.data_ptr()), ctypes.c_void_p(cost.data_ptr())))
         times.append(frame(cam))
     ref_ok = True
     print(f"{W}x{H}, camera moving {deg} deg/frame, {mode:48s}: median {np.median(times[5:]):.4f} ms, min {min(times[5:]):.4f}")
+# and the steady state with two frames in flight (bench.py's timed region), fixed camera: default order against the
+# order by this camera's own cost
+cam = camera(0)
+check(lib.sdfhip_debug_tile_order(sc._h, None, ctypes.c_void_p(cost.data_ptr()))); frame(cam)
+c = cost.cpu().numpy().view(np.uint16); c = ((c & 0xFF) + (c >> 8)).astype(np.uint16)
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in streams]
+for name, p in (("default order", None), ("by cost, descending per XCD", sorted_perm(c)), ("long tiles first, threshold 60", long_first_perm(c, 60))):
+    if p is not None:
+        perm.copy_(torch.from_numpy(p.view(np.int32)))
+    check(lib.sdfhip_debug_tile_order(sc._h, ctypes.c_void_p(perm.data_ptr()) if p is not None else None, None))
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n = 400
+        for k in range(n):
+            sc.DrawDevice(cam, W, H, bufs[k & 1].data_ptr(), stream=streams[k & 1].cuda_stream)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n * 1e3
+    print(f"{W}x{H}, two frames in flight, fixed camera, {name:40s}: {dt:.4f} ms per frame")
 check(lib.sdfhip_debug_tile_order(sc._h, None, None))

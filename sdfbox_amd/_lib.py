@@ -30,6 +30,7 @@ OK, ERR_ARG, ERR_IO, ERR_BAD_TREE, ERR_DEVICE, ERR_NOMEM = range(6)
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_STACK = 0, 1, 2
 FLAG_COMPACT, FLAG_COUNT, FLAG_DISPLAY, FLAG_DISPLAY_DEBUG = 0x10, 0x20, 0x40, 0x80
 FLAG_WIRE = 0x10000
+FLAG_TILE_ORDER = 0x100000    # launch the tiles in descending order of their cost in this stream's last frame (latency of one frame)
 TUNE_ONE_KERNEL = 0x20000     # A/B knob: round 1's one-kernel lane state machine where the default is k_march
 TUNE_LDS_TOP = 0x40000        # measurement variant: top grid (level <= 3) staged in LDS per workgroup
 TUNE_SHADOW_QUEUE = 0x80000   # A/B knob: k_march queues its shadow rays for a second kernel (k_shadow), 64 to a wave

@@ -151,6 +151,63 @@ __global__ __launch_bounds__(256) void k_split_assign(TopCell *__restrict__ coar
     }
 }
 
+// SDFHIP_FLAG_TILE_ORDER: the launch order of the next frame's tiles from the wave-iterations of this frame's (k_march's per-tile
+// cost output).  A frame alone ends when its longest wave does -- a 100-step tile launched in the last round of workgroups adds
+// its whole chain of dependent steps to the frame time -- so the expensive tiles go first.  Workgroup b runs on XCD b & 7 and the
+// default order gives XCD x the tile rows x, x + 8, ...: every XCD keeps its own tiles (its L2 keeps seeing whole rows) and
+// launches them in 8 classes of descending cost, in their old order within a class (a stable partition: neighbouring tiles of
+// equal cost -- the sky -- still run together).  One workgroup per XCD label; thread t owns a contiguous span of the label's tiles.
+constexpr int ORDER_CLASSES = 8;
+__device__ __forceinline__ uint32_t order_class(uint16_t cost)
+{
+    const uint32_t c = (cost & 0xFFu) + (cost >> 8);                  // primary + shadow loop iterations, <= 140
+    const uint32_t k = c / 18u;                                        // 0 .. 7
+    return (uint32_t)(ORDER_CLASSES - 1) - (k < (uint32_t)ORDER_CLASSES ? k : (uint32_t)(ORDER_CLASSES - 1));   // class 0 = the longest
+}
+__global__ __launch_bounds__(1024) void k_tile_order(const uint16_t *__restrict__ cost, uint32_t *__restrict__ perm,
+                                                     uint32_t tiles_x, uint32_t tiles_y)
+{
+    __shared__ uint32_t cnt[ORDER_CLASSES][1024];
+    __shared__ uint32_t base[ORDER_CLASSES];
+    const uint32_t x = blockIdx.x, t = threadIdx.x;
+    const uint32_t per_label = ((tiles_y + 7u) >> 3) * tiles_x;       // workgroups (and order slots) per XCD label
+    const uint32_t span = (per_label + 1023u) / 1024u, lo = min(per_label, t * span), hi = min(per_label, lo + span);
+    auto tile_of = [&](uint32_t j) { const uint32_t r = j / tiles_x, row = r * 8u + x; return row < tiles_y ? row * tiles_x + (j - r * tiles_x) : 0xFFFFFFFFu; };
+    uint32_t mine[ORDER_CLASSES];
+    for (int k = 0; k < ORDER_CLASSES; k++) mine[k] = 0;
+    uint32_t pad = 0;
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t tile = tile_of(j);
+        if (tile == 0xFFFFFFFFu) pad++; else mine[order_class(cost[tile])]++;
+    }
+    for (int k = 0; k < ORDER_CLASSES; k++) cnt[k][t] = mine[k];
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {                         // inclusive scans over the threads, all classes at once
+        uint32_t add[ORDER_CLASSES];
+        for (int k = 0; k < ORDER_CLASSES; k++) add[k] = t >= o ? cnt[k][t - o] : 0u;
+        __syncthreads();
+        for (int k = 0; k < ORDER_CLASSES; k++) cnt[k][t] += add[k];
+        __syncthreads();
+    }
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < ORDER_CLASSES; k++) { base[k] = run; run += cnt[k][1023]; }
+    }
+    __syncthreads();
+    uint32_t at[ORDER_CLASSES];
+    for (int k = 0; k < ORDER_CLASSES; k++) at[k] = base[k] + cnt[k][t] - mine[k];
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t tile = tile_of(j);
+        if (tile == 0xFFFFFFFFu) continue;
+        const uint32_t k = order_class(cost[tile]);
+        perm[(size_t)at[k]++ * 8u + x] = tile;
+    }
+    // the label's idle workgroups (rows past the frame's last tile row) behind its tiles
+    const uint32_t real = base[ORDER_CLASSES - 1] + cnt[ORDER_CLASSES - 1][1023];
+    for (uint32_t j = real + t; j < per_label; j += 1024u) perm[(size_t)j * 8u + x] = 0xFFFFFFFFu;
+    (void)pad;
+}
+
 // Gathered compact band buffers -> frame rows (rank-0 side of the tile gather).
 // Which rank rendered a band, and where: round robin (n == 0), or an explicit map with
 // src[band] = rank << 10 | local band (layouts with unequal shares).
@@ -357,6 +414,13 @@ struct sdfhip_scene {
         uint32_t launches;           // two-kernel launch pairs so far: its parity selects the set of fill counts
         char *pt_buf;                // path-traced pipeline: two hit queues, then the per-path results
         size_t pt_bytes;
+        // SDFHIP_FLAG_TILE_ORDER: the wave-iterations of every tile of the last frame rendered on this stream, the launch order
+        // made from them for the next one, and the frame geometry both belong to
+        uint16_t *ord_cost;
+        uint32_t *ord_perm;
+        uint32_t ord_tiles, ord_blocks;      // capacity of the two arrays
+        uint32_t ord_sig[8];                 // width, height, nrows_out, band_rows, band_first, band_stride, n_band_list, hash of the list
+        bool ord_valid;
     };
     static constexpr int MAX_SCRATCH = 16;
     static constexpr size_t CTL_HIT_WORDS = (size_t)2 * MAX_BATCH * HIT_QUEUES * 32, CTL_QUEUE_WORDS = 8 * 32,
@@ -416,6 +480,8 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
         for (int i = 0; i < s->n_scratch; i++) {
             if (s->scratch[i].hit_buf) (void)hipFree(s->scratch[i].hit_buf);
             if (s->scratch[i].pt_buf) (void)hipFree(s->scratch[i].pt_buf);
+            if (s->scratch[i].ord_cost) (void)hipFree(s->scratch[i].ord_cost);
+            if (s->scratch[i].ord_perm) (void)hipFree(s->scratch[i].ord_perm);
             if (s->scratch[i].ctl) (void)hipFree(s->scratch[i].ctl);
         }
         if (s->d_frame) (void)hipFree(s->d_frame);
@@ -638,6 +704,7 @@ int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::S
             return fail(SDFHIP_ERR_ARG, "render: more than %d streams render on one scene handle", sdfhip_scene::MAX_SCRATCH);
         sc = &s->scratch[s->n_scratch];
         sc->stream = st; sc->hit_buf = nullptr; sc->records = 0; sc->ctl = nullptr; sc->launches = 0; sc->pt_buf = nullptr; sc->pt_bytes = 0;
+        sc->ord_cost = nullptr; sc->ord_perm = nullptr; sc->ord_tiles = sc->ord_blocks = 0; sc->ord_valid = false; memset(sc->ord_sig, 0, sizeof sc->ord_sig);
         const size_t ctl_bytes = (sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS + sdfhip_scene::CTL_PT_WORDS) * sizeof(uint32_t);
         HIP_TRY(hipMalloc((void **)&sc->ctl, ctl_bytes));
         // zeroed IN the stream that will use it: a hipMemset on the null stream is not ordered against a non-blocking
@@ -839,6 +906,28 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     P.tile_perm = s->dbg_tile_perm; P.tile_cost = s->dbg_tile_cost;
     P.pt_q[0] = P.pt_q[1] = nullptr; P.pt_ctl = nullptr; P.pt_cap = 0; P.pt_level = 0; P.pt_e = nullptr; P.pt_t = nullptr; P.pt_n = nullptr;
     const bool queued = two && (flags & SDFHIP_TUNE_SHADOW_QUEUE) != 0;
+    // SDFHIP_FLAG_TILE_ORDER: this frame's tiles in the order made from the last frame of the same geometry on this stream
+    // (frames of more than 65 536 tiles -- 4K -- run 16 rounds of workgroups: their tail is short and the order costs locality)
+    const bool ordered = two && (flags & SDFHIP_FLAG_TILE_ORDER) != 0 && n_frames == 1 && P.n_tiles <= 65536u &&
+                         !s->dbg_tile_perm && !s->dbg_tile_cost;
+    if (ordered) {
+        int rcs = get_scratch(s, st, 0, &sc);
+        if (rcs != SDFHIP_OK) return rcs;
+        uint32_t sig[8] = { width, height, nrows_out, band_rows, band_first, band_stride, P.n_band_list, 0u };
+        for (uint32_t i = 0; i < P.n_band_list; i++) sig[7] = sig[7] * 31u + P.band_list[i] + 1u;
+        if (P.n_tiles > sc->ord_tiles || grid.x > sc->ord_blocks) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (sc->ord_cost) (void)hipFree(sc->ord_cost);
+            if (sc->ord_perm) (void)hipFree(sc->ord_perm);
+            sc->ord_cost = nullptr; sc->ord_perm = nullptr; sc->ord_tiles = sc->ord_blocks = 0; sc->ord_valid = false;
+            HIP_TRY(hipMalloc((void **)&sc->ord_cost, (size_t)P.n_tiles * sizeof(uint16_t)));
+            HIP_TRY(hipMalloc((void **)&sc->ord_perm, (size_t)grid.x * sizeof(uint32_t)));
+            sc->ord_tiles = P.n_tiles; sc->ord_blocks = grid.x;
+        }
+        if (memcmp(sig, sc->ord_sig, sizeof sig) != 0) { sc->ord_valid = false; memcpy(sc->ord_sig, sig, sizeof sig); }
+        P.tile_perm = sc->ord_valid ? sc->ord_perm : nullptr;
+        P.tile_cost = sc->ord_cost;
+    }
     if (queued) {
         // a queue takes the hits of every 64th workgroup: room for all their pixels
         P.hit_cap = ((grid.x + HIT_QUEUES - 1u) / HIT_QUEUES) * 64u;
@@ -865,6 +954,10 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     if (two) {
         if (cur == CUR_STACK_SPLIT) { if (count) launch_two<CUR_STACK_SPLIT, true>(out_mode, grid, shade_grid, st, P, queued); else launch_two<CUR_STACK_SPLIT, false>(out_mode, grid, shade_grid, st, P, queued); }
         else                        { if (count) launch_two<CUR_STACK_FULL, true>(out_mode, grid, shade_grid, st, P, queued); else launch_two<CUR_STACK_FULL, false>(out_mode, grid, shade_grid, st, P, queued); }
+        if (ordered) {                                  // the next frame's launch order, behind this frame in its stream
+            hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, st, sc->ord_cost, sc->ord_perm, P.tiles_x, P.tiles_y);
+            sc->ord_valid = true;
+        }
     }
     else if (pt && (cur == CUR_STACK_FULL || cur == CUR_STACK_SPLIT) && !(flags & SDFHIP_TUNE_ONE_KERNEL)) {
         // the pipeline of kernels (k_pt_primary -> k_pt_bounce per level -> k_pt_resolve)

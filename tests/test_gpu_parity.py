@@ -695,6 +695,64 @@ def test_tile_order_hook_permutes_work_not_results(sb, oracle_mod, scenes):
             assert shadow[t_] == 0 and primary[t_] == steps[y0:y0 + 8, x0:x0 + 8].max(), t_
 
 
+@pytest.mark.parametrize("split", [None, "4"])
+def test_tile_order_flag_changes_no_pixel(sb, oracle_mod, scenes, split):
+    # SDFHIP_FLAG_TILE_ORDER: a frame's tiles are launched in descending order of their cost in the LAST frame of the same
+    # geometry on the same stream.  Every frame must still be the oracle's: the first (default order), the same camera again
+    # (its own costs), other cameras (a stale order), after a change of frame size and back, bands of a frame, two streams
+    # taking turns, the counting build, the shadow-queue form -- output buffers start as NaN, so a tile that no workgroup
+    # took would show
+    import torch
+    od = scenes["torus_d6"]
+    prev = os.environ.get("SDFHIP_TOP_GRID_SPLIT")
+    if split is not None:
+        os.environ["SDFHIP_TOP_GRID_SPLIT"] = split
+    try:
+        with sb.Scene(od) as sc:
+            F = sb.KERNEL_STACK | sb.FLAG_TILE_ORDER
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            refs = {}
+
+            def ref(name, W, H):
+                if (name, W, H) not in refs:
+                    refs[(name, W, H)] = oracle_mod.render(od.Structs, od.Values, make_camera(name, W, H).State, W, H, nthreads=8)
+                return refs[(name, W, H)]
+
+            def draw(name, W, H, flags=F, stream=None):
+                buf = torch.full((H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+                st = sb.Stats()
+                sc.DrawDevice(make_camera(name, W, H), W, H, buf.data_ptr(), flags=flags,
+                              stream=stream.cuda_stream if stream is not None else None, stats=st if flags & sb.FLAG_COUNT else None)
+                torch.cuda.synchronize()
+                assert_frames_identical(buf.cpu().numpy(), ref(name, W, H)[0], f"tile order, {name} {W}x{H} flags {flags:#x}")
+                if flags & sb.FLAG_COUNT:
+                    assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in ref(name, W, H)[1])
+
+            for name, W, H in (("closeup", 200, 120), ("closeup", 200, 120), ("rotated", 200, 120), ("default", 200, 120),
+                               ("closeup", 97, 61), ("closeup", 200, 120), ("rotated", 200, 120), ("rotated", 200, 120)):
+                draw(name, W, H)
+            for k in range(6):                                   # two streams, each with its own last frame
+                draw(("closeup", "rotated", "default")[k % 3], 200, 120, stream=streams[k & 1])
+            draw("closeup", 200, 120, flags=F | sb.FLAG_COUNT)
+            draw("rotated", 200, 120, flags=F | sb.FLAG_COUNT)
+            draw("closeup", 200, 120, flags=F | sb.TUNE_SHADOW_QUEUE)
+            draw("rotated", 200, 120, flags=F | sb.TUNE_SHADOW_QUEUE)
+            # bands of a frame (what a rank of the sharded pipeline renders): rows 16..31, 48..63, ... twice, then the other ranks' bands
+            W, H = 200, 128
+            whole = ref("closeup", W, H)[0]
+            for first in (1, 1, 0, 1):
+                rows = [y for y in range(H) if (y // 16) % 2 == first]
+                buf = torch.full((len(rows), W, 4), float("nan"), dtype=torch.float32, device="cuda")
+                sc.DrawDevice(make_camera("closeup", W, H), W, H, buf.data_ptr(), nrows_out=len(rows), band_rows=16, band_first=first, band_stride=2, flags=F)
+                torch.cuda.synchronize()
+                assert_frames_identical(buf.cpu().numpy(), whole[rows], f"tile order, bands from {first}")
+    finally:
+        if prev is None:
+            os.environ.pop("SDFHIP_TOP_GRID_SPLIT", None)
+        else:
+            os.environ["SDFHIP_TOP_GRID_SPLIT"] = prev
+
+
 def test_frames_in_flight_on_one_handle_do_not_share_scratch(sb, oracle_mod, scenes, gpu_scenes):
     # Several streams render on ONE scene handle at once, each its own camera (frames in flight): the hit
     # queues of the queued-shadow pipeline (SDFHIP_TUNE_SHADOW_QUEUE) and the tile queues of the compact kernel are per-stream scratch, so
