@@ -66,6 +66,9 @@ def parse():
                     help="timed region with a camera that moves every frame: N precomputed Info blocks on a circle "
                          "around the scene's centre (1 degree apart), used round-robin (0 = the fixed cfg-2 camera; "
                          "the default line reports an orbit pass beside it in `latency`)")
+    ap.add_argument("--tile-order", action="store_true",
+                    help="render every frame with SDFHIP_FLAG_TILE_ORDER (tiles in descending order of their cost in the stream's "
+                         "last frame); without it only the latency.tile_order figures use the flag")
     ap.add_argument("--shadow-queue", action="store_true",
                     help="A/B knob: k_march queues its shadow rays for a second kernel (k_shadow), 64 to a wave")
     ap.add_argument("--one-kernel", action="store_true",
@@ -154,7 +157,8 @@ def main():
     kflag = {"auto": sb.KERNEL_AUTO, "generic": sb.KERNEL_GENERIC, "stack": sb.KERNEL_STACK}[args.kernel]
     compact = (args.compact == 1) if args.compact >= 0 else DEFAULT_COMPACT
     flags = kflag | (sb.FLAG_COMPACT if compact else 0) | (sb.FLAG_DISPLAY if args.display else 0) | \
-        (sb.TUNE_ONE_KERNEL if args.one_kernel else 0) | (sb._lib.TUNE_SHADOW_QUEUE if args.shadow_queue else 0)
+        (sb.TUNE_ONE_KERNEL if args.one_kernel else 0) | (sb._lib.TUNE_SHADOW_QUEUE if args.shadow_queue else 0) | \
+        (sb.FLAG_TILE_ORDER if args.tile_order else 0)
     px_shape, px_dtype, px_bytes = ((), torch.int32, 4) if args.display else ((4,), torch.float32, 16)
     pt = sb.PathTrace(spp=args.spp) if args.spp > 0 else None
     # what travels in the gather: the frame's own pixels, or 5-byte wire pixels that rank 0 expands

@@ -58,7 +58,11 @@ def row_perm(c, key):
         tiles = np.concatenate([r * tx + np.arange(tx) for r in order]).astype(np.uint32)
         out[idx] = np.concatenate([tiles, np.full(len(idx) - len(tiles), 0xFFFFFFFF, np.uint32)])
     return out
-for mode in ("default order", "previous frame's cost, descending per XCD", "same frame's cost (oracle for the idea)",
+def dilate(c, R):
+    from scipy.ndimage import maximum_filter
+    return maximum_filter(c.reshape(ty, tx), size=2 * R + 1, mode="nearest").reshape(-1)
+for mode in ("default order", "previous frame's cost, descending per XCD", "previous cost dilated 1", "previous cost dilated 2", "previous cost dilated 4",
+             "same frame's cost (oracle for the idea)",
              "rows by previous frame's summed cost", "rows by previous frame's max cost",
              "long tiles first, threshold 60", "long tiles first, threshold 90", "long tiles first, threshold 110"):
     times = []
@@ -71,6 +75,8 @@ for mode in ("default order", "previous frame's cost, descending per XCD", "same
                 check(lib.sdfhip_debug_tile_order(sc._h, None, ctypes.c_void_p(cost.data_ptr()))); frame(cam)
             c = cost.cpu().numpy().view(np.uint16)
             c = ((c & 0xFF) + (c >> 8)).astype(np.uint16)       # primary + shadow loop iterations of the tile's wave
+            if "dilated" in mode:
+                c = dilate(c, int(mode.split()[-1]))
             p = row_perm(c, "sum") if "summed" in mode else row_perm(c, "max") if "rows" in mode else \
                 long_first_perm(c, int(mode.split()[-1])) if mode.startswith("long") else sorted_perm(c)
             perm.copy_(torch.from_numpy(p.view(np.int32)))
