@@ -24,6 +24,23 @@ def test_every_declared_symbol_is_exported(sb):
     assert sorted(sb._lib.EXPORTED_SYMBOLS) == names
 
 
+def test_flag_constants_match_the_header(sb):
+    # every SDFHIP_FLAG_* / SDFHIP_TUNE_* / SDFHIP_KERNEL_* enumerator of include/sdfhip.h that the Python mirror names has the
+    # header's value, and no two render flags share a bit
+    text = open(os.path.join(REPO, "include", "sdfhip.h")).read()
+    header = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"\bSDFHIP_((?:FLAG|TUNE|KERNEL)_\w+)\s*=\s*(0x[0-9A-Fa-f]+|\d+)", text)}
+    assert {"FLAG_COMPACT", "FLAG_COUNT", "FLAG_DISPLAY", "FLAG_WIRE", "FLAG_TILE_ORDER", "TUNE_ONE_KERNEL", "TUNE_SHADOW_QUEUE"} <= set(header)
+    L = sb._lib
+    seen = 0
+    for name, value in header.items():
+        if hasattr(L, name):
+            assert getattr(L, name) == value, name
+            seen += 1
+    assert seen >= 10
+    bits = [v for k, v in header.items() if k.startswith(("FLAG_", "TUNE_")) and not k.endswith("_SHIFT")]
+    assert len(bits) == len(set(bits)) and all(v & (v - 1) == 0 for v in bits)      # single, distinct bits
+
+
 def test_info_layout_matches_logic_cs(sb):
     # Logic.cs:407-420 (Pack 16, Size 112) / Compute.hlsl:70-81
     I = sb.Info
