@@ -94,6 +94,53 @@ __global__ void k_fine_blocks(const NodeRec *__restrict__ nodes, const uint32_t 
     }
 }
 
+// sdfhip_octdata_validate (asdf_io.cpp) on the device, for the upload: the arrays are on their way to HBM anyway (8 ms for
+// 451 MB) and the host's single-threaded pass over 28 M nodes takes 110 ms.  One thread per node; the same verdicts:
+//   bad          a link out of range, or a parent chain of more than 64 links / a cycle (the host function then names the node)
+//   inconsistent the root has a parent, a node's children block is block 0 or does not point back at it
+//   depth        the most links from a node to the root among the nodes the root reaches (every link of the chain is mirrored by
+//                its parent's children block): the host function's walk down from the root
+// Reads nothing through a link it has not range-checked.
+__global__ __launch_bounds__(256) void k_validate(const int2 *__restrict__ structs, uint32_t n, uint32_t *__restrict__ verdict)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const int2 me = valid ? structs[i] : make_int2(-1, -1);
+    bool bad = false, inconsistent = false;
+    if (valid) {
+        if (me.x >= 0 && (uint32_t)me.x >= n) bad = true;
+        if (me.y >= 0 && (uint64_t)(uint32_t)me.y + 8u > (uint64_t)n) bad = true;
+        if (i == 0 && me.x >= 0) inconsistent = true;
+        if (!bad && me.y >= 0) {
+            if (me.y == 0) inconsistent = true;
+            for (int k = 0; k < 8; k++)
+                if (structs[(uint32_t)me.y + (uint32_t)k].x != (int32_t)i) inconsistent = true;
+        }
+    }
+    uint32_t links = 0;
+    bool attached = valid && !bad;
+    if (attached) {
+        uint32_t j = i;
+        int32_t p = me.x;
+        while (p >= 0) {
+            if ((uint32_t)p >= n) { attached = false; break; }            // that node's own thread reports the bad link
+            const int2 up = structs[(uint32_t)p];
+            if (!(up.y >= 0 && j >= (uint32_t)up.y && j - (uint32_t)up.y < 8u)) attached = false;
+            j = (uint32_t)p; p = up.x;
+            if (++links > 64u) { bad = true; attached = false; break; }
+        }
+        if (j != 0u) attached = false;
+    }
+    // one atomic per wave and verdict
+    uint32_t m = attached ? links : 0u;
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    const uint32_t flags = (__ballot(bad) ? 1u : 0u) | (__ballot(inconsistent) ? 2u : 0u);
+    if ((threadIdx.x & 63u) == 0) {
+        if (flags) atomicOr(&verdict[0], flags);
+        if (m) atomicMax(&verdict[1], m);
+    }
+}
+
 // Numbering the internal cells of a split grid's coarse level in cell order (an exclusive prefix sum of "is internal"),
 // on the device: chunks of 256 cells; count per chunk, scan of the chunk counts by one workgroup, then every internal cell
 // gets its block -- children = the block's first fine cell -- and the block its node.
@@ -582,8 +629,6 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     *out = nullptr;
     uint32_t depth = 0;
     int consistent = 0;
-    int rc = sdfhip_octdata_validate(structs, n, &depth, &consistent);
-    if (rc != SDFHIP_OK) return rc;
 
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -598,8 +643,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
 
     sdfhip_scene *s = new (std::nothrow) sdfhip_scene();
     if (!s) return fail(SDFHIP_ERR_NOMEM, "scene_upload: out of host memory");
-    s->device = device; s->n = n; s->depth = depth;
-    s->stack_ok = (consistent && depth <= (uint32_t)MAX_STACK) ? 1 : 0;
+    s->device = device; s->n = n; s->depth = 0; s->stack_ok = 0;       // (both set once the tree has been validated, below)
     s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0;
     s->d_top2 = s->d_fine2 = nullptr; s->top2_level = s->fine2_bits = s->fine2_order = s->scatter_tried = 0; s->top2_bytes = 0; s->total_mem = prop.totalGlobalMem;
     s->n_scratch = 0; s->d_frame = nullptr; s->dbg_tile_perm = nullptr; s->dbg_tile_cost = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
@@ -624,6 +668,24 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if ((e = hipMalloc(&d_v, bytes)) != hipSuccess) return bail(e, "hipMalloc(values)");
     if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
     if ((e = hipMemcpyAsync(d_v, values, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(values)");
+    {   // validation (sdfhip_octdata_validate's verdicts, on the device: see k_validate); d_counters lends two words
+        uint32_t *d_verdict = reinterpret_cast<uint32_t *>(s->d_counters), verdict[2] = { 0u, 0u };
+        if ((e = hipMemsetAsync(d_verdict, 0, sizeof verdict, s->stream)) != hipSuccess) return bail(e, "hipMemset(verdict)");
+        hipLaunchKernelGGL(k_validate, dim3((n + 255u) / 256u), dim3(256), 0, s->stream, (const int2 *)d_s, n, d_verdict);
+        if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_validate launch");
+        if ((e = hipMemcpyAsync(verdict, d_verdict, sizeof verdict, hipMemcpyDeviceToHost, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(verdict)");
+        if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail(e, "k_validate");
+        if (verdict[0] & 1u) {                          // a bad link: the host function finds it again and says which
+            (void)hipFree(d_s); (void)hipFree(d_v); d_s = d_v = nullptr;
+            sdfhip_scene_free(s);
+            const int rcv = sdfhip_octdata_validate(structs, n, &depth, &consistent);
+            return rcv != SDFHIP_OK ? rcv : fail(SDFHIP_ERR_BAD_TREE, "scene_upload: the tree has a link out of range or an endless parent chain");
+        }
+        consistent = (verdict[0] & 2u) ? 0 : 1;
+        depth = consistent ? verdict[1] : 0xFFFFFFFFu;
+        s->depth = depth;
+        s->stack_ok = (consistent && depth <= (uint32_t)MAX_STACK) ? 1 : 0;
+    }
     uint32_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_fuse, dim3(blocks), dim3(256), 0, s->stream, (const int2 *)d_s,

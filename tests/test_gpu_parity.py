@@ -183,6 +183,60 @@ def test_inconsistent_parent_links_use_the_generic_kernel(sb, oracle_mod, scenes
     assert e.value.code == sb._lib.ERR_BAD_TREE
 
 
+def test_upload_validates_on_the_device_like_the_host_function(sb):
+    # sdfhip_scene_upload checks the tree on the device (k_validate: 14 ms of upload for the 28 M-node scene instead of 128);
+    # its verdicts must be sdfhip_octdata_validate's: error code, consistency, depth -- on good trees, inconsistent ones,
+    # orphan subtrees deeper than anything the root reaches, and every kind of bad link
+    rng = np.random.default_rng(11)
+    od = sb.sphere_d4()
+    N = od.Length
+    cases = [("sphere_d4", od.Structs.copy())]
+    for seed, depth in ((1, 5), (2, 9), (3, 12)):
+        s, _ = _random_tree(np.random.default_rng(seed), depth, p_split=0.5)
+        cases.append((f"random tree depth {depth}", s))
+    s = od.Structs.copy(); s[0, 0] = 3; cases.append(("root with a parent", s))
+    s = od.Structs.copy(); s[9:17, 0] = 2; cases.append(("a block that names another node as its parent", s))
+    s = od.Structs.copy(); s[5, 1] = 0 if s[5, 1] < 0 else s[5, 1]; s[5, 1] = 0; cases.append(("children block 0", s))
+    # an orphan chain hanging under a leaf that does not list it: deeper than the tree, but nothing reaches it
+    s = np.concatenate([od.Structs, np.full((40, 2), -1, np.int32)]); leaf = int(np.nonzero(od.Structs[:, 1] < 0)[0][-1])
+    s[N, 0] = leaf
+    for k in range(1, 40):
+        s[N + k, 0] = N + k - 1
+    cases.append(("orphan chain of 40 under a leaf", s))
+    s = od.Structs.copy(); s[5, 1] = N - 3; cases.append(("children block past the end", s))
+    s = od.Structs.copy(); s[9, 0] = N + 10; cases.append(("parent out of range", s))
+    s = od.Structs.copy(); s[9, 0] = 17; s[17, 0] = 9; cases.append(("parent cycle", s))
+    s = od.Structs.copy(); s[1:200, 0] = np.arange(0, 199); cases.append(("199-link parent chain", s))
+    s = np.concatenate([od.Structs, np.full((70, 2), -1, np.int32)])
+    for k in range(70):
+        s[N + k, 0] = (N + k - 1) if k else 0
+    cases.append(("a 70-link chain", s))
+    s = np.concatenate([od.Structs, np.full((60, 2), -1, np.int32)])
+    for k in range(60):
+        s[N + k, 0] = (N + k - 1) if k else 0
+    cases.append(("a 60-link chain (allowed; nothing reaches it)", s))
+    assert rng is not None
+    for name, s in cases:
+        s = np.ascontiguousarray(s, dtype=np.int32)
+        v = np.zeros((len(s), 8), dtype=np.uint8); v[:] = 128
+        tree = sb.OctData(s, v)
+        try:
+            depth, consistent = tree.validate()
+            expect = ("ok", depth, consistent)
+        except sb.SdfHipError as e:
+            expect = ("error", e.code, None)
+        try:
+            with sb.Scene(tree) as sc:
+                got = ("ok", sc.depth, sc.stack_kernel_ok)
+        except sb.SdfHipError as e:
+            got = ("error", e.code, None)
+        if expect[0] == "ok":
+            depth, consistent = expect[1], expect[2]
+            assert got == ("ok", depth if consistent else 0xFFFFFFFF, bool(consistent and depth <= 12)), (name, expect, got)
+        else:
+            assert got == expect, (name, expect, got)
+
+
 def test_band_rendering_reassembles_the_frame(sb, gpu_scenes):
     # the multi-GPU sharding, all ranks played by one GPU: each rank's bands into a compact
     # buffer, "gathered" side by side, de-interleaved by the rank-0 kernel
