@@ -517,6 +517,10 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 4),
             "latency_ms": latency["ms"],
+            # the same frame as a viewer would ask for it (SDFHIP_FLAG_TILE_ORDER: tiles in the order of the last frame's cost), at rest
+            # and with the camera moving one degree per frame; null where the flag does not apply (sharded, compact, one-kernel runs)
+            "latency_ms_tile_order": latency["tile_order"]["ms"] if "tile_order" in latency else None,
+            "latency_ms_tile_order_moving_camera": latency["tile_order"]["orbit_ms"] if "tile_order" in latency else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -39,6 +39,7 @@ def test_bench_line_small_workload():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["algorithmic"]["own_bytes_per_frame"] > 0 and r["algorithmic"]["reference_bytes_per_frame"] > 0
     assert j["latency"]["ms"] == j["latency_ms"] > 0 and j["latency"]["orbit_ms"] > 0
+    assert j["latency_ms_tile_order"] == j["latency"]["tile_order"]["ms"] > 0 and j["latency_ms_tile_order_moving_camera"] > 0
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mray/s" and c["cores"] == os.cpu_count() and c["value"] > 0
     assert c["native_build_equals_portable_build"] in (True, None)
