@@ -227,6 +227,7 @@ __global__ __launch_bounds__(BT) void k_corners(GenParams P, LevelArrays L, cons
 // of k_center / k_corners idle through the list, and the eight 6-step butterfly reductions of k_corners cost more
 // than the list itself.  Here G = 16 lanes work on a node and a wavefront takes 64 / G nodes: the same arithmetic
 // per candidate and the same tie-breaking (earliest list position), so the same bytes.
+constexpr int SUB_UNROLL = 4;
 template <int G> __device__ __forceinline__ Best sub_min(Best b)
 {
     for (int off = G / 2; off > 0; off >>= 1) {
@@ -251,11 +252,25 @@ __global__ __launch_bounds__(64) void k_center_sub(GenParams P, LevelArrays L, c
         transform(P, L.px[node] + h, L.py[node] + h, L.pz[node] + h, cx, cy, cz);
         off = L.cand_off[node]; cnt = L.cand_cnt[node];
     }
+    // (both passes take SUB_UNROLL list entries per lane at a time: the gathers index -> position of all of them are issued
+    // before the first is used -- the passes are chains of dependent loads, not arithmetic; the order of the comparisons,
+    // and with it the tie-breaking, is the list's)
     Best b{INFINITY, 0xFFFFFFFFu};
-    for (uint32_t k = sub; k < cnt; k += G) {
-        const float *v = P.verts + 6 * (size_t)cand[off + k];
-        float d = lensq(v[0] - cx, v[1] - cy, v[2] - cz);
-        if (d < b.d) { b.d = d; b.k = k; }
+    for (uint32_t k0 = sub; k0 < cnt; k0 += SUB_UNROLL * G) {
+        uint32_t idx[SUB_UNROLL];
+        float x[SUB_UNROLL], y[SUB_UNROLL], z[SUB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SUB_UNROLL; u++) idx[u] = k0 + u * G < cnt ? cand[off + k0 + u * G] : 0u;
+#pragma unroll
+        for (int u = 0; u < SUB_UNROLL; u++) { const float *v = P.verts + 6 * (size_t)idx[u]; x[u] = v[0]; y[u] = v[1]; z[u] = v[2]; }
+#pragma unroll
+        for (int u = 0; u < SUB_UNROLL; u++) {
+            const uint32_t k = k0 + u * G;
+            if (k < cnt) {
+                float d = lensq(x[u] - cx, y[u] - cy, z[u] - cz);
+                if (d < b.d) { b.d = d; b.k = k; }
+            }
+        }
     }
     b = sub_min<G>(b);
     const bool bad = b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d);      // "Did not find" / "NaN distance"
@@ -265,9 +280,16 @@ __global__ __launch_bounds__(64) void k_center_sub(GenParams P, LevelArrays L, c
     r *= r;
     uint32_t count = 0;
     if (!bad)
-        for (uint32_t k = sub; k < cnt; k += G) {
-            const float *v = P.verts + 6 * (size_t)cand[off + k];
-            if (lensq(v[0] - cx, v[1] - cy, v[2] - cz) < r) count++;
+        for (uint32_t k0 = sub; k0 < cnt; k0 += SUB_UNROLL * G) {
+            uint32_t idx[SUB_UNROLL];
+            float x[SUB_UNROLL], y[SUB_UNROLL], z[SUB_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SUB_UNROLL; u++) idx[u] = k0 + u * G < cnt ? cand[off + k0 + u * G] : 0u;
+#pragma unroll
+            for (int u = 0; u < SUB_UNROLL; u++) { const float *v = P.verts + 6 * (size_t)idx[u]; x[u] = v[0]; y[u] = v[1]; z[u] = v[2]; }
+#pragma unroll
+            for (int u = 0; u < SUB_UNROLL; u++)
+                if (k0 + u * G < cnt && lensq(x[u] - cx, y[u] - cy, z[u] - cz) < r) count++;
         }
     for (int o = G / 2; o > 0; o >>= 1) count += __shfl_xor(count, o);
     if (have && sub == 0) {
@@ -540,7 +562,6 @@ bool scan_u32(Arena &scratch, const uint32_t *in, uint32_t *out, uint32_t n, uns
 }
 
 constexpr uint32_t WIDE_LEVEL = 4096;
-constexpr uint32_t SHORT_LIST = 40;       // average candidates per node below which 16 lanes, not 64, work on a node
 struct KeptLevel { LevelArrays L; uint32_t n; uint32_t *cnt, *rank; int32_t *index; };
 
 }  // namespace
@@ -609,7 +630,7 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
         std::vector<KeptLevel> levels;
         uint32_t n_nodes = 1;
         size_t total_nodes = 0;
-        unsigned long long cand_entries = n, prev_possible = n;
+        unsigned long long cand_entries = n;
         for (int lvl = 0;; lvl++) {
             Arena &mine = scratch[lvl & 1], &other = scratch[(lvl + 1) & 1];
             P.depth = lvl;
@@ -617,10 +638,10 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
             uint32_t *poff = mine.alloc<uint32_t>(n_nodes);
             if (!poff) return GEN_NOMEM();
             const bool wide = n_nodes >= WIDE_LEVEL;      // enough nodes to fill the GPU with one wavefront each
-            // short lists (on average at most SHORT_LIST entries; prev_possible * 8 bounds the level's entries): 16 lanes per node
-            const bool shortl = wide && n_nodes >= 4 * WIDE_LEVEL && 8.0 * (double)prev_possible <= (double)SHORT_LIST * n_nodes;
-            if (shortl) hipLaunchKernelGGL(k_center_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
-            else if (wide) hipLaunchKernelGGL(k_center<64>, dim3(n_nodes), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
+            // wide levels: 16 lanes per node, four nodes per wavefront -- whatever the lists' lengths: the passes over a list are
+            // chains of dependent gathers (index -> position), and four lists per wave keep four times as many of them in flight
+            // (1 M-point knot: depth 9 in 40 ms instead of 56, depth 10 in 58 instead of 90; scripts/sdfgen_short_list.py)
+            if (wide) hipLaunchKernelGGL(k_center_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
             else hipLaunchKernelGGL(k_center<1024>, dim3(n_nodes), dim3(1024), 0, 0, P, L, cand, n_nodes, d_err);
             if (!scan_u32(mine, L.pcount, poff, n_nodes, d_total)) return GEN_NOMEM();
             unsigned long long total = 0;
@@ -630,10 +651,8 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
             uint32_t *possible = lists[(lvl + 1) & 1].alloc<uint32_t>((size_t)total);
             if (!possible) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory for %llu candidate entries", total);
             cand_entries += total;
-            if (shortl) hipLaunchKernelGGL(k_corners_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
-            else if (wide) hipLaunchKernelGGL(k_corners<64>, dim3(n_nodes), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            if (wide) hipLaunchKernelGGL(k_corners_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
             else hipLaunchKernelGGL(k_corners<1024>, dim3(n_nodes), dim3(1024), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
-            prev_possible = total;
             if (!scan_u32(mine, L.split, L.block_of, n_nodes, d_total)) return GEN_NOMEM();
             struct { unsigned long long n_split; uint32_t err; } back;
             GEN_TRY(hipMemcpy(&back.n_split, d_total, sizeof back.n_split, hipMemcpyDeviceToHost));
