@@ -1,13 +1,15 @@
 // Point cloud -> ASDF on the GPU: SdfGen's builder (SdfGen/dllmain.cpp:67-207,295-319),
-// level-synchronous instead of recursive, one wavefront per octree node.
+// level-synchronous instead of recursive: sixteen lanes per octree node, several workgroups per node on the first levels.
 //
 // What the reference does per node (construct, dllmain.cpp:163-190), and where it is here:
-//   centerValue = distance from the cell centre to the nearest candidate   k_center
-//   possible    = candidates within (centerValue + sqrt(3)/2 * scale)       k_center (count),
-//                 of the centre, in list order                              k_corners (stable compaction)
-//   corner i    = signed distance to the nearest *surviving* point, unless  k_corners
+//   centerValue = distance from the cell centre to the nearest candidate   k_center_*
+//   possible    = candidates within (centerValue + sqrt(3)/2 * scale)       k_center_* (count),
+//                 of the centre, in list order                              k_corners_* (stable compaction)
+//   corner i    = signed distance to the nearest *surviving* point, unless  k_corners_*
 //                 inherited from the parent (child i inherits corner i)
-//   split       = centerValue < 2 * scale && depth < MaxDepth               k_corners
+//   split       = centerValue < 2 * scale && depth < MaxDepth               k_corners_*
+// (levels of fewer than 4 096 nodes: k_center_seg_min / _seg_count, k_corners_seg / _fin -- several workgroups per node;
+//  the others: k_center_sub / k_corners_sub -- four nodes per wavefront)
 //   children    = 8 new nodes whose candidates are this node's `possible`   k_children
 // The recursion becomes a loop over levels; the reference's node order (children blocks
 // appended in depth-first pre-order) is restored afterwards, still on the GPU, from subtree
@@ -75,8 +77,7 @@ __device__ __forceinline__ Best wave_min(Best b)
     return b;
 }
 
-// Reductions over the BT threads that work on one node: BT = 64 (one wavefront, no LDS) for the wide
-// levels, BT = 1024 for the first levels, whose few nodes have the longest candidate lists.
+// Reduction over the BT = 1024 threads of a workgroup that works on (a segment of) one node's list.
 template <int BT> __device__ __forceinline__ Best node_min(Best b, Best *sh)
 {
     b = wave_min(b);
@@ -91,59 +92,99 @@ template <int BT> __device__ __forceinline__ Best node_min(Best b, Best *sh)
     return b;
 }
 
-// centerValue and |possible| of every node of the level (TrueDistanceAt + the count of GetPossible)
-template <int BT>
-__global__ __launch_bounds__(BT) void k_center(GenParams P, LevelArrays L, const uint32_t *__restrict__ cand,
-                                               uint32_t n_nodes, uint32_t *err)
+// ---- several workgroups per node (the first levels) ---------------------------------------------------
+// Levels 0 .. 4 have 1 .. 4 095 nodes with up to a million candidates each: one workgroup per node leaves the chip idle (the 1 M-
+// point knot: 16 ms of a 40 ms build).  Here a node's list is cut into S segments of whole 1 024-entry chunks, one workgroup
+// each; the nearest-candidate searches meet in 64-bit atomic minima of {distance bits, list position} -- for non-negative
+// floats the bit patterns order as the values do, and equal distances go to the earlier position: the same winner as the
+// strict `<` scan -- and the `possible` list stays in list order: segment s writes behind the survivors of the segments
+// before it (their counts are known from the centre pass).
+struct SegArrays {
+    unsigned long long *best;      // per node: the candidate nearest to the cell centre
+    unsigned long long *corner;    // 8 per node: ... to every corner, among the survivors
+    uint32_t *count;               // per node and segment: survivors
+    uint32_t S;
+};
+__device__ __forceinline__ unsigned long long pack_best(const Best &b) { return ((unsigned long long)__float_as_uint(b.d) << 32) | b.k; }
+__device__ __forceinline__ Best unpack_best(unsigned long long p) { return Best{__uint_as_float((uint32_t)(p >> 32)), (uint32_t)p}; }
+__device__ __forceinline__ void segment_of(uint32_t cnt, uint32_t S, uint32_t s, uint32_t &lo, uint32_t &hi)
 {
-    __shared__ Best sh[BT / 64];
-    __shared__ uint32_t shc[BT / 64];
-    const uint32_t node = blockIdx.x, tid = threadIdx.x;
+    const uint32_t len = ((cnt + S - 1u) / S + 1023u) & ~1023u;          // whole chunks
+    lo = min(cnt, s * len); hi = min(cnt, lo + len);
+}
+
+__global__ __launch_bounds__(1024) void k_center_seg_min(GenParams P, LevelArrays L, SegArrays A, const uint32_t *__restrict__ cand, uint32_t n_nodes)
+{
+    __shared__ Best sh[16];
+    const uint32_t node = blockIdx.x / A.S, s = blockIdx.x % A.S, tid = threadIdx.x;
     if (node >= n_nodes) return;
-    const float h = 0.5f * P.scale;                      // Vector3(1) * 0.5f * scale
+    const float h = 0.5f * P.scale;
     float cx, cy, cz;
     transform(P, L.px[node] + h, L.py[node] + h, L.pz[node] + h, cx, cy, cz);
     const uint32_t off = L.cand_off[node], cnt = L.cand_cnt[node];
+    uint32_t lo, hi;
+    segment_of(cnt, A.S, s, lo, hi);
     Best b{INFINITY, 0xFFFFFFFFu};
-    for (uint32_t k = tid; k < cnt; k += BT) {
+    for (uint32_t k = lo + tid; k < hi; k += 1024u) {
         const float *v = P.verts + 6 * (size_t)cand[off + k];
         float d = lensq(v[0] - cx, v[1] - cy, v[2] - cz);
         if (d < b.d) { b.d = d; b.k = k; }
     }
-    b = node_min<BT>(b, sh);
+    b = node_min<1024>(b, sh);
+    if (tid == 0 && b.k != 0xFFFFFFFFu) atomicMin(&A.best[node], pack_best(b));
+}
+
+__global__ __launch_bounds__(1024) void k_center_seg_count(GenParams P, LevelArrays L, SegArrays A, const uint32_t *__restrict__ cand,
+                                                           uint32_t n_nodes, uint32_t *err)
+{
+    __shared__ uint32_t shc[16];
+    const uint32_t node = blockIdx.x / A.S, s = blockIdx.x % A.S, tid = threadIdx.x;
+    if (node >= n_nodes) return;
+    const Best b = unpack_best(A.best[node]);
     if (b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d)) {    // "Did not find" / "NaN distance"
-        if (tid == 0) { atomicExch(err, 2u); L.center_value[node] = 0.0f; L.pcount[node] = 0; }
+        if (tid == 0) {
+            A.count[blockIdx.x] = 0;
+            if (s == 0) { atomicExch(err, 2u); L.center_value[node] = 0.0f; }
+        }
         return;
     }
+    const float h = 0.5f * P.scale;
+    float cx, cy, cz;
+    transform(P, L.px[node] + h, L.py[node] + h, L.pz[node] + h, cx, cy, cz);
+    const uint32_t off = L.cand_off[node], cnt = L.cand_cnt[node];
+    uint32_t lo, hi;
+    segment_of(cnt, A.S, s, lo, hi);
     const float center_value = sqrtf(b.d) / P.gs;
     float r = center_value + 0.866025404f * P.scale;     // GetPossible, dllmain.cpp:151-162
     r *= P.gs;
     r *= r;
     uint32_t count = 0;
-    for (uint32_t k = tid; k < cnt; k += BT) {
+    for (uint32_t k = lo + tid; k < hi; k += 1024u) {
         const float *v = P.verts + 6 * (size_t)cand[off + k];
         if (lensq(v[0] - cx, v[1] - cy, v[2] - cz) < r) count++;
     }
     for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
-    if constexpr (BT > 64) {
-        if ((tid & 63u) == 0) shc[tid >> 6] = count;
-        __syncthreads();
+    if ((tid & 63u) == 0) shc[tid >> 6] = count;
+    __syncthreads();
+    if (tid == 0) {
         count = 0;
-        for (int w = 0; w < BT / 64; w++) count += shc[w];
+        for (int w = 0; w < 16; w++) count += shc[w];
+        A.count[blockIdx.x] = count;
+        if (count) atomicAdd(&L.pcount[node], count);
+        if (s == 0) L.center_value[node] = center_value;
     }
-    if (tid == 0) { L.center_value[node] = center_value; L.pcount[node] = count; }
 }
 
-// `possible` list (stable), the corner values, the split decision
-template <int BT>
-__global__ __launch_bounds__(BT) void k_corners(GenParams P, LevelArrays L, const uint32_t *__restrict__ cand,
-                                                const uint32_t *__restrict__ poff, uint32_t *__restrict__ possible,
-                                                uint32_t n_nodes, uint32_t *err)
+__global__ __launch_bounds__(1024) void k_corners_seg(GenParams P, LevelArrays L, SegArrays A, const uint32_t *__restrict__ cand,
+                                                      const uint32_t *__restrict__ poff, uint32_t *__restrict__ possible, uint32_t n_nodes)
 {
-    __shared__ Best sh[BT / 64];
-    __shared__ uint32_t kept[2][BT / 64];                // survivors per wavefront, double-buffered over chunks
-    const uint32_t node = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ Best sh[16];
+    __shared__ uint32_t kept[2][16];                     // survivors per wavefront, double-buffered over chunks
+    __shared__ uint32_t ahead[16];
+    const uint32_t node = blockIdx.x / A.S, s = blockIdx.x % A.S, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (node >= n_nodes) return;
+    const Best c = unpack_best(A.best[node]);
+    if (c.k == 0xFFFFFFFFu || isinf(c.d) || isnan(c.d)) return;          // no centre value: the build fails (k_center_seg_count said so)
     const float px = L.px[node], py = L.py[node], pz = L.pz[node];
     const float h = 0.5f * P.scale;
     float cx, cy, cz;
@@ -152,7 +193,6 @@ __global__ __launch_bounds__(BT) void k_corners(GenParams P, LevelArrays L, cons
     float r = center_value + 0.866025404f * P.scale;
     r *= P.gs;
     r *= r;
-    // the 8 corner positions, transformed: pos + split(i) * scale
     float qx[8], qy[8], qz[8];
 #pragma unroll
     for (int i = 0; i < 8; i++)
@@ -161,27 +201,35 @@ __global__ __launch_bounds__(BT) void k_corners(GenParams P, LevelArrays L, cons
     Best best[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) best[i] = Best{INFINITY, 0xFFFFFFFFu};
-    const uint32_t off = L.cand_off[node], cnt = L.cand_cnt[node], out = poff[node];
+    const uint32_t off = L.cand_off[node], cnt = L.cand_cnt[node];
+    uint32_t lo, hi;
+    segment_of(cnt, A.S, s, lo, hi);
+    // where this segment's survivors go: behind those of the segments before it
+    uint32_t before_seg = 0;
+    for (uint32_t j = tid; j < s; j += 1024u) before_seg += A.count[node * A.S + j];
+    for (int o = 32; o > 0; o >>= 1) before_seg += __shfl_xor(before_seg, o);
+    if (lane == 0) ahead[wave] = before_seg;
+    __syncthreads();
+    before_seg = 0;
+    for (int w = 0; w < 16; w++) before_seg += ahead[w];
+    const uint32_t out = poff[node] + before_seg;
     uint32_t base = 0, flip = 0;
-    for (uint32_t k0 = 0; k0 < cnt; k0 += BT, flip ^= 1u) {
+    for (uint32_t k0 = lo; k0 < hi; k0 += 1024u, flip ^= 1u) {
         const uint32_t k = k0 + tid;
         bool keep = false;
         uint32_t vi = 0;
         float vx = 0, vy = 0, vz = 0;
-        if (k < cnt) {
+        if (k < hi) {
             vi = cand[off + k];
             const float *v = P.verts + 6 * (size_t)vi;
             vx = v[0]; vy = v[1]; vz = v[2];
             keep = lensq(vx - cx, vy - cy, vz - cz) < r;
         }
         const unsigned long long m = __ballot(keep);
-        uint32_t before = 0, all = (uint32_t)__popcll(m);
-        if constexpr (BT > 64) {
-            if (lane == 0) kept[flip][wave] = all;
-            __syncthreads();
-            all = 0;
-            for (uint32_t w = 0; w < BT / 64; w++) { const uint32_t c = kept[flip][w]; before += w < wave ? c : 0u; all += c; }
-        }
+        uint32_t before = 0, all = 0;
+        if (lane == 0) kept[flip][wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        for (uint32_t w = 0; w < 16; w++) { const uint32_t n = kept[flip][w]; before += w < wave ? n : 0u; all += n; }
         if (keep) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             possible[out + base + before + rank] = vi;
@@ -193,33 +241,47 @@ __global__ __launch_bounds__(BT) void k_corners(GenParams P, LevelArrays L, cons
         }
         base += all;
     }
-    const int slot = L.slot[node];
-    float myval = 0.0f;                                  // thread i < 8 ends up holding corner i
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        Best b = node_min<BT>(best[i], sh);
-        float val;
-        if (i == slot) {
-            val = L.inherit[node];                       // n[i] = vals[insert][i], dllmain.cpp:181
-        } else if (b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d)) {
-            if (tid == 0) atomicExch(err, 2u);
-            val = 0.0f;
-        } else {                                         // DistanceAt, dllmain.cpp:119-149
-            const float *v = P.verts + 6 * (size_t)cand[off + b.k];
-            float md = sqrtf(b.d);
-            const float ex = qx[i] - v[0], ey = qy[i] - v[1], ez = qz[i] - v[2];      // p - closest.Position
-            if ((double)md < 0.015) {
-                const float nl = sqrtf(lensq(v[3], v[4], v[5]));
-                md = (v[3] / nl) * ex + (v[4] / nl) * ey + (v[5] / nl) * ez;
-            } else if (v[3] * (v[0] - qx[i]) + v[4] * (v[1] - qy[i]) + v[5] * (v[2] - qz[i]) > 0) {   // Inside
-                md *= -1;
-            }
-            val = md / P.gs;
-        }
-        if ((int)tid == i) myval = val;
+        const Best b = node_min<1024>(best[i], sh);
+        if (tid == 0 && b.k != 0xFFFFFFFFu) atomicMin(&A.corner[8 * (size_t)node + i], pack_best(b));
     }
-    if (tid < 8) L.vals[8 * (size_t)node + tid] = myval;
-    if (tid == 0) L.split[node] = (center_value < P.scale * 2 && P.depth < P.max_depth) ? 1u : 0u;
+}
+
+// the corner values and the split decision from the segments' minima: thread i of a node's eight, corner i
+__global__ __launch_bounds__(256) void k_corners_fin(GenParams P, LevelArrays L, SegArrays A, const uint32_t *__restrict__ cand,
+                                                     uint32_t n_nodes, uint32_t *err)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, node = g >> 3;
+    const int i = (int)(g & 7u);
+    if (node >= n_nodes) return;
+    const Best c = unpack_best(A.best[node]);
+    const bool no_centre = c.k == 0xFFFFFFFFu || isinf(c.d) || isnan(c.d);
+    const float px = L.px[node], py = L.py[node], pz = L.pz[node];
+    float qx, qy, qz;
+    transform(P, px + (float)(i % 2) * P.scale, py + (float)((i / 2) % 2) * P.scale, pz + (float)((i / 2 / 2) % 2) * P.scale, qx, qy, qz);
+    const Best b = unpack_best(A.corner[8 * (size_t)node + i]);
+    const uint32_t off = L.cand_off[node];
+    float val;
+    if (i == L.slot[node]) {
+        val = L.inherit[node];                           // n[i] = vals[insert][i], dllmain.cpp:181
+    } else if (no_centre || b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d)) {
+        atomicExch(err, 2u);
+        val = 0.0f;
+    } else {                                             // DistanceAt, dllmain.cpp:119-149
+        const float *v = P.verts + 6 * (size_t)cand[off + b.k];
+        float md = sqrtf(b.d);
+        const float ex = qx - v[0], ey = qy - v[1], ez = qz - v[2];      // p - closest.Position
+        if ((double)md < 0.015) {
+            const float nl = sqrtf(lensq(v[3], v[4], v[5]));
+            md = (v[3] / nl) * ex + (v[4] / nl) * ey + (v[5] / nl) * ez;
+        } else if (v[3] * (v[0] - qx) + v[4] * (v[1] - qy) + v[5] * (v[2] - qz) > 0) {   // Inside
+            md *= -1;
+        }
+        val = md / P.gs;
+    }
+    L.vals[8 * (size_t)node + i] = val;
+    if (i == 0) L.split[node] = (L.center_value[node] < P.scale * 2 && P.depth < P.max_depth) ? 1u : 0u;
 }
 
 // ---- several nodes per wavefront --------------------------------------------------------------------
@@ -641,8 +703,19 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
             // wide levels: 16 lanes per node, four nodes per wavefront -- whatever the lists' lengths: the passes over a list are
             // chains of dependent gathers (index -> position), and four lists per wave keep four times as many of them in flight
             // (1 M-point knot: depth 9 in 40 ms instead of 56, depth 10 in 58 instead of 90; scripts/sdfgen_short_list.py)
+            // narrow levels: a node's list over S workgroups, so that the level still fills the chip (k_center_seg_min, ...)
+            SegArrays A{ nullptr, nullptr, nullptr, wide ? 0u : (WIDE_LEVEL + n_nodes - 1) / n_nodes };
             if (wide) hipLaunchKernelGGL(k_center_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
-            else hipLaunchKernelGGL(k_center<1024>, dim3(n_nodes), dim3(1024), 0, 0, P, L, cand, n_nodes, d_err);
+            else {
+                A.best = mine.alloc<unsigned long long>(n_nodes); A.corner = mine.alloc<unsigned long long>(8 * (size_t)n_nodes);
+                A.count = mine.alloc<uint32_t>((size_t)n_nodes * A.S);
+                if (!A.best || !A.corner || !A.count) return GEN_NOMEM();
+                GEN_TRY(hipMemsetAsync(A.best, 0xFF, (size_t)n_nodes * 8, 0));
+                GEN_TRY(hipMemsetAsync(A.corner, 0xFF, (size_t)n_nodes * 64, 0));
+                GEN_TRY(hipMemsetAsync(L.pcount, 0, (size_t)n_nodes * 4, 0));
+                hipLaunchKernelGGL(k_center_seg_min, dim3(n_nodes * A.S), dim3(1024), 0, 0, P, L, A, cand, n_nodes);
+                hipLaunchKernelGGL(k_center_seg_count, dim3(n_nodes * A.S), dim3(1024), 0, 0, P, L, A, cand, n_nodes, d_err);
+            }
             if (!scan_u32(mine, L.pcount, poff, n_nodes, d_total)) return GEN_NOMEM();
             unsigned long long total = 0;
             GEN_TRY(hipMemcpy(&total, d_total, sizeof total, hipMemcpyDeviceToHost));
@@ -652,7 +725,10 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
             if (!possible) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory for %llu candidate entries", total);
             cand_entries += total;
             if (wide) hipLaunchKernelGGL(k_corners_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
-            else hipLaunchKernelGGL(k_corners<1024>, dim3(n_nodes), dim3(1024), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            else {
+                hipLaunchKernelGGL(k_corners_seg, dim3(n_nodes * A.S), dim3(1024), 0, 0, P, L, A, cand, poff, possible, n_nodes);
+                hipLaunchKernelGGL(k_corners_fin, dim3((8 * n_nodes + 255) / 256), dim3(256), 0, 0, P, L, A, cand, n_nodes, d_err);
+            }
             if (!scan_u32(mine, L.split, L.block_of, n_nodes, d_total)) return GEN_NOMEM();
             struct { unsigned long long n_split; uint32_t err; } back;
             GEN_TRY(hipMemcpy(&back.n_split, d_total, sizeof back.n_split, hipMemcpyDeviceToHost));
