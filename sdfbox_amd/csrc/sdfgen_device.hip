@@ -29,6 +29,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
+#include <sys/mman.h>
 #include <new>
 #include <vector>
 
@@ -40,6 +42,11 @@ struct GenParams {
     float scale;               // 2^-depth of this level
     int depth, max_depth;
 };
+
+// A candidate list entry carries its point's position: the passes over a list stream 16-byte entries instead of chasing an
+// index into the point array (the lists of the 1 M-point knot: 741 M entries at depth 10, the passes were chains of dependent
+// gathers); the index (w, as bits) is needed once per corner, for the winner's normal.
+typedef float4 Cand;
 
 struct LevelArrays {           // one entry per node of the level
     float *px, *py, *pz;       // cell lower corner (unit-cube coordinates)
@@ -113,7 +120,7 @@ __device__ __forceinline__ void segment_of(uint32_t cnt, uint32_t S, uint32_t s,
     lo = min(cnt, s * len); hi = min(cnt, lo + len);
 }
 
-__global__ __launch_bounds__(1024) void k_center_seg_min(GenParams P, LevelArrays L, SegArrays A, const uint32_t *__restrict__ cand, uint32_t n_nodes)
+__global__ __launch_bounds__(1024) void k_center_seg_min(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand, uint32_t n_nodes)
 {
     __shared__ Best sh[16];
     const uint32_t node = blockIdx.x / A.S, s = blockIdx.x % A.S, tid = threadIdx.x;
@@ -126,15 +133,15 @@ __global__ __launch_bounds__(1024) void k_center_seg_min(GenParams P, LevelArray
     segment_of(cnt, A.S, s, lo, hi);
     Best b{INFINITY, 0xFFFFFFFFu};
     for (uint32_t k = lo + tid; k < hi; k += 1024u) {
-        const float *v = P.verts + 6 * (size_t)cand[off + k];
-        float d = lensq(v[0] - cx, v[1] - cy, v[2] - cz);
+        const Cand v = cand[off + k];
+        float d = lensq(v.x - cx, v.y - cy, v.z - cz);
         if (d < b.d) { b.d = d; b.k = k; }
     }
     b = node_min<1024>(b, sh);
     if (tid == 0 && b.k != 0xFFFFFFFFu) atomicMin(&A.best[node], pack_best(b));
 }
 
-__global__ __launch_bounds__(1024) void k_center_seg_count(GenParams P, LevelArrays L, SegArrays A, const uint32_t *__restrict__ cand,
+__global__ __launch_bounds__(1024) void k_center_seg_count(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand,
                                                            uint32_t n_nodes, uint32_t *err)
 {
     __shared__ uint32_t shc[16];
@@ -160,8 +167,8 @@ __global__ __launch_bounds__(1024) void k_center_seg_count(GenParams P, LevelArr
     r *= r;
     uint32_t count = 0;
     for (uint32_t k = lo + tid; k < hi; k += 1024u) {
-        const float *v = P.verts + 6 * (size_t)cand[off + k];
-        if (lensq(v[0] - cx, v[1] - cy, v[2] - cz) < r) count++;
+        const Cand v = cand[off + k];
+        if (lensq(v.x - cx, v.y - cy, v.z - cz) < r) count++;
     }
     for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
     if ((tid & 63u) == 0) shc[tid >> 6] = count;
@@ -175,8 +182,8 @@ __global__ __launch_bounds__(1024) void k_center_seg_count(GenParams P, LevelArr
     }
 }
 
-__global__ __launch_bounds__(1024) void k_corners_seg(GenParams P, LevelArrays L, SegArrays A, const uint32_t *__restrict__ cand,
-                                                      const uint32_t *__restrict__ poff, uint32_t *__restrict__ possible, uint32_t n_nodes)
+__global__ __launch_bounds__(1024) void k_corners_seg(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand,
+                                                      const uint32_t *__restrict__ poff, Cand *__restrict__ possible, uint32_t n_nodes)
 {
     __shared__ Best sh[16];
     __shared__ uint32_t kept[2][16];                     // survivors per wavefront, double-buffered over chunks
@@ -217,12 +224,11 @@ __global__ __launch_bounds__(1024) void k_corners_seg(GenParams P, LevelArrays L
     for (uint32_t k0 = lo; k0 < hi; k0 += 1024u, flip ^= 1u) {
         const uint32_t k = k0 + tid;
         bool keep = false;
-        uint32_t vi = 0;
+        Cand vi = make_float4(0, 0, 0, 0);
         float vx = 0, vy = 0, vz = 0;
         if (k < hi) {
             vi = cand[off + k];
-            const float *v = P.verts + 6 * (size_t)vi;
-            vx = v[0]; vy = v[1]; vz = v[2];
+            vx = vi.x; vy = vi.y; vz = vi.z;
             keep = lensq(vx - cx, vy - cy, vz - cz) < r;
         }
         const unsigned long long m = __ballot(keep);
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(1024) void k_corners_seg(GenParams P, LevelArrays L
 }
 
 // the corner values and the split decision from the segments' minima: thread i of a node's eight, corner i
-__global__ __launch_bounds__(256) void k_corners_fin(GenParams P, LevelArrays L, SegArrays A, const uint32_t *__restrict__ cand,
+__global__ __launch_bounds__(256) void k_corners_fin(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand,
                                                      uint32_t n_nodes, uint32_t *err)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, node = g >> 3;
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void k_corners_fin(GenParams P, LevelArrays L,
         atomicExch(err, 2u);
         val = 0.0f;
     } else {                                             // DistanceAt, dllmain.cpp:119-149
-        const float *v = P.verts + 6 * (size_t)cand[off + b.k];
+        const float *v = P.verts + 6 * (size_t)__float_as_uint(cand[off + b.k].w);
         float md = sqrtf(b.d);
         const float ex = qx - v[0], ey = qy - v[1], ez = qz - v[2];      // p - closest.Position
         if ((double)md < 0.015) {
@@ -302,7 +308,7 @@ template <int G> __device__ __forceinline__ Best sub_min(Best b)
 }
 
 template <int G>
-__global__ __launch_bounds__(64) void k_center_sub(GenParams P, LevelArrays L, const uint32_t *__restrict__ cand,
+__global__ __launch_bounds__(64) void k_center_sub(GenParams P, LevelArrays L, const Cand *__restrict__ cand,
                                                    uint32_t n_nodes, uint32_t *err)
 {
     const uint32_t tid = threadIdx.x, sub = tid % G, node = blockIdx.x * (64 / G) + tid / G;
@@ -314,22 +320,18 @@ __global__ __launch_bounds__(64) void k_center_sub(GenParams P, LevelArrays L, c
         transform(P, L.px[node] + h, L.py[node] + h, L.pz[node] + h, cx, cy, cz);
         off = L.cand_off[node]; cnt = L.cand_cnt[node];
     }
-    // (both passes take SUB_UNROLL list entries per lane at a time: the gathers index -> position of all of them are issued
-    // before the first is used -- the passes are chains of dependent loads, not arithmetic; the order of the comparisons,
-    // and with it the tie-breaking, is the list's)
+    // (both passes take SUB_UNROLL list entries per lane at a time, loaded before the first is used; the order of the
+    // comparisons, and with it the tie-breaking, is the list's)
     Best b{INFINITY, 0xFFFFFFFFu};
     for (uint32_t k0 = sub; k0 < cnt; k0 += SUB_UNROLL * G) {
-        uint32_t idx[SUB_UNROLL];
-        float x[SUB_UNROLL], y[SUB_UNROLL], z[SUB_UNROLL];
+        Cand e[SUB_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SUB_UNROLL; u++) idx[u] = k0 + u * G < cnt ? cand[off + k0 + u * G] : 0u;
-#pragma unroll
-        for (int u = 0; u < SUB_UNROLL; u++) { const float *v = P.verts + 6 * (size_t)idx[u]; x[u] = v[0]; y[u] = v[1]; z[u] = v[2]; }
+        for (int u = 0; u < SUB_UNROLL; u++) e[u] = k0 + u * G < cnt ? cand[off + k0 + u * G] : make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < SUB_UNROLL; u++) {
             const uint32_t k = k0 + u * G;
             if (k < cnt) {
-                float d = lensq(x[u] - cx, y[u] - cy, z[u] - cz);
+                float d = lensq(e[u].x - cx, e[u].y - cy, e[u].z - cz);
                 if (d < b.d) { b.d = d; b.k = k; }
             }
         }
@@ -343,15 +345,12 @@ __global__ __launch_bounds__(64) void k_center_sub(GenParams P, LevelArrays L, c
     uint32_t count = 0;
     if (!bad)
         for (uint32_t k0 = sub; k0 < cnt; k0 += SUB_UNROLL * G) {
-            uint32_t idx[SUB_UNROLL];
-            float x[SUB_UNROLL], y[SUB_UNROLL], z[SUB_UNROLL];
+            Cand e[SUB_UNROLL];
 #pragma unroll
-            for (int u = 0; u < SUB_UNROLL; u++) idx[u] = k0 + u * G < cnt ? cand[off + k0 + u * G] : 0u;
-#pragma unroll
-            for (int u = 0; u < SUB_UNROLL; u++) { const float *v = P.verts + 6 * (size_t)idx[u]; x[u] = v[0]; y[u] = v[1]; z[u] = v[2]; }
+            for (int u = 0; u < SUB_UNROLL; u++) e[u] = k0 + u * G < cnt ? cand[off + k0 + u * G] : make_float4(0, 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < SUB_UNROLL; u++)
-                if (k0 + u * G < cnt && lensq(x[u] - cx, y[u] - cy, z[u] - cz) < r) count++;
+                if (k0 + u * G < cnt && lensq(e[u].x - cx, e[u].y - cy, e[u].z - cz) < r) count++;
         }
     for (int o = G / 2; o > 0; o >>= 1) count += __shfl_xor(count, o);
     if (have && sub == 0) {
@@ -361,8 +360,8 @@ __global__ __launch_bounds__(64) void k_center_sub(GenParams P, LevelArrays L, c
 }
 
 template <int G>
-__global__ __launch_bounds__(64) void k_corners_sub(GenParams P, LevelArrays L, const uint32_t *__restrict__ cand,
-                                                    const uint32_t *__restrict__ poff, uint32_t *__restrict__ possible,
+__global__ __launch_bounds__(64) void k_corners_sub(GenParams P, LevelArrays L, const Cand *__restrict__ cand,
+                                                    const uint32_t *__restrict__ poff, Cand *__restrict__ possible,
                                                     uint32_t n_nodes, uint32_t *err)
 {
     const uint32_t tid = threadIdx.x, sub = tid % G, grp = tid / G, node = blockIdx.x * (64 / G) + grp;
@@ -395,12 +394,11 @@ __global__ __launch_bounds__(64) void k_corners_sub(GenParams P, LevelArrays L, 
     for (uint32_t k0 = 0; k0 < longest; k0 += G) {
         const uint32_t k = k0 + sub;
         bool keep = false;
-        uint32_t vi = 0;
+        Cand vi = make_float4(0, 0, 0, 0);
         float vx = 0, vy = 0, vz = 0;
         if (k < cnt) {
             vi = cand[off + k];
-            const float *v = P.verts + 6 * (size_t)vi;
-            vx = v[0]; vy = v[1]; vz = v[2];
+            vx = vi.x; vy = vi.y; vz = vi.z;
             keep = lensq(vx - cx, vy - cy, vz - cz) < r;
         }
         const unsigned long long m = __ballot(keep);
@@ -427,7 +425,7 @@ __global__ __launch_bounds__(64) void k_corners_sub(GenParams P, LevelArrays L, 
             bad_any = true;
             val = 0.0f;
         } else {                                         // DistanceAt, dllmain.cpp:119-149
-            const float *v = P.verts + 6 * (size_t)cand[off + b.k];
+            const float *v = P.verts + 6 * (size_t)__float_as_uint(cand[off + b.k].w);
             float md = sqrtf(b.d);
             const float ex = qx[i] - v[0], ey = qy[i] - v[1], ez = qz[i] - v[2];      // p - closest.Position
             if ((double)md < 0.015) {
@@ -465,9 +463,11 @@ __global__ void k_children(LevelArrays L, LevelArrays N, const uint32_t *__restr
     N.cand_cnt[c] = L.pcount[node];
 }
 
-__global__ void k_iota(uint32_t *p, uint32_t n)
+// the root's list: every point, in input order
+__global__ void k_cand_init(Cand *p, const float *__restrict__ verts, uint32_t n)
 {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        p[i] = make_float4(verts[6 * (size_t)i], verts[6 * (size_t)i + 1], verts[6 * (size_t)i + 2], __uint_as_float(i));
 }
 
 // exclusive scan of n uint32 in two launches: per-chunk sums, then every workgroup adds the sums of
@@ -673,11 +673,11 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
         float *d_verts = keep.alloc<float>(6 * (size_t)n);
         uint32_t *d_err = keep.alloc<uint32_t>(1);
         unsigned long long *d_total = keep.alloc<unsigned long long>(1);
-        uint32_t *cand = lists[0].alloc<uint32_t>(n);
+        Cand *cand = lists[0].alloc<Cand>(n);
         if (!d_verts || !d_err || !d_total || !cand) return GEN_NOMEM();
         GEN_TRY(hipMemcpy(d_verts, verts6, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
         GEN_TRY(hipMemset(d_err, 0, sizeof(uint32_t)));
-        hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, 0, cand, n);
+        hipLaunchKernelGGL(k_cand_init, dim3(1024), dim3(256), 0, 0, cand, (const float *)d_verts, n);
         P.verts = d_verts;
 
         LevelArrays L;
@@ -721,7 +721,7 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
             GEN_TRY(hipMemcpy(&total, d_total, sizeof total, hipMemcpyDeviceToHost));
             if (total > 0xFFFFFFF0ull) return fail(SDFHIP_ERR_NOMEM, "sdfgen: candidate lists of level %d exceed 2^32 entries", lvl);
             lists[(lvl + 1) & 1].reset();                 // the lists of level lvl-1: dead since k_children of lvl-1
-            uint32_t *possible = lists[(lvl + 1) & 1].alloc<uint32_t>((size_t)total);
+            Cand *possible = lists[(lvl + 1) & 1].alloc<Cand>((size_t)total);
             if (!possible) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory for %llu candidate entries", total);
             cand_entries += total;
             if (wide) hipLaunchKernelGGL(k_corners_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
@@ -749,6 +749,13 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
             n_nodes = (uint32_t)(8 * n_split);
         }
 
+        const bool timing = getenv("SDFHIP_GEN_TIMING") != nullptr;       // debug aid: phase times on stderr
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            (void)hipDeviceSynchronize();
+            fprintf(stderr, "sdfgen: %-28s at %.2f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        };
+        lap("levels done");
         // ---- the reference's node order and bytes (k_subtree bottom-up, k_emit top-down) ----
         int32_t *d_S = keep.alloc<int32_t>(2 * total_nodes);
         uint8_t *d_V = keep.alloc<uint8_t>(8 * total_nodes);
@@ -769,12 +776,24 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
                                ldexpf(1.0f, -(int)l), kl.n, d_S, d_V);
         }
         GEN_TRY(hipGetLastError());
-        int32_t *S = (int32_t *)malloc(total_nodes * 8);
-        uint8_t *V = (uint8_t *)malloc(total_nodes * 8);
+        lap("order + bytes done");
+        // the result arrays (the caller frees them with free()): large ones on 2 MB pages where the kernel offers them -- the
+        // copy from the device writes every page for the first time, and 47 000 page faults of 4 KB take five times as long as
+        // the 192 MB of a 12 M-node tree take over the link
+        auto result_alloc = [](size_t bytes) -> void * {
+            if (bytes < ((size_t)8 << 20)) return malloc(bytes);
+            void *p = nullptr;
+            if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0) return malloc(bytes);
+            (void)madvise(p, bytes, MADV_HUGEPAGE);
+            return p;
+        };
+        int32_t *S = (int32_t *)result_alloc(total_nodes * 8);
+        uint8_t *V = (uint8_t *)result_alloc(total_nodes * 8);
         if (!S || !V) { free(S); free(V); return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of host memory for %zu nodes", total_nodes); }
         hipError_t e1 = hipMemcpy(S, d_S, total_nodes * 8, hipMemcpyDeviceToHost);
         hipError_t e2 = e1 == hipSuccess ? hipMemcpy(V, d_V, total_nodes * 8, hipMemcpyDeviceToHost) : e1;
         if (e2 != hipSuccess) { free(S); free(V); return fail(SDFHIP_ERR_DEVICE, "sdfgen: copying the tree back failed: %s", hipGetErrorString(e2)); }
+        lap("copied to the host");
         out->length = (uint32_t)total_nodes; out->structs = S; out->values = V;
         if (stats) {
             stats->nodes = (uint32_t)total_nodes;
