@@ -79,14 +79,16 @@ enum {
     SDFHIP_FLAG_TILE_ORDER = 0x100000, /* for a viewer that renders one frame at a time: launch this frame's 8x8 tiles in
                                      descending order of the march iterations they (or a tile within two of them) took in the
                                      last frame rendered with the same geometry on the same stream; the order is made on the
-                                     device behind every such frame (two small kernels, 13 us).  The first frame of a geometry,
-                                     frames of a batch and frames of more than 65 536 tiles take the default order.  A frame
-                                     alone ends when its longest wave does, so the tiles that were expensive a moment ago go
-                                     first: 0.174 -> 0.146 ms per 1080p frame with the camera at rest, 0.170 -> 0.146 with a
-                                     quarter of a degree between frames, 0.188 -> 0.148 with one degree.  NOT for frames in
-                                     flight on several streams (0.090 -> 0.103 ms per frame: the ordering kernels sit between
-                                     a stream's frames), and no gain at 4K (16 rounds of workgroups: the tail is short and
-                                     neighbouring tiles no longer run together), hence the limit.  Never changes a pixel. */
+                                     device behind every such frame whose camera block differs from the one the order in use
+                                     came from (two small kernels, 13 us; a camera at rest pays once).  The first frame of a
+                                     geometry, frames of a batch and frames of more than 65 536 tiles take the default order.
+                                     A frame alone ends when its longest wave does, so the tiles that were expensive a moment
+                                     ago go first: 0.174 -> 0.133 ms per 1080p frame with the camera at rest, 0.170 -> 0.146
+                                     with a quarter of a degree between frames, 0.188 -> 0.148 with one degree.  Not for
+                                     frames in flight on several streams (0.090 -> 0.095 ms per frame with a fixed camera,
+                                     0.093 -> 0.109 with a moving one: the ordering kernels sit between a stream's frames), and
+                                     no gain at 4K (16 rounds of workgroups: the tail is short and neighbouring tiles no longer
+                                     run together), hence the limit.  Never changes a pixel. */
     SDFHIP_FLAG_WIRE = 0x10000,   /* device-resident entry points only: 5-byte wire pixels for the
                                      tile gather (see sdfhip_deinterleave_device), lossless */
     /* tuning knobs for A/B measurements (0 = the default): bits 8..11 blockIdx -> tile

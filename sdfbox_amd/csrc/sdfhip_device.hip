@@ -500,6 +500,7 @@ struct sdfhip_scene {
         uint32_t ord_tiles, ord_blocks;      // capacity of the two arrays
         uint32_t ord_sig[8];                 // width, height, nrows_out, band_rows, band_first, band_stride, n_band_list, hash of the list
         bool ord_valid;
+        sdfhip_info ord_info;                // the camera block of the frame the order was made from
     };
     static constexpr int MAX_SCRATCH = 16;
     static constexpr size_t CTL_HIT_WORDS = (size_t)2 * MAX_BATCH * HIT_QUEUES * 32, CTL_QUEUE_WORDS = 8 * 32,
@@ -1051,7 +1052,10 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     if (two) {
         if (cur == CUR_STACK_SPLIT) { if (count) launch_two<CUR_STACK_SPLIT, true>(out_mode, grid, shade_grid, st, P, queued); else launch_two<CUR_STACK_SPLIT, false>(out_mode, grid, shade_grid, st, P, queued); }
         else                        { if (count) launch_two<CUR_STACK_FULL, true>(out_mode, grid, shade_grid, st, P, queued); else launch_two<CUR_STACK_FULL, false>(out_mode, grid, shade_grid, st, P, queued); }
-        if (ordered) {                                  // the next frame's launch order, behind this frame in its stream
+        // the next frame's launch order, behind this frame in its stream -- unless the order in use was made from a frame with this
+        // very camera block: the same camera gives the same costs and the same order (a viewer at rest pays for the order once)
+        if (ordered && !(sc->ord_valid && memcmp(info, &sc->ord_info, sizeof(sdfhip_info)) == 0)) {
+            sc->ord_info = *info;
             hipLaunchKernelGGL(k_tile_class, dim3((P.n_tiles + 255u) / 256u), dim3(256), 0, st, sc->ord_cost, sc->ord_class, P.tiles_x, P.tiles_y);
             hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, st, sc->ord_class, sc->ord_perm, P.tiles_x, P.tiles_y);
             sc->ord_valid = true;
