@@ -36,7 +36,7 @@ def build_native():
     return NATIVE_PATH
 
 
-VARIANTS = {"unfused": "-DO_UNFUSED", "lerp_mathcs": "-DO_LERP_MATHCS", "sampler8": "-DO_SAMPLER8"}
+VARIANTS = {"unfused": "-DO_UNFUSED", "lerp_mathcs": "-DO_LERP_MATHCS", "sampler8": "-DO_SAMPLER8", "rsqrt1ulp": "-DO_RSQRT1ULP"}
 
 
 def build_variant(name):

@@ -41,7 +41,7 @@
  *
  * CONTRACT VARIANTS (measurement only; DESIGN.md section 2 "how far is the contract from other
  * readings of the shader").  The contract above is one legal reading of D3D11's `mad` and of its
- * texture sampler; nothing in the reference pins it.  Three build-time variants restate the other
+ * texture sampler; nothing in the reference pins it.  Four build-time variants restate the other
  * readings so that tests/test_oracle_variants.py can put a number on the distance between them (the
  * parity statement of SURVEY.md 8d: RGB within 1e-5 and equal step count, fraction of pixels):
  *   -DO_UNFUSED       SURVEY.md 8c's literal text: lerp = a + t*(b-a), dot and pos += dir*s with
@@ -50,7 +50,10 @@
  *                     a*(1-p) + b*p, unfused;
  *   -DO_SAMPLER8      the bilinear weights of the two texture taps (Compute.hlsl:15-29, sampler
  *                     Program.cs:147) reduced to 8 fractional bits, as D3D11 hardware filtering
- *                     does at its minimum precision (the z-lerp stays in shader arithmetic).
+ *                     does at its minimum precision (the z-lerp stays in shader arithmetic);
+ *   -DO_RSQRT1ULP     HLSL's normalize is v * rsqrt(dot(v,v)), and a GPU's rsqrt is an approximation (D3D11 allows
+ *                     it one ulp): every reciprocal square root one ulp off the correctly rounded 1/sqrtf(x), up or
+ *                     down by the lowest bit of x -- ray directions, light directions and normals all move.
  * The default build (none of them) is the oracle; the variants are never compared with the kernels.
  */
 #include <math.h>
@@ -118,6 +121,16 @@ O_INLINE float o_dot(float ax, float ay, float az, float bx, float by, float bz)
 {
     return fmaf(az, bz, fmaf(ay, by, ax * bx));
 }
+#endif
+#if defined(O_RSQRT1ULP)
+O_INLINE float o_rsqrt(float x)
+{
+    union { float f; uint32_t u; } in = { x }, r = { 1.0f / sqrtf(x) };
+    if (r.f == r.f && r.u != 0 && (r.u & 0x7F800000u) != 0x7F800000u) r.u += (in.u & 1u) ? 1u : 0xFFFFFFFFu;     /* finite, non-zero: +- 1 ulp */
+    return r.f;
+}
+#else
+O_INLINE float o_rsqrt(float x) { return 1.0f / sqrtf(x); }
 #endif
 #if defined(O_SAMPLER8)
 /* a bilinear weight as the texture unit sees it at D3D11's minimum filtering precision: 8 fractional bits */
@@ -260,7 +273,7 @@ O_INLINE void o_ray(const o_info *inf, uint32_t cx, uint32_t cy, float dir[3])
     float d1 = o_dot(vx, vy, vz, inf->heading[1][0], inf->heading[1][1], inf->heading[1][2]);
     float d2 = o_dot(vx, vy, vz, inf->heading[2][0], inf->heading[2][1], inf->heading[2][2]);
     /* normalize(v) = v * rsqrt(dot(v, v)) in HLSL; here rsqrt(x) = 1 / sqrtf(x) */
-    float rl = 1.0f / sqrtf(o_dot(d0, d1, d2, d0, d1, d2));
+    float rl = o_rsqrt(o_dot(d0, d1, d2, d0, d1, d2));
     dir[0] = d0 * rl;
     dir[1] = d1 * rl;
     dir[2] = d2 * rl;
@@ -298,7 +311,7 @@ O_INLINE void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_
     {
         /* dir = normalize(inf.light - pos); pos += dir * inf.margin; */
         float lx = inf->light[0] - px, ly = inf->light[1] - py, lz = inf->light[2] - pz;
-        float rl = 1.0f / sqrtf(o_dot(lx, ly, lz, lx, ly, lz));
+        float rl = o_rsqrt(o_dot(lx, ly, lz, lx, ly, lz));
         dir[0] = lx * rl; dir[1] = ly * rl; dir[2] = lz * rl;
         px = o_mad(dir[0], margin, px);
         py = o_mad(dir[1], margin, py);
@@ -306,7 +319,7 @@ O_INLINE void o_pixel(const o_scene *sc, const o_info *inf, float exp2_strength_
         /* angle = dot(dir, normalize(gradient(pos))) */
         float g[3];
         o_gradient(&t, px, py, pz, g);
-        float rg = 1.0f / sqrtf(o_dot(g[0], g[1], g[2], g[0], g[1], g[2]));
+        float rg = o_rsqrt(o_dot(g[0], g[1], g[2], g[0], g[1], g[2]));
         float angle = o_dot(dir[0], dir[1], dir[2], g[0] * rg, g[1] * rg, g[2] * rg);
         if (angle < 0.0f) {
             out[0] = out[1] = out[2] = 0.0f; out[3] = (float)i;
@@ -381,7 +394,7 @@ O_INLINE void o_ray_f(const o_info *inf, float fx, float fy, float dir[3])
     float d0 = o_dot(vx, vy, vz, inf->heading[0][0], inf->heading[0][1], inf->heading[0][2]);
     float d1 = o_dot(vx, vy, vz, inf->heading[1][0], inf->heading[1][1], inf->heading[1][2]);
     float d2 = o_dot(vx, vy, vz, inf->heading[2][0], inf->heading[2][1], inf->heading[2][2]);
-    float rl = 1.0f / sqrtf(o_dot(d0, d1, d2, d0, d1, d2));
+    float rl = o_rsqrt(o_dot(d0, d1, d2, d0, d1, d2));
     dir[0] = d0 * rl; dir[1] = d1 * rl; dir[2] = d2 * rl;
 }
 
@@ -422,12 +435,12 @@ O_INLINE void o_pixel_pt(const o_scene *sc, const o_info *inf, float k, uint32_t
             }
             /* shade, Compute.hlsl:205-213 */
             float lx = inf->light[0] - px, ly = inf->light[1] - py, lz = inf->light[2] - pz;
-            float rl = 1.0f / sqrtf(o_dot(lx, ly, lz, lx, ly, lz));
+            float rl = o_rsqrt(o_dot(lx, ly, lz, lx, ly, lz));
             float L0 = lx * rl, L1 = ly * rl, L2 = lz * rl;
             px = fmaf(L0, margin, px); py = fmaf(L1, margin, py); pz = fmaf(L2, margin, pz);
             float g[3];
             o_gradient(&t, px, py, pz, g);
-            float rg = 1.0f / sqrtf(o_dot(g[0], g[1], g[2], g[0], g[1], g[2]));
+            float rg = o_rsqrt(o_dot(g[0], g[1], g[2], g[0], g[1], g[2]));
             float n0 = g[0] * rg, n1 = g[1] * rg, n2 = g[2] * rg;
             float angle = o_dot(L0, L1, L2, n0, n1, n2);
             if (!(angle < 0.0f)) {
@@ -467,11 +480,11 @@ O_INLINE void o_pixel_pt(const o_scene *sc, const o_info *inf, float k, uint32_t
                 float qq = o_dot(c0, c1, c2, c0, c1, c2);
                 if (qq <= 1.0f && qq > 1e-12f) { u0 = c0; u1 = c1; u2 = c2; q = qq; break; }
             }
-            float ru = 1.0f / sqrtf(q);
+            float ru = o_rsqrt(q);
             float d0 = fmaf(u0, ru, n0), d1 = fmaf(u1, ru, n1), d2 = fmaf(u2, ru, n2);
             float qd = o_dot(d0, d1, d2, d0, d1, d2);
             if (!(qd > 1e-12f)) { d0 = n0; d1 = n1; d2 = n2; qd = o_dot(n0, n1, n2, n0, n1, n2); }
-            float rd = 1.0f / sqrtf(qd);
+            float rd = o_rsqrt(qd);
             dir[0] = d0 * rd; dir[1] = d1 * rd; dir[2] = d2 * rd;
             float off = margin * 4.0f;
             px = fmaf(n0, off, px); py = fmaf(n1, off, py); pz = fmaf(n2, off, pz);
