@@ -81,6 +81,15 @@ def parse():
     ap.add_argument("--sparse-cap-scale", type=float, default=1.25,
                     help="sparse wire shares: capacity = this x the lit pixels measured before the timed region (a value "
                          "below 1 forces overflows, to exercise the dense resend)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 (or --devices) through the library's own multi-device entry points (sdfhip_multi_*: one process, one "
+                         "host thread and stream per device, peer copies or RCCL inside the library) instead of one process per GPU "
+                         "under torch.distributed; the A/B of the two host designs")
+    ap.add_argument("--devices", default=None,
+                    help="--single-process: the device list, e.g. 0,0,0,0 to rehearse four ranks on one GPU (default 0..gpus-1)")
+    ap.add_argument("--multi-mode", default="groups", choices=["groups", "frame"],
+                    help="--single-process: 'groups' = groups of --gather-every frames, four groups in flight (throughput); "
+                         "'frame' = one frame at a time across all devices, launch to completion (what a viewer waits for)")
     ap.add_argument("--wire", type=int, default=2,
                     help="sharded runs: what the ranks send.  2 = sparse wire shares (code bytes + the non-zero grey "
                          "levels packed per 8x8 tile; capacity measured before the timed region), 1 = 5-byte wire "
@@ -98,6 +107,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_process or args.devices:
+        if "WORLD_SIZE" in os.environ and world > 1:
+            raise SystemExit("--single-process is one process for all devices: start it without a launcher")
+        return main_single_process(args, json_fd)
     if world != args.gpus:
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
             os.dup2(json_fd, 1)
@@ -569,6 +582,171 @@ def main():
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_single_process(args, json_fd):
+    """`--single-process`: the N-device frame behind the library's one call (sdfhip_multi_submit / _wait): one process, one
+    host thread and one stream per device inside libsdfhip.so, sparse shares written by the march kernel, pushed into
+    device 0 over the peers' own links, assembled there.  Same workload, same JSON line; `config.parallelism` says which
+    of the two things it measures."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+
+    import sdfbox_amd as sb
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    ndev = torch.cuda.device_count()
+    if max(devices) >= ndev:
+        raise SystemExit(f"--devices {devices}: this box has {ndev} GPU(s)")
+    W, H = (int(v) for v in args.size.lower().split("x"))
+    t0 = time.time()
+    if args.asdf:
+        od = sb.OctData.LoadAsdf(args.asdf)
+        scene_name = os.path.basename(args.asdf)
+    else:
+        od = sb.dragon_standin(args.depth, nthreads=max(1, min(32, os.cpu_count() or 1)))
+        scene_name = f"dragon_standin_d{args.depth}"
+    t_gen = time.time() - t0
+    torch.cuda.set_device(devices[0])
+    ms = sb.MultiScene(od, devices)
+    if args.band_rows != 16 or args.rank0_weight > 0:
+        ms.configure(band_rows=args.band_rows, rank0_weight=args.rank0_weight if args.rank0_weight > 0 else 1.0)
+    cam = sb.Logic(W, H)
+    cam.Position = (0.5, 0.5, -0.35)
+    cam.Heading = (-0.2, 0.35)
+    cams = orbit_cameras(sb, W, H, args.orbit) if args.orbit > 0 else [cam]
+    pt = sb.PathTrace(spp=args.spp) if args.spp > 0 else None
+    flags = (sb.FLAG_DISPLAY if args.display else 0) | (sb.FLAG_TILE_ORDER if args.tile_order else 0)
+    frame_mode = args.multi_mode == "frame" or pt is not None
+    G = 1 if frame_mode else (args.gather_every if args.gather_every > 0 else (8 if len(devices) >= 8 else 4))
+    nslots = 1 if frame_mode else min(4, args.frames_in_flight if args.frames_in_flight > 0 else 4)
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    inflight = [None] * nslots              # the step index of the group a slot holds
+    stats_seen = []
+
+    def run(n, collect=False):
+        """n steps (frames) through the slots; returns the host time"""
+        for k in range(nslots):
+            if inflight[k] is not None:
+                ms.Wait(k); inflight[k] = None
+        sync_all()
+        t = time.perf_counter()
+        k = 0
+        while k < n:
+            g = min(G, n - k)
+            slot = (k // G) % nslots
+            if inflight[slot] is not None:
+                _, st = ms.Wait(slot, want_stats=True)
+                if collect:
+                    stats_seen.append(st)
+            ms.Submit(slot, [cams[(k + i) % len(cams)] for i in range(g)], W, H, flags=flags, pt=pt)
+            inflight[slot] = k
+            if frame_mode:
+                _, st = ms.Wait(slot, want_stats=True)
+                inflight[slot] = None
+                if collect:
+                    stats_seen.append(st)
+            k += g
+        for q in range(nslots):
+            if inflight[q] is not None:
+                _, st = ms.Wait(q, want_stats=True)
+                inflight[q] = None
+                if collect:
+                    stats_seen.append(st)
+        sync_all()
+        return time.perf_counter() - t
+
+    run(args.warmup if args.warmup > 0 else 1)
+    elapsed = run(args.steps, collect=True)
+    # one frame alone across the devices: submit + wait, nothing else in flight (median)
+    lat = []
+    for j in range(20 if pt is None else 3):
+        sync_all()
+        t = time.perf_counter()
+        ms.Submit(0, cams[j % len(cams)], W, H, flags=flags, pt=pt)
+        ms.Wait(0)
+        lat.append(time.perf_counter() - t)
+    latency_ms = float(np.median(lat)) * 1e3
+    # the frame to a HOST array, one call (what the C# host makes): sdfhip_multi_render
+    host = np.empty((H, W, 4), dtype=np.uint8 if args.display else np.float32)
+    hl = []
+    for j in range(8 if pt is None else 2):
+        t = time.perf_counter()
+        ms.Draw(cams[j % len(cams)], W, H, flags=flags, pt=pt, out=host)
+        hl.append(time.perf_counter() - t)
+    host_ms = float(np.median(hl[1:])) * 1e3
+
+    check_ok = None
+    one = sb.Scene(od, device=devices[0])
+    st = sb.Stats()
+    ref = torch.zeros((H, W) if args.display else (H, W, 4), dtype=torch.int32 if args.display else torch.float32, device=f"cuda:{devices[0]}")
+    main_stream = torch.cuda.current_stream().cuda_stream
+    if pt is not None:
+        one.DrawPathDevice(cam, W, H, ref.data_ptr(), pt=pt, flags=sb.FLAG_COUNT, stream=main_stream, stats=st)
+    else:
+        one.DrawDevice(cam, W, H, ref.data_ptr(), flags=sb.FLAG_COUNT, stream=main_stream, stats=st)
+    torch.cuda.synchronize()
+    if args.check:
+        check_ok = True
+        for j in range(min(len(cams), 6)):
+            if pt is not None:
+                one.DrawPathDevice(cams[j], W, H, ref.data_ptr(), pt=pt, stream=main_stream)
+            else:
+                one.DrawDevice(cams[j], W, H, ref.data_ptr(), flags=flags & ~sb.FLAG_TILE_ORDER, stream=main_stream)
+            torch.cuda.synchronize()
+            ms.Draw(cams[j], W, H, flags=flags, pt=pt, out=host)
+            check_ok = check_ok and bool(np.array_equal(host.view(np.uint32 if not args.display else np.uint8),
+                                                        ref.cpu().numpy().view(np.uint32 if not args.display else np.uint8).reshape(host.shape)))
+    sec_per_step = elapsed / args.steps
+    px_bytes = 4 if args.display else 16
+    ref_bytes = 8 * st.n_nodes + 8 * st.n_samples + px_bytes * W * H
+    own_bytes = 16 * st.n_loads + px_bytes * W * H
+    roof = roofline(sec_per_step, own_bytes, ref_bytes, None, measured_copy_bandwidth())
+    roof.update({"time_ms": round(sec_per_step * 1e3, 4), "note": "whole-node figure over the steady-state time per frame; no PMC pass exists for a multi-device run"})
+    n_st = max(1, len(stats_seen))
+    out = {
+        "metric": "Mray/s (primary rays; frame W*H / time per frame)",
+        "value": round(W * H * max(1, args.spp) / sec_per_step / 1e6, 2),
+        "unit": "Mray/s",
+        "n_gpus": len(devices),
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(sec_per_step * 1e3, 4),
+        "latency_ms": round(latency_ms, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": (f"{W}x{H} path trace, {args.spp} spp, 3 diffuse bounces, seed 0x5DFB0C5, " if pt is not None else
+                         f"{W}x{H} primary-ray sphere trace + shadow march, ") + f"{scene_name} (N={od.Length} nodes, {od.nbytes / 1e6:.1f} MB), "
+                        "camera (0.5,0.5,-0.35) yaw 0.35 pitch -0.2" + (f", moving 1 degree per frame ({len(cams)} cameras)" if args.orbit > 0 else ""),
+            "parallelism": f"single process, devices {devices} through sdfhip_multi_submit/_wait (one host thread + stream per device, "
+                           f"{args.band_rows}-row bands, sparse shares written by the march kernel, gather by {ms.transport} into device {devices[0]})",
+            "measures": ("one frame at a time across all devices, submit to completion: the viewer's latency (strong scaling of ONE frame)"
+                         if frame_mode else
+                         f"throughput of groups: {G} frames per launch and gather, {nslots} groups in flight ({G * nslots} frames in flight)"),
+            "frames_per_gather": G, "groups_in_flight": nslots,
+            "gathered_bytes_per_frame": round(sum(s.gathered_bytes for s in stats_seen) / n_st / G, 1),
+            "float_tails_sent_again": int(sum(s.resends for s in stats_seen)),
+            "rank_ms_per_group": [round(sum(s.rank_ms[r] for s in stats_seen) / n_st, 4) for r in range(len(devices))],
+            "host_frame_ms": round(host_ms, 4),
+            "output": "RGBA8, display pass at assembly" if args.display else "RGBA32F, alpha = step count",
+            "scene_build_s": round(t_gen, 2),
+        },
+        "latency": {"frames": 1, "ms": round(latency_ms, 4), "to_host_array_ms": round(host_ms, 4)},
+        "roofline": roof,
+    }
+    if check_ok is not None:
+        out["config"]["assembled_frame_equals_whole_frame_render"] = check_ok
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    one.close()
+    ms.close()
 
 
 def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_shape, wpx_dtype, wpx_bytes, rank, nccl, pt, compact,

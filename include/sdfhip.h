@@ -405,12 +405,90 @@ SDFHIP_API int sdfhip_deinterleave_sparse_device(int device, const void *d_gathe
                                                  uint32_t capacity, uint32_t frames, uint32_t *d_overflow,
                                                  void *stream);
 
+/* ---- sparse wire shares written by the march kernel itself ------------------------------------------------------------
+ * A wave of the default kernel renders one 8x8 tile, which is the unit of the sparse wire format: at its end it holds the tile's
+ * 64 wire pixels in registers and writes the tile's mask (one ballot), its code bytes (one 64-byte store) and its non-zero floats
+ * (slots from one atomic add) straight into the share -- no dense wire buffer and no sdfhip_wire_compact_device behind the render.
+ * One share holds all `frames` frames of a launch: 64-byte header (word 0 = float slots handed out; beyond `capacity` they are
+ * dropped, and the count says so) | masks | slot bases | codes (tile order) | floats, so a gather copies the fixed part and as many
+ * floats as were used.  The order of the tiles' floats is whatever order the waves finished in; the expanded frame does not
+ * depend on it (bit for bit the frame sdfhip_render_device writes).
+ *   sdfhip_sparse2_bytes / _floats_offset   size of a share; offset of its float array (= bytes of the fixed part)
+ *   sdfhip_render_sparse_device             like sdfhip_render_bands_device (explicit band list, n_frames <= 8 in one launch),
+ *                                           output = one share at d_share; zeroes the header on `stream` first
+ *   sdfhip_deinterleave_sparse2_device      d_shares[r] = rank r's share (device pointers valid on `device`; world <= 16) ->
+ *                                           d_frame [frames][height][width] RGBA32F, or with SDFHIP_FLAG_DISPLAY[_DEBUG] in
+ *                                           `flags` RGBA8 through the display pass; only_rank >= 0: write that rank's rows only */
+SDFHIP_API uint64_t sdfhip_sparse2_bytes(uint32_t width, uint32_t rows, uint32_t frames, uint32_t capacity);
+SDFHIP_API uint64_t sdfhip_sparse2_floats_offset(uint32_t width, uint32_t rows, uint32_t frames);
+SDFHIP_API int sdfhip_render_sparse_device(sdfhip_scene *scene, const sdfhip_info *infos, uint32_t n_frames, uint32_t width,
+                                           uint32_t height, uint32_t band_rows, const uint16_t *bands, uint32_t n_bands,
+                                           uint32_t nrows_out, uint32_t capacity, uint32_t flags, void *d_share, void *stream);
+SDFHIP_API int sdfhip_deinterleave_sparse2_device(int device, const void *const *d_shares, void *d_frame, uint32_t width,
+                                                  uint32_t height, uint32_t band_rows, uint32_t world, uint32_t rows_per_rank,
+                                                  const uint8_t *owner, uint32_t capacity, uint32_t frames, uint32_t flags,
+                                                  int only_rank, void *stream);
+
+/* ---- one frame over several GPUs, behind one call -----------------------------------------------------------
+ * Replaces: Program.Draw's UpdateBuffer(info) + DispatchSized(W, H, 1) (SdfBox/Program.cs:81,94) when the frame is rendered by
+ * the GPUs of a node: the host still makes ONE call per frame.  One process; the scene is replicated on every device at
+ * create; the frame's 16-row bands are dealt to the devices; every device renders its bands with the default kernel, which
+ * writes the sparse wire share itself; ranks > 0 push their shares into device devices[0]'s memory over their own xGMI links
+ * (peer copies on the rank's stream; SDFHIP_MULTI_TRANSPORT=rccl in the environment at create: ncclSend / ncclRecv inside
+ * ncclGroupStart/End instead, RCCL loaded with dlopen); devices[0] expands them into the frame in row order.  Inside the
+ * library: one host thread per device, the band layout, the gather, the float tail of a share that needed more than was
+ * sent, no Python.  The same device may appear several times (a rehearsal of the pipeline on one GPU; not with RCCL).
+ *   sdfhip_multi_render        one frame to a host array: the viewer's call (latency: every device works on this frame)
+ *   sdfhip_multi_submit/_wait  groups of n_frames <= 8 frames (one camera block each, one launch per device), up to 4 groups
+ *                              in flight (slot 0..3): throughput.  d_frames_out: device memory on devices[0] for
+ *                              [n_frames][height][width] pixels, or NULL for the slot's own buffer (returned by _wait, valid
+ *                              until the slot's next submit).  _wait blocks until the slot's frames are complete.
+ *   ..._path                   the path-traced mode (one frame; gathers dense RGBA32F bands)
+ * Flags: 0, SDFHIP_FLAG_DISPLAY[_DEBUG] (RGBA8 frames: the display pass runs where the frame is assembled),
+ * SDFHIP_FLAG_TILE_ORDER.  Pixels are bit for bit those of sdfhip_render on one device. */
+typedef struct sdfhip_multi sdfhip_multi;
+typedef struct sdfhip_multi_stats {
+    float total_ms;             /* host clock: submit -> frames complete (sdfhip_multi_render: -> frame in the host array) */
+    uint32_t n_devices;
+    uint32_t resends;           /* shares whose float tail had to be sent again */
+    uint32_t pad_;
+    uint64_t gathered_bytes;    /* bytes that crossed into devices[0] */
+    float rank_ms[16];          /* per device: first launch -> share sent (HIP events on its stream) */
+    uint32_t floats_used[16];   /* per device: float slots of its share */
+} sdfhip_multi_stats;
+SDFHIP_API int sdfhip_multi_create(const int *devices, uint32_t n_devices, const int32_t *structs, const uint8_t *values,
+                                   uint32_t n, sdfhip_multi **out);
+SDFHIP_API int sdfhip_multi_free(sdfhip_multi *m);
+/* band height (a multiple of 8; default 16, or SDFHIP_MULTI_BAND_ROWS) and the share of devices[0], which also assembles
+ * the frame, as a fraction of a peer's (default 1, or SDFHIP_MULTI_RANK0_WEIGHT); no slot may be in flight */
+SDFHIP_API int sdfhip_multi_configure(sdfhip_multi *m, uint32_t band_rows, float rank0_weight);
+SDFHIP_API int sdfhip_multi_info(const sdfhip_multi *m, uint32_t *n_devices, int *devices, uint32_t *band_rows,
+                                 float *rank0_weight, int *transport /* 0 peer copies, 1 RCCL */);
+SDFHIP_API int sdfhip_multi_render(sdfhip_multi *m, const sdfhip_info *info, uint32_t width, uint32_t height, uint32_t flags,
+                                   float *rgba_out, sdfhip_multi_stats *stats);
+SDFHIP_API int sdfhip_multi_render_path(sdfhip_multi *m, const sdfhip_info *info, const sdfhip_pathtrace *pt, uint32_t width,
+                                        uint32_t height, uint32_t flags, float *rgba_out, sdfhip_multi_stats *stats);
+SDFHIP_API int sdfhip_multi_submit(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint32_t n_frames, uint32_t width,
+                                   uint32_t height, uint32_t flags, void *d_frames_out);
+SDFHIP_API int sdfhip_multi_submit_path(sdfhip_multi *m, uint32_t slot, const sdfhip_info *info, const sdfhip_pathtrace *pt,
+                                        uint32_t width, uint32_t height, uint32_t flags, void *d_frame_out);
+SDFHIP_API int sdfhip_multi_wait(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_stats *stats);
+/* Test hook: how many packed floats the next share of every device carries (normally 1.25 x what its last share used; 0 = all
+ * of them): a small value forces the float tail of the next shares to be sent again (sdfhip_multi_stats.resends). */
+SDFHIP_API int sdfhip_multi_debug_floats_sent(sdfhip_multi *m, uint32_t floats);
+
 /* Experiment hook (scripts/ab_tile_order.py): the primary-march kernel of the following single-frame renders
  * on this scene takes workgroup b's tile from d_perm[b] (device array, one entry per workgroup of its grid =
  * 8 * ceil(tiles_y / 8) * tiles_x with 8x8 tiles; entries >= the tile count idle) and writes the march
  * iterations of every tile's wave to d_cost[tile] (device array): the primary loop's in the low byte, the
  * shadow loop's in the high byte.  NULL switches either off. */
 SDFHIP_API int sdfhip_debug_tile_order(sdfhip_scene *scene, const uint32_t *d_perm, uint16_t *d_cost);
+
+/* Diagnostics: after a SDFHIP_FLAG_COUNT render of the default kernel on `stream` (the stream argument of the
+ * sdfhip_render_device call that made it; synchronises with it), how many lane-steps sampled which kind of cell: out6 = {flat leaf at or above the grid's coarse level, flat leaf below it, non-flat at or above the coarse level,
+ * non-flat as deep as the grid, non-flat in between, non-flat with the position outside the cube (or NaN)}.  What the
+ * layout of the grid's cells is tuned by. */
+SDFHIP_API int sdfhip_debug_step_classes(sdfhip_scene *scene, void *stream, uint64_t *out6);
 
 /* Test hook: the kernel's R8_UNorm decode of bytes 0..255 (256 floats to the
  * host), checked exhaustively against byte/255.0f. */

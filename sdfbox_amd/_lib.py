@@ -106,6 +106,13 @@ class SdfGenStats(ctypes.Structure):
     ]
 
 
+class MultiStats(ctypes.Structure):
+    _fields_ = [
+        ("total_ms", ctypes.c_float), ("n_devices", ctypes.c_uint32), ("resends", ctypes.c_uint32), ("pad_", ctypes.c_uint32),
+        ("gathered_bytes", ctypes.c_uint64), ("rank_ms", ctypes.c_float * 16), ("floats_used", ctypes.c_uint32 * 16),
+    ]
+
+
 class SdfHipError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"sdfhip error {code}: {message}")
@@ -172,6 +179,27 @@ _SIG = {
                                                      _c.c_uint32, _c.POINTER(_c.c_uint8), _c.c_uint32, _c.c_uint32, _vp, _vp]),
     "sdfhip_debug_tile_order": (_c.c_int, [_vp, _vp, _vp]),
     "sdfhip_debug_unorm_table": (_c.c_int, [_c.c_int, _vp]),
+    "sdfhip_debug_step_classes": (_c.c_int, [_vp, _vp, _c.POINTER(_c.c_uint64)]),
+    "sdfhip_sparse2_bytes": (_c.c_uint64, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32]),
+    "sdfhip_sparse2_floats_offset": (_c.c_uint64, [_c.c_uint32, _c.c_uint32, _c.c_uint32]),
+    "sdfhip_render_sparse_device": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                               _c.POINTER(_c.c_uint16), _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp, _vp]),
+    "sdfhip_deinterleave_sparse2_device": (_c.c_int, [_c.c_int, _c.POINTER(_vp), _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                                      _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_uint8), _c.c_uint32, _c.c_uint32,
+                                                      _c.c_uint32, _c.c_int, _vp]),
+    "sdfhip_multi_create": (_c.c_int, [_c.POINTER(_c.c_int), _c.c_uint32, _vp, _vp, _c.c_uint32, _c.POINTER(_vp)]),
+    "sdfhip_multi_free": (_c.c_int, [_vp]),
+    "sdfhip_multi_configure": (_c.c_int, [_vp, _c.c_uint32, _c.c_float]),
+    "sdfhip_multi_info": (_c.c_int, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint32),
+                                     _c.POINTER(_c.c_float), _c.POINTER(_c.c_int)]),
+    "sdfhip_multi_render": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp, _c.POINTER(MultiStats)]),
+    "sdfhip_multi_render_path": (_c.c_int, [_vp, _c.POINTER(Info), _c.POINTER(PathTrace), _c.c_uint32, _c.c_uint32, _c.c_uint32,
+                                            _vp, _c.POINTER(MultiStats)]),
+    "sdfhip_multi_submit": (_c.c_int, [_vp, _c.c_uint32, _c.POINTER(Info), _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+    "sdfhip_multi_submit_path": (_c.c_int, [_vp, _c.c_uint32, _c.POINTER(Info), _c.POINTER(PathTrace), _c.c_uint32, _c.c_uint32,
+                                            _c.c_uint32, _vp]),
+    "sdfhip_multi_wait": (_c.c_int, [_vp, _c.c_uint32, _c.POINTER(_vp), _c.POINTER(MultiStats)]),
+    "sdfhip_multi_debug_floats_sent": (_c.c_int, [_vp, _c.c_uint32]),
 }
 # every symbol include/sdfhip.h declares must be exported: fail at import otherwise
 for _name, (_res, _args) in _SIG.items():

@@ -88,7 +88,8 @@ struct RenderParams {
     // fused display pass (DisplayFrag.hlsl): out_mode 0 = RGBA32F frame, 1 = gamma RGBA8,
     // 2 = step-count heat map RGBA8 (`out` aliased as one uint32 per pixel), 3 = wire pixels of the
     // tile gather (per frame a float plane and a byte plane, 5 bytes per pixel)
-    uint32_t out_mode;
+    uint32_t out_mode;         // 4: the sparse wire share of sdfhip_render_sparse_device (`out` = the share of all frames of the launch)
+    uint32_t sparse_cap;       // ... and the float slots it holds
     uint32_t sky8;             // the sky constant through the display pass (host-computed, alpha excluded)
     // path-traced mode (k_path): samples per pixel, diffuse bounces, RNG seed, albedo
     uint32_t pt_spp, pt_bounces, pt_seed;

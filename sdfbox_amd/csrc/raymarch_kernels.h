@@ -255,6 +255,32 @@ __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const Fram
     return reads;
 }
 
+// Diagnostics of the counting builds of k_march (sdfhip_debug_step_classes): what kind of cell every lane-step sampled.
+// [0] flat leaf of the coarse level or above  [1] flat leaf inside a fine block (or, dense grid: below level 8)
+// [2] non-flat, coarse  [3] non-flat, as deep as the grid (k = 0)  [4] non-flat below the coarse level but not at the
+// grid's full depth  [5] non-flat steps whose position is outside the cube or NaN
+struct StepClasses { unsigned long long n[6] = {0, 0, 0, 0, 0, 0}; };
+template <class CursorT>
+__device__ __forceinline__ void classify_step(StepClasses &, const CursorT &, const RenderParams &, float, float, float) {}
+template <bool SPLIT, bool ORDERED>
+__device__ __forceinline__ void classify_step(StepClasses &k, const CursorFT<true, SPLIT, ORDERED> &c, const RenderParams &P, float px, float py, float pz)
+{
+    const int level = LM - (int)(c.s & 15u), F = P.top_level + (SPLIT ? P.fine_bits : 0), C = SPLIT ? P.top_level : (P.top_level < 8 ? P.top_level : 8);
+    const bool flat = (c.s & FLAT_BIT) != 0, coarse = level <= C;
+    const bool inside = px >= 0.0f && py >= 0.0f && pz >= 0.0f && px < 1.0f && py < 1.0f && pz < 1.0f;
+    k.n[0] += (flat && coarse) ? 1u : 0u; k.n[1] += (flat && !coarse) ? 1u : 0u;
+    k.n[2] += (!flat && coarse) ? 1u : 0u; k.n[3] += (!flat && !coarse && level == F) ? 1u : 0u;
+    k.n[4] += (!flat && !coarse && level != F) ? 1u : 0u; k.n[5] += (!flat && !inside) ? 1u : 0u;
+}
+__device__ __forceinline__ void flush_classes(const RenderParams &P, StepClasses &k)
+{
+    for (int i = 0; i < 6; i++) {
+        unsigned long long v = k.n[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&P.counters[6 + i], v);
+    }
+}
+
 // loads: 16-byte node records / grid cells the kernel itself loaded (the cursor counts them); hits: shadow rays queued for k_shadow
 __device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned long long nodes,
                                                unsigned long long samples, unsigned long long steps,
@@ -375,7 +401,55 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
 // ray ends: lanes on 52 % there), 64 bytes per shadow ray written and read once, a second launch: 0.107 ms per 1080p frame
 // against 0.090, 0.346 against 0.311 at 4K.  Measured, kept as a knob.
 // =====================================================================================
-enum { OUT_RGBA32F = 0, OUT_GAMMA8 = 1, OUT_HEAT8 = 2, OUT_WIRE = 3 };
+enum { OUT_RGBA32F = 0, OUT_GAMMA8 = 1, OUT_HEAT8 = 2, OUT_WIRE = 3, OUT_SPARSE = 4 };
+
+// OUT_SPARSE: what a rank of a sharded frame puts on xGMI, written by the march kernel itself.  A wave of k_march IS one
+// 8x8 tile, so at its end it knows the tile's 64 wire pixels (a, code) in registers: the mask of pixels whose a has any bit
+// set is one ballot, the tile's slots in the packed float array one atomic add of its popcount (the order of the tiles in
+// that array is whatever order the waves finish in; each tile records where its floats start), and the code bytes are one
+// 64-byte store, in tile order.  No dense wire buffer, no mask / scan / scatter kernels behind the render (sdfhip_wire_compact_device:
+// 265 us per group of four 4K frames), and rank 0 expands the shares exactly as before.  One share holds the `frames` frames of a
+// launch: header (word 0: float slots handed out; slots beyond the capacity are dropped and the count says so) | masks
+// [frames][tiles] | slot bases [frames][tiles] | codes [frames][tiles][64] | floats [capacity], so that a gather is two
+// contiguous copies: the fixed part, and as many floats as were used.
+struct Sparse2Layout {
+    uint32_t width, rows, tiles_x, tiles_y, tiles, frames, capacity;
+    size_t off_masks, off_bases, off_codes, off_floats, bytes;
+};
+__host__ __device__ inline Sparse2Layout sparse2_layout(uint32_t width, uint32_t rows, uint32_t frames, uint32_t capacity)
+{
+    Sparse2Layout L;
+    L.width = width; L.rows = rows; L.frames = frames; L.capacity = capacity;
+    L.tiles_x = (width + 7) / 8; L.tiles_y = (rows + 7) / 8; L.tiles = L.tiles_x * L.tiles_y;
+    const size_t ft = (size_t)frames * L.tiles;
+    L.off_masks = 64;
+    L.off_bases = L.off_masks + ft * 8;
+    L.off_codes = (L.off_bases + ft * 4 + 63) & ~(size_t)63;
+    L.off_floats = L.off_codes + ft * 64;
+    L.bytes = (L.off_floats + (size_t)capacity * 4 + 63) & ~(size_t)63;
+    return L;
+}
+struct SparseLane { float a; uint32_t code; };     // a lane's wire pixel, until the wave's flush
+__device__ __forceinline__ void sparse2_flush(const RenderParams &P, uint32_t f, uint32_t tile, uint32_t lane, const SparseLane &px)
+{
+    const Sparse2Layout L = sparse2_layout(P.width, P.nrows_out, P.n_frames, P.sparse_cap);
+    char *share = reinterpret_cast<char *>(P.out);
+    const size_t ft = (size_t)f * L.tiles + tile;
+    const bool lit = __float_as_uint(px.a) != 0u;
+    const unsigned long long m = __ballot(lit);
+    uint32_t base = 0;
+    if (m) {
+        if (lane == 0) base = atomicAdd(reinterpret_cast<uint32_t *>(share), (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    }
+    reinterpret_cast<uint8_t *>(share + L.off_codes)[ft * 64 + lane] = (uint8_t)px.code;
+    if (lane == 0) {
+        reinterpret_cast<unsigned long long *>(share + L.off_masks)[ft] = m;
+        reinterpret_cast<uint32_t *>(share + L.off_bases)[ft] = base;
+    }
+    const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (lit && slot < P.sparse_cap) reinterpret_cast<float *>(share + L.off_floats)[slot] = px.a;
+}
 
 // Where a finished pixel goes, by output mode (a template parameter: no dispatch at the store, and no
 // display-pass code in the RGBA32F kernels).  idx = pixel index within the launch's frame f.
@@ -384,11 +458,14 @@ struct PixelSink {
     float4 *out;             // frame f of the launch: RGBA32F pixels / uint32 pixels / the frame's wire planes
     uint8_t *codes;          // OUT_WIRE: the byte plane behind the float plane
     uint32_t sky8;
-    __device__ __forceinline__ PixelSink(const RenderParams &P, uint32_t f)
+    SparseLane *px;          // OUT_SPARSE: the lane's wire pixel stays in registers until the wave's flush (sparse2_flush)
+    __device__ __forceinline__ PixelSink(const RenderParams &P, uint32_t f, SparseLane *lane_px = nullptr)
     {
         const size_t npx = (size_t)P.nrows_out * P.width;
         sky8 = P.sky8;
-        if (MODE == OUT_RGBA32F) { out = P.out + f * npx; codes = nullptr; }
+        px = lane_px;
+        if (MODE == OUT_SPARSE) { out = nullptr; codes = nullptr; }
+        else if (MODE == OUT_RGBA32F) { out = P.out + f * npx; codes = nullptr; }
         else if (MODE == OUT_WIRE) {
             char *base = reinterpret_cast<char *>(P.out) + f * npx * 5;
             out = reinterpret_cast<float4 *>(base); codes = reinterpret_cast<uint8_t *>(base) + 4 * npx;
@@ -396,26 +473,27 @@ struct PixelSink {
     }
     __device__ __forceinline__ void wire(size_t idx, float a, uint32_t code) const
     {
+        if (MODE == OUT_SPARSE) { px->a = a; px->code = code; return; }
         reinterpret_cast<float *>(out)[idx] = a;
         codes[idx] = (uint8_t)code;
     }
     __device__ __forceinline__ void sky(size_t idx, float steps) const
     {
         if (MODE == OUT_RGBA32F) out[idx] = make_float4(0.005f, 0.01f, 0.2f, steps);
-        else if (MODE == OUT_WIRE) wire(idx, 0.0f, 255u - (uint32_t)steps);
+        else if (MODE == OUT_WIRE || MODE == OUT_SPARSE) wire(idx, 0.0f, 255u - (uint32_t)steps);
         else reinterpret_cast<uint32_t *>(out)[idx] = MODE == OUT_HEAT8 ? heat8(steps) : (sky8 | alpha8(steps));
     }
     __device__ __forceinline__ void grey(size_t idx, float a, float steps) const
     {
         if (MODE == OUT_RGBA32F) out[idx] = make_float4(a, a, a, steps);
-        else if (MODE == OUT_WIRE) wire(idx, a, (uint32_t)steps);
+        else if (MODE == OUT_WIRE || MODE == OUT_SPARSE) wire(idx, a, (uint32_t)steps);
         else if (MODE == OUT_HEAT8) reinterpret_cast<uint32_t *>(out)[idx] = heat8(steps);
         else { const uint32_t q = gamma8(a); reinterpret_cast<uint32_t *>(out)[idx] = q | (q << 8) | (q << 16) | alpha8(steps); }
     }
     __device__ __forceinline__ void black(size_t idx, float steps) const
     {
         if (MODE == OUT_RGBA32F) out[idx] = make_float4(0.0f, 0.0f, 0.0f, steps);
-        else if (MODE == OUT_WIRE) wire(idx, 0.0f, (uint32_t)steps);
+        else if (MODE == OUT_WIRE || MODE == OUT_SPARSE) wire(idx, 0.0f, (uint32_t)steps);
         else reinterpret_cast<uint32_t *>(out)[idx] = MODE == OUT_HEAT8 ? heat8(steps) : alpha8(steps);
     }
 };
@@ -445,7 +523,7 @@ __device__ __forceinline__ uint32_t *hit_count(const RenderParams &P, uint32_t s
 // the lanes close to the surface), and which one ended the march is read off the lane's final state afterwards.
 template <bool COUNT, class CursorT>
 __device__ __forceinline__ bool shadow_march(const RenderParams &P, const FrameInfo &I, RayState &r, CursorT &c,
-                                             unsigned long long &cn, unsigned long long &cs)
+                                             unsigned long long &cn, unsigned long long &cs, StepClasses *classes = nullptr)
 {
     // any(pos < 0) || any(pos > 1) as min3 / max3: v_min3_f32 and v_max3_f32 skip NaN operands, and a
     // comparison with NaN is false either way, so the two forms agree for every input
@@ -462,8 +540,9 @@ __device__ __forceinline__ bool shadow_march(const RenderParams &P, const FrameI
             go = !(dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f);
         }
         if (!go) break;
+        const float qx = r.px, qy = r.py, qz = r.pz;
         uint32_t reads = march_step(P, I, r, c, nullptr, 0);
-        if (COUNT) { cn += reads; cs += 1; }
+        if (COUNT) { cn += reads; cs += 1; if (classes) classify_step(*classes, c, P, qx, qy, qz); }
     }
     asm volatile("" : "+v"(r.prox), "+v"(r.n));       // (see k_march: keeps the exit reasons out of the loop)
     return header() && at_light();
@@ -485,6 +564,8 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x, lane = threadIdx.x;
     const uint32_t x = tx * 8 + (lane & 7u), yl = ty * 8 + (lane >> 3);
     unsigned long long cn = 0, cs = 0, ct = 0;   // nodes, samples, steps (of the pixels that end here)
+    StepClasses classes;                         // (counting builds only)
+    SparseLane wire_px{0.0f, 0u};                // (OUT_SPARSE only; a lane without a pixel keeps a = +0, code 0)
     bool live = x < P.width && yl < P.nrows_out;
     uint32_t y = 0;
     if (live) { y = global_row(P, yl); live = y < P.height; }
@@ -500,11 +581,13 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
         // (both tests every time, combined without a branch: the escape test is three instructions)
         auto go_on = [&]() { return ((int)marching() & (int)!(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit)) != 0; };
         if (go_on()) {                               // the first step, from the root, apart: see find_fresh
+            float qx = r.px, qy = r.py, qz = r.pz;
             uint32_t reads = march_step<CursorT, true>(P, I, r, c, nullptr, 0);
-            if (COUNT) { cn += reads; cs += 1; }
+            if (COUNT) { cn += reads; cs += 1; classify_step(classes, c, P, qx, qy, qz); }
             while (go_on()) {
+                if (COUNT) { qx = r.px; qy = r.py; qz = r.pz; }
                 reads = march_step(P, I, r, c, nullptr, 0);
-                if (COUNT) { cn += reads; cs += 1; }
+                if (COUNT) { cn += reads; cs += 1; classify_step(classes, c, P, qx, qy, qz); }
             }
         }
     }
@@ -520,7 +603,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     // ---- the wave is converged again ----
     const size_t lidx = (size_t)yl * P.width + x;
     if (end == 2) {
-        const PixelSink<MODE> dst(P, f);
+        const PixelSink<MODE> dst(P, f, &wire_px);
         dst.sky(lidx, (float)r.n);
         if (COUNT) ct = (unsigned long long)r.n;
     }
@@ -541,7 +624,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
             const float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
             r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
             if (r.angle < 0.0f) {
-                const PixelSink<MODE> dst(P, f);
+                const PixelSink<MODE> dst(P, f, &wire_px);
                 dst.black(lidx, (float)r.n);
                 if (COUNT) ct = (unsigned long long)r.n;
             } else {
@@ -551,11 +634,11 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     }
     if (!QUEUE) {
         if (shadow) {
-            const PixelSink<MODE> dst(P, f);
+            const PixelSink<MODE> dst(P, f, &wire_px);
             const float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;      // Compute.hlsl:212
             r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
             r.base = r.n; r.n = 0; r.phase = PH_SHADOW;           // i stays, j starts; steps are prox + margin from here
-            const bool lit = shadow_march<COUNT>(P, I, r, c, cn, cs);
+            const bool lit = shadow_march<COUNT>(P, I, r, c, cn, cs, &classes);
             if (lit) dst.grey(lidx, r.angle / (r.dist * r.dist) * I.k_strength, (float)(r.base + r.n));
             else dst.black(lidx, (float)(r.base + r.n));
             if (COUNT) ct = (unsigned long long)(r.base + r.n);
@@ -565,7 +648,8 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
             for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
             if (lane == 0) P.tile_cost[(size_t)f * P.n_tiles + tile] |= (uint16_t)(m << 8);
         }
-        if (COUNT) flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, 0u);
+        if (MODE == OUT_SPARSE) sparse2_flush(P, f, tile, lane, wire_px);     // the tile's share of the sparse wire share
+        if (COUNT) { flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, 0u); flush_classes(P, classes); }
         return;
     }
     const unsigned long long hits = __ballot(shadow);

@@ -439,6 +439,47 @@ __global__ void k_deinterleave_sparse(const uint8_t *__restrict__ gathered, floa
     }
 }
 
+// rank 0: the sparse shares the ranks' march kernels wrote themselves (OUT_SPARSE, raymarch_kernels.h) -> frames in row
+// order.  One pointer per rank (a rank's share holds all frames of the group; rank 0's own is read where it was rendered).
+// MODE: RGBA32F as Compute.hlsl writes it, or through the display pass (DisplayFrag.hlsl) as RGBA8.
+constexpr uint32_t MULTI_MAX_RANKS = 16;
+struct ShareTable { const uint8_t *p[MULTI_MAX_RANKS]; };
+template <int MODE>
+__global__ __launch_bounds__(256) void k_deinterleave_sparse2(const ShareTable S, void *__restrict__ frame, uint32_t width, uint32_t height,
+                                                              uint32_t band_rows, uint32_t world, Sparse2Layout L, const BandMap M,
+                                                              uint32_t only_rank, uint32_t sky8)
+{
+    const size_t per_frame = (size_t)width * height, total = per_frame * L.frames;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t f = (uint32_t)(i / per_frame);
+        const size_t r = i - (size_t)f * per_frame;
+        const uint32_t y = (uint32_t)(r / width), x = (uint32_t)(r - (size_t)y * width);
+        uint32_t band = y / band_rows, rank = band % world, lband = band / world;
+        if (M.n) { const uint32_t e = M.src[band]; rank = e >> 10; lband = e & 1023u; }
+        if (only_rank != 0xFFFFFFFFu && rank != only_rank) continue;
+        const uint32_t yl = lband * band_rows + (y - band * band_rows);
+        const uint8_t *src = S.p[rank];
+        const size_t ft = (size_t)f * L.tiles + (size_t)(yl >> 3) * L.tiles_x + (x >> 3);
+        const uint32_t bit = (yl & 7u) * 8u + (x & 7u);
+        const uint32_t code = src[L.off_codes + ft * 64 + bit];
+        const unsigned long long m = reinterpret_cast<const unsigned long long *>(src + L.off_masks)[ft];
+        float a = 0.0f;
+        if ((m >> bit) & 1ull) {
+            const uint32_t slot = reinterpret_cast<const uint32_t *>(src + L.off_bases)[ft] + (uint32_t)__popcll(m & ((1ull << bit) - 1ull));
+            if (slot < L.capacity) a = reinterpret_cast<const float *>(src + L.off_floats)[slot];
+        }
+        if (MODE == OUT_RGBA32F) reinterpret_cast<float4 *>(frame)[i] = wire_expand(a, code);
+        else {
+            const float4 v = wire_expand(a, code);
+            uint32_t q;
+            if (MODE == OUT_HEAT8) q = heat8(v.w);
+            else if (code > 140u) q = sky8 | alpha8(v.w);
+            else { const uint32_t g = gamma8(a); q = g | (g << 8) | (g << 16) | alpha8(v.w); }
+            reinterpret_cast<uint32_t *>(frame)[i] = q;
+        }
+    }
+}
+
 __global__ void k_unorm_table(float *out)
 {
     out[threadIdx.x] = unorm8((float)threadIdx.x);
@@ -479,7 +520,7 @@ struct sdfhip_scene {
     int top2_level, fine2_bits, fine2_order, scatter_tried;
     uint64_t top2_bytes;
     size_t total_mem;
-    unsigned long long *d_counters;  // 6 x u64: nodes, samples, steps, shadow rays, loads, hits
+    uint32_t *d_verdict;             // k_validate's two words (upload)
     // Per-stream scratch of the render launches: the hit queues of the two-kernel pipeline and their
     // control words, and the tile-queue heads of the compact kernel.  Launches on one stream run in
     // order and may share a scratch; launches on different streams overlap (frames in flight) and
@@ -503,8 +544,11 @@ struct sdfhip_scene {
         sdfhip_info ord_info;                // the camera block of the frame the order was made from
     };
     static constexpr int MAX_SCRATCH = 16;
+    // ... then the counters of SDFHIP_FLAG_COUNT renders on this stream, 16 x u64: nodes, samples, steps, shadow rays, loads,
+    // hits, and from [6] the step classes of sdfhip_debug_step_classes (per stream: counting renders on two streams of one
+    // handle do not add into each other's figures)
     static constexpr size_t CTL_HIT_WORDS = (size_t)2 * MAX_BATCH * HIT_QUEUES * 32, CTL_QUEUE_WORDS = 8 * 32,
-                            CTL_PT_WORDS = (size_t)2 * HIT_QUEUES * 32;
+                            CTL_PT_WORDS = (size_t)2 * HIT_QUEUES * 32, CTL_COUNTER_WORDS = 32;
     Scratch scratch[MAX_SCRATCH];
     int n_scratch;
     float4 *d_frame;        // grown on demand by sdfhip_render
@@ -552,7 +596,7 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
         DeviceGuard g(s->device);
         if (s->stream) (void)hipStreamSynchronize(s->stream);
         if (s->alloc) (void)hipFree(s->alloc);
-        if (s->d_counters) (void)hipFree(s->d_counters);
+        if (s->d_verdict) (void)hipFree(s->d_verdict);
         if (s->d_top) (void)hipFree(s->d_top);
         if (s->d_fine) (void)hipFree(s->d_fine);
         if (s->d_top2) (void)hipFree(s->d_top2);
@@ -645,7 +689,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     sdfhip_scene *s = new (std::nothrow) sdfhip_scene();
     if (!s) return fail(SDFHIP_ERR_NOMEM, "scene_upload: out of host memory");
     s->device = device; s->n = n; s->depth = 0; s->stack_ok = 0;       // (both set once the tree has been validated, below)
-    s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_counters = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0;
+    s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_verdict = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0;
     s->d_top2 = s->d_fine2 = nullptr; s->top2_level = s->fine2_bits = s->fine2_order = s->scatter_tried = 0; s->top2_bytes = 0; s->total_mem = prop.totalGlobalMem;
     s->n_scratch = 0; s->d_frame = nullptr; s->dbg_tile_perm = nullptr; s->dbg_tile_cost = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
     s->cu_count = prop.multiProcessorCount;
@@ -664,13 +708,13 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if ((e = hipEventCreate(&s->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(&s->alloc, (size_t)n * 16 + 128)) != hipSuccess) return bail(e, "hipMalloc(records)");
     s->nodes = reinterpret_cast<NodeRec *>(static_cast<char *>(s->alloc) + 112);
-    if ((e = hipMalloc((void **)&s->d_counters, 6 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMalloc((void **)&s->d_verdict, 2 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(verdict)");
     if ((e = hipMalloc(&d_s, bytes)) != hipSuccess) return bail(e, "hipMalloc(structs)");
     if ((e = hipMalloc(&d_v, bytes)) != hipSuccess) return bail(e, "hipMalloc(values)");
     if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
     if ((e = hipMemcpyAsync(d_v, values, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(values)");
-    {   // validation (sdfhip_octdata_validate's verdicts, on the device: see k_validate); d_counters lends two words
-        uint32_t *d_verdict = reinterpret_cast<uint32_t *>(s->d_counters), verdict[2] = { 0u, 0u };
+    {   // validation (sdfhip_octdata_validate's verdicts, on the device: see k_validate)
+        uint32_t *d_verdict = s->d_verdict, verdict[2] = { 0u, 0u };
         if ((e = hipMemsetAsync(d_verdict, 0, sizeof verdict, s->stream)) != hipSuccess) return bail(e, "hipMemset(verdict)");
         hipLaunchKernelGGL(k_validate, dim3((n + 255u) / 256u), dim3(256), 0, s->stream, (const int2 *)d_s, n, d_verdict);
         if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_validate launch");
@@ -801,7 +845,8 @@ int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::S
         sc = &s->scratch[s->n_scratch];
         sc->stream = st; sc->hit_buf = nullptr; sc->records = 0; sc->ctl = nullptr; sc->launches = 0; sc->pt_buf = nullptr; sc->pt_bytes = 0;
         sc->ord_cost = nullptr; sc->ord_class = nullptr; sc->ord_perm = nullptr; sc->ord_tiles = sc->ord_blocks = 0; sc->ord_valid = false; memset(sc->ord_sig, 0, sizeof sc->ord_sig);
-        const size_t ctl_bytes = (sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS + sdfhip_scene::CTL_PT_WORDS) * sizeof(uint32_t);
+        const size_t ctl_bytes = (sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS + sdfhip_scene::CTL_PT_WORDS +
+                                  sdfhip_scene::CTL_COUNTER_WORDS) * sizeof(uint32_t);
         HIP_TRY(hipMalloc((void **)&sc->ctl, ctl_bytes));
         // zeroed IN the stream that will use it: a hipMemset on the null stream is not ordered against a non-blocking
         // stream (the first frame on a new scratch would, now and then, have met counters that were not zero yet)
@@ -871,6 +916,7 @@ void launch_two(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, const
         if (mode == OUT_RGBA32F)     hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_RGBA32F, false>), grid, dim3(64), 0, st, P);
         else if (mode == OUT_GAMMA8) hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_GAMMA8, false>), grid, dim3(64), 0, st, P);
         else if (mode == OUT_HEAT8)  hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_HEAT8, false>), grid, dim3(64), 0, st, P);
+        else if (mode == OUT_SPARSE) hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_SPARSE, false>), grid, dim3(64), 0, st, P);
         else                         hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_WIRE, false>), grid, dim3(64), 0, st, P);
         return;
     }
@@ -897,7 +943,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
                 uint32_t band_rows, uint32_t band_first, uint32_t band_stride, uint32_t nrows_out,
                 uint32_t flags, float *d_out, hipStream_t st, sdfhip_stats *stats,
                 const sdfhip_pathtrace *pt = nullptr, uint32_t n_frames = 1,
-                const uint16_t *bands = nullptr, uint32_t n_bands = 0)
+                const uint16_t *bands = nullptr, uint32_t n_bands = 0, uint32_t sparse_cap = 0, bool sparse = false)
 {
     // `info` points at n_frames consecutive Info blocks (batched launch: plain kernel only)
     if (n_frames == 0 || n_frames > (uint32_t)MAX_BATCH)
@@ -914,7 +960,9 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     const bool compact = (flags & SDFHIP_FLAG_COMPACT) != 0;
     const bool count = (flags & SDFHIP_FLAG_COUNT) != 0;
     const bool wire = (flags & SDFHIP_FLAG_WIRE) != 0;
-    const uint32_t out_mode = wire ? 3u : (flags & SDFHIP_FLAG_DISPLAY_DEBUG) ? 2u : ((flags & SDFHIP_FLAG_DISPLAY) ? 1u : 0u);
+    const uint32_t out_mode = sparse ? 4u : wire ? 3u : (flags & SDFHIP_FLAG_DISPLAY_DEBUG) ? 2u : ((flags & SDFHIP_FLAG_DISPLAY) ? 1u : 0u);
+    if (sparse && (wire || compact || pt || (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG | SDFHIP_TUNE_SHADOW_QUEUE | SDFHIP_TUNE_ONE_KERNEL))))
+        return fail(SDFHIP_ERR_ARG, "render_sparse: sparse shares come from the default kernel only (no display pass, path tracing, compaction or A/B forms)");
     if (wire && (compact || pt || (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG))))
         return fail(SDFHIP_ERR_ARG, "render: wire pixels come from the plain kernel only, without the display pass");
     if (wire && ((uint64_t)nrows_out * width) % 4 != 0)
@@ -976,13 +1024,14 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     if (compact && (width > 65535u || nrows_out > 65535u))
         return fail(SDFHIP_ERR_ARG, "render: the compact kernel packs a pixel's x and row into 16 bits each (frame %u x %u)", width, nrows_out);
     P.out_mode = out_mode;
+    P.sparse_cap = sparse_cap;
     {   // the sky constant of Compute.hlsl:196 through DisplayFrag.hlsl:24, alpha excluded
         auto q = [](float c) { float v = powf(c, 1.0f / 2.2f); v = v > 1.0f ? 1.0f : (v > 0.0f ? v : 0.0f); return (uint32_t)(v * 255.0f + 0.5f); };
         P.sky8 = q(0.005f) | (q(0.01f) << 8) | (q(0.2f) << 16);
     }
     P.pt_spp = pt ? pt->spp : 0; P.pt_bounces = pt ? pt->max_bounces : 0; P.pt_seed = pt ? pt->seed : 0;
     P.pt_albedo = pt ? pt->albedo : 0.0f;
-    P.counters = s->d_counters;
+    P.counters = nullptr;
     // cursor kind: generic, cursor stack, or cursor stack with a top grid as deep as the tree
     const int cur = !use_stack ? CUR_GENERIC : (s->d_top && s->fine_bits) ? CUR_STACK_SPLIT :
                     (s->d_top && (uint32_t)s->top_level >= s->depth) ? CUR_STACK_FULL : CUR_STACK;
@@ -1047,7 +1096,15 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         P.queue = sc->ctl + sdfhip_scene::CTL_HIT_WORDS;
         HIP_TRY(hipMemsetAsync(P.queue, 0, sdfhip_scene::CTL_QUEUE_WORDS * sizeof(uint32_t), st));
     }
-    if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 6 * sizeof(unsigned long long), st));
+    if (count) {                                          // this stream's own counters (its scratch)
+        if (!sc) { int rcs = get_scratch(s, st, 0, &sc); if (rcs != SDFHIP_OK) return rcs; }
+        P.counters = reinterpret_cast<unsigned long long *>(sc->ctl + sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS + sdfhip_scene::CTL_PT_WORDS);
+        HIP_TRY(hipMemsetAsync(P.counters, 0, sdfhip_scene::CTL_COUNTER_WORDS * sizeof(uint32_t), st));
+    }
+    if (sparse) {
+        if (!two) return fail(SDFHIP_ERR_ARG, "render_sparse: this scene has no full-depth grid (trees deeper than 12 levels or with inconsistent links render dense shares)");
+        HIP_TRY(hipMemsetAsync(d_out, 0, 64, st));          // the share's header: float slots handed out
+    }
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     if (two) {
         if (cur == CUR_STACK_SPLIT) { if (count) launch_two<CUR_STACK_SPLIT, true>(out_mode, grid, shade_grid, st, P, queued); else launch_two<CUR_STACK_SPLIT, false>(out_mode, grid, shade_grid, st, P, queued); }
@@ -1126,7 +1183,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
                              (compact ? SDFHIP_FLAG_COMPACT : 0u);
         if (count) {
             unsigned long long h[6];
-            HIP_TRY(hipMemcpyAsync(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h, P.counters, sizeof h, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             stats->n_nodes = h[0]; stats->n_samples = h[1]; stats->n_steps = h[2]; stats->n_shadow_rays = h[3];
             stats->n_loads = h[4]; stats->n_hits = h[5];
@@ -1400,12 +1457,104 @@ extern "C" int sdfhip_deinterleave_sparse_device(int device, const void *d_gathe
     return SDFHIP_OK;
 }
 
+// ---- sparse shares written by the march kernel itself (OUT_SPARSE) ---------------------------------------------
+extern "C" uint64_t sdfhip_sparse2_bytes(uint32_t width, uint32_t rows, uint32_t frames, uint32_t capacity)
+{
+    return (uint64_t)sparse2_layout(width, rows, frames, capacity).bytes;
+}
+
+extern "C" uint64_t sdfhip_sparse2_floats_offset(uint32_t width, uint32_t rows, uint32_t frames)
+{
+    return (uint64_t)sparse2_layout(width, rows, frames, 0).off_floats;
+}
+
+extern "C" int sdfhip_render_sparse_device(sdfhip_scene *s, const sdfhip_info *infos, uint32_t n_frames, uint32_t width,
+                                           uint32_t height, uint32_t band_rows, const uint16_t *bands, uint32_t n_bands,
+                                           uint32_t nrows_out, uint32_t capacity, uint32_t flags, void *d_share, void *stream)
+{
+    if (!s || !infos || !bands || !d_share) return fail(SDFHIP_ERR_ARG, "render_sparse_device: null argument");
+    if (capacity == 0) return fail(SDFHIP_ERR_ARG, "render_sparse_device: capacity 0");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render_sparse_device: hipSetDevice(%d) failed", s->device);
+    return render_impl(s, infos, width, height, band_rows, 0, 1, nrows_out, flags, reinterpret_cast<float *>(d_share),
+                       (hipStream_t)stream, nullptr, nullptr, n_frames, bands, n_bands, capacity, true);
+}
+
+extern "C" int sdfhip_deinterleave_sparse2_device(int device, const void *const *d_shares, void *d_frame, uint32_t width,
+                                                  uint32_t height, uint32_t band_rows, uint32_t world, uint32_t rows_per_rank,
+                                                  const uint8_t *owner, uint32_t capacity, uint32_t frames, uint32_t flags,
+                                                  int only_rank, void *stream)
+{
+    if (frames == 0 || frames > (uint32_t)MAX_BATCH || !d_shares || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
+        return fail(SDFHIP_ERR_ARG, "deinterleave_sparse2: null or zero argument");
+    if (world > MULTI_MAX_RANKS) return fail(SDFHIP_ERR_ARG, "deinterleave_sparse2: %u ranks (at most %u)", world, MULTI_MAX_RANKS);
+    if (only_rank >= (int)world) return fail(SDFHIP_ERR_ARG, "deinterleave_sparse2: rank %d of %u", only_rank, world);
+    const uint32_t nbands = (height + band_rows - 1) / band_rows;
+    BandMap M;
+    M.n = 0;
+    memset(M.src, 0, sizeof M.src);
+    uint32_t need_rows = ((nbands + world - 1) / world) * band_rows;
+    if (owner) {
+        if (nbands > (uint32_t)MAX_BAND_LIST)
+            return fail(SDFHIP_ERR_ARG, "deinterleave_sparse2: %u bands (max %d)", nbands, MAX_BAND_LIST);
+        uint32_t have[MULTI_MAX_RANKS] = { 0 };
+        for (uint32_t b = 0; b < nbands; b++) {
+            if (owner[b] >= world) return fail(SDFHIP_ERR_ARG, "deinterleave_sparse2: band %u belongs to rank %u of %u", b, (unsigned)owner[b], world);
+            M.src[b] = (uint16_t)((uint32_t)owner[b] << 10 | have[owner[b]]++);
+        }
+        M.n = nbands;
+        need_rows = 0;
+        for (uint32_t r = 0; r < world; r++) need_rows = have[r] * band_rows > need_rows ? have[r] * band_rows : need_rows;
+    }
+    if (rows_per_rank < need_rows)
+        return fail(SDFHIP_ERR_ARG, "deinterleave_sparse2: rows_per_rank %u < %u needed", rows_per_rank, need_rows);
+    ShareTable S;
+    memset(&S, 0, sizeof S);
+    for (uint32_t r = 0; r < world; r++) {
+        if (!d_shares[r] && (only_rank < 0 || (uint32_t)only_rank == r)) return fail(SDFHIP_ERR_ARG, "deinterleave_sparse2: rank %u has no share", r);
+        S.p[r] = static_cast<const uint8_t *>(d_shares[r]);
+    }
+    DeviceGuard g(device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "deinterleave_sparse2: hipSetDevice(%d) failed", device);
+    const Sparse2Layout L = sparse2_layout(width, rows_per_rank, frames, capacity);
+    const size_t total = (size_t)width * height * frames;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    const uint32_t only = only_rank < 0 ? 0xFFFFFFFFu : (uint32_t)only_rank;
+    auto q = [](float c) { float v = powf(c, 1.0f / 2.2f); v = v > 1.0f ? 1.0f : (v > 0.0f ? v : 0.0f); return (uint32_t)(v * 255.0f + 0.5f); };
+    const uint32_t sky8 = q(0.005f) | (q(0.01f) << 8) | (q(0.2f) << 16);
+    if (flags & SDFHIP_FLAG_DISPLAY_DEBUG)
+        hipLaunchKernelGGL((k_deinterleave_sparse2<OUT_HEAT8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, world, L, M, only, sky8);
+    else if (flags & SDFHIP_FLAG_DISPLAY)
+        hipLaunchKernelGGL((k_deinterleave_sparse2<OUT_GAMMA8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, world, L, M, only, sky8);
+    else
+        hipLaunchKernelGGL((k_deinterleave_sparse2<OUT_RGBA32F>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, world, L, M, only, sky8);
+    HIP_TRY(hipGetLastError());
+    return SDFHIP_OK;
+}
+
 extern "C" int sdfhip_debug_tile_order(sdfhip_scene *s, const uint32_t *d_perm, uint16_t *d_cost)
 {
     if (!s) return fail(SDFHIP_ERR_ARG, "debug_tile_order: null scene");
     std::lock_guard<std::mutex> lk(s->lock);
     s->dbg_tile_perm = d_perm; s->dbg_tile_cost = d_cost;
     return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_debug_step_classes(sdfhip_scene *s, void *stream, uint64_t *out6)
+{
+    if (!s || !out6) return fail(SDFHIP_ERR_ARG, "debug_step_classes: null argument");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "debug_step_classes: hipSetDevice(%d) failed", s->device);
+    for (int i = 0; i < s->n_scratch; i++)
+        if (s->scratch[i].stream == (hipStream_t)stream) {
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            const uint32_t *c = s->scratch[i].ctl + sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS + sdfhip_scene::CTL_PT_WORDS;
+            HIP_TRY(hipMemcpy(out6, reinterpret_cast<const unsigned long long *>(c) + 6, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            return SDFHIP_OK;
+        }
+    return fail(SDFHIP_ERR_ARG, "debug_step_classes: no counting render has run on that stream of this scene");
 }
 
 extern "C" int sdfhip_debug_unorm_table(int device, float *out256)

@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import Info, PathTrace, Stats, check, lib
+from ._lib import Info, MultiStats, PathTrace, Stats, check, lib
 
 
 class Scene:
@@ -140,6 +140,89 @@ class Scene:
                                        int(nrows_out), int(flags), ctypes.c_void_p(int(out_ptr)),
                                        ctypes.c_void_p(int(stream)) if stream else None,
                                        ctypes.byref(stats) if stats is not None else None))
+
+    def step_classes(self, stream=None):
+        """After a FLAG_COUNT DrawDevice on `stream`: lane-steps by the kind of cell they sampled
+        (sdfhip_debug_step_classes)."""
+        out = (ctypes.c_uint64 * 6)()
+        check(lib.sdfhip_debug_step_classes(self._h, ctypes.c_void_p(int(stream)) if stream else None, out))
+        return dict(zip(("flat_coarse", "flat_fine", "nonflat_coarse", "nonflat_full_depth", "nonflat_between", "nonflat_outside"),
+                        (int(v) for v in out)))
+
+
+class MultiScene:
+    """A scene replicated on several GPUs of one node; a frame is ONE call (sdfhip_multi_*: bands dealt to the devices,
+    sparse wire shares gathered into devices[0] over xGMI, assembled there).  `devices` may repeat a device
+    (rehearsal of the pipeline on one GPU)."""
+
+    def __init__(self, octdata, devices):
+        self._h = ctypes.c_void_p()
+        self.devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        check(lib.sdfhip_multi_create(arr, len(self.devices), octdata.Structs.ctypes.data, octdata.Values.ctypes.data,
+                                      octdata.Length, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib.sdfhip_multi_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def configure(self, band_rows=16, rank0_weight=1.0):
+        check(lib.sdfhip_multi_configure(self._h, int(band_rows), float(rank0_weight)))
+
+    @property
+    def transport(self):
+        t = ctypes.c_int()
+        check(lib.sdfhip_multi_info(self._h, None, None, None, None, ctypes.byref(t)))
+        return "rccl" if t.value else "peer"
+
+    def Draw(self, state, width, height, flags=0, pt=None, want_stats=False, out=None):
+        """One frame across the devices to a host array: (H, W, 4) float32, or uint8 with FLAG_DISPLAY[_DEBUG]."""
+        display = bool(flags & (_lib.FLAG_DISPLAY | _lib.FLAG_DISPLAY_DEBUG))
+        if out is None:
+            out = np.empty((int(height), int(width), 4), dtype=np.uint8 if display else np.float32)
+        st = MultiStats()
+        info = state if isinstance(state, Info) else state.State
+        if pt is not None:
+            check(lib.sdfhip_multi_render_path(self._h, ctypes.byref(info), ctypes.byref(pt), int(width), int(height), int(flags),
+                                               out.ctypes.data, ctypes.byref(st)))
+        else:
+            check(lib.sdfhip_multi_render(self._h, ctypes.byref(info), int(width), int(height), int(flags), out.ctypes.data,
+                                          ctypes.byref(st)))
+        return (out, st) if want_stats else out
+
+    def Submit(self, slot, states, width, height, flags=0, out_ptr=None, pt=None):
+        """A group of frames (one camera block each) into slot 0..3; frames land in device memory of devices[0]."""
+        if not isinstance(states, (list, tuple)):
+            states = [states]
+        infos = (Info * len(states))(*[s if isinstance(s, Info) else s.State for s in states])
+        dst = ctypes.c_void_p(int(out_ptr)) if out_ptr else None
+        if pt is not None:
+            check(lib.sdfhip_multi_submit_path(self._h, int(slot), infos, ctypes.byref(pt), int(width), int(height), int(flags), dst))
+        else:
+            check(lib.sdfhip_multi_submit(self._h, int(slot), infos, len(states), int(width), int(height), int(flags), dst))
+
+    def Wait(self, slot, want_stats=False):
+        """Block until the slot's frames are complete; returns the device pointer of its frames (and the stats)."""
+        p = ctypes.c_void_p()
+        st = MultiStats()
+        check(lib.sdfhip_multi_wait(self._h, int(slot), ctypes.byref(p), ctypes.byref(st)))
+        return (p.value, st) if want_stats else p.value
+
+    def debug_floats_sent(self, floats):
+        check(lib.sdfhip_multi_debug_floats_sent(self._h, int(floats)))
 
 
 def device_count():
