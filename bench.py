@@ -856,50 +856,76 @@ def kernel_source_hash():
 
 
 def load_pmc(key):
-    """rocprofv3 PMC figures of this workload (HBM bytes and issued VALU / SALU wave instructions per frame), or
-    None.  bench.py cannot run rocprofv3 on itself: scripts/profile.sh collects the separate --pmc passes of this
-    very command and scripts/summarise_profile.py writes profiles/hbm_traffic.json together with the hash of the
-    kernel sources they were measured on; figures of another build are not reported."""
+    """rocprofv3 PMC figures of this workload (HBM bytes, issued VALU / SALU wave instructions and VALU-busy quad-cycles per
+    frame), or a dict {"dropped": reason}.  bench.py cannot run rocprofv3 on itself: scripts/profile.sh collects the
+    separate --pmc passes of this very command and scripts/summarise_profile.py writes profiles/hbm_traffic.json together
+    with the hash of the kernel sources they were measured on; figures of another build are not reported, and the line
+    says so."""
     try:
         with open(os.path.join(REPO, "profiles", "hbm_traffic.json")) as f:
             e = json.load(f).get(key)
     except (OSError, ValueError):
-        return None
-    if not isinstance(e, dict) or e.get("kernel_source_sha") != kernel_source_hash():
-        return None
+        return {"dropped": "profiles/hbm_traffic.json is missing or unreadable"}
+    if not isinstance(e, dict):
+        return {"dropped": f"no PMC pass of workload '{key}' under profiles/ (scripts/profile.sh)"}
+    here = kernel_source_hash()
+    if e.get("kernel_source_sha") != here:
+        return {"dropped": f"the PMC pass of '{key}' ({e.get('profile')}) was measured on kernel sources {e.get('kernel_source_sha')}; "
+                           f"this build is {here}: figures of another build are not reported"}
     return e
 
 
-# VALU issue: 256 CUs x 4 SIMDs at 2.4 GHz, and 2.35 cycles for the cheapest wave64 VALU instruction (v_mov_b32; simple
-# two-operand ops take 2.4-2.6, three-operand and conversion ops 4.1-4.4: scripts/micro/valu_mix.hip,
-# profiles/r02_micro_valu_mix.txt) -- a ceiling for ANY instruction mix
+# VALU issue ceilings, in wave64 instructions per second chip-wide:
+#   spec      256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles: a SIMD retires 32 lanes per clock (the 157.3 TFLOP/s fp32 vector figure
+#             = 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flops), so a wave64 instruction takes two
+#   measured  / 2.35 cycles: the cheapest instruction on this chip with 8 waves per SIMD (v_mov_b32; v_and / v_add / v_sub /
+#             v_mul / v_fmac 2.4-2.6; shifts, compares, conversions, v_fma_f32 (VOP3), min3 / med3 4.0-4.4; a packed fp32
+#             instruction 4.4-4.7 for two results: scripts/micro/valu_mix.hip, profiles/r03_micro_valu_mix.txt)
+# Both bound ANY instruction mix from above; `valu_busy` below is the measured utilisation.
+VALU_PEAK_SPEC_GINSTR = 256 * 4 * 2.4 / 2.0
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.35
 HBM_PEAK_GBS = 8000.0                    # HBM3E spec (MI355X_MICROARCH.md)
+N_SIMD, CLOCK_GHZ = 256 * 4, 2.4
 
 
 def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
-    """Which roof does the frame sit under?  Candidates, each achieved / peak over the steady-state time per frame
-    (the driver-verifiable ms_per_step; with frames in flight the per-launch durations overlap):
-      hbm-traffic      HBM bytes per frame from the rocprofv3 counters (2 x FETCH_SIZE + WRITE_SIZE, separate passes, the
-                       guide's gfx950 correction), against 8 TB/s;
-      valu             issued VALU wave instructions per frame (SQ_INSTS_VALU), against the chip's ceiling for the
-                       cheapest instruction.
-    Both are measured quantities against a hard ceiling, so frac <= 1; `frac` is the larger -- the binding roof -- and
-    `bound` names it.  They need a PMC pass of this build and workload (profiles/hbm_traffic.json); without one the only
-    figure left is `algorithmic`: the bytes this kernel's own algorithm asks for per frame (16 B per grid cell / node
-    record a LANE loads, 128 B per queued shadow ray, the pixel store; counted by the counting build) -- a demand on the memory
-    system, not on HBM: the lanes of a wave mostly ask for the same few cells, which L1 serves once, so it is not
-    bounded by 8 TB/s (at 4K it reads 9 TB/s).  The reference algorithm's bytes (8 B per node visit of
-    find(), Compute.hlsl:88-108) are the work-equivalent rate: the kernel does not perform those loads (one grid lookup
-    replaces up to nine node visits).  Where that demand exceeds 8 TB/s, `frac` is null (`demand_over_hbm_peak` holds the ratio)."""
+    """Which roof does the frame sit under?  Over the steady-state time per frame (the driver-verifiable ms_per_step; with
+    frames in flight the per-launch durations overlap), from the rocprofv3 counters of THIS build and workload
+    (profiles/hbm_traffic.json; the PMC passes serialise launches: one frame in flight while they count, which changes times,
+    not counts):
+      hbm_frac     HBM bytes per frame (2 x FETCH_SIZE + WRITE_SIZE, separate passes, the guide's gfx950 correction) / time
+                   / 8 TB/s -- what BASELINE's "% of HBM roofline" asks; hbm_frac_of_measured_copy: the same over the
+                   box's own device-to-device copy rate
+      valu_busy    SQ_ACTIVE_INST_VALU (quad-cycles a SIMD's VALU was executing) x 4 / (1024 SIMDs x 2.4 GHz x time): the
+                   measured utilisation of the vector pipes -- near 1 means the frame is bound by its VALU instructions
+      valu         issued VALU wave instructions per frame (SQ_INSTS_VALU) against the ceiling of the cheapest instruction
+                   (peak = measured 2.35 cycles; peak_spec = 2 cycles beside it)
+    `frac` is the larger of hbm-traffic and valu (both measured quantities against hard ceilings, <= 1) and `bound` names it.
+    Without a PMC pass of this build the only figure left is `algorithmic`: the bytes this kernel's own algorithm asks for per
+    frame (16 or 32 B per grid cell a LANE loads, the pixel store; counted by the counting build) -- a demand on the memory
+    system, not on HBM: the lanes of a wave mostly ask for the same few cells, which L1 serves once.  The reference
+    algorithm's bytes (8 B per node visit of find(), Compute.hlsl:88-108) are the work-equivalent rate: the
+    kernel does not perform those loads (one grid lookup replaces up to nine node visits).  Where that demand exceeds
+    8 TB/s, `frac` is null (`demand_over_hbm_peak` holds the ratio)."""
     cands = {}
     traffic = None
+    dropped = pmc.get("dropped") if isinstance(pmc, dict) else None
+    if dropped:
+        pmc = None
+    hbm_frac = hbm_frac_copy = valu_busy = None
     if pmc:
         traffic = int(pmc["hbm_bytes_per_frame"])
         cands["hbm-traffic"] = {"achieved": traffic / sec_per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": traffic}
+        hbm_frac = round(traffic / sec_per_frame / 1e9 / HBM_PEAK_GBS, 4)
+        if copy_gbs:
+            hbm_frac_copy = round(traffic / sec_per_frame / 1e9 / copy_gbs, 4)
         if pmc.get("valu_insts_per_frame"):
             cands["valu"] = {"achieved": pmc["valu_insts_per_frame"] / sec_per_frame / 1e9, "peak": round(VALU_PEAK_GINSTR, 1),
-                             "unit": "G wave-instr/s", "per_frame": int(pmc["valu_insts_per_frame"])}
+                             "peak_is": "measured: the cheapest VALU instruction, 2.35 cycles per wave64 instruction (scripts/micro/valu_mix.hip)",
+                             "peak_spec": round(VALU_PEAK_SPEC_GINSTR, 1), "unit": "G wave-instr/s", "per_frame": int(pmc["valu_insts_per_frame"])}
+            cands["valu"]["frac_of_spec"] = round(cands["valu"]["achieved"] / VALU_PEAK_SPEC_GINSTR, 4)
+        if pmc.get("valu_active_quad_cycles_per_frame"):
+            valu_busy = round(pmc["valu_active_quad_cycles_per_frame"] * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9 * sec_per_frame), 4)
     measured = bool(cands)
     if not measured:
         cands["hbm-algorithmic"] = {"achieved": own_bytes / sec_per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": int(own_bytes)}
@@ -917,9 +943,11 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
         "binding": name,
         "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"],
         "frac_is_measured_against_a_ceiling": measured,
+        "hbm_frac": hbm_frac, "hbm_frac_of_measured_copy": hbm_frac_copy, "valu_busy": valu_busy,
         "traffic": traffic,
-        "traffic_source": ({"profile": pmc.get("profile"), "kernel_source_sha": pmc.get("kernel_source_sha")} if pmc else
-                           "no PMC pass of this build and workload under profiles/ (scripts/profile.sh)"),
+        "traffic_source": ({"profile": pmc.get("profile"), "kernel_source_sha": pmc.get("kernel_source_sha"),
+                            "frames_in_flight_while_counting": 1} if pmc else
+                           (dropped or "no PMC pass of this build and workload under profiles/ (scripts/profile.sh)")),
         "candidates": cands,
         "algorithmic": {"own_bytes_per_frame": int(own_bytes), "own_gbs": round(own_bytes / sec_per_frame / 1e9, 1),
                         "reference_bytes_per_frame": int(ref_bytes), "reference_gbs": round(ref_bytes / sec_per_frame / 1e9, 1)},

@@ -105,7 +105,10 @@ enum {
     SDFHIP_TUNE_LDS_TOP = 0x40000,
     /* A/B knob: k_march appends its shadow rays to a queue that a second kernel (k_shadow) marches 64 to a
      * wave, where by default every wave marches its own shadow rays after the shading step */
-    SDFHIP_TUNE_SHADOW_QUEUE = 0x80000
+    SDFHIP_TUNE_SHADOW_QUEUE = 0x80000,
+    /* A/B knob: the default kernel reads the 16-byte cells of a split grid (8 value bytes, decoded in every non-flat
+     * sample) where by default it reads the grid's 32-byte cells with pre-decoded corners.  Same pixels. */
+    SDFHIP_TUNE_BYTE_CELLS = 0x200000
 };
 
 /* Per-call statistics (all optional: pass NULL). */

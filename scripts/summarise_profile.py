@@ -81,8 +81,10 @@ def main():
         fpl = float(bench["roofline"].get("frames_per_launch", 1.0)) if bench else 1.0
         valu = per_frame.get("SQ_INSTS_VALU", 0.0) / fpl
         salu = per_frame.get("SQ_INSTS_SALU", 0.0) / fpl
+        busy = per_frame.get("SQ_ACTIVE_INST_VALU", 0.0) / fpl      # quad-cycles in which a SIMD's VALU was executing (x 4 = cycles)
         t[sys.argv[2]] = {"hbm_bytes_per_frame": int(out["hbm_bytes_per_frame"]), "read_x2": int(out["hbm_read_bytes_x2_per_frame"]),
                           "write": int(out["hbm_write_bytes_per_frame"]), "valu_insts_per_frame": int(valu), "salu_insts_per_frame": int(salu),
+                          "valu_active_quad_cycles_per_frame": int(busy),
                           "profile": f"profiles/{tag}_pmc.json", "kernel_source_sha": out["kernel_source_sha"]}
         json.dump(t, open(p, "w"), indent=1, sort_keys=True)
 

@@ -33,6 +33,7 @@ FLAG_WIRE = 0x10000
 FLAG_TILE_ORDER = 0x100000    # launch the tiles in descending order of their cost in this stream's last frame (latency of one frame)
 TUNE_ONE_KERNEL = 0x20000     # A/B knob: round 1's one-kernel lane state machine where the default is k_march
 TUNE_LDS_TOP = 0x40000        # measurement variant: top grid (level <= 3) staged in LDS per workgroup
+TUNE_BYTE_CELLS = 0x200000    # A/B knob: 16-byte cells (bytes decoded per sample) where the default reads 32-byte pre-decoded ones
 TUNE_SHADOW_QUEUE = 0x80000   # A/B knob: k_march queues its shadow rays for a second kernel (k_shadow), 64 to a wave
 SHAPE_SPHERE, SHAPE_TORUS, SHAPE_GYROID = 0, 1, 2
 

@@ -35,11 +35,20 @@ constexpr int MAX_STACK = LM;          // the shader's own descent limit (Comput
 #endif
 
 // cursor kinds of the kernels: generic, cursor stack, cursor stack with a top grid as deep as the tree
-enum { CUR_GENERIC = 0, CUR_STACK = 1, CUR_STACK_FULL = 2, CUR_STACK_SPLIT = 3 };
+// CUR_DENSE4: the default kernel through the grid's second form, 4-byte words + sample records (CursorFF, raymarch_device.h)
+enum { CUR_GENERIC = 0, CUR_STACK = 1, CUR_STACK_FULL = 2, CUR_STACK_SPLIT = 3, CUR_DENSE4 = 4 };
 template <int CUR, bool COUNT> struct CursorOf { typedef CursorG type; };
 template <bool COUNT> struct CursorOf<CUR_STACK, COUNT> { typedef CursorS type; };
 template <bool COUNT> struct CursorOf<CUR_STACK_FULL, COUNT> { typedef CursorFT<COUNT, false> type; };
 template <bool COUNT> struct CursorOf<CUR_STACK_SPLIT, COUNT> { typedef CursorFT<COUNT, true> type; };
+template <> struct CursorOf<CUR_DENSE4, false> { typedef CursorFF type; };
+// the cell a cursor sits in, for the gradient: most cursors carry its bytes; CursorFF looks them up again
+template <class CursorT>
+__device__ __forceinline__ Cell cell_of(const CursorT &c, const RenderParams &) { return c.cell(); }
+__device__ __forceinline__ Cell cell_of(const CursorFF &c, const RenderParams &P)
+{
+    return cell_of(c, GridRef{P.top, P.fine, P.top_level, P.fine_bits, P.fine_order, P.d4, P.recs}, P.nodes);
+}
 // the bounce kernels of the path tracer may read a split grid whose blocks are stored sub-cube by sub-cube (GridRef::fine_order)
 template <int CUR, bool COUNT> struct ScatterCursorOf { typedef typename CursorOf<CUR, COUNT>::type type; };
 template <bool COUNT> struct ScatterCursorOf<CUR_STACK_SPLIT, COUNT> { typedef CursorFT<COUNT, true, true> type; };
@@ -243,7 +252,7 @@ __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const Fram
 {
     typename CursorT::Pos u;
     // top: the top grid somewhere else than P.top (the workgroup's LDS copy, k_plain<..., LDSTOP>)
-    const GridRef g{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order};
+    const GridRef g{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order, P.d4, P.recs};
     uint32_t reads = FRESH ? find_fresh(c, P.nodes, g, P.n_nodes, stack, stride, r.px, r.py, r.pz, u)
                            : find(c, P.nodes, g, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
     r.prox = sample_after_find(c, u, r.px, r.py, r.pz);
@@ -536,7 +545,7 @@ __device__ __forceinline__ bool shadow_march(const RenderParams &P, const FrameI
         bool go = ((int)header() & (int)!at_light()) != 0;
         if (go && r.prox < I.margin) {
             float gx, gy, gz;
-            gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
+            gradient(cell_of(c, P), r.px, r.py, r.pz, gx, gy, gz);
             go = !(dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f);
         }
         if (!go) break;
@@ -620,7 +629,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
             r.py = __builtin_fmaf(r.dy, I.margin, r.py);
             r.pz = __builtin_fmaf(r.dz, I.margin, r.pz);
             float gx, gy, gz;
-            gradient(c.cell(), r.px, r.py, r.pz, gx, gy, gz);
+            gradient(cell_of(c, P), r.px, r.py, r.pz, gx, gy, gz);
             const float rg = 1.0f / sqrtf(dot3(gx, gy, gz, gx, gy, gz));
             r.angle = dot3(r.dx, r.dy, r.dz, gx * rg, gy * rg, gz * rg);
             if (r.angle < 0.0f) {
@@ -652,6 +661,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
         if (COUNT) { flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, 0u); flush_classes(P, classes); }
         return;
     }
+    if constexpr (QUEUE) {
     const unsigned long long hits = __ballot(shadow);
     if (hits) {
         const uint32_t q = blockIdx.x & (HIT_QUEUES - 1u);
@@ -668,6 +678,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
         }
     }
     if (COUNT) flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, shadow ? 1u : 0u);
+    }
 }
 
 // One lane per queued shadow ray; a wave takes 64 consecutive records of one queue at a time (chunks are

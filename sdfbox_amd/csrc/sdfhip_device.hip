@@ -94,6 +94,94 @@ __global__ void k_fine_blocks(const NodeRec *__restrict__ nodes, const uint32_t 
     }
 }
 
+// ---- the grid's second form for the default kernel's loop: 4-byte words + sample records (CursorFF, raymarch_device.h) -------
+// the 64-byte sample record of a non-flat leaf: s = LM - its level, its 8 value bytes, its lower corner a in units of 2^-F
+__device__ __forceinline__ void write_sample_record(uint4 *__restrict__ rec, uint32_t s, uint32_t v0, uint32_t v1, uint32_t ax, uint32_t ay,
+                                                    uint32_t az, int F)
+{
+    const uint32_t k = s - (uint32_t)(LM - F);                                              // the leaf is 2^k of the grid's cells wide
+    const float inv = __uint_as_float((127u - k) << 23);
+    const Texels q = decode(v0, v1);
+    rec[0] = make_uint4(__float_as_uint(-((float)ax * inv)), __float_as_uint(-((float)ay * inv)), __float_as_uint(-((float)az * inv)), __float_as_uint(inv));
+    rec[1] = make_uint4(__float_as_uint(q.v[0]), __float_as_uint(q.v[4]), __float_as_uint(q.v[2]), __float_as_uint(q.v[6]));
+    rec[2] = make_uint4(__float_as_uint(q.v[1] - q.v[0]), __float_as_uint(q.v[5] - q.v[4]), __float_as_uint(q.v[3] - q.v[2]),
+                        __float_as_uint(q.v[7] - q.v[6]));
+    rec[3] = make_uint4(0u, 0u, 0u, 0u);
+}
+constexpr uint32_t D4_ANCHOR = 0x7FC00001u, D4_OTHER = 0x7FC00002u;       // pass-1 marks of a non-flat leaf's cells (NaNs: no distance)
+// the leaf of the cell stored at word i of the level-F array, from the 16-byte cells; its anchor = its first cell, which will own the record
+__device__ __forceinline__ uint4 d4_leaf(const GridRef &g, uint32_t i, int F, uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &anchor)
+{
+    const uint32_t mask = (1u << F) - 1u;
+#ifdef TOP_Z_MAJOR
+    z = i & mask; y = (i >> F) & mask; x = i >> (2 * F);
+#else
+    x = i & mask; y = (i >> F) & mask; z = i >> (2 * F);                  // (the inverse of top_index with TOP_BLOCK_BITS = 0)
+#endif
+    const uint4 e = cell_at(g, (int32_t)x, (int32_t)y, (int32_t)z);
+    const uint32_t keep = 0xFFFFFFFFu << ((e.x & 15u) - (uint32_t)(LM - F));
+    anchor = top_index(x & keep, y & keep, z & keep, F);
+    return e;
+}
+// pass 1: a flat leaf's cells get its distance, the others a mark
+__global__ __launch_bounds__(256) void k_d4_fill(const GridRef g, uint32_t *__restrict__ d4, int F)
+{
+    const size_t total = (size_t)1 << (3 * F);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t x, y, z, a;
+        const uint4 e = d4_leaf(g, (uint32_t)i, F, x, y, z, a);
+        d4[i] = (e.x & FLAT_BIT) ? e.z : (a == (uint32_t)i ? D4_ANCHOR : D4_OTHER);
+    }
+}
+// numbering the anchors in cell order (chunks of 256: count, k_split_scan over the chunk counts, then assign)
+__global__ __launch_bounds__(256) void k_d4_count(const uint32_t *__restrict__ d4, size_t ncell, uint32_t n_chunks, uint32_t *__restrict__ chunk_sums)
+{
+    __shared__ uint32_t part[4];
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const size_t i = (size_t)c * 256u + threadIdx.x;
+        const unsigned long long m = __ballot(i < ncell && d4[i] == D4_ANCHOR);
+        if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) chunk_sums[c] = part[0] + part[1] + part[2] + part[3];
+        __syncthreads();
+    }
+}
+// pass 2: an anchor takes the next record, writes it, and its word becomes TAG + the record's index in 16-byte units
+__global__ __launch_bounds__(256) void k_d4_anchor(const GridRef g, uint32_t *__restrict__ d4, size_t ncell, uint32_t n_chunks,
+                                                   const uint32_t *__restrict__ chunk_offsets, uint4 *__restrict__ recs, int F)
+{
+    __shared__ uint32_t part[4];
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const size_t i = (size_t)c * 256u + threadIdx.x;
+        const uint32_t w = threadIdx.x >> 6;
+        const bool anchor = i < ncell && d4[i] == D4_ANCHOR;
+        const unsigned long long m = __ballot(anchor);
+        if ((threadIdx.x & 63u) == 0) part[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = chunk_offsets[c];
+        for (uint32_t k = 0; k < w; k++) before += part[k];
+        if (anchor) {
+            const uint32_t id = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            uint32_t x, y, z, a;
+            const uint4 e = d4_leaf(g, (uint32_t)i, F, x, y, z, a);
+            write_sample_record(recs + (size_t)id * 4u, e.x & 15u, e.y, e.z, x, y, z, F);
+            d4[i] = D4_TAG + id * 4u;
+        }
+        __syncthreads();
+    }
+}
+// pass 3: the other cells of a non-flat leaf take their anchor's word (final since pass 2: no cell reads a cell this pass writes)
+__global__ __launch_bounds__(256) void k_d4_share(const GridRef g, uint32_t *__restrict__ d4, int F)
+{
+    const size_t total = (size_t)1 << (3 * F);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        if (d4[i] != D4_OTHER) continue;
+        uint32_t x, y, z, a;
+        (void)d4_leaf(g, (uint32_t)i, F, x, y, z, a);
+        d4[i] = d4[a];
+    }
+}
+
 // sdfhip_octdata_validate (asdf_io.cpp) on the device, for the upload: the arrays are on their way to HBM anyway (8 ms for
 // 451 MB) and the host's single-threaded pass over 28 M nodes takes 110 ms.  One thread per node; the same verdicts:
 //   bad          a link out of range, or a parent chain of more than 64 links / a cycle (the host function then names the node)
@@ -512,6 +600,9 @@ struct sdfhip_scene {
     TopCell *d_fine;                 // split grid: blocks of fine cells below the internal cells of d_top, or null
     int fine_bits;
     uint64_t fine_bytes;
+    uint32_t *d_d4;                  // the grid's second form, for the default kernel's loop (CursorFF, raymarch_device.h): one word per
+    uint4 *d_recs;                   // cell of the deepest level + the sample records of the non-flat leaves; or null
+    uint64_t d4_bytes;
     // A second, split grid beside a dense full-depth one, for the kernels whose rays are incoherent (the bounce levels of
     // the path-traced pipeline are HBM-bound: every lookup in the 8^depth-cell dense grid is a cache miss, while a ray
     // that stays near the surface stays inside one block of fine cells).  Same cells, same cursor; built on the first
@@ -599,6 +690,8 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
         if (s->d_verdict) (void)hipFree(s->d_verdict);
         if (s->d_top) (void)hipFree(s->d_top);
         if (s->d_fine) (void)hipFree(s->d_fine);
+        if (s->d_d4) (void)hipFree(s->d_d4);
+        if (s->d_recs) (void)hipFree(s->d_recs);
         if (s->d_top2) (void)hipFree(s->d_top2);
         if (s->d_fine2) (void)hipFree(s->d_fine2);
         for (int i = 0; i < s->n_scratch; i++) {
@@ -666,6 +759,51 @@ static bool build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_t
     return ok;
 }
 
+// The grid's second form (CursorFF, raymarch_device.h), made from the 16-byte cells once they exist -- a dense grid as deep as the
+// tree, or a split one: a word per cell of the deepest level and a 64-byte sample record per non-flat leaf.  An accelerator of an
+// accelerator: trees deeper than 10 levels (4 GB of words at depth 10), a grid that is not as deep as the tree, or too little
+// memory do without it, and the default kernel reads the 16-byte cells.
+// MEASURED SLOWER than the 16-byte cells on the bench frames (30 % fewer VALU instructions, 1.7 x the L1 tag
+// lookups and 2.7 x the HBM bytes; 0.112 against 0.090 ms per 1080p frame), so it is built only when SDFHIP_SAMPLE_RECORDS=1 is in
+// the environment at upload: an experiment that stays bit-identical (tests/test_gpu_parity.py::test_pre_decoded_cells...).
+static void build_dense4(sdfhip_scene *s)
+{
+    const int F = (int)s->depth;
+    if (!s->stack_ok || !s->d_top || F < 1 || F > 10 || s->top_level + s->fine_bits != F) return;
+    const char *env = getenv("SDFHIP_SAMPLE_RECORDS");
+    if (!env || atoi(env) != 1) return;
+    const size_t ncell = (size_t)1 << (3 * F);
+    if (ncell * 4 > s->total_mem / 32) return;
+    const GridRef g{s->d_top, s->d_fine, s->top_level, s->fine_bits, 0};
+    const uint32_t n_chunks = (uint32_t)((ncell + 255) / 256);
+    uint32_t *d4 = nullptr, *d_chunks = nullptr;
+    uint4 *recs = nullptr;
+    do {
+        if (hipMalloc((void **)&d4, ncell * 4) != hipSuccess) break;
+        if (hipMalloc((void **)&d_chunks, ((size_t)n_chunks + 1) * 4) != hipSuccess) break;
+        const uint32_t tb = (uint32_t)((ncell + 255) / 256 < 16384 ? (ncell + 255) / 256 : 16384), cb = n_chunks < 16384u ? n_chunks : 16384u;
+        hipLaunchKernelGGL(k_d4_fill, dim3(tb), dim3(256), 0, s->stream, g, d4, F);
+        hipLaunchKernelGGL(k_d4_count, dim3(cb), dim3(256), 0, s->stream, d4, ncell, n_chunks, d_chunks);
+        hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, s->stream, d_chunks, n_chunks);
+        uint32_t n_rec = 0;
+        if (hipMemcpyAsync(&n_rec, d_chunks + n_chunks, 4, hipMemcpyDeviceToHost, s->stream) != hipSuccess) break;
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) break;
+        if ((uint64_t)n_rec * 4 >= 0x3F000000ull) break;                          // TAG + index must stay a finite float
+        if ((uint64_t)n_rec * 64 > s->total_mem / 16) break;
+        if (hipMalloc((void **)&recs, ((size_t)n_rec + 1) * 64) != hipSuccess) break;
+        hipLaunchKernelGGL(k_d4_anchor, dim3(cb), dim3(256), 0, s->stream, g, d4, ncell, n_chunks, d_chunks, recs, F);
+        hipLaunchKernelGGL(k_d4_share, dim3(tb), dim3(256), 0, s->stream, g, d4, F);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) break;
+        s->d_d4 = d4; d4 = nullptr;
+        s->d_recs = recs; recs = nullptr;
+        s->d4_bytes = (uint64_t)ncell * 4 + ((uint64_t)n_rec + 1) * 64;
+    } while (false);
+    (void)hipGetLastError();
+    if (d4) (void)hipFree(d4);
+    if (recs) (void)hipFree(recs);
+    if (d_chunks) (void)hipFree(d_chunks);
+}
+
 extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uint8_t *values,
                                    uint32_t n, sdfhip_scene **out)
 {
@@ -689,7 +827,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     sdfhip_scene *s = new (std::nothrow) sdfhip_scene();
     if (!s) return fail(SDFHIP_ERR_NOMEM, "scene_upload: out of host memory");
     s->device = device; s->n = n; s->depth = 0; s->stack_ok = 0;       // (both set once the tree has been validated, below)
-    s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_verdict = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0;
+    s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_verdict = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0; s->d_d4 = nullptr; s->d_recs = nullptr; s->d4_bytes = 0;
     s->d_top2 = s->d_fine2 = nullptr; s->top2_level = s->fine2_bits = s->fine2_order = s->scatter_tried = 0; s->top2_bytes = 0; s->total_mem = prop.totalGlobalMem;
     s->n_scratch = 0; s->d_frame = nullptr; s->dbg_tile_perm = nullptr; s->dbg_tile_cost = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
     s->cu_count = prop.multiProcessorCount;
@@ -805,6 +943,7 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
         }
     }
     if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail(e, "k_fuse");
+    build_dense4(s);
     (void)hipFree(d_s); d_s = nullptr;
     (void)hipFree(d_v); d_v = nullptr;
     *out = s;
@@ -815,7 +954,7 @@ extern "C" int sdfhip_scene_top_grid(const sdfhip_scene *s, int32_t *level, uint
 {
     if (!s) return fail(SDFHIP_ERR_ARG, "scene_top_grid: null scene");
     if (level) *level = s->d_top ? s->top_level : 0;
-    if (bytes) *bytes = s->d_top ? ((uint64_t)sizeof(TopCell) << (3 * s->top_level)) + s->fine_bytes + s->top2_bytes : 0;
+    if (bytes) *bytes = s->d_top ? ((uint64_t)sizeof(TopCell) << (3 * s->top_level)) + s->fine_bytes + s->d4_bytes + s->top2_bytes : 0;
     return SDFHIP_OK;
 }
 
@@ -930,6 +1069,16 @@ void launch_two(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, const
     else                         go(k_march<CUR, COUNT, OUT_WIRE, true>, k_shadow<CUR, COUNT, OUT_WIRE>);
 }
 
+// the default kernel through the grid's second form, 4-byte words + sample records (CursorFF): not counting, shadow rays marched in the wave
+void launch_fast(uint32_t mode, dim3 grid, hipStream_t st, const RenderParams &P)
+{
+    if (mode == OUT_RGBA32F)     hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_RGBA32F, false>), grid, dim3(64), 0, st, P);
+    else if (mode == OUT_GAMMA8) hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_GAMMA8, false>), grid, dim3(64), 0, st, P);
+    else if (mode == OUT_HEAT8)  hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_HEAT8, false>), grid, dim3(64), 0, st, P);
+    else if (mode == OUT_SPARSE) hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_SPARSE, false>), grid, dim3(64), 0, st, P);
+    else                         hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_WIRE, false>), grid, dim3(64), 0, st, P);
+}
+
 template <int CUR, bool COUNT>
 void launch_pair(bool compact, int bt, dim3 grid, hipStream_t st, const RenderParams &P)
 {
@@ -975,7 +1124,9 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
 
     RenderParams P;
-    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level; P.fine = s->d_fine; P.fine_bits = s->fine_bits; P.fine_order = 0;
+    P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level; P.fine = s->d_fine; P.fine_bits = s->fine_bits; P.fine_order = 0; P.d4 = s->d_d4;
+    // (a word of d4 is TAG + the record's index in 16-byte units: the kernel adds the whole word to this pointer)
+    P.recs = reinterpret_cast<const uint4 *>(reinterpret_cast<uintptr_t>(s->d_recs) - ((uintptr_t)D4_TAG << 4));
     P.out = reinterpret_cast<float4 *>(d_out);
     P.width = width; P.height = height;
     P.band_rows = band_rows; P.band_first = band_first; P.band_stride = band_stride;
@@ -1107,7 +1258,8 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     if (two) {
-        if (cur == CUR_STACK_SPLIT) { if (count) launch_two<CUR_STACK_SPLIT, true>(out_mode, grid, shade_grid, st, P, queued); else launch_two<CUR_STACK_SPLIT, false>(out_mode, grid, shade_grid, st, P, queued); }
+        if (!count && !queued && s->d_d4 && !(flags & SDFHIP_TUNE_BYTE_CELLS)) launch_fast(out_mode, grid, st, P);
+        else if (cur == CUR_STACK_SPLIT) { if (count) launch_two<CUR_STACK_SPLIT, true>(out_mode, grid, shade_grid, st, P, queued); else launch_two<CUR_STACK_SPLIT, false>(out_mode, grid, shade_grid, st, P, queued); }
         else                        { if (count) launch_two<CUR_STACK_FULL, true>(out_mode, grid, shade_grid, st, P, queued); else launch_two<CUR_STACK_FULL, false>(out_mode, grid, shade_grid, st, P, queued); }
         // the next frame's launch order, behind this frame in its stream -- unless the order in use was made from a frame with this
         // very camera block: the same camera gives the same costs and the same order (a viewer at rest pays for the order once)

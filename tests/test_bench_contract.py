@@ -93,7 +93,15 @@ def test_roofline_reports_only_measured_fractions():
     small = bench.roofline(0.388e-3, 1.0e9, 4.0e9, None, None)
     assert 0.0 < small["frac"] <= 1.0 and not small["frac_is_measured_against_a_ceiling"]
     # PMC figures are reported only for the build they were measured on
-    assert bench.load_pmc("no such workload") is None
+    assert "dropped" in bench.load_pmc("no such workload")            # ... and the line says why there are none
+    gone = bench.roofline(0.1e-3, 1.0e9, 4.0e9, bench.load_pmc("no such workload"), 5000.0)
+    assert gone["traffic"] is None and "no PMC pass" in gone["traffic_source"] and gone["hbm_frac"] is None and gone["valu_busy"] is None
+    # the three first-class figures: HBM fraction (of 8 TB/s and of the measured copy rate) and the measured VALU utilisation
+    full = bench.roofline(0.098e-3, 968e6, 3.92e9, {"hbm_bytes_per_frame": 236_142_336, "valu_insts_per_frame": 59_606_143,
+                                                    "valu_active_quad_cycles_per_frame": 59_900_000, "profile": "p", "kernel_source_sha": "s"}, 5100.0)
+    assert abs(full["hbm_frac"] - 236_142_336 / 0.098e-3 / 8e12) < 1e-3 and abs(full["hbm_frac_of_measured_copy"] - 236_142_336 / 0.098e-3 / 5.1e12) < 1e-3
+    assert abs(full["valu_busy"] - 59.9e6 * 4 / (1024 * 2.4e9 * 0.098e-3)) < 1e-3 and 0.9 < full["valu_busy"] < 1.05
+    assert full["candidates"]["valu"]["peak_spec"] == 1228.8 and full["traffic_source"]["frames_in_flight_while_counting"] == 1
     import json as _json
     with open(os.path.join(REPO, "profiles", "hbm_traffic.json")) as f:
         t = _json.load(f)

@@ -16,13 +16,14 @@ pytestmark = pytest.mark.gpu
 # "stack" = the default: k_march (primary march, shading, shadow march as wave-converged loops) wherever the scene has a full-depth or split
 # grid (every test scene of depth <= 12 does); "stack+one" = the one-kernel form of the same traversal;
 # "stack+queue" = k_march queues its shadow rays for k_shadow (the A/B knob SDFHIP_TUNE_SHADOW_QUEUE)
-ALL_VARIANTS = ["generic", "stack", "stack+one", "stack+queue", "generic+compact", "stack+compact"]
+# "stack+bytes" = the default kernel reading the 16-byte cells of a split grid where it would read the 32-byte pre-decoded ones
+ALL_VARIANTS = ["generic", "stack", "stack+one", "stack+queue", "stack+bytes", "generic+compact", "stack+compact"]
 
 
 def flags_of(sb, name):
     f = {"generic": sb.KERNEL_GENERIC, "stack": sb.KERNEL_STACK}[name.split("+")[0]]
     return f | (sb.FLAG_COMPACT if name.endswith("compact") else 0) | (sb.TUNE_ONE_KERNEL if name.endswith("+one") else 0) | \
-        (sb._lib.TUNE_SHADOW_QUEUE if name.endswith("+queue") else 0)
+        (sb._lib.TUNE_SHADOW_QUEUE if name.endswith("+queue") else 0) | (sb._lib.TUNE_BYTE_CELLS if name.endswith("+bytes") else 0)
 
 
 @pytest.fixture(scope="module")
@@ -575,6 +576,7 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
                                 assert_frames_identical(img, ref, f"split grid {sp}")
                                 assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), sp
                                 assert_frames_identical(scene.Draw(c, W, H, flags), ref, f"split grid {sp}, not counting")
+                                assert_frames_identical(scene.Draw(c, W, H, flags | sb._lib.TUNE_BYTE_CELLS), ref, f"split grid {sp}, byte cells")
                             pimg = scene.DrawPath(c, W, H, pt=sb.PathTrace(spp=2))
                             pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
                             assert_frames_identical(pimg, pref, f"split grid {sp}, path-traced")
@@ -963,6 +965,71 @@ def test_nan_coordinates_select_the_low_cells(sb, oracle_mod):
             pref, _ = oracle_mod.render_pt(s, v, cam.State, W, H, spp=2, nthreads=4)
             for fl in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL, sb.KERNEL_GENERIC):
                 assert_frames_identical(sc.DrawPath(cam, W, H, pt=sb.PathTrace(spp=2), flags=fl), pref, f"NaN camera {ci} path-traced {fl:#x}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SDFHIP_FUZZ_SEEDS", "4"))))
+def test_pre_decoded_cells_of_split_grids(sb, oracle_mod, seed):
+    # SDFHIP_SAMPLE_RECORDS=1 (an experiment, measured slower: DESIGN.md section 4.3): the default kernel reads the grid's second form,
+    # one 4-byte word per cell of the deepest level + 64-byte sample records with pre-decoded corners (CursorFF).  Random trees with
+    # random bytes -- non-flat leaves at every level -- behind dense grids and split grids with blocks of 1 to 4 levels, cameras
+    # inside, outside, on cell faces, at tiny and denormal coordinates and at NaN; against the oracle, and the 16-byte cells (the
+    # A/B knob SDFHIP_TUNE_BYTE_CELLS) beside it
+    rng = np.random.default_rng(4000 + seed)
+    depth = [6, 7, 8, 9][seed % 4]
+    s, v = _random_tree(rng, depth, p_split=[0.7, 0.6, 0.5, 0.45][seed % 4])
+    if seed % 2:
+        v = rng.integers(0, 256, size=v.shape, dtype=np.uint8)              # no flat cell anywhere
+    od = sb.OctData(s, v)
+    W, H = 64, 48
+    cams = []
+    for kind in range(7):
+        cam = sb.Logic(W, H)
+        if kind == 0:
+            cam.Position = tuple(float(x) for x in rng.uniform(0.05, 0.95, 3))
+        elif kind == 1:
+            cam.Position = tuple(float(x) for x in rng.uniform(-0.6, 1.6, 3))
+        elif kind == 2:
+            k = int(rng.integers(1, 10))
+            cam.Position = tuple(float(rng.integers(0, 2 ** k + 1)) / 2 ** k for _ in range(3))
+        elif kind == 3:
+            cam.Position = (1e-42, 0.5, 3e-39)                               # denormal coordinates inside the cube
+        elif kind == 4:
+            cam.Position = (-1e-42, 1.0, 0.99999994)                         # a denormal below zero; the far faces
+        elif kind == 5:
+            cam.Position = (0.5, 0.25, -0.25); cam.State.fov = 0.0           # every pixel the same axis ray
+        else:
+            cam.Position = (0.3, 0.6, 0.2); cam.State.position[1] = float("nan")
+        if kind != 5:
+            cam.Heading = (float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-3, 3)))
+        cams.append(cam)
+    prev = os.environ.get("SDFHIP_TOP_GRID_SPLIT")
+    os.environ["SDFHIP_SAMPLE_RECORDS"] = "1"
+    try:
+        for fb in (0, 1, 2, 3, 4):
+            if depth - fb < 1:
+                continue
+            if fb:
+                os.environ["SDFHIP_TOP_GRID_SPLIT"] = str(depth - fb)
+            else:
+                os.environ.pop("SDFHIP_TOP_GRID_SPLIT", None)        # fb 0: the tree's default grid (dense up to depth 8)
+            with sb.Scene(od) as sc:
+                if fb and sc.depth <= depth - fb:
+                    continue
+                if fb:
+                    assert sc.top_grid_level == depth - fb
+                assert sc.top_grid_bytes > (16 << (3 * sc.top_grid_level)) + (4 << (3 * sc.depth))     # the second form is there
+                for ci, cam in enumerate(cams):
+                    ref, _ = oracle_mod.render(s, v, cam.State, W, H, nthreads=8)
+                    assert_frames_identical(sc.Draw(cam, W, H), ref, f"seed {seed} blocks of {fb} levels, camera {ci}: pre-decoded cells")
+                    assert_frames_identical(sc.Draw(cam, W, H, sb._lib.TUNE_BYTE_CELLS), ref, f"seed {seed} blocks of {fb} levels, camera {ci}: byte cells")
+                    assert_frames_identical(sc.Draw(cam, W, H, sb.FLAG_TILE_ORDER), ref, "tile order")
+                    assert (sc.DrawDisplay(cam, W, H) == sc.DrawDisplay(cam, W, H, flags=sb._lib.TUNE_BYTE_CELLS)).all()
+    finally:
+        os.environ.pop("SDFHIP_SAMPLE_RECORDS", None)
+        if prev is None:
+            os.environ.pop("SDFHIP_TOP_GRID_SPLIT", None)
+        else:
+            os.environ["SDFHIP_TOP_GRID_SPLIT"] = prev
 
 
 # SDFHIP_FUZZ_SEEDS=n runs n seeds instead of 6 (a one-off campaign; the committed default stays small)
