@@ -418,19 +418,25 @@ SDFHIP_API int sdfhip_deinterleave_sparse_device(int device, const void *d_gathe
  * depend on it (bit for bit the frame sdfhip_render_device writes).
  *   sdfhip_sparse2_bytes / _floats_offset   size of a share; offset of its float array (= bytes of the fixed part)
  *   sdfhip_render_sparse_device             like sdfhip_render_bands_device (explicit band list, n_frames <= 8 in one launch),
- *                                           output = one share at d_share; zeroes the header on `stream` first
+ *                                           output = one share at d_share.  The share's counter (header word 0) is never zeroed
+ *                                           by the library: a launch counts on from `count_base`, which must be the counter's
+ *                                           value before the launch (0 for a buffer the caller zeroed; after a launch that used n
+ *                                           slots, count_base + n, modulo 2^32) -- no memset between the frames of a viewer
  *   sdfhip_deinterleave_sparse2_device      d_shares[r] = rank r's share (device pointers valid on `device`; world <= 16) ->
  *                                           d_frame [frames][height][width] RGBA32F, or with SDFHIP_FLAG_DISPLAY[_DEBUG] in
- *                                           `flags` RGBA8 through the display pass; only_rank >= 0: write that rank's rows only */
+ *                                           `flags` RGBA8 through the display pass; only_rank >= 0: write that rank's rows only;
+ *                                           counts_out (may be NULL; device-accessible, e.g. pinned host memory): receives the
+ *                                           `world` counters of the shares as they arrived */
 SDFHIP_API uint64_t sdfhip_sparse2_bytes(uint32_t width, uint32_t rows, uint32_t frames, uint32_t capacity);
 SDFHIP_API uint64_t sdfhip_sparse2_floats_offset(uint32_t width, uint32_t rows, uint32_t frames);
 SDFHIP_API int sdfhip_render_sparse_device(sdfhip_scene *scene, const sdfhip_info *infos, uint32_t n_frames, uint32_t width,
                                            uint32_t height, uint32_t band_rows, const uint16_t *bands, uint32_t n_bands,
-                                           uint32_t nrows_out, uint32_t capacity, uint32_t flags, void *d_share, void *stream);
+                                           uint32_t nrows_out, uint32_t capacity, uint32_t count_base, uint32_t flags, void *d_share,
+                                           void *stream);
 SDFHIP_API int sdfhip_deinterleave_sparse2_device(int device, const void *const *d_shares, void *d_frame, uint32_t width,
                                                   uint32_t height, uint32_t band_rows, uint32_t world, uint32_t rows_per_rank,
                                                   const uint8_t *owner, uint32_t capacity, uint32_t frames, uint32_t flags,
-                                                  int only_rank, void *stream);
+                                                  int only_rank, uint32_t *counts_out, void *stream);
 
 /* ---- one frame over several GPUs, behind one call -----------------------------------------------------------
  * Replaces: Program.Draw's UpdateBuffer(info) + DispatchSized(W, H, 1) (SdfBox/Program.cs:81,94) when the frame is rendered by

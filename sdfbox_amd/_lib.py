@@ -184,10 +184,10 @@ _SIG = {
     "sdfhip_sparse2_bytes": (_c.c_uint64, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32]),
     "sdfhip_sparse2_floats_offset": (_c.c_uint64, [_c.c_uint32, _c.c_uint32, _c.c_uint32]),
     "sdfhip_render_sparse_device": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
-                                               _c.POINTER(_c.c_uint16), _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp, _vp]),
+                                               _c.POINTER(_c.c_uint16), _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp, _vp]),
     "sdfhip_deinterleave_sparse2_device": (_c.c_int, [_c.c_int, _c.POINTER(_vp), _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                                       _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_uint8), _c.c_uint32, _c.c_uint32,
-                                                      _c.c_uint32, _c.c_int, _vp]),
+                                                      _c.c_uint32, _c.c_int, _vp, _vp]),
     "sdfhip_multi_create": (_c.c_int, [_c.POINTER(_c.c_int), _c.c_uint32, _vp, _vp, _c.c_uint32, _c.POINTER(_vp)]),
     "sdfhip_multi_free": (_c.c_int, [_vp]),
     "sdfhip_multi_configure": (_c.c_int, [_vp, _c.c_uint32, _c.c_float]),

@@ -94,6 +94,7 @@ struct RenderParams {
     // tile gather (per frame a float plane and a byte plane, 5 bytes per pixel)
     uint32_t out_mode;         // 4: the sparse wire share of sdfhip_render_sparse_device (`out` = the share of all frames of the launch)
     uint32_t sparse_cap;       // ... and the float slots it holds
+    uint32_t sparse_base;      // ... and the value of its counter (header word 0) before this launch
     uint32_t sky8;             // the sky constant through the display pass (host-computed, alpha excluded)
     // path-traced mode (k_path): samples per pixel, diffuse bounces, RNG seed, albedo
     uint32_t pt_spp, pt_bounces, pt_seed;

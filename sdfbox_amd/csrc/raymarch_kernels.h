@@ -418,7 +418,8 @@ enum { OUT_RGBA32F = 0, OUT_GAMMA8 = 1, OUT_HEAT8 = 2, OUT_WIRE = 3, OUT_SPARSE 
 // that array is whatever order the waves finish in; each tile records where its floats start), and the code bytes are one
 // 64-byte store, in tile order.  No dense wire buffer, no mask / scan / scatter kernels behind the render (sdfhip_wire_compact_device:
 // 265 us per group of four 4K frames), and rank 0 expands the shares exactly as before.  One share holds the `frames` frames of a
-// launch: header (word 0: float slots handed out; slots beyond the capacity are dropped and the count says so) | masks
+// launch: header (word 0: float slots handed out SINCE THE BUFFER WAS ZEROED -- a launch counts on from where the last one stopped and is
+// told that value; slots beyond the capacity are dropped and the count says so) | masks
 // [frames][tiles] | slot bases [frames][tiles] | codes [frames][tiles][64] | floats [capacity], so that a gather is two
 // contiguous copies: the fixed part, and as many floats as were used.
 struct Sparse2Layout {
@@ -448,7 +449,8 @@ __device__ __forceinline__ void sparse2_flush(const RenderParams &P, uint32_t f,
     const unsigned long long m = __ballot(lit);
     uint32_t base = 0;
     if (m) {
-        if (lane == 0) base = atomicAdd(reinterpret_cast<uint32_t *>(share), (uint32_t)__popcll(m));
+        // (the share's counter is never zeroed: it counts on from P.sparse_base, its value before this launch -- no memset in front of the march)
+        if (lane == 0) base = atomicAdd(reinterpret_cast<uint32_t *>(share), (uint32_t)__popcll(m)) - P.sparse_base;
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     }
     reinterpret_cast<uint8_t *>(share + L.off_codes)[ft * 64 + lane] = (uint8_t)px.code;

@@ -535,8 +535,10 @@ struct ShareTable { const uint8_t *p[MULTI_MAX_RANKS]; };
 template <int MODE>
 __global__ __launch_bounds__(256) void k_deinterleave_sparse2(const ShareTable S, void *__restrict__ frame, uint32_t width, uint32_t height,
                                                               uint32_t band_rows, uint32_t world, Sparse2Layout L, const BandMap M,
-                                                              uint32_t only_rank, uint32_t sky8)
+                                                              uint32_t only_rank, uint32_t sky8, uint32_t *__restrict__ counts)
 {
+    // the shares' counters (header word 0), for the host: `counts` may be pinned host memory -- no copy of its own behind the frame
+    if (counts && blockIdx.x == 0 && threadIdx.x < world && S.p[threadIdx.x]) counts[threadIdx.x] = *reinterpret_cast<const uint32_t *>(S.p[threadIdx.x]);
     const size_t per_frame = (size_t)width * height, total = per_frame * L.frames;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t f = (uint32_t)(i / per_frame);
@@ -1103,7 +1105,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
                 uint32_t band_rows, uint32_t band_first, uint32_t band_stride, uint32_t nrows_out,
                 uint32_t flags, float *d_out, hipStream_t st, sdfhip_stats *stats,
                 const sdfhip_pathtrace *pt = nullptr, uint32_t n_frames = 1,
-                const uint16_t *bands = nullptr, uint32_t n_bands = 0, uint32_t sparse_cap = 0, bool sparse = false)
+                const uint16_t *bands = nullptr, uint32_t n_bands = 0, uint32_t sparse_cap = 0, bool sparse = false, uint32_t sparse_base = 0)
 {
     // `info` points at n_frames consecutive Info blocks (batched launch: plain kernel only)
     if (n_frames == 0 || n_frames > (uint32_t)MAX_BATCH)
@@ -1187,6 +1189,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         return fail(SDFHIP_ERR_ARG, "render: the compact kernel packs a pixel's x and row into 16 bits each (frame %u x %u)", width, nrows_out);
     P.out_mode = out_mode;
     P.sparse_cap = sparse_cap;
+    P.sparse_base = sparse_base;
     {   // the sky constant of Compute.hlsl:196 through DisplayFrag.hlsl:24, alpha excluded
         auto q = [](float c) { float v = powf(c, 1.0f / 2.2f); v = v > 1.0f ? 1.0f : (v > 0.0f ? v : 0.0f); return (uint32_t)(v * 255.0f + 0.5f); };
         P.sky8 = q(0.005f) | (q(0.01f) << 8) | (q(0.2f) << 16);
@@ -1265,7 +1268,6 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
     if (sparse) {
         if (!two) return fail(SDFHIP_ERR_ARG, "render_sparse: this scene has no full-depth grid (trees deeper than 12 levels or with inconsistent links render dense shares)");
-        HIP_TRY(hipMemsetAsync(d_out, 0, 64, st));          // the share's header: float slots handed out
     }
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     if (two) {
@@ -1678,7 +1680,7 @@ extern "C" uint64_t sdfhip_sparse2_floats_offset(uint32_t width, uint32_t rows, 
 
 extern "C" int sdfhip_render_sparse_device(sdfhip_scene *s, const sdfhip_info *infos, uint32_t n_frames, uint32_t width,
                                            uint32_t height, uint32_t band_rows, const uint16_t *bands, uint32_t n_bands,
-                                           uint32_t nrows_out, uint32_t capacity, uint32_t flags, void *d_share, void *stream)
+                                           uint32_t nrows_out, uint32_t capacity, uint32_t count_base, uint32_t flags, void *d_share, void *stream)
 {
     if (!s || !infos || !bands || !d_share) return fail(SDFHIP_ERR_ARG, "render_sparse_device: null argument");
     if (capacity == 0) return fail(SDFHIP_ERR_ARG, "render_sparse_device: capacity 0");
@@ -1686,13 +1688,13 @@ extern "C" int sdfhip_render_sparse_device(sdfhip_scene *s, const sdfhip_info *i
     DeviceGuard g(s->device);
     if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "render_sparse_device: hipSetDevice(%d) failed", s->device);
     return render_impl(s, infos, width, height, band_rows, 0, 1, nrows_out, flags, reinterpret_cast<float *>(d_share),
-                       (hipStream_t)stream, nullptr, nullptr, n_frames, bands, n_bands, capacity, true);
+                       (hipStream_t)stream, nullptr, nullptr, n_frames, bands, n_bands, capacity, true, count_base);
 }
 
 extern "C" int sdfhip_deinterleave_sparse2_device(int device, const void *const *d_shares, void *d_frame, uint32_t width,
                                                   uint32_t height, uint32_t band_rows, uint32_t world, uint32_t rows_per_rank,
                                                   const uint8_t *owner, uint32_t capacity, uint32_t frames, uint32_t flags,
-                                                  int only_rank, void *stream)
+                                                  int only_rank, uint32_t *counts_out, void *stream)
 {
     if (frames == 0 || frames > (uint32_t)MAX_BATCH || !d_shares || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
         return fail(SDFHIP_ERR_ARG, "deinterleave_sparse2: null or zero argument");
@@ -1732,11 +1734,11 @@ extern "C" int sdfhip_deinterleave_sparse2_device(int device, const void *const 
     auto q = [](float c) { float v = powf(c, 1.0f / 2.2f); v = v > 1.0f ? 1.0f : (v > 0.0f ? v : 0.0f); return (uint32_t)(v * 255.0f + 0.5f); };
     const uint32_t sky8 = q(0.005f) | (q(0.01f) << 8) | (q(0.2f) << 16);
     if (flags & SDFHIP_FLAG_DISPLAY_DEBUG)
-        hipLaunchKernelGGL((k_deinterleave_sparse2<OUT_HEAT8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, world, L, M, only, sky8);
+        hipLaunchKernelGGL((k_deinterleave_sparse2<OUT_HEAT8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, world, L, M, only, sky8, counts_out);
     else if (flags & SDFHIP_FLAG_DISPLAY)
-        hipLaunchKernelGGL((k_deinterleave_sparse2<OUT_GAMMA8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, world, L, M, only, sky8);
+        hipLaunchKernelGGL((k_deinterleave_sparse2<OUT_GAMMA8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, world, L, M, only, sky8, counts_out);
     else
-        hipLaunchKernelGGL((k_deinterleave_sparse2<OUT_RGBA32F>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, world, L, M, only, sky8);
+        hipLaunchKernelGGL((k_deinterleave_sparse2<OUT_RGBA32F>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, world, L, M, only, sky8, counts_out);
     HIP_TRY(hipGetLastError());
     return SDFHIP_OK;
 }

@@ -27,6 +27,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -85,6 +86,10 @@ struct Rccl {
 constexpr int NCCL_UINT8 = 1;              // ncclUint8 (nccl.h: ncclInt8 = 0, ncclUint8 = 1)
 
 // ---- one worker thread per rank > 0: runs the jobs the caller posts, one at a time -------------------------------------
+// A frame is tens of microseconds of device work per rank, and a thread that sleeps on a condition variable takes about
+// as long to wake: a worker polls for the next job for SPIN_US after its last one (a viewer's frames come back to back)
+// before it goes to sleep, and the caller polls for the workers' completion the same way.
+constexpr int SPIN_US = 200;
 struct Worker {
     std::thread th;
     std::mutex mu;
@@ -92,36 +97,53 @@ struct Worker {
     int (*fn)(void *, uint32_t) = nullptr;     // job: fn(arg, rank)
     void *arg = nullptr;
     uint32_t rank = 0;
-    bool has = false, done = true, quit = false;
+    std::atomic<uint32_t> posted{0}, finished{0};
+    std::atomic<bool> quit{false};
     int rc = SDFHIP_OK;
     char err[256] = { 0 };                     // the job's sdfhip_last_error text (thread-local there)
+    static bool spin(const std::atomic<uint32_t> &a, uint32_t seen, const std::atomic<bool> *stop)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 64; i++) {
+                if (a.load(std::memory_order_acquire) != seen || (stop && stop->load(std::memory_order_acquire))) return true;
+                __builtin_ia32_pause();
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) return false;
+        }
+    }
     void run()
     {
+        uint32_t seen = 0;
         for (;;) {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return has || quit; });
-            if (quit) return;
-            has = false;
-            lk.unlock();
+            if (!spin(posted, seen, &quit)) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit.load(); });
+            }
+            if (quit.load()) return;
+            seen = posted.load(std::memory_order_acquire);
             const int r = fn(arg, rank);
-            lk.lock();
             rc = r;
             if (r != SDFHIP_OK) { strncpy(err, sdfhip_last_error(), sizeof err - 1); err[sizeof err - 1] = 0; }
-            done = true;
+            { std::lock_guard<std::mutex> lk(mu); finished.store(seen, std::memory_order_release); }
             cv.notify_all();
         }
     }
     void post(int (*f)(void *, uint32_t), void *a)
     {
-        std::lock_guard<std::mutex> lk(mu);
-        fn = f; arg = a; has = true; done = false;
+        { std::lock_guard<std::mutex> lk(mu); fn = f; arg = a; posted.fetch_add(1, std::memory_order_release); }
         cv.notify_all();
     }
     int join()
     {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return done; });
-        return rc;
+        const uint32_t want = posted.load(std::memory_order_acquire);
+        for (;;) {
+            if (finished.load(std::memory_order_acquire) == want) return rc;
+            if (!spin(finished, want - 1, nullptr)) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return finished.load(std::memory_order_acquire) == want; });
+            }
+        }
     }
 };
 
@@ -131,7 +153,7 @@ struct RankBuf {
     uint8_t *d_share = nullptr;            // on the rank's device: what it renders (sparse share, or dense RGBA32F bands)
     uint8_t *d_gather = nullptr;           // on rank 0's device: where rank r > 0's share lands (sparse mode)
     size_t share_cap = 0, gather_cap = 0;  // bytes allocated
-    uint32_t *h_count = nullptr;           // pinned: float slots the share used
+    uint32_t count_base = 0;               // the share's counter before this slot's launch (it is never zeroed, see sdfhip_render_sparse_device)
     uint32_t sent = 0;                     // floats copied with this slot's share
 };
 
@@ -143,8 +165,10 @@ struct Slot {
     size_t frames_cap = 0;
     uint8_t *d_dense = nullptr;            // rank 0's device: [world] dense shares (path-traced mode)
     size_t dense_cap = 0;
+    uint32_t *h_counts = nullptr;          // pinned, [MAX_RANKS]: the shares' counters as the assembly kernel found them
+    uint32_t last_used[MAX_RANKS] = { 0 };
     void *out = nullptr;                   // where this submission's frames go (the caller's buffer or d_frames)
-    bool busy = false, path = false;
+    bool busy = false, path = false, dirty = false;   // dirty: a submission failed half-way: the shares' counters are re-zeroed before the next one
     uint32_t n_frames = 0, width = 0, height = 0, flags = 0;
     std::chrono::steady_clock::time_point t_submit;
 };
@@ -285,25 +309,21 @@ int rank_submit(void *arg, uint32_t r)
     }
     const ShareShape sh = share_shape(m, J.n_frames);
     int rc = sdfhip_render_sparse_device(m->scenes[r], J.infos, J.n_frames, L.width, L.height, L.band_rows, L.bands[r].data(),
-                                         (uint32_t)L.bands[r].size(), L.rows_per_rank, sh.capacity, J.flags, B.d_share, B.stream);
+                                         (uint32_t)L.bands[r].size(), L.rows_per_rank, sh.capacity, B.count_base, J.flags, B.d_share, B.stream);
     if (rc != SDFHIP_OK) return rc;
-    M_TRY(hipMemcpyAsync(B.h_count, B.d_share, sizeof(uint32_t), hipMemcpyDeviceToHost, B.stream));
     if (r > 0 || m->rccl_self) {
+        // ONE copy: the share's fixed part and, right behind it, as many floats as this rank's last shares needed
         const uint32_t nf = m->est[r] ? (m->est[r] < sh.capacity ? m->est[r] : sh.capacity) : sh.capacity;
+        const size_t bytes = sh.fixed + (size_t)nf * 4;
         B.sent = nf;
         if (m->use_rccl) {
             int e = m->rccl.GroupStart();
             if (e) return nccl_fail(m, e, "ncclGroupStart");
-            if ((e = m->rccl.Send(B.d_share, sh.fixed, NCCL_UINT8, 0, m->comms[r], B.stream)) != 0) return nccl_fail(m, e, "ncclSend");
-            if ((e = m->rccl.Send(B.d_share + sh.off_floats, (size_t)nf * 4, NCCL_UINT8, 0, m->comms[r], B.stream)) != 0) return nccl_fail(m, e, "ncclSend");
-            if (r == 0) {                                      // (self test: the receives belong to the same group)
-                if ((e = m->rccl.Recv(B.d_gather, sh.fixed, NCCL_UINT8, 0, m->comms[0], B.stream)) != 0) return nccl_fail(m, e, "ncclRecv");
-                if ((e = m->rccl.Recv(B.d_gather + sh.off_floats, (size_t)nf * 4, NCCL_UINT8, 0, m->comms[0], B.stream)) != 0) return nccl_fail(m, e, "ncclRecv");
-            }
+            if ((e = m->rccl.Send(B.d_share, bytes, NCCL_UINT8, 0, m->comms[r], B.stream)) != 0) return nccl_fail(m, e, "ncclSend");
+            if (r == 0 && (e = m->rccl.Recv(B.d_gather, bytes, NCCL_UINT8, 0, m->comms[0], B.stream)) != 0) return nccl_fail(m, e, "ncclRecv");   // (self test: same group)
             if ((e = m->rccl.GroupEnd()) != 0) return nccl_fail(m, e, "ncclGroupEnd");
         } else {
-            M_TRY(push(B.d_gather, m->devices[0], B.d_share, m->devices[r], sh.fixed, B.stream));
-            if (nf) M_TRY(push(B.d_gather + sh.off_floats, m->devices[0], B.d_share + sh.off_floats, m->devices[r], (size_t)nf * 4, B.stream));
+            M_TRY(push(B.d_gather, m->devices[0], B.d_share, m->devices[r], bytes, B.stream));
         }
     } else {
         B.sent = sh.capacity;
@@ -344,8 +364,13 @@ int prepare_slot(sdfhip_multi *m, Slot &S, uint32_t n_frames, bool path, bool in
             if (r > 0) { int rc = grow(&B.d_share, &B.share_cap, (size_t)L.rows_per_rank * L.width * 16, B.stream); if (rc) return rc; }
         } else {
             const ShareShape sh = share_shape(m, n_frames);
+            const uint8_t *before = B.d_share;
             int rc = grow(&B.d_share, &B.share_cap, sh.bytes, B.stream);
             if (rc) return rc;
+            if (B.d_share != before || S.dirty) {                       // a new buffer: its counter starts at zero (and is never zeroed again)
+                M_TRY(hipMemsetAsync(B.d_share, 0, 64, B.stream));
+                B.count_base = 0;
+            }
             if (r > 0 || m->rccl_self) {
                 DevGuard g0(m->devices[0]);
                 rc = grow(&B.d_gather, &B.gather_cap, sh.bytes, S.rb[0].stream);
@@ -356,6 +381,7 @@ int prepare_slot(sdfhip_multi *m, Slot &S, uint32_t n_frames, bool path, bool in
     DevGuard g0(m->devices[0]);
     if (path) { int rc = grow(&S.d_dense, &S.dense_cap, (size_t)m->n * L.rows_per_rank * L.width * 16, S.rb[0].stream); if (rc) return rc; }
     if (internal_frames) { int rc = grow(&S.d_frames, &S.frames_cap, (size_t)n_frames * L.width * L.height * frame_px_bytes, S.rb[0].stream); if (rc) return rc; }
+    S.dirty = false;
     return SDFHIP_OK;
 }
 
@@ -376,7 +402,8 @@ int assemble(sdfhip_multi *m, Slot &S, int only_rank)
     for (uint32_t r = 0; r < m->n; r++) shares[r] = (r == 0 && !m->rccl_self) ? S.rb[0].d_share : S.rb[r].d_gather;
     const ShareShape sh = share_shape(m, S.n_frames);
     return sdfhip_deinterleave_sparse2_device(m->devices[0], shares, S.out, L.width, L.height, L.band_rows, m->n, L.rows_per_rank, owner,
-                                              sh.capacity, S.n_frames, S.flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG), only_rank, st);
+                                              sh.capacity, S.n_frames, S.flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG), only_rank,
+                                              only_rank < 0 ? S.h_counts : nullptr, st);
 }
 
 // rank 0's RCCL receives of one submission (peer copies need none: the senders write into rank 0's memory)
@@ -395,8 +422,7 @@ int post_receives(sdfhip_multi *m, Slot &S)
         } else {
             const ShareShape sh = share_shape(m, S.n_frames);
             const uint32_t nf = m->est[r] ? (m->est[r] < sh.capacity ? m->est[r] : sh.capacity) : sh.capacity;   // what rank r sends (same state, read before the jobs start)
-            if ((e = m->rccl.Recv(S.rb[r].d_gather, sh.fixed, NCCL_UINT8, (int)r, m->comms[0], S.rx_stream)) != 0) return nccl_fail(m, e, "ncclRecv");
-            if ((e = m->rccl.Recv(S.rb[r].d_gather + sh.off_floats, (size_t)nf * 4, NCCL_UINT8, (int)r, m->comms[0], S.rx_stream)) != 0) return nccl_fail(m, e, "ncclRecv");
+            if ((e = m->rccl.Recv(S.rb[r].d_gather, sh.fixed + (size_t)nf * 4, NCCL_UINT8, (int)r, m->comms[0], S.rx_stream)) != 0) return nccl_fail(m, e, "ncclRecv");
         }
     }
     if ((e = m->rccl.GroupEnd()) != 0) return nccl_fail(m, e, "ncclGroupEnd");
@@ -436,12 +462,14 @@ int submit_locked(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint
     m->job.m = m; m->job.slot = slot; m->job.infos = infos; m->job.n_frames = n_frames; m->job.width = width; m->job.height = height;
     m->job.flags = flags & ~(uint32_t)(SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG);   // the display pass runs where the frame is assembled
     m->job.pt = pt;
+    S.dirty = true;                                   // until everything below has been issued
     rc = post_receives(m, S);
     if (rc != SDFHIP_OK) return rc;
     rc = on_all_ranks(m, rank_submit);
     if (rc != SDFHIP_OK) return rc;
     rc = assemble(m, S, -1);
     if (rc != SDFHIP_OK) return rc;
+    S.dirty = false;
     {
         DevGuard g0(m->devices[0]);
         M_TRY(hipEventRecord(S.ev_done, S.rb[0].stream));
@@ -466,7 +494,9 @@ int wait_locked(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_st
         for (uint32_t r = 0; r < m->n; r++) {
             if (L.bands[r].empty()) continue;
             RankBuf &B = S.rb[r];
-            const uint32_t used = *B.h_count < sh.capacity ? *B.h_count : sh.capacity;
+            const uint32_t handed = S.h_counts[r] - B.count_base;          // slots this launch handed out (the counter runs on, modulo 2^32)
+            B.count_base = S.h_counts[r];
+            const uint32_t used = handed < sh.capacity ? handed : sh.capacity;
             if ((r > 0 || m->rccl_self) && used > B.sent) {
                 // the share needed more floats than were sent with it: the tail now, and this rank's rows again
                 {
@@ -486,6 +516,7 @@ int wait_locked(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_st
             const uint64_t want = ((uint64_t)used + used / 4 + 1024 + 1023) / 1024 * 1024;
             const uint32_t e = (uint32_t)(want < sh.capacity ? want : sh.capacity);
             m->est[r] = (m->est[r] == 0 || e > m->est[r]) ? e : (m->est[r] - (m->est[r] - e) / 8);   // up at once, down slowly
+            S.last_used[r] = used;
         }
     }
     m->resends += resent;
@@ -504,7 +535,7 @@ int wait_locked(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_st
             (void)hipGetLastError();
             if (!S.path) {
                 const ShareShape sh = share_shape(m, S.n_frames);
-                stats->floats_used[r] = *S.rb[r].h_count;
+                stats->floats_used[r] = S.last_used[r];
                 if (r > 0) stats->gathered_bytes += sh.fixed + (uint64_t)S.rb[r].sent * 4;
             } else if (r > 0) {
                 stats->gathered_bytes += (uint64_t)L.rows_per_rank * L.width * 16;
@@ -522,7 +553,8 @@ extern "C" int sdfhip_multi_free(sdfhip_multi *m)
     for (uint32_t r = 1; r < m->n; r++) {
         Worker *w = m->workers[r];
         if (!w) continue;
-        { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; w->cv.notify_all(); }
+        { std::lock_guard<std::mutex> lk(w->mu); w->quit.store(true); }
+        w->cv.notify_all();
         if (w->th.joinable()) w->th.join();
         delete w;
     }
@@ -533,7 +565,6 @@ extern "C" int sdfhip_multi_free(sdfhip_multi *m)
             DevGuard g(m->devices[r]);
             if (B.stream) (void)hipStreamSynchronize(B.stream);
             if (B.d_share) (void)hipFree(B.d_share);
-            if (B.h_count) (void)hipHostFree(B.h_count);
             if (B.ev_start) (void)hipEventDestroy(B.ev_start);
             if (B.ev_sent) (void)hipEventDestroy(B.ev_sent);
             if (B.stream) (void)hipStreamDestroy(B.stream);
@@ -543,6 +574,7 @@ extern "C" int sdfhip_multi_free(sdfhip_multi *m)
         if (S.rx_stream) { (void)hipStreamSynchronize(S.rx_stream); (void)hipStreamDestroy(S.rx_stream); }
         if (S.d_frames) (void)hipFree(S.d_frames);
         if (S.d_dense) (void)hipFree(S.d_dense);
+        if (S.h_counts) (void)hipHostFree(S.h_counts);
         if (S.ev_rx) (void)hipEventDestroy(S.ev_rx);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         if (S.ev_t0) (void)hipEventDestroy(S.ev_t0);
@@ -599,13 +631,14 @@ extern "C" int sdfhip_multi_create(const int *devices, uint32_t n_devices, const
             DevGuard g(devices[r]);
             hipError_t e;
             if ((e = hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking)) != hipSuccess ||
-                (e = hipEventCreate(&B.ev_start)) != hipSuccess || (e = hipEventCreate(&B.ev_sent)) != hipSuccess ||
-                (e = hipHostMalloc((void **)&B.h_count, 64, hipHostMallocDefault)) != hipSuccess)
-                return bail(fail(SDFHIP_ERR_DEVICE, "multi_create: stream / event / pinned memory on device %d: %s", devices[r], hipGetErrorString(e)));
-            *B.h_count = 0;
+                (e = hipEventCreate(&B.ev_start)) != hipSuccess || (e = hipEventCreate(&B.ev_sent)) != hipSuccess)
+                return bail(fail(SDFHIP_ERR_DEVICE, "multi_create: stream / event on device %d: %s", devices[r], hipGetErrorString(e)));
         }
         DevGuard g0(devices[0]);
         hipError_t e;
+        if ((e = hipHostMalloc((void **)&S.h_counts, MAX_RANKS * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+            return bail(fail(SDFHIP_ERR_DEVICE, "multi_create: pinned memory: %s", hipGetErrorString(e)));
+        memset(S.h_counts, 0, MAX_RANKS * sizeof(uint32_t));
         if ((e = hipStreamCreateWithFlags(&S.rx_stream, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreate(&S.ev_rx)) != hipSuccess ||
             (e = hipEventCreate(&S.ev_done)) != hipSuccess || (e = hipEventCreate(&S.ev_t0)) != hipSuccess)
             return bail(fail(SDFHIP_ERR_DEVICE, "multi_create: stream / event on device %d: %s", devices[0], hipGetErrorString(e)));

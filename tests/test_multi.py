@@ -82,14 +82,17 @@ def test_sparse_share_written_by_the_march_kernel_expands_to_the_frame(sb, torch
         shares = [torch.full((nbytes,), 0xA5, dtype=torch.uint8, device="cuda") for _ in range(world)]      # garbage: the render must define all it reads
         for r in range(world):
             bands = (ctypes.c_uint16 * len(lay.bands_of(r)))(*lay.bands_of(r))
+            # (the share's counter is never zeroed by the library: it counts on from the value it is told -- here the garbage's)
             sb._lib.check(L.sdfhip_render_sparse_device(scene._h, infos, G, W, H, lay.band_rows, bands, len(bands), lay.rows_per_rank, cap,
-                                                        0, ctypes.c_void_p(shares[r].data_ptr()), ctypes.c_void_p(st)))
+                                                        0xA5A5A5A5, 0, ctypes.c_void_p(shares[r].data_ptr()), ctypes.c_void_p(st)))
         ptrs = (ctypes.c_void_p * world)(*[s.data_ptr() for s in shares])
         owner = (ctypes.c_uint8 * lay.n_bands)(*lay.owner) if lay.weighted else None
         for flags in (0, sb.FLAG_DISPLAY, sb.FLAG_DISPLAY_DEBUG):
             out = torch.zeros((G, H, W, 4) if flags == 0 else (G, H, W), dtype=torch.float32 if flags == 0 else torch.int32, device="cuda")
+            counts = torch.zeros(world, dtype=torch.int32, device="cuda")
             sb._lib.check(L.sdfhip_deinterleave_sparse2_device(0, ptrs, ctypes.c_void_p(out.data_ptr()), W, H, lay.band_rows, world,
-                                                               lay.rows_per_rank, owner, cap, G, flags, -1, ctypes.c_void_p(st)))
+                                                               lay.rows_per_rank, owner, cap, G, flags, -1, ctypes.c_void_p(counts.data_ptr()),
+                                                               ctypes.c_void_p(st)))
             torch.cuda.synchronize()
             for f in range(G):
                 ref = whole_frame(sb, torch, scene, cams[f], W, H, flags)
@@ -100,8 +103,9 @@ def test_sparse_share_written_by_the_march_kernel_expands_to_the_frame(sb, torch
             fr = whole_frame(sb, torch, scene, cams[f], W, H)
             sky = (fr[..., 0] == 0.005) & (fr[..., 1] == 0.01) & (fr[..., 2] == 0.2)
             lit += int(((fr[..., 0].view(torch.int32) != 0) & ~sky).sum())
-        used = sum(int(s[:4].view(torch.int32).item()) for s in shares)
+        used = sum((int(s[:4].view(torch.int32).item()) - 0xA5A5A5A5) % (1 << 32) for s in shares)
         assert used == lit                    # float slots = pixels whose grey level has any bit set
+        assert [int(c) % (1 << 32) for c in counts.tolist()] == [int(s[:4].view(torch.int32).item()) % (1 << 32) for s in shares]
 
 
 @pytest.mark.gpu
