@@ -90,10 +90,12 @@ def parse():
     ap.add_argument("--multi-mode", default="groups", choices=["groups", "frame"],
                     help="--single-process: 'groups' = groups of --gather-every frames, four groups in flight (throughput); "
                          "'frame' = one frame at a time across all devices, launch to completion (what a viewer waits for)")
-    ap.add_argument("--wire", type=int, default=2,
-                    help="sharded runs: what the ranks send.  2 = sparse wire shares (code bytes + the non-zero grey "
-                         "levels packed per 8x8 tile; capacity measured before the timed region), 1 = 5-byte wire "
-                         "pixels, 0 = RGBA32F pixels.  Rank 0 expands 1 and 2 to the same RGBA32F frame, bit for bit")
+    ap.add_argument("--wire", type=int, default=3,
+                    help="sharded runs: what the ranks send.  3 = sparse shares written by the march kernel itself (per 8x8 tile "
+                         "a mask, the code bytes and the non-zero grey levels; the floats that travel are measured before the timed "
+                         "region, a longer tail is sent again), 2 = the same format made by three compaction kernels from dense wire "
+                         "shares (round 2's form), 1 = 5-byte wire pixels, 0 = RGBA32F pixels.  Rank 0 expands 1-3 to the same "
+                         "RGBA32F frame, bit for bit")
     return ap.parse_args()
 
 
@@ -122,8 +124,9 @@ def main():
     import torch.distributed as dist
 
     import sdfbox_amd as sb
-    from sdfbox_amd.tiles import (BandLayout, deinterleave, deinterleave_share, deinterleave_sparse, render_bands,
-                                  render_bands_batch, sparse_count, sparse_headers, sparse_share_bytes, wire_compact, wire_shape)
+    from sdfbox_amd.tiles import (BandLayout, deinterleave, deinterleave_share, deinterleave_sparse, deinterleave_sparse2, render_bands,
+                                  render_bands_batch, render_sparse2, sparse2_bytes, sparse2_floats_offset, sparse_count, sparse_headers,
+                                  sparse_share_bytes, wire_compact, wire_shape)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
@@ -177,7 +180,11 @@ def main():
     # what travels in the gather: the frame's own pixels, or 5-byte wire pixels that rank 0 expands
     # to the RGBA32F frame while it restores row order (lossless; sdfbox_amd/tiles.py)
     wire = sharded and args.wire >= 1 and not args.display and pt is None and not compact
-    sparse = wire and args.wire == 2       # ... compacted before the gather: most of the float plane is zeros (sky)
+    # 3: the march kernel writes the sparse share itself (sdfhip_render_sparse_device) -- where the scene has a full-depth grid
+    sparse2 = wire and args.wire == 3 and scene.top_grid_level > 0 and scene.stack_kernel_ok
+    if sparse2:
+        wire = False
+    sparse = wire and args.wire >= 2       # ... compacted before the gather: most of the float plane is zeros (sky)
     wpx_dtype, wpx_bytes = (torch.uint8, 5) if wire else (px_dtype, px_bytes)
 
     def share_shape(rows):                 # one frame-share of `rows` rows as it is rendered and gathered
@@ -203,15 +210,38 @@ def main():
     w0 = args.rank0_weight if world > 1 else 1.0
     if sharded and world > 1 and w0 <= 0:
         w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, share_shape, wpx_dtype, wpx_bytes,
-                                  rank, nccl, pt, compact, G, nbuf, sparse)
+                                  rank, nccl, pt, compact, G, nbuf, sparse, sparse2)
     if (H + args.band_rows - 1) // args.band_rows > 512 or w0 > 0.98:
         w0 = 1.0
     layout = BandLayout(H, world, args.band_rows, w0)
     streams = [torch.cuda.Stream() for _ in range(nbuf)]                       # one per group in flight
     main = torch.cuda.current_stream().cuda_stream
     rows_local = layout.rows_per_rank if sharded else H
-    local = [torch.zeros((G,) + share_shape(rows_local), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
+    local = [torch.zeros((G,) + share_shape(rows_local), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)] if not sparse2 else None
     gathered = frame = None
+    # sparse2: a share holds the G frames of a group and room for every float; what travels is its fixed part and the first
+    # `s2_send` floats (measured now, x --sparse-cap-scale); a share that needed more sends the tail again, point to point
+    s2 = None
+    if sparse2:
+        full = rows_local * W * G
+        s2 = {"full": full, "bytes": sparse2_bytes(rows_local, W, G, full), "off": sparse2_floats_offset(rows_local, W, G),
+              "share": [torch.zeros(sparse2_bytes(rows_local, W, G, full), dtype=torch.uint8, device="cuda") for _ in range(nbuf)],
+              "base": [0] * nbuf, "own": [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(nbuf)],
+              "ev": [torch.cuda.Event() for _ in range(nbuf)]}
+        render_sparse2(scene, [cam] * G, W, layout, rank, s2["share"][0].data_ptr(), full, 0, flags=flags, stream=main)
+        torch.cuda.synchronize()
+        used = int(s2["share"][0][:4].view(torch.int32).item())
+        s2["share"][0][:4].zero_()             # (every rank's counters start at zero: rank 0 keeps the peers' bases from there)
+        torch.cuda.synchronize()
+        need = torch.tensor([used], dtype=torch.int64, device="cuda" if nccl else "cpu")
+        if world > 1:
+            dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        s2["send"] = min(full, max(1024, (int(int(need.item()) * args.sparse_cap_scale) + 1023) // 1024 * 1024))
+        s2["prefix"] = s2["off"] + 4 * s2["send"]
+        if rank == 0:
+            s2["gath"] = [torch.zeros((world, s2["bytes"]), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+            s2["counts"] = [torch.zeros(world, dtype=torch.int32).pin_memory() for _ in range(nbuf)]
+            s2["bases"] = [[0] * world for _ in range(nbuf)]
     send = local                                    # what the gather carries
     cap = 0
     overflow = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -241,8 +271,12 @@ def main():
         if rank == 0:
             hdr_all = [torch.zeros((world, G, 8), dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
     if sharded and rank == 0:
-        gathered = [torch.zeros((world,) + tuple(send[0].shape), dtype=send[0].dtype, device="cuda") for _ in range(nbuf)]
+        if not sparse2:
+            gathered = [torch.zeros((world,) + tuple(send[0].shape), dtype=send[0].dtype, device="cuda") for _ in range(nbuf)]
         frame = [torch.zeros((G, H, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
+
+    def s2_ptrs(slot):                     # rank 0 reads its own share where it rendered it
+        return [s2["share"][slot].data_ptr()] + [s2["gath"][slot][r].data_ptr() for r in range(1, world)]
 
     def assemble(slot, st):
         if sparse:
@@ -275,6 +309,8 @@ def main():
         if w is None:
             return
         st = streams[slot]
+        if sparse2:
+            return finish_sparse2(slot, w, st)
         if nccl:
             with torch.cuda.stream(st):
                 w.wait()                              # the group's stream waits for its gather
@@ -324,6 +360,59 @@ def main():
                 else:
                     dist.send(local[slot].cpu(), dst=0)
 
+    def finish_sparse2(slot, w, st):
+        """the gather of sparse2 shares: rank 0 expands them; a share whose floats did not all travel sends the tail again"""
+        nonlocal resent
+        off, nsend = s2["off"], s2["send"]
+        if nccl:
+            with torch.cuda.stream(st):
+                w.wait()
+                if rank == 0:
+                    deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=G,
+                                         counts_ptr=s2["counts"][slot].data_ptr(), stream=st.cuda_stream)
+                    s2["ev"][slot].record(st)
+        elif rank == 0:                                   # gloo rehearsal: through host buffers
+            for r in range(1, world):
+                s2["gath"][slot][r][:s2["prefix"]].copy_(w[r].cuda())
+            deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=G,
+                                 counts_ptr=s2["counts"][slot].data_ptr(), stream=main)
+            torch.cuda.synchronize()
+        if rank == 0:
+            if nccl:
+                s2["ev"][slot].synchronize()
+            counters = [int(c) & 0xFFFFFFFF for c in s2["counts"][slot].tolist()]
+            for r in range(world):
+                used = (counters[r] - s2["bases"][slot][r]) & 0xFFFFFFFF
+                s2["bases"][slot][r] = counters[r]
+                if r == 0:
+                    s2["base"][slot] = counters[0]
+                    continue
+                if used > nsend:                          # the tail of rank r's floats, then its rows again
+                    resent += 1
+                    tail = s2["gath"][slot][r][off + 4 * nsend: off + 4 * min(used, s2["full"])]
+                    if nccl:
+                        with torch.cuda.stream(st):
+                            dist.recv(tail, src=r)
+                    else:
+                        host = torch.empty(tail.shape, dtype=tail.dtype)
+                        dist.recv(host, src=r)
+                        tail.copy_(host)
+                    with torch.cuda.stream(st):
+                        deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=G, only_rank=r,
+                                             stream=(st.cuda_stream if nccl else main))
+        else:
+            s2["ev"][slot].synchronize()
+            counter = int(s2["own"][slot].item()) & 0xFFFFFFFF
+            used = (counter - s2["base"][slot]) & 0xFFFFFFFF
+            s2["base"][slot] = counter
+            if used > nsend:
+                tail = s2["share"][slot][off + 4 * nsend: off + 4 * min(used, s2["full"])]
+                if nccl:
+                    with torch.cuda.stream(st):
+                        dist.send(tail, dst=0)
+                else:
+                    dist.send(tail.cpu(), dst=0)
+
     def step(k, timed=False, last=False):
         group, within = divmod(k, G)
         slot = group % nbuf
@@ -337,8 +426,13 @@ def main():
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(s)
-            render_bands_batch(scene, [cam_of(k - within + i) for i in range(within + 1)], W, layout, rank,
-                               local[slot].data_ptr(), flags=flags, stream=s.cuda_stream)
+            group = [cam_of(k - within + i) for i in range(within + 1)]
+            if sparse2:
+                # (a partial last group renders its last camera again: the share's layout is that of G frames)
+                render_sparse2(scene, group + [group[-1]] * (G - len(group)), W, layout, rank, s2["share"][slot].data_ptr(), s2["full"],
+                               s2["base"][slot], flags=flags, stream=s.cuda_stream)
+            else:
+                render_bands_batch(scene, group, W, layout, rank, local[slot].data_ptr(), flags=flags, stream=s.cuda_stream)
             if timed:
                 e1.record(s)
                 ev.append((e0, e1, within + 1))
@@ -351,6 +445,26 @@ def main():
                 e1.record(s)
                 ev.append((e0, e1, 1))
         if not sharded or not group_ends:
+            return
+        if sparse2:
+            if rank != 0:                             # this rank's own counter, for finish()
+                with torch.cuda.stream(s):
+                    s2["own"][slot].copy_(s2["share"][slot][:4].view(torch.int32), non_blocking=True)
+                    s2["ev"][slot].record(s)
+            mine = s2["share"][slot][:s2["prefix"]]
+            if nccl:
+                glist = [s2["gath"][slot][r][:s2["prefix"]] for r in range(world)] if rank == 0 else None
+                with torch.cuda.stream(s):
+                    pending[slot] = dist.gather(mine, glist, dst=0, async_op=True)
+            else:
+                s.synchronize()
+                if rank != 0:
+                    s2["ev"][slot].synchronize()
+                host = mine.cpu()
+                glist = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, glist, dst=0)
+                pending[slot] = glist if rank == 0 else True
+                finish(slot)
             return
         if sparse:                                    # three small launches behind the render, on its stream
             wire_compact(device, local[slot].data_ptr(), send[slot].data_ptr(), W, rows_local, G, cap, stream=s.cuda_stream)
@@ -382,8 +496,10 @@ def main():
 
     # ---- algorithmic work of one frame: counting build of the same kernel, untimed ------
     st = sb.Stats()
-    render(local[0], main, stats=st, fl=flags | sb.FLAG_COUNT)
+    count_buf = local[0] if not sparse2 else torch.zeros((rows_local, W, 4), dtype=torch.float32, device="cuda")
+    render(count_buf, main, stats=st, fl=flags | sb.FLAG_COUNT)
     torch.cuda.synchronize()
+    del count_buf
     my_pixels = len(layout.rows_of(rank)) * W if sharded else W * H
     # the bytes the REFERENCE algorithm reads and writes for these pixels (Compute.hlsl:88-108: entry +
     # ascents + descents, 8 B of topology each; 8 B of values per sample; the pixel store)
@@ -558,9 +674,12 @@ def main():
                                f" + gather to rank 0 ({args.backend})",
                 "frames_in_flight": nbuf * G,
                 "frames_per_gather": G if sharded else None,
-                "gather_pixel_bytes": (round(send[0].shape[1] / (rows_local * W), 3) if sparse else wpx_bytes) if sharded else None,
-                "gather_format": ("sparse wire" if sparse else "wire" if wire else "frame pixels") if sharded else None,
+                "gather_pixel_bytes": (round(s2["prefix"] / (rows_local * W * G), 3) if sparse2 else
+                                       round(send[0].shape[1] / (rows_local * W), 3) if sparse else wpx_bytes) if sharded else None,
+                "gather_format": ("sparse shares written by the march kernel" if sparse2 else "sparse wire" if sparse else
+                                  "wire" if wire else "frame pixels") if sharded else None,
                 "sparse_shares_resent_dense": resent if sparse else None,
+                "float_tails_sent_again": resent if sparse2 else None,
                 "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
                 "gstep_per_s": round(float(counters[2]) / sec_per_step / 1e9, 3),
                 "shadow_rays_per_frame": int(counters[3]),
@@ -750,7 +869,7 @@ def main_single_process(args, json_fd):
 
 
 def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_shape, wpx_dtype, wpx_bytes, rank, nccl, pt, compact,
-                         G, nbuf, sparse):
+                         G, nbuf, sparse, sparse2=False):
     """Rank 0 also assembles the frame (de-interleave and wire expansion of all ranks' rows), so an
     even deal makes it the slowest rank.  Before anything is timed, rank 0 tries layouts that give it
     0.3 .. 1.0 of a peer's share: for each it times its own work (render + assembly) and the largest
@@ -758,7 +877,8 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
     receives the weight with the smallest max of the two."""
     import torch
     import torch.distributed as dist
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch, sparse_share_bytes, wire_compact
+    from sdfbox_amd.tiles import (BandLayout, deinterleave, deinterleave_sparse2, render_bands, render_bands_batch, render_sparse2,
+                                  sparse2_bytes, sparse_share_bytes, wire_compact)
     w = torch.ones(1, dtype=torch.float64)
     if rank == 0:
         streams = [torch.cuda.Stream() for _ in range(nbuf)]
@@ -769,6 +889,15 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
         def work(lay, r, local, gathered, packed):
             def one(k):
                 s = streams[k % nbuf].cuda_stream
+                if sparse2:          # the march kernel writes the share; rank 0 expands `world` of them (its own stands in for the peers')
+                    share = local[k % nbuf]
+                    with torch.cuda.stream(streams[k % nbuf]):
+                        share[:4].zero_()
+                    render_sparse2(scene, [cam] * G, W, lay, r, share.data_ptr(), lay.rows_per_rank * W * G, 0, flags=flags, stream=s)
+                    if r == 0:
+                        deinterleave_sparse2(torch.cuda.current_device(), [share.data_ptr()] * world, frame.data_ptr(), W, lay,
+                                             lay.rows_per_rank * W * G, frames=G, stream=s)
+                    return
                 if pt is None and not compact:
                     render_bands_batch(scene, [cam] * G, W, lay, r, local[k % nbuf].data_ptr(), flags=flags, stream=s)
                 else:
@@ -793,8 +922,12 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
         tried = []
         for cand in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3):
             lay = BandLayout(H, world, band_rows, cand)
-            local = [torch.zeros((G,) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
-            gathered = torch.zeros((world, G) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda")
+            if sparse2:
+                local = [torch.zeros(sparse2_bytes(lay.rows_per_rank, W, G, lay.rows_per_rank * W * G), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+                gathered = torch.zeros(1, dtype=torch.uint8, device="cuda")
+            else:
+                local = [torch.zeros((G,) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
+                gathered = torch.zeros((world, G) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda")
             packed = torch.zeros(G * sparse_share_bytes(lay.rows_per_rank, W, lay.rows_per_rank * W // 4) if sparse else 1,
                                  dtype=torch.uint8, device="cuda")
             t0, t1 = work(lay, 0, local, gathered, packed), work(lay, 1, local, gathered, packed)

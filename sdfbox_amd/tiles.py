@@ -206,3 +206,42 @@ def deinterleave_sparse(device, gathered_ptr, frame_ptr, width, layout, capacity
                                                 int(capacity), int(frames),
                                                 ctypes.c_void_p(int(overflow_ptr)) if overflow_ptr else None,
                                                 ctypes.c_void_p(int(stream)) if stream else None))
+
+
+# ---- sparse shares written by the march kernel itself (sdfhip_render_sparse_device) ----------------------------
+def sparse2_bytes(rows, width, frames, capacity):
+    """Bytes of one share that holds `frames` frames of `rows` x `width` pixels and `capacity` packed floats."""
+    return int(lib.sdfhip_sparse2_bytes(int(width), int(rows), int(frames), int(capacity)))
+
+
+def sparse2_floats_offset(rows, width, frames):
+    """Byte offset of a share's float array = the bytes of its fixed part (header, masks, slot bases, codes)."""
+    return int(lib.sdfhip_sparse2_floats_offset(int(width), int(rows), int(frames)))
+
+
+def render_sparse2(scene, states, width, layout, rank, share_ptr, capacity, count_base, flags=0, stream=None):
+    """`rank`'s bands of the frames of a group (one camera each) in ONE launch of the default kernel, which writes the sparse
+    share itself: no dense wire buffer, no compaction kernels.  count_base = the value of the share's counter (its first
+    word) before this launch: the library never zeroes it."""
+    from ._lib import Info
+    if not isinstance(states, (list, tuple)):
+        states = [states]
+    infos = (Info * len(states))(*[s if isinstance(s, Info) else s.State for s in states])
+    blist = layout.bands_of(rank)
+    bands = (ctypes.c_uint16 * len(blist))(*blist)
+    check(lib.sdfhip_render_sparse_device(scene._h, infos, len(states), int(width), layout.height, layout.band_rows, bands, len(blist),
+                                          layout.rows_per_rank, int(capacity), int(count_base) & 0xFFFFFFFF, int(flags),
+                                          ctypes.c_void_p(int(share_ptr)), ctypes.c_void_p(int(stream)) if stream else None))
+
+
+def deinterleave_sparse2(device, share_ptrs, frame_ptr, width, layout, capacity, frames=1, flags=0, only_rank=-1, counts_ptr=None,
+                         stream=None):
+    """Rank 0: the ranks' shares (one device pointer per rank; rank 0's own may be the buffer it rendered into) ->
+    frames x height x width RGBA32F (RGBA8 with FLAG_DISPLAY[_DEBUG] in `flags`).  counts_ptr: device-accessible memory
+    (pinned host memory will do) for the `world` counters of the shares."""
+    ptrs = (ctypes.c_void_p * layout.world)(*[int(p) if p else None for p in share_ptrs])
+    owner = (ctypes.c_uint8 * layout.n_bands)(*layout.owner) if layout.weighted else None
+    check(lib.sdfhip_deinterleave_sparse2_device(int(device), ptrs, ctypes.c_void_p(int(frame_ptr)), int(width), layout.height,
+                                                 layout.band_rows, layout.world, layout.rows_per_rank, owner, int(capacity), int(frames),
+                                                 int(flags), int(only_rank), ctypes.c_void_p(int(counts_ptr)) if counts_ptr else None,
+                                                 ctypes.c_void_p(int(stream)) if stream else None))

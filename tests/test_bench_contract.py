@@ -14,7 +14,7 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
 
 
-def run_bench(*args, timeout=900):
+def run_bench(*args, timeout=360):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + [str(a) for a in args],
@@ -51,7 +51,10 @@ def test_bench_gpus_n_starts_its_own_ranks():
     # (here both ranks share the one GPU through gloo) and relays the one JSON line
     j = run_bench("--gpus", 2, "--backend", "gloo", "--steps", 8, "--warmup", 4, "--depth", 6, "--size", "640x360", "--check")
     assert j["n_gpus"] == 2 and j["config"]["assembled_frame_equals_whole_frame_render"] is True
-    assert j["config"]["gather_format"] == "sparse wire"
+    assert j["config"]["gather_format"] == "sparse shares written by the march kernel"
+    # round 2's form (dense wire shares compacted by three kernels before the gather) stays as --wire 2
+    j = run_bench("--gpus", 2, "--backend", "gloo", "--steps", 8, "--warmup", 4, "--depth", 6, "--size", "640x360", "--check", "--wire", 2)
+    assert j["config"]["assembled_frame_equals_whole_frame_render"] is True and j["config"]["gather_format"] == "sparse wire"
 
 
 @pytest.mark.gpu
@@ -60,17 +63,47 @@ def test_cfg4_frame_through_the_sharded_pipeline_one_rank():
     # sparse compaction, gather, assembly; every assembled frame must equal the whole-frame render bit for bit
     j = run_bench("--exercise-gather", "--check", "--size", "3840x2160", "--steps", 8, "--warmup", 4, "--no-cpu-baseline")
     assert j["config"]["assembled_frame_equals_whole_frame_render"] is True
-    assert j["config"]["gather_format"] == "sparse wire" and j["config"]["sparse_shares_resent_dense"] == 0
+    assert j["config"]["gather_format"] == "sparse shares written by the march kernel" and j["config"]["float_tails_sent_again"] == 0
 
 
 @pytest.mark.gpu
 def test_cfg4_frame_two_ranks_moving_camera_and_dense_resend():
-    # two ranks (gloo, one GPU) on the 4K frame with a camera that moves every frame and a sparse capacity far too
-    # small: overflowed shares must come again in the dense format and the assembled frames must still be exact
+    # two ranks (gloo, one GPU) on the 4K frame with a camera that moves every frame and far too few floats travelling with
+    # the shares: the tails must come again, point to point, and the assembled frames must still be exact
     j = run_bench("--gpus", 2, "--backend", "gloo", "--check", "--size", "3840x2160", "--steps", 8, "--warmup", 4,
                   "--orbit", 16, "--sparse-cap-scale", 0.2, "--no-cpu-baseline")
     assert j["n_gpus"] == 2 and j["config"]["assembled_frame_equals_whole_frame_render"] is True
-    assert j["config"]["sparse_shares_resent_dense"] > 0
+    assert j["config"]["float_tails_sent_again"] > 0
+    # ... and round 2's form: overflowed sparse wire shares come again dense
+    j = run_bench("--gpus", 2, "--backend", "gloo", "--check", "--size", "3840x2160", "--steps", 8, "--warmup", 4,
+                  "--orbit", 16, "--sparse-cap-scale", 0.2, "--no-cpu-baseline", "--wire", 2)
+    assert j["config"]["assembled_frame_equals_whole_frame_render"] is True and j["config"]["sparse_shares_resent_dense"] > 0
+
+
+@pytest.mark.gpu
+def test_cfg5_frame_through_the_sharded_pipelines():
+    # BASELINE cfg-5's frame (3840x2160, 16 spp, 3 bounces) through the gather pipelines: the NCCL code path with one rank, two
+    # gloo ranks on the one GPU, and the library's own multi-device entry points over the device list [0, 0, 0, 0]; every
+    # assembled frame must equal the whole-frame render bit for bit
+    j = run_bench("--exercise-gather", "--check", "--size", "3840x2160", "--spp", 16, "--steps", 2, "--warmup", 1, "--no-cpu-baseline")
+    assert j["config"]["assembled_frame_equals_whole_frame_render"] is True and j["config"]["gather_format"] == "frame pixels"
+    j = run_bench("--gpus", 2, "--backend", "gloo", "--check", "--size", "3840x2160", "--spp", 16, "--steps", 2, "--warmup", 1, "--no-cpu-baseline")
+    assert j["n_gpus"] == 2 and j["config"]["assembled_frame_equals_whole_frame_render"] is True
+    j = run_bench("--single-process", "--devices", "0,0,0,0", "--check", "--size", "3840x2160", "--spp", 16, "--steps", 2, "--warmup", 1)
+    assert j["n_gpus"] == 4 and j["config"]["assembled_frame_equals_whole_frame_render"] is True
+
+
+@pytest.mark.gpu
+def test_single_process_bench_line():
+    # `bench.py --single-process`: the N-device frame through sdfhip_multi_submit / _wait, groups and one frame at a time
+    for mode in ("groups", "frame"):
+        j = run_bench("--single-process", "--devices", "0,0,0", "--check", "--size", "1280x720", "--depth", 7, "--steps", 24, "--warmup", 8,
+                      "--multi-mode", mode, "--orbit", 8)
+        for k in REQUIRED:
+            if k != "cpu_baseline":
+                assert k in j, k
+        assert j["n_gpus"] == 3 and j["config"]["assembled_frame_equals_whole_frame_render"] is True
+        assert ("one frame at a time" in j["config"]["measures"]) == (mode == "frame")
 
 
 def test_roofline_reports_only_measured_fractions():
