@@ -194,6 +194,14 @@ typedef struct sdfhip_sdfgen_stats {
 SDFHIP_API int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_t depth,
                              sdfhip_octdata *out, sdfhip_sdfgen_stats *stats);
 
+/* Replaces: the viewer's generate -> upload flow, NativeOctData.Generate (SdfBox/Program.cs:613-650: LoadPly / LoadObj -> SdfGen) followed
+ * by OctData.StructBuffer() / ValueTexture() and their binding (:543-572, :147-152): the point cloud goes in, a scene handle on `device`
+ * comes out, and the tree never leaves HBM -- sdfhip_sdfgen's copy of the result to the host (12 ms for the 192 MB of a 12 M-node tree)
+ * and sdfhip_scene_upload's copy back (8 ms) do not happen.  out (may be NULL): also the host arrays, e.g. for the .asdf cache the
+ * reference writes next to the mesh (Program.cs:638-641).  The handle's renders are those of sdfhip_sdfgen + sdfhip_scene_upload. */
+SDFHIP_API int sdfhip_sdfgen_scene(int device, const float *verts6, uint32_t n, int32_t depth, sdfhip_scene **scene,
+                                   sdfhip_octdata *out, sdfhip_sdfgen_stats *stats);
+
 /* Structural check used by upload: 0 = ok; SDFHIP_ERR_BAD_TREE for an index out of
  * range, a cycle in the parent links or a parent chain of more than 64 links (either
  * would keep the shader's ascend loop from terminating).  depth_out = deepest level,

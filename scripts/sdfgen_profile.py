@@ -1,9 +1,9 @@
-"""Dev script: one GPU SdfGen build of the 200 k-point sphere at depth 8, for rocprofv3 (profiles/r01_sdfgen_d8_kernel_stats.csv)."""
+"""Dev script (GPU, under rocprofv3): ONE build of the 1 M-point knot at the depth given (default 9) after a warm-up build of a
+small cloud -- the kernels' per-build totals are then what the profiler's sums hold (scripts/profile_sdfgen.sh)."""
 import sys
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, ".")
 import sdfbox_amd as sb
-from test_sdfgen import fib_sphere
-v = fib_sphere(200000)
-sb.OctData.SdfGen(fib_sphere(1000), 3)
-od, st = sb.OctData.SdfGen(v, 8, want_stats=True)
-print(od.Length, st.candidate_entries, st.total_ms)
+d = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+pts = sb.knot_point_cloud(1000000)
+od, st = sb.OctData.SdfGen(pts, d, want_stats=True)
+print(f"depth {d}: {od.Length} nodes, {st.candidate_entries} candidate entries, {st.total_ms:.1f} ms in the library")

@@ -636,12 +636,15 @@ struct KeptLevel { LevelArrays L; uint32_t n; uint32_t *cnt, *rank; int32_t *ind
     } while (0)
 #define GEN_NOMEM() fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory")
 
-extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_t depth, sdfhip_octdata *out,
-                             sdfhip_sdfgen_stats *stats)
+// out: the tree on the host (may be null); scene_out: the tree as a scene handle on `device`, made from the builder's own device
+// arrays (may be null)
+static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t depth, sdfhip_octdata *out, sdfhip_scene **scene_out,
+                       sdfhip_sdfgen_stats *stats)
 {
-    if (!verts6 || !out || n == 0) return fail(SDFHIP_ERR_ARG, "sdfgen: null argument or empty point cloud");
+    if (!verts6 || (!out && !scene_out) || n == 0) return fail(SDFHIP_ERR_ARG, "sdfgen: null argument or empty point cloud");
     if (depth < 0 || depth > 12) return fail(SDFHIP_ERR_ARG, "sdfgen: depth %d outside 0..12", depth);
-    out->length = 0; out->structs = nullptr; out->values = nullptr;
+    if (out) { out->length = 0; out->structs = nullptr; out->values = nullptr; }
+    if (scene_out) *scene_out = nullptr;
     auto t0 = std::chrono::steady_clock::now();
 
     // FindDimensions, dllmain.cpp:67-80 (host: one pass over the points)
@@ -787,14 +790,31 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
             (void)madvise(p, bytes, MADV_HUGEPAGE);
             return p;
         };
-        int32_t *S = (int32_t *)result_alloc(total_nodes * 8);
-        uint8_t *V = (uint8_t *)result_alloc(total_nodes * 8);
-        if (!S || !V) { free(S); free(V); return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of host memory for %zu nodes", total_nodes); }
-        hipError_t e1 = hipMemcpy(S, d_S, total_nodes * 8, hipMemcpyDeviceToHost);
-        hipError_t e2 = e1 == hipSuccess ? hipMemcpy(V, d_V, total_nodes * 8, hipMemcpyDeviceToHost) : e1;
-        if (e2 != hipSuccess) { free(S); free(V); return fail(SDFHIP_ERR_DEVICE, "sdfgen: copying the tree back failed: %s", hipGetErrorString(e2)); }
-        lap("copied to the host");
-        out->length = (uint32_t)total_nodes; out->structs = S; out->values = V;
+        if (scene_out) {
+            // the viewer's generate -> upload flow (Program.cs:613-650 -> :147-152) without the round trip: the scene's records
+            // and grids are made from the arrays the builder has just written (12 ms of copy to the host and 8 ms back, at depth 10)
+            GEN_TRY(hipDeviceSynchronize());
+            const int rc = sdfhip::scene_from_arrays(device, d_S, d_V, (uint32_t)total_nodes, true, scene_out);
+            if (rc != SDFHIP_OK) return rc;
+            lap("scene made on the device");
+        }
+        if (out) {
+            int32_t *S = (int32_t *)result_alloc(total_nodes * 8);
+            uint8_t *V = (uint8_t *)result_alloc(total_nodes * 8);
+            hipError_t e2 = hipSuccess;
+            if (!S || !V) e2 = hipErrorOutOfMemory;
+            else {
+                e2 = hipMemcpy(S, d_S, total_nodes * 8, hipMemcpyDeviceToHost);
+                if (e2 == hipSuccess) e2 = hipMemcpy(V, d_V, total_nodes * 8, hipMemcpyDeviceToHost);
+            }
+            if (e2 != hipSuccess) {
+                free(S); free(V);
+                if (scene_out && *scene_out) { (void)sdfhip_scene_free(*scene_out); *scene_out = nullptr; }
+                return fail(SDFHIP_ERR_DEVICE, "sdfgen: copying the tree back failed: %s", hipGetErrorString(e2));
+            }
+            lap("copied to the host");
+            out->length = (uint32_t)total_nodes; out->structs = S; out->values = V;
+        }
         if (stats) {
             stats->nodes = (uint32_t)total_nodes;
             stats->levels = (uint32_t)levels.size();
@@ -807,4 +827,18 @@ extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
     } catch (const std::bad_alloc &) {
         return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of host memory");
     }
+}
+
+extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_t depth, sdfhip_octdata *out,
+                             sdfhip_sdfgen_stats *stats)
+{
+    if (!out) return fail(SDFHIP_ERR_ARG, "sdfgen: null argument or empty point cloud");
+    return sdfgen_impl(device, verts6, n, depth, out, nullptr, stats);
+}
+
+extern "C" int sdfhip_sdfgen_scene(int device, const float *verts6, uint32_t n, int32_t depth, sdfhip_scene **scene,
+                                   sdfhip_octdata *out, sdfhip_sdfgen_stats *stats)
+{
+    if (!scene) return fail(SDFHIP_ERR_ARG, "sdfgen_scene: null argument");
+    return sdfgen_impl(device, verts6, n, depth, out, scene, stats);
 }

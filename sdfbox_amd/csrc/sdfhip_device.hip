@@ -819,6 +819,13 @@ static void build_dense4(sdfhip_scene *s)
 extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uint8_t *values,
                                    uint32_t n, sdfhip_scene **out)
 {
+    return sdfhip::scene_from_arrays(device, structs, values, n, false, out);
+}
+
+// structs / values on the host (sdfhip_scene_upload), or already in `device`'s memory (sdfhip_sdfgen_scene: the tree the GPU
+// builder has just made never leaves HBM)
+int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t *values, uint32_t n, bool resident, sdfhip_scene **out)
+{
     if (!structs || !values || !out || n == 0)
         return fail(SDFHIP_ERR_ARG, "scene_upload: null argument or empty scene");
     *out = nullptr;
@@ -847,8 +854,8 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
 
     void *d_s = nullptr, *d_v = nullptr;
     auto bail = [&](hipError_t e, const char *what) {
-        if (d_s) (void)hipFree(d_s);
-        if (d_v) (void)hipFree(d_v);
+        if (d_s && !resident) (void)hipFree(d_s);
+        if (d_v && !resident) (void)hipFree(d_v);
         sdfhip_scene_free(s);
         return fail(SDFHIP_ERR_DEVICE, "scene_upload: %s failed: %s", what, hipGetErrorString(e));
     };
@@ -860,10 +867,14 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     if ((e = hipMalloc(&s->alloc, (size_t)n * 16 + 128)) != hipSuccess) return bail(e, "hipMalloc(records)");
     s->nodes = reinterpret_cast<NodeRec *>(static_cast<char *>(s->alloc) + 112);
     if ((e = hipMalloc((void **)&s->d_verdict, 2 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(verdict)");
-    if ((e = hipMalloc(&d_s, bytes)) != hipSuccess) return bail(e, "hipMalloc(structs)");
-    if ((e = hipMalloc(&d_v, bytes)) != hipSuccess) return bail(e, "hipMalloc(values)");
-    if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
-    if ((e = hipMemcpyAsync(d_v, values, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(values)");
+    if (resident) {
+        d_s = const_cast<int32_t *>(structs); d_v = const_cast<uint8_t *>(values);
+    } else {
+        if ((e = hipMalloc(&d_s, bytes)) != hipSuccess) return bail(e, "hipMalloc(structs)");
+        if ((e = hipMalloc(&d_v, bytes)) != hipSuccess) return bail(e, "hipMalloc(values)");
+        if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
+        if ((e = hipMemcpyAsync(d_v, values, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(values)");
+    }
     {   // validation (sdfhip_octdata_validate's verdicts, on the device: see k_validate)
         uint32_t *d_verdict = s->d_verdict, verdict[2] = { 0u, 0u };
         if ((e = hipMemsetAsync(d_verdict, 0, sizeof verdict, s->stream)) != hipSuccess) return bail(e, "hipMemset(verdict)");
@@ -872,8 +883,10 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
         if ((e = hipMemcpyAsync(verdict, d_verdict, sizeof verdict, hipMemcpyDeviceToHost, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(verdict)");
         if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail(e, "k_validate");
         if (verdict[0] & 1u) {                          // a bad link: the host function finds it again and says which
-            (void)hipFree(d_s); (void)hipFree(d_v); d_s = d_v = nullptr;
+            if (!resident) { (void)hipFree(d_s); (void)hipFree(d_v); }
+            d_s = d_v = nullptr;
             sdfhip_scene_free(s);
+            if (resident) return fail(SDFHIP_ERR_BAD_TREE, "scene_from_arrays: the tree has a link out of range or an endless parent chain");
             const int rcv = sdfhip_octdata_validate(structs, n, &depth, &consistent);
             return rcv != SDFHIP_OK ? rcv : fail(SDFHIP_ERR_BAD_TREE, "scene_upload: the tree has a link out of range or an endless parent chain");
         }
@@ -957,8 +970,8 @@ extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uin
     }
     if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail(e, "k_fuse");
     build_dense4(s);
-    (void)hipFree(d_s); d_s = nullptr;
-    (void)hipFree(d_v); d_v = nullptr;
+    if (!resident) { (void)hipFree(d_s); (void)hipFree(d_v); }
+    d_s = nullptr; d_v = nullptr;
     *out = s;
     return SDFHIP_OK;
 }

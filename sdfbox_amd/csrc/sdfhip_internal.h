@@ -13,6 +13,9 @@ void clear_error();
 
 // Deterministic double-precision sin/cos (no libm): the same bytes come out of
 // the scene generator on every x86-64 host, whatever glibc's ifunc picks.
+// sdfhip_scene_upload, or the same from arrays that are already in `device`'s memory (sdfhip_device.hip)
+int scene_from_arrays(int device, const int32_t *structs, const uint8_t *values, uint32_t n, bool resident, sdfhip_scene **out);
+
 double det_sin(double x);
 double det_cos(double x);
 

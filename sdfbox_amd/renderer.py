@@ -20,6 +20,9 @@ class Scene:
         check(lib.sdfhip_scene_upload(self.device, octdata.Structs.ctypes.data,
                                       octdata.Values.ctypes.data, octdata.Length,
                                       ctypes.byref(self._h)))
+        self._describe()
+
+    def _describe(self):
         n = ctypes.c_uint32(); d = ctypes.c_uint32(); ok = ctypes.c_int(); dev = ctypes.c_int()
         check(lib.sdfhip_scene_info(self._h, ctypes.byref(n), ctypes.byref(d), ctypes.byref(ok),
                                     ctypes.byref(dev)))
@@ -27,6 +30,28 @@ class Scene:
         lvl = ctypes.c_int32(); nb = ctypes.c_uint64()
         check(lib.sdfhip_scene_top_grid(self._h, ctypes.byref(lvl), ctypes.byref(nb)))
         self.top_grid_level, self.top_grid_bytes = lvl.value, nb.value
+
+    @classmethod
+    def FromPoints(cls, vertices, depth, device=0, want_octdata=False, want_stats=False):
+        """The viewer's generate -> upload flow in one call (sdfhip_sdfgen_scene; Program.cs:613-650 + :147-152): point
+        cloud (n, 6) float32 {position, normal} -> scene handle, the tree never leaving HBM.  want_octdata: also the host
+        arrays (for the .asdf cache)."""
+        from .octdata import OctData
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 6)
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        self.device = int(device)
+        raw = _lib.COctData()
+        st = _lib.SdfGenStats()
+        check(lib.sdfhip_sdfgen_scene(self.device, v.ctypes.data, len(v), int(depth), ctypes.byref(self._h),
+                                      ctypes.byref(raw) if want_octdata else None, ctypes.byref(st)))
+        self._describe()
+        out = [self]
+        if want_octdata:
+            out.append(OctData._from_native(raw))
+        if want_stats:
+            out.append(st)
+        return out[0] if len(out) == 1 else tuple(out)
 
     def close(self):
         if self._h:

@@ -178,3 +178,34 @@ def test_mesh_scale_import_and_render(sb, oracle_mod, tmp_path, depth):
     ref, cnt = oracle_mod.render(back.Structs, back.Values, cam.State, W, H, row0=3, nrows=len(rows), row_step=41, nthreads=16)
     got = img[rows]
     assert ((got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))).all()
+
+
+@pytest.mark.gpu
+def test_points_to_scene_without_leaving_the_device(sb):
+    # sdfhip_sdfgen_scene (the viewer's generate -> upload flow in one call): the handle it returns renders what
+    # sdfhip_sdfgen + sdfhip_scene_upload render, and the host copy it can also return is the same tree, byte for byte
+    from conftest import assert_frames_identical, make_camera
+    v = torus_cloud(60_000)
+    for depth in (5, 8):
+        od = sb.OctData.SdfGen(v, depth)
+        sc, od2, st = sb.Scene.FromPoints(v, depth, want_octdata=True, want_stats=True)
+        try:
+            assert st.nodes == od.Length == sc.Length and sc.depth == depth
+            assert (od2.Structs == od.Structs).all() and (od2.Values == od.Values).all()
+            with sb.Scene(od) as ref:
+                assert (sc.top_grid_level, sc.top_grid_bytes) == (ref.top_grid_level, ref.top_grid_bytes)
+                for cname, (W, H) in (("default", (160, 120)), ("rotated", (200, 96)), ("closeup", (64, 64))):
+                    cam = make_camera(cname, W, H)
+                    assert_frames_identical(sc.Draw(cam, W, H), ref.Draw(cam, W, H), f"depth {depth} {cname}")
+                    assert_frames_identical(sc.Draw(cam, W, H, sb.KERNEL_GENERIC), ref.Draw(cam, W, H), f"depth {depth} {cname}, generic kernel")
+        finally:
+            sc.close()
+        only = sb.Scene.FromPoints(v, depth)                     # without the host copy
+        try:
+            cam = make_camera("rotated", 96, 96)
+            with sb.Scene(od) as ref:
+                assert_frames_identical(only.Draw(cam, 96, 96), ref.Draw(cam, 96, 96), "no host copy")
+        finally:
+            only.close()
+    with pytest.raises(sb.SdfHipError):
+        sb.Scene.FromPoints(np.full((10, 6), np.nan, np.float32), 3)
