@@ -667,6 +667,9 @@ def main():
                            if args.shadow_queue else
                            ", k_march: primary march, shading and shadow march as three wave-converged loops of one kernel"),
                 "top_grid": {"level": scene.top_grid_level, "bytes": scene.top_grid_bytes},
+                # BASELINE cfg-3 says "wavefront ray compaction on": which of its readings this line is (both are built, both measured slower)
+                "compaction": "persistent waves, ballot/prefix lane refill (k_compact)" if compact else
+                              "shadow rays compacted by ballot/prefix into a queue, marched by k_shadow" if args.shadow_queue else "off",
                 "parallelism": "1 GPU" if not sharded else
                                f"{world} GPU(s), {args.band_rows}-row bands " +
                                ("round-robin" if not layout.weighted else
@@ -1139,10 +1142,14 @@ def cpu_baseline(od, cam, W, H, target_seconds):
         same = bool(((a == b) | (np.isnan(img[::k]) & np.isnan(ref))).all())
     # one thread beside it, on a sparser sample of the same frame: about 2 s
     step1 = max(1, int(H * per_row * nthreads / 2.0))
-    nrows1 = (H + step1 - 1) // step1
-    t0 = time.perf_counter()
-    oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=nrows1, row_step=step1, nthreads=1, **kw)
-    dt1 = time.perf_counter() - t0
+    for _ in range(4):                                 # (per_row comes from the all-threads run: SMT siblings and uneven rows make it
+        nrows1 = (H + step1 - 1) // step1              # a poor predictor of one thread alone, so the sample grows until it takes a second)
+        t0 = time.perf_counter()
+        oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=nrows1, row_step=step1, nthreads=1, **kw)
+        dt1 = time.perf_counter() - t0
+        if dt1 >= 1.0 or step1 == 1:
+            break
+        step1 = max(1, int(step1 * dt1 / 1.6))
     model, physical = host_cpu()
     return {
         "value": round(pix / dt / 1e6, 3),

@@ -76,6 +76,8 @@ enum {
     SDFHIP_FLAG_COUNT = 0x20,     /* also count algorithmic node/sample reads (slower)     */
     SDFHIP_FLAG_DISPLAY = 0x40,   /* fused display pass: output is RGBA8, gamma 1/2.2 (DisplayFrag.hlsl:24) */
     SDFHIP_FLAG_DISPLAY_DEBUG = 0x80, /* fused display pass, debug heat map w/140 (DisplayFrag.hlsl:21-22) */
+    /* (a scene handle keeps scratch memory per stream that renders on it, 16 at a time; a 17th stream takes over the least
+     * recently used scratch whose stream has drained) */
     SDFHIP_FLAG_TILE_ORDER = 0x100000, /* for a viewer that renders one frame at a time: launch this frame's 8x8 tiles in
                                      descending order of the march iterations they (or a tile within two of them) took in the
                                      last frame rendered with the same geometry on the same stream; the order is made on the
@@ -314,6 +316,14 @@ typedef struct sdfhip_pathtrace {
     uint32_t seed;          /* config 5: 0x5DFB0C5                                  */
     float albedo;           /* diffuse reflectance of the surface (0.8)             */
 } sdfhip_pathtrace;
+/* The bounce levels of the path-traced pipeline read a second split grid of the scene's cells, with larger blocks (+0.83 GB for
+ * the depth-9 bench scene).  sdfhip_scene_prepare_path builds it at load time (allocations, kernels and two
+ * stream synchronisations on the scene's own stream); without the call the first path-traced render builds it before its clock
+ * starts.  Environment, read then: SDFHIP_SCATTER_GRID=0 no second grid, 1..4 the levels of its blocks (default 3);
+ * SDFHIP_SCATTER_ORDER=0 blocks in x-y-z order (default: 2x2x2 sub-cubes, one cache line each).  sdfhip_scene_top_grid counts its
+ * bytes once it exists.  sdfhip_render_path returns SDFHIP_ERR_NOMEM, not a wrong image, if a hit ever found no room in its queue
+ * (their capacity is the worst case of every sub-queue, so this is a check, not a limit). */
+SDFHIP_API int sdfhip_scene_prepare_path(sdfhip_scene *scene);
 SDFHIP_API int sdfhip_render_path(sdfhip_scene *scene, const sdfhip_info *info,
                                   const sdfhip_pathtrace *pt, uint32_t width, uint32_t height,
                                   uint32_t flags, float *rgba_out, sdfhip_stats *stats);

@@ -154,6 +154,7 @@ _SIG = {
     "sdfhip_render_batch_device": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                               _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                               _c.c_uint32, _vp, _vp, _c.POINTER(Stats)]),
+    "sdfhip_scene_prepare_path": (_c.c_int, [_vp]),
     "sdfhip_render_path": (_c.c_int, [_vp, _c.POINTER(Info), _c.POINTER(PathTrace), _c.c_uint32, _c.c_uint32,
                                       _c.c_uint32, _vp, _c.POINTER(Stats)]),
     "sdfhip_render_path_device": (_c.c_int, [_vp, _c.POINTER(Info), _c.POINTER(PathTrace), _c.c_uint32,

@@ -1075,6 +1075,9 @@ __device__ __forceinline__ void pt_push(const RenderParams &P, uint32_t queue, u
     if (lane == 0) base = atomicAdd(pt_count(P, queue, q), (uint32_t)__popcll(hits));
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hits, 0u));
+    // (the capacity covers the worst case of every sub-queue -- sdfhip_device.hip sizes it so -- and a hit that found no room
+    // anyway is not lost silently: the word behind the fill counts says so, and the synchronous entry points return an error)
+    if (hit && base + rank >= P.pt_cap) atomicOr(P.pt_ctl + (size_t)2 * HIT_QUEUES * 32u, 1u);
     if (hit && base + rank < P.pt_cap) {
         const size_t total = (size_t)HIT_QUEUES * P.pt_cap, i = (size_t)q * P.pt_cap + base + rank;
         float4 *Q = P.pt_q[queue];

@@ -624,6 +624,7 @@ struct sdfhip_scene {
         size_t records;
         uint32_t *ctl;               // hit fill counts (two sets), then the compact kernel's tile queues
         uint32_t launches;           // two-kernel launch pairs so far: its parity selects the set of fill counts
+        uint64_t last_use;           // the handle's render count when this scratch was last handed out (the oldest idle one is recycled)
         char *pt_buf;                // path-traced pipeline: two hit queues, then the per-path results
         size_t pt_bytes;
         // SDFHIP_FLAG_TILE_ORDER: the wave-iterations of every tile of the last frame rendered on this stream, the launch order
@@ -641,9 +642,10 @@ struct sdfhip_scene {
     // hits, and from [6] the step classes of sdfhip_debug_step_classes (per stream: counting renders on two streams of one
     // handle do not add into each other's figures)
     static constexpr size_t CTL_HIT_WORDS = (size_t)2 * MAX_BATCH * HIT_QUEUES * 32, CTL_QUEUE_WORDS = 8 * 32,
-                            CTL_PT_WORDS = (size_t)2 * HIT_QUEUES * 32, CTL_COUNTER_WORDS = 32;
+                            CTL_PT_WORDS = (size_t)2 * HIT_QUEUES * 32 + 32 /* + the overflow word's line */, CTL_COUNTER_WORDS = 32;
     Scratch scratch[MAX_SCRATCH];
     int n_scratch;
+    uint64_t uses;
     float4 *d_frame;        // grown on demand by sdfhip_render
     size_t frame_cap;
     hipEvent_t ev0, ev1;
@@ -848,7 +850,7 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
     s->device = device; s->n = n; s->depth = 0; s->stack_ok = 0;       // (both set once the tree has been validated, below)
     s->alloc = nullptr; s->nodes = nullptr; s->stream = nullptr; s->d_verdict = nullptr; s->d_top = nullptr; s->top_level = 0; s->d_fine = nullptr; s->fine_bits = 0; s->fine_bytes = 0; s->d_d4 = nullptr; s->d_recs = nullptr; s->d4_bytes = 0;
     s->d_top2 = s->d_fine2 = nullptr; s->top2_level = s->fine2_bits = s->fine2_order = s->scatter_tried = 0; s->top2_bytes = 0; s->total_mem = prop.totalGlobalMem;
-    s->n_scratch = 0; s->d_frame = nullptr; s->dbg_tile_perm = nullptr; s->dbg_tile_cost = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
+    s->n_scratch = 0; s->uses = 0; s->d_frame = nullptr; s->dbg_tile_perm = nullptr; s->dbg_tile_cost = nullptr; s->frame_cap = 0; s->ev0 = s->ev1 = nullptr;
     s->cu_count = prop.multiProcessorCount;
     for (int b = 0; b < sdfhip_scene::HOST_BANDS; b++) { s->band_stream[b] = nullptr; s->band_done[b] = nullptr; }
 
@@ -995,6 +997,40 @@ extern "C" int sdfhip_scene_info(const sdfhip_scene *s, uint32_t *n, uint32_t *d
     return SDFHIP_OK;
 }
 
+// Beside the scene's own grid, the bounce levels of the path-traced pipeline read a split grid of the same cells with larger,
+// sub-cube-ordered blocks -- unless the scene's grid already has that coarse level.  Built once: by
+// sdfhip_scene_prepare_path (at load time: allocations and two stream synchronisations), or else in front of the first
+// path-traced render, before its clock starts.  SDFHIP_SCATTER_GRID=0 turns it off, 1..4 sets the blocks' levels (default 3);
+// SDFHIP_SCATTER_ORDER=0 stores the blocks in x-y-z order.  Without memory for it (1/32 of the device's) the bounce levels
+// read the scene's own grid.
+static void ensure_scatter_grid(sdfhip_scene *s)
+{
+    if (s->scatter_tried) return;
+    s->scatter_tried = 1;
+    if (!s->stack_ok || !s->d_top || !((s->fine_bits && s->d_fine) || (uint32_t)s->top_level >= s->depth)) return;   // the pipeline needs a full-depth grid
+    const char *env = getenv("SDFHIP_SCATTER_GRID");
+    const int FB = env ? atoi(env) : 3;                                     // blocks of 8^FB fine cells; 0 = off
+    if (FB >= 1 && FB <= 4 && (int)s->depth - FB >= 1 && (int)s->depth - FB <= MAX_TOP_LEVEL &&
+        !(s->fine_bits && s->top_level == (int)s->depth - FB)) {
+        uint64_t fbytes = 0;
+        s->fine2_order = (FB >= 2 && !(getenv("SDFHIP_SCATTER_ORDER") && atoi(getenv("SDFHIP_SCATTER_ORDER")) == 0)) ? 1 : 0;
+        if (build_split_grid(s, (int)s->depth - FB, FB, s->fine2_order, s->total_mem / 32, &s->d_top2, &s->d_fine2, &fbytes)) {
+            s->top2_level = (int)s->depth - FB; s->fine2_bits = FB;
+            s->top2_bytes = ((uint64_t)sizeof(TopCell) << (3 * s->top2_level)) + fbytes;
+        }
+    }
+}
+
+extern "C" int sdfhip_scene_prepare_path(sdfhip_scene *s)
+{
+    if (!s) return fail(SDFHIP_ERR_ARG, "scene_prepare_path: null scene");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "scene_prepare_path: hipSetDevice(%d) failed", s->device);
+    ensure_scatter_grid(s);
+    return SDFHIP_OK;
+}
+
 namespace {
 
 // The scratch of stream `st` on this scene, with room for `records` hit records (0: control words only).
@@ -1004,9 +1040,25 @@ int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::S
     sdfhip_scene::Scratch *sc = nullptr;
     for (int i = 0; i < s->n_scratch; i++)
         if (s->scratch[i].stream == st) sc = &s->scratch[i];
+    if (!sc && s->n_scratch == sdfhip_scene::MAX_SCRATCH) {
+        // every slot is taken (a host that makes a stream per frame gets here after 16 frames): the least recently used scratch whose
+        // stream has drained goes to the new stream -- its buffers stay, its state (launch parity, tile order, counters) starts afresh.
+        // (A destroyed stream whose handle value HIP hands out again finds its old slot above: harmless for the buffers, and the tile
+        // order is dropped by the geometry / camera check or is simply a valid order of the same tiles.)
+        int best = -1;
+        for (int i = 0; i < s->n_scratch; i++) {
+            if (hipStreamQuery(s->scratch[i].stream) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (best < 0 || s->scratch[i].last_use < s->scratch[best].last_use) best = i;
+        }
+        if (best < 0)
+            return fail(SDFHIP_ERR_ARG, "render: %d streams have renders in flight on one scene handle (at most %d at a time)", sdfhip_scene::MAX_SCRATCH, sdfhip_scene::MAX_SCRATCH);
+        sc = &s->scratch[best];
+        sc->stream = st; sc->launches = 0; sc->ord_valid = false; memset(sc->ord_sig, 0, sizeof sc->ord_sig);
+        const size_t ctl_bytes = (sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS + sdfhip_scene::CTL_PT_WORDS +
+                                  sdfhip_scene::CTL_COUNTER_WORDS) * sizeof(uint32_t);
+        HIP_TRY(hipMemsetAsync(sc->ctl, 0, ctl_bytes, st));
+    }
     if (!sc) {
-        if (s->n_scratch == sdfhip_scene::MAX_SCRATCH)
-            return fail(SDFHIP_ERR_ARG, "render: more than %d streams render on one scene handle", sdfhip_scene::MAX_SCRATCH);
         sc = &s->scratch[s->n_scratch];
         sc->stream = st; sc->hit_buf = nullptr; sc->records = 0; sc->ctl = nullptr; sc->launches = 0; sc->pt_buf = nullptr; sc->pt_bytes = 0;
         sc->ord_cost = nullptr; sc->ord_class = nullptr; sc->ord_perm = nullptr; sc->ord_tiles = sc->ord_blocks = 0; sc->ord_valid = false; memset(sc->ord_sig, 0, sizeof sc->ord_sig);
@@ -1018,6 +1070,7 @@ int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::S
         HIP_TRY(hipMemsetAsync(sc->ctl, 0, ctl_bytes, st));
         s->n_scratch++;
     }
+    sc->last_use = ++s->uses;
     if (records > sc->records) {
         HIP_TRY(hipStreamSynchronize(st));
         if (sc->hit_buf) { (void)hipFree(sc->hit_buf); sc->hit_buf = nullptr; sc->records = 0; }
@@ -1047,7 +1100,8 @@ int get_pt_scratch(sdfhip_scene *s, hipStream_t st, size_t bytes, sdfhip_scene::
 template <int CUR, bool COUNT>
 int launch_pt(sdfhip_scene *s, sdfhip_scene::Scratch *sc, dim3 grid, hipStream_t st, RenderParams &P)
 {
-    const uint32_t resident = (uint32_t)s->cu_count * 32u;
+    // (a multiple of 64: the bounce waves' pushes then spread evenly over the 64 sub-queues, which is what their capacity assumes)
+    const uint32_t resident = ((uint32_t)s->cu_count * 32u + 63u) & ~63u;
     hipError_t e;
     if ((e = hipMemsetAsync(P.pt_ctl, 0, sdfhip_scene::CTL_PT_WORDS * sizeof(uint32_t), st)) != hipSuccess)
         return fail(SDFHIP_ERR_DEVICE, "render_path: hipMemsetAsync failed: %s", hipGetErrorString(e));
@@ -1226,7 +1280,8 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     }
     sdfhip_scene::Scratch *sc = nullptr;
     P.queue = nullptr; P.hit_a = nullptr; P.hit_b = nullptr; P.hit_c = nullptr; P.hit_d = nullptr; P.hit_ctl = nullptr; P.hit_cap = 0; P.hit_set = 0;
-    P.tile_perm = s->dbg_tile_perm; P.tile_cost = s->dbg_tile_cost;
+    P.tile_perm = n_frames == 1 ? s->dbg_tile_perm : nullptr;      // (the experiment hook is for single frames: its arrays hold one frame's tiles)
+    P.tile_cost = n_frames == 1 ? s->dbg_tile_cost : nullptr;
     P.pt_q[0] = P.pt_q[1] = nullptr; P.pt_ctl = nullptr; P.pt_cap = 0; P.pt_level = 0; P.pt_e = nullptr; P.pt_t = nullptr; P.pt_n = nullptr;
     const bool queued = two && (flags & SDFHIP_TUNE_SHADOW_QUEUE) != 0;
     // SDFHIP_FLAG_TILE_ORDER: this frame's tiles in the order made from the last frame of the same geometry on this stream
@@ -1282,6 +1337,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     if (sparse) {
         if (!two) return fail(SDFHIP_ERR_ARG, "render_sparse: this scene has no full-depth grid (trees deeper than 12 levels or with inconsistent links render dense shares)");
     }
+    if (pt && (cur == CUR_STACK_FULL || cur == CUR_STACK_SPLIT) && !(flags & SDFHIP_TUNE_ONE_KERNEL)) ensure_scatter_grid(s);   // (before the clock)
     if (stats) HIP_TRY(hipEventRecord(s->ev0, st));
     if (two) {
         if (!count && !queued && s->d_d4 && !(flags & SDFHIP_TUNE_BYTE_CELLS)) launch_fast(out_mode, grid, st, P);
@@ -1313,22 +1369,6 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         P.pt_t = reinterpret_cast<float *>(sc->pt_buf + 2 * qbytes + ebytes);
         P.pt_n = reinterpret_cast<uint32_t *>(sc->pt_buf + 2 * qbytes + ebytes + tbytes);
         P.pt_ctl = sc->ctl + sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS;
-        // beside the scene's own grid, the bounce levels read a split grid of the same cells with larger, sub-cube-ordered
-        // blocks (built now, once) -- unless the scene's grid already has that coarse level
-        if (!s->scatter_tried) {
-            s->scatter_tried = 1;
-            const char *env = getenv("SDFHIP_SCATTER_GRID");
-            const int FB = env ? atoi(env) : 3;                                     // blocks of 8^FB fine cells; 0 = off
-            if (FB >= 1 && FB <= 4 && (int)s->depth - FB >= 1 && (int)s->depth - FB <= MAX_TOP_LEVEL &&
-                !(cur == CUR_STACK_SPLIT && s->top_level == (int)s->depth - FB)) {
-                uint64_t fbytes = 0;
-                s->fine2_order = (FB >= 2 && !(getenv("SDFHIP_SCATTER_ORDER") && atoi(getenv("SDFHIP_SCATTER_ORDER")) == 0)) ? 1 : 0;
-                if (build_split_grid(s, (int)s->depth - FB, FB, s->fine2_order, s->total_mem / 32, &s->d_top2, &s->d_fine2, &fbytes)) {
-                    s->top2_level = (int)s->depth - FB; s->fine2_bits = FB;
-                    s->top2_bytes = ((uint64_t)sizeof(TopCell) << (3 * s->top2_level)) + fbytes;
-                }
-            }
-        }
         int rcl;
         if (cur == CUR_STACK_SPLIT) rcl = count ? launch_pt<CUR_STACK_SPLIT, true>(s, sc, grid, st, P) : launch_pt<CUR_STACK_SPLIT, false>(s, sc, grid, st, P);
         else                        rcl = count ? launch_pt<CUR_STACK_FULL, true>(s, sc, grid, st, P) : launch_pt<CUR_STACK_FULL, false>(s, sc, grid, st, P);
@@ -1519,7 +1559,13 @@ extern "C" int sdfhip_render_path(sdfhip_scene *s, const sdfhip_info *info, cons
                          reinterpret_cast<float *>(s->d_frame), s->stream, stats, pt);
     if (rc != SDFHIP_OK) return rc;
     HIP_TRY(hipMemcpyAsync(rgba_out, s->d_frame, need * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    uint32_t overflow = 0;                              // a hit that found no room in its queue (see pt_push): never silently
+    for (int i = 0; i < s->n_scratch; i++)
+        if (s->scratch[i].stream == s->stream && s->scratch[i].pt_buf)
+            HIP_TRY(hipMemcpyAsync(&overflow, s->scratch[i].ctl + sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS + (size_t)2 * HIT_QUEUES * 32,
+                                   sizeof overflow, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (overflow) return fail(SDFHIP_ERR_NOMEM, "render_path: a hit queue of the path-traced pipeline overflowed; the frame is incomplete");
     if (stats)
         stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SDFHIP_OK;
