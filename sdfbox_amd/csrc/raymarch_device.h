@@ -307,9 +307,6 @@ constexpr int LM = 12;
 __host__ __device__ __forceinline__ uint32_t top_index(uint32_t x, uint32_t y, uint32_t z, int TG)
 {
     constexpr int B = TOP_BLOCK_BITS;
-#ifdef TOP_Z_MAJOR
-    if (B == 0 || TG <= B) return (((x << TG) | y) << TG) | z;       // experiment: cache lines run along z
-#endif
     if (B == 0 || TG <= B) return (((z << TG) | y) << TG) | x;       // two v_lshl_or_b32
     constexpr uint32_t m = (1u << B) - 1u;
     const int H = TG - B;

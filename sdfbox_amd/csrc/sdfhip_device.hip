@@ -113,11 +113,7 @@ constexpr uint32_t D4_ANCHOR = 0x7FC00001u, D4_OTHER = 0x7FC00002u;       // pas
 __device__ __forceinline__ uint4 d4_leaf(const GridRef &g, uint32_t i, int F, uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &anchor)
 {
     const uint32_t mask = (1u << F) - 1u;
-#ifdef TOP_Z_MAJOR
-    z = i & mask; y = (i >> F) & mask; x = i >> (2 * F);
-#else
     x = i & mask; y = (i >> F) & mask; z = i >> (2 * F);                  // (the inverse of top_index with TOP_BLOCK_BITS = 0)
-#endif
     const uint4 e = cell_at(g, (int32_t)x, (int32_t)y, (int32_t)z);
     const uint32_t keep = 0xFFFFFFFFu << ((e.x & 15u) - (uint32_t)(LM - F));
     anchor = top_index(x & keep, y & keep, z & keep, F);
