@@ -189,4 +189,32 @@ private:
     sdfhip_scene *scene = nullptr;
 };
 
+// The same two calls with the frame rendered by several GPUs of the node (sdfhip_multi_*: the scene on every device, the frame's
+// bands dealt to them, sparse shares gathered into devices[0], assembled there): Program.Draw stays ONE call.
+class ProgramMulti {
+public:
+    explicit ProgramMulti(std::vector<int> devices) : devices(std::move(devices)) {}
+    ~ProgramMulti() { if (multi) sdfhip_multi_free(multi); }
+    ProgramMulti(const ProgramMulti &) = delete;
+    ProgramMulti &operator=(const ProgramMulti &) = delete;
+
+    void Load(const OctData &model)
+    {
+        sdfhip_multi *fresh = nullptr;
+        Check(sdfhip_multi_create(devices.data(), (uint32_t)devices.size(), &model.Structs[0].Parent, model.Values.data(), (uint32_t)model.Length(), &fresh));
+        if (multi) sdfhip_multi_free(multi);
+        multi = fresh;
+    }
+    void Draw(const Info &state, int width, int height, std::vector<float> &frame, uint32_t flags = 0)
+    {
+        if (!multi) throw Error(SDFHIP_ERR_ARG, "Draw: no model loaded");
+        frame.resize((size_t)width * height * 4);
+        Check(sdfhip_multi_render(multi, &state, (uint32_t)width, (uint32_t)height, flags, frame.data(), nullptr));
+    }
+
+private:
+    std::vector<int> devices;
+    sdfhip_multi *multi = nullptr;
+};
+
 }  // namespace SDFbox

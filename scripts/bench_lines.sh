@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's bench lines (GPU box, via gpurun): gpurun_out/bench_lines/<tag>_<name>.json -> copy to profiles/bench_lines/
-R=${1:-r02}; O=gpurun_out/bench_lines; mkdir -p $O
+R=${1:-r03}; O=gpurun_out/bench_lines; mkdir -p $O
 run() { n=$1; shift; python bench.py "$@" > $O/${R}_$n.json 2> $O/${R}_$n.err || echo "$n failed"; }
 run 1080p_default
 run 1080p_driver_style --steps 20 --warmup 5
@@ -20,12 +20,26 @@ run 4k_compact --no-cpu-baseline --size 3840x2160 --compact 1
 run cfg5_4k_spp16 --no-cpu-baseline --size 3840x2160 --spp 16 --steps 8 --warmup 2
 run cfg5_4k_spp16_one_kernel --no-cpu-baseline --size 3840x2160 --spp 16 --steps 8 --warmup 2 --one-kernel
 run sharded_1rank_nccl_4k --no-cpu-baseline --exercise-gather --check --size 3840x2160
+run sharded_1rank_nccl_4k_wire2 --no-cpu-baseline --exercise-gather --check --size 3840x2160 --wire 2
 run sharded_2rank_gloo_1080p --no-cpu-baseline --gpus 2 --backend gloo --check --steps 40 --warmup 8
+# the library's own multi-device entry points (sdfhip_multi_*), the ranks played by the one GPU
+run multi_4k_groups_1rank --single-process --devices 0 --size 3840x2160 --check --steps 64 --warmup 16
+run multi_4k_groups_2ranks --single-process --devices 0,0 --size 3840x2160 --check --steps 64 --warmup 16
+run multi_4k_groups_4ranks --single-process --devices 0,0,0,0 --size 3840x2160 --check --steps 64 --warmup 16
+run multi_4k_groups_8ranks --single-process --devices 0,0,0,0,0,0,0,0 --size 3840x2160 --check --steps 64 --warmup 16
+run multi_4k_frame_4ranks --single-process --devices 0,0,0,0 --size 3840x2160 --check --steps 64 --warmup 16 --multi-mode frame
+run multi_4k_frame_4ranks_moving --single-process --devices 0,0,0,0 --size 3840x2160 --check --steps 64 --warmup 16 --multi-mode frame --orbit 90
+run multi_1080p_groups_4ranks --single-process --devices 0,0,0,0 --check --steps 128 --warmup 32
+run multi_1080p_frame_4ranks --single-process --devices 0,0,0,0 --check --steps 128 --warmup 32 --multi-mode frame
+run multi_tiny_frame_1rank --single-process --devices 0 --size 64x64 --depth 6 --steps 300 --warmup 30 --multi-mode frame
+run multi_tiny_frame_4ranks --single-process --devices 0,0,0,0 --size 64x64 --depth 6 --steps 300 --warmup 30 --multi-mode frame
+run multi_cfg5_4ranks --single-process --devices 0,0,0,0 --size 3840x2160 --spp 16 --check --steps 4 --warmup 1
 for f in $O/${R}_*.json; do python - "$f" <<PY
 import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
-    print(sys.argv[1].split("/")[-1], d["value"], "Mray/s", d["ms_per_step"], "ms/step, latency", d["latency_ms"], "frac", d["roofline"]["frac"], d["roofline"]["binding"])
+    r = d["roofline"]
+    print(sys.argv[1].split("/")[-1], d["value"], "Mray/s", d["ms_per_step"], "ms/step, latency", d["latency_ms"], "frac", r["frac"], r["binding"], "hbm_frac", r.get("hbm_frac"), "valu_busy", r.get("valu_busy"))
 except Exception as e: print(sys.argv[1], "unreadable", e)
 PY
 done

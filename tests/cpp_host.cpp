@@ -5,6 +5,7 @@
 // exit 0 ok, 3 = no usable GPU, anything else = failure.
 #include "sdfbox.hpp"
 #include <cstdio>
+#include <cstring>
 
 int main(int argc, char **argv)
 {
@@ -58,6 +59,15 @@ int main(int argc, char **argv)
         }
         program.Load(model);                       // reload swaps the scene (Program.cs:59-65)
         program.Draw(logic.State, W, H, frame);
+        {   // the same frame over three ranks (the one GPU named three times): ProgramMulti.Draw is still one call
+            ProgramMulti multi({0, 0, 0});
+            multi.Load(model);
+            std::vector<float> frame3;
+            multi.Draw(logic.State, W, H, frame3);
+            if (frame3.size() != frame.size() || memcmp(frame3.data(), frame.data(), frame.size() * 4) != 0) return 19;
+            multi.Draw(logic.State, W, H, frame3);
+            if (memcmp(frame3.data(), frame.data(), frame.size() * 4) != 0) return 19;
+        }
         try {                                      // errors are exceptions of one type, never a crash
             Logic other;
             other.MakeData("/nonexistent/model");
