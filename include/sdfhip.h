@@ -344,6 +344,21 @@ SDFHIP_API int sdfhip_render_display(sdfhip_scene *scene, const sdfhip_info *inf
                                      uint32_t width, uint32_t height, uint32_t flags, int debug,
                                      uint8_t *rgba8_out, sdfhip_stats *stats);
 
+/* The host's frame array, page-locked: sdfhip_render / sdfhip_render_display into such memory run the frame in
+ * row bands whose copies to the host go beside the march (into pageable memory every copy is staged inside the copy call,
+ * with the host waiting in it), and below 4 M pixels the march kernel stores its pixels into the array itself -- no device
+ * frame, no copy: 1080p 0.735 -> 0.676 ms per call, RGBA8 0.296 -> 0.260.  Replaces nothing in the reference
+ * -- Program.cs:94-99 leaves the frame in a GPU texture -- it is what a host that wants the pixels does once, beside
+ * its one frame array:
+ *   sdfhip_host_alloc(bytes, &p)   page-locked memory of the library's (any device may copy into it);
+ *   sdfhip_host_register(p, bytes) page-locks the caller's own array where it lies: it must not move or be freed while
+ *                                  registered (C#: a GCHandleType.Pinned handle kept for as long);
+ *   sdfhip_host_release(p)         frees / unregisters (p = the start of the range; NULL is a no-op).
+ * A destination that is neither is rendered as before: nothing here is required. */
+SDFHIP_API int sdfhip_host_alloc(uint64_t bytes, void **out);
+SDFHIP_API int sdfhip_host_register(void *p, uint64_t bytes);
+SDFHIP_API int sdfhip_host_release(void *p);
+
 /* Several frames in one launch: infos[0..n_frames-1] (n_frames <= 8) are rendered into
  * d_rgba_out[f * nrows_out * width ...], each with its own camera block; same band
  * arguments as sdfhip_render_device.  For sharded rendering, where one rank's share of a

@@ -16,8 +16,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sc = sb.Scene(od)
     for W, H in ((1920, 1080), (3840, 2160)):
         cams = bench.orbit_cameras(sb, W, H, 90)
-        out = np.empty((H, W, 4), dtype=np.float32)
-        out8 = np.empty((H, W, 4), dtype=np.uint8)
+        if os.environ.get("HOST_FRAME_LOCKED") == "alloc":
+            keep = (sb.HostFrame(H, W, np.float32), sb.HostFrame(H, W, np.uint8))
+            out, out8 = keep[0].array, keep[1].array
+        else:
+            out = np.empty((H, W, 4), dtype=np.float32)
+            out8 = np.empty((H, W, 4), dtype=np.uint8)
+            if os.environ.get("HOST_FRAME_LOCKED") == "register":
+                keep = (sb.HostFrame(array=out), sb.HostFrame(array=out8))
         for what, fn in (("RGBA32F", lambda c: sc.Draw(c, W, H, out=out)), ("RGBA8 display", lambda c: sb._lib.check(sb._lib.lib.sdfhip_render_display(sc._h, __import__("ctypes").byref(c.State), W, H, 0, 0, out8.ctypes.data, None)))):
             for moving in (False, True):
                 ts = []
@@ -27,6 +33,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                 print(f"  {W}x{H} {what:14s} camera {'moving' if moving else 'at rest'}: {1e3 * float(np.median(ts[10:])):.3f} ms per frame")
     sys.exit(0)
 
+for locked in ("alloc", "register") if "--locked" in sys.argv else ():
+    for bands in ("", "1", "4"):
+        print(f"page-locked destination ({locked}), " + (f"SDFHIP_HOST_BANDS={bands} (band copies)" if bands else "default"))
+        sys.stdout.flush()
+        env = {k: v for k, v in os.environ.items() if k != "SDFHIP_HOST_BANDS"}
+        env["HOST_FRAME_LOCKED"] = locked
+        if bands:
+            env["SDFHIP_HOST_BANDS"] = bands
+        subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env)
+if "--locked" in sys.argv:
+    sys.exit(0)
 for bands in ("", "1", "2", "4", "0"):
     print(f"SDFHIP_HOST_BANDS={bands or chr(34)+chr(34)}" + (" (default: one band per 16 MB of frame, copies beside the march, tile order)" if not bands else " (one launch, one copy, no tile order)" if bands == "0" else ""))
     sys.stdout.flush()

@@ -162,6 +162,9 @@ _SIG = {
                                              _c.c_uint32, _c.c_uint32, _vp, _vp, _c.POINTER(Stats)]),
     "sdfhip_render_display": (_c.c_int, [_vp, _c.POINTER(Info), _c.c_uint32, _c.c_uint32, _c.c_uint32,
                                          _c.c_int, _vp, _c.POINTER(Stats)]),
+    "sdfhip_host_alloc": (_c.c_int, [_c.c_uint64, _c.POINTER(_vp)]),
+    "sdfhip_host_register": (_c.c_int, [_vp, _c.c_uint64]),
+    "sdfhip_host_release": (_c.c_int, [_vp]),
     "sdfhip_deinterleave_device": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.c_uint32,
                                               _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "sdfhip_camera_update": (None, [_c.POINTER(Info), _c.POINTER(_c.c_float), _c.c_float, _c.c_uint32, _c.c_float]),

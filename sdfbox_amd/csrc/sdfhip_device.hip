@@ -1435,6 +1435,73 @@ extern "C" int sdfhip_render_batch_device(sdfhip_scene *s, const sdfhip_info *in
                        d_rgba_out, (hipStream_t)stream, stats, nullptr, n_frames);
 }
 
+// ---- host frames the copy engine can write by itself ---------------------------------------------------------------------
+// A copy into pageable memory is staged by the runtime inside the copy call: the host sits in it, and the copies of a frame's
+// bands go one after another behind the host.  Into page-locked memory the call returns at once and the band's copy starts when
+// its march ends.  A host that keeps ONE frame array for its lifetime (the viewer: Program.cs:94-99 reads every frame back into
+// the same texture-sized array) either lets the library allocate it (sdfhip_host_alloc) or page-locks its own once
+// (sdfhip_host_register: C#, a GCHandleType.Pinned handle held as long as the registration); sdfhip_render looks the
+// destination up here.
+namespace {
+struct HostRange { uintptr_t p; size_t bytes; uintptr_t dev; bool ours; };
+std::mutex g_host_lock;
+std::vector<HostRange> g_host_ranges;
+// the address the devices know [p, p + bytes) by, or null when the range is not page-locked here; ours: it is the library's own
+void *host_range_device_pointer(const void *p, size_t bytes, bool *ours)
+{
+    std::lock_guard<std::mutex> lk(g_host_lock);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    for (const HostRange &r : g_host_ranges)
+        if (a >= r.p && a + bytes <= r.p + r.bytes) { *ours = r.ours; return reinterpret_cast<void *>(r.dev + (a - r.p)); }
+    return nullptr;
+}
+int host_range_add(void *p, size_t bytes, bool ours, const char *what)
+{
+    void *dev = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&dev, p, 0);
+    if (e != hipSuccess || !dev) {
+        (void)hipGetLastError();
+        if (ours) (void)hipHostFree(p); else (void)hipHostUnregister(p);
+        return fail(SDFHIP_ERR_DEVICE, "%s: hipHostGetDevicePointer failed: %s", what, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lk(g_host_lock);
+    g_host_ranges.push_back(HostRange{reinterpret_cast<uintptr_t>(p), bytes, reinterpret_cast<uintptr_t>(dev), ours});
+    return SDFHIP_OK;
+}
+}
+extern "C" int sdfhip_host_alloc(uint64_t bytes, void **out)
+{
+    if (!out || bytes == 0) return fail(SDFHIP_ERR_ARG, "host_alloc: null or zero argument");
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(SDFHIP_ERR_NOMEM, "host_alloc: hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e)); }
+    int rc = host_range_add(p, (size_t)bytes, true, "host_alloc");
+    if (rc != SDFHIP_OK) return rc;
+    *out = p;
+    return SDFHIP_OK;
+}
+extern "C" int sdfhip_host_register(void *p, uint64_t bytes)
+{
+    if (!p || bytes == 0) return fail(SDFHIP_ERR_ARG, "host_register: null or zero argument");
+    hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(SDFHIP_ERR_DEVICE, "host_register: hipHostRegister(%llu bytes) failed: %s", (unsigned long long)bytes, hipGetErrorString(e)); }
+    return host_range_add(p, (size_t)bytes, false, "host_register");
+}
+extern "C" int sdfhip_host_release(void *p)
+{
+    if (!p) return SDFHIP_OK;
+    HostRange r{0, 0, 0, false};
+    {
+        std::lock_guard<std::mutex> lk(g_host_lock);
+        for (size_t i = 0; i < g_host_ranges.size(); i++)
+            if (g_host_ranges[i].p == reinterpret_cast<uintptr_t>(p)) { r = g_host_ranges[i]; g_host_ranges.erase(g_host_ranges.begin() + (long)i); break; }
+    }
+    if (!r.p) return fail(SDFHIP_ERR_ARG, "host_release: %p was neither allocated nor registered here", p);
+    hipError_t e = r.ours ? hipHostFree(p) : hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(SDFHIP_ERR_DEVICE, "host_release: %s", hipGetErrorString(e)); }
+    return SDFHIP_OK;
+}
+
 extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t width,
                              uint32_t height, uint32_t flags, float *rgba_out, sdfhip_stats *stats)
 {
@@ -1461,7 +1528,25 @@ extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t 
                         ((flags >> 8) & 0xFFu) == 0 && !(hb && atoi(hb) == 0);
     uint32_t nb = 1;
     if (viewer) {
-        nb = (size_t)width * height >= ((size_t)4 << 20) ? (uint32_t)sdfhip_scene::HOST_BANDS : 1u;
+        // A page-locked destination (sdfhip_host_alloc / _register): the march can store its pixels into the host's array
+        // itself -- no device frame, no copy: the stores cross PCIe while the other waves march.  Measured (scripts/host_frame.py
+        // --locked, profiles/r03_host_frame.txt): into the library's own allocation 1080p 0.676 ms against 0.711-0.731 with band
+        // copies into the same memory (RGBA8: 0.260 against 0.292); at 4K the copy engine's 55 GB/s beat the stores' 51 (2.47
+        // against 2.58 ms), so frames of 4 M pixels and more go in bands.  Into the caller's own registered array (4 KB pages
+        // wherever they happened to lie) the stores are slower -- 1080p RGBA32F 0.758 against 0.714 -- and are used for frames of
+        // less than 16 MB only (1080p RGBA8: 0.270 against 0.293).
+        bool ours = false;
+        const size_t frame_bytes = (size_t)width * height * px_bytes;
+        void *const known = host_range_device_pointer(rgba_out, frame_bytes, &ours), *const direct = hb ? nullptr : known;
+        const bool locked = known != nullptr;
+        if (direct && (ours ? (size_t)width * height < ((size_t)4 << 20) : frame_bytes < ((size_t)16 << 20))) {
+            int rc = render_impl(s, info, width, height, height, 0, 1, height, flags | SDFHIP_FLAG_TILE_ORDER,
+                                 reinterpret_cast<float *>(direct), s->stream, nullptr);
+            if (rc != SDFHIP_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            return SDFHIP_OK;
+        }
+        nb = ((size_t)width * height >= ((size_t)4 << 20) || (locked && frame_bytes >= ((size_t)16 << 20))) ? 4u : 1u;
         if (hb && atoi(hb) > 0) nb = (uint32_t)atoi(hb);
         nb = nb < 1u ? 1u : (nb > (uint32_t)sdfhip_scene::HOST_BANDS ? (uint32_t)sdfhip_scene::HOST_BANDS : nb);
         if (height < 64u * nb) nb = 1;

@@ -10,6 +10,48 @@ from . import _lib
 from ._lib import Info, MultiStats, PathTrace, Stats, check, lib
 
 
+class HostFrame:
+    """A frame array in page-locked host memory (sdfhip_host_alloc), or the caller's own array page-locked where it lies
+    (sdfhip_host_register): Scene.Draw / DrawDisplay into `.array` run the frame's copy to the host beside its march.
+    Keep the object for as long as the array is in use; close() (or the end of a `with`) gives the memory back."""
+
+    def __init__(self, height=None, width=None, dtype=np.float32, array=None):
+        self._p = None
+        self._owned = array is None
+        if array is None:
+            shape = (int(height), int(width), 4)
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            p = ctypes.c_void_p()
+            check(lib.sdfhip_host_alloc(nbytes, ctypes.byref(p)))
+            self._p = p.value
+            buf = (ctypes.c_uint8 * nbytes).from_address(self._p)
+            self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        else:
+            if not array.flags.c_contiguous or not array.flags.writeable:
+                raise ValueError("HostFrame: the array must be C-contiguous and writeable")
+            check(lib.sdfhip_host_register(array.ctypes.data, array.nbytes))
+            self._p = array.ctypes.data
+            self.array = array
+
+    def close(self):
+        if self._p is not None:
+            p, self._p = self._p, None
+            self.array = None
+            check(lib.sdfhip_host_release(ctypes.c_void_p(p)))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Scene:
     """A scene resident in one GPU's HBM (replaces the `data` / `values`
     bindings of Program.cs:147-152)."""
@@ -140,10 +182,13 @@ class Scene:
                                             ctypes.c_void_p(int(stream)) if stream else None,
                                             ctypes.byref(stats) if stats is not None else None))
 
-    def DrawDisplay(self, state, width, height, debug=False, flags=_lib.KERNEL_AUTO, want_stats=False):
+    def DrawDisplay(self, state, width, height, debug=False, flags=_lib.KERNEL_AUTO, want_stats=False, out=None):
         """Render + display pass (DisplayFrag.hlsl) fused: host array (H, W, 4) uint8, R,G,B,A.
-        debug=True gives the step-count heat map of DisplayFrag.hlsl:21-22."""
-        out = np.empty((int(height), int(width), 4), dtype=np.uint8)
+        debug=True gives the step-count heat map of DisplayFrag.hlsl:21-22.  out: reuse this array."""
+        if out is None:
+            out = np.empty((int(height), int(width), 4), dtype=np.uint8)
+        elif out.shape != (int(height), int(width), 4) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("DrawDisplay: out must be a C-contiguous uint8 array of shape (height, width, 4)")
         st = Stats()
         info = state if isinstance(state, Info) else state.State
         check(lib.sdfhip_render_display(self._h, ctypes.byref(info), int(width), int(height), int(flags),

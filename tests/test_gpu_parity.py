@@ -959,6 +959,42 @@ def test_bench_frame_equals_the_oracle_on_every_pixel(sb, oracle_mod, dragon):
     assert st.n_nodes == 433305936 and st.n_samples == 52988750          # the figures DESIGN.md section 6 quotes
 
 
+def test_host_frames_in_page_locked_memory(sb, dragon):
+    # sdfhip_host_alloc / sdfhip_host_register: below 4 M pixels sdfhip_render's kernel stores its pixels straight into the
+    # host's array (no device frame, no copy), above it the band copies go into it.  Both must leave the frame a pageable
+    # destination gets -- every byte, NaN pixels included -- for a moving camera (the launch order of the tiles is the last
+    # frame's), for RGBA32F and the fused display pass, for a window inside a larger registered array, and after release.
+    import ctypes
+    od, sc = dragon
+    L = sb._lib
+    for W, H in ((1920, 1080), (3840, 2160), (333, 211)):
+        cams = []
+        for k in range(3):
+            c = sb.Logic(W, H); c.Position = (0.5 + 0.02 * k, 0.5, -0.35 + 0.05 * k); c.Heading = (-0.2 + 0.1 * k, 0.35)
+            cams.append(c)
+        plain = [sc.Draw(c, W, H).copy() for c in cams]
+        plain8 = [sc.DrawDisplay(c, W, H).copy() for c in cams]
+        with sb.HostFrame(H, W, np.float32) as hf, sb.HostFrame(H, W, np.uint8) as hf8:
+            for k, c in enumerate(cams):
+                hf.array[...] = np.float32(-1.0); hf8.array[...] = 7
+                assert sc.Draw(c, W, H, out=hf.array) is hf.array
+                assert_frames_identical(hf.array, plain[k], f"library-allocated host frame, {W}x{H}, camera {k}")
+                sc.DrawDisplay(c, W, H, out=hf8.array)
+                assert np.array_equal(hf8.array, plain8[k])
+        own = np.full((H + 16, W, 4), -1.0, dtype=np.float32)
+        with sb.HostFrame(array=own):
+            window = own[8:8 + H]                                  # a frame somewhere inside the registered range
+            for k, c in enumerate(cams):
+                sc.Draw(c, W, H, out=window)
+                assert_frames_identical(window, plain[k], f"registered host frame, {W}x{H}, camera {k}")
+            assert (own[:8] == -1.0).all() and (own[8 + H:] == -1.0).all()
+        sc.Draw(cams[0], W, H, out=own[:H])                        # released: an ordinary destination again
+        assert_frames_identical(own[:H], plain[0], "after release")
+    assert L.lib.sdfhip_host_release(ctypes.c_void_p(own.ctypes.data)) == L.ERR_ARG and b"neither" in L.lib.sdfhip_last_error()
+    assert L.lib.sdfhip_host_release(None) == L.OK
+    assert L.lib.sdfhip_host_register(None, 16) == L.ERR_ARG and L.lib.sdfhip_host_alloc(0, ctypes.byref(ctypes.c_void_p())) == L.ERR_ARG
+
+
 # ---- fuzz: random trees, on-grid cameras, axis-aligned rays ---------------------------------
 def _random_tree(rng, max_depth, p_split, max_nodes=60000):
     """A consistent octree with random splits (DFS pre-order, like SdfGen) and random bytes."""
