@@ -242,6 +242,17 @@ def main():
             s2["gath"] = [torch.zeros((world, s2["bytes"]), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
             s2["counts"] = [torch.zeros(world, dtype=torch.int32).pin_memory() for _ in range(nbuf)]
             s2["bases"] = [[0] * world for _ in range(nbuf)]
+    if sharded and world > 1 and (sparse or sparse2):
+        # the point-to-point path of a resend, used once before anything is timed: the first send / recv between two ranks sets
+        # their channel up (with NCCL: hundreds of milliseconds), and the first overflow of a run may come inside the timed region
+        probe = torch.zeros(1, dtype=torch.int32, device="cuda" if nccl else "cpu")
+        if rank == 0:
+            for r in range(1, world):
+                dist.recv(probe, src=r)
+        else:
+            dist.send(probe, dst=0)
+        if nccl:
+            torch.cuda.synchronize()
     send = local                                    # what the gather carries
     cap = 0
     overflow = torch.zeros(1, dtype=torch.int32, device="cuda")
