@@ -5,6 +5,7 @@
  * exit 0 ok, 3 = no usable GPU (SDFHIP_ERR_DEVICE), anything else = failure. */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "sdfhip.h"
 
 int main(int argc, char **argv)
@@ -31,6 +32,16 @@ int main(int argc, char **argv)
     if (rc != SDFHIP_OK) { fprintf(stderr, "render: %s\n", sdfhip_last_error()); return 7; }
     printf("kernel %.3f ms, %llu node reads, %llu samples, %llu steps\n", st.kernel_ms,
            (unsigned long long)st.n_nodes, (unsigned long long)st.n_samples, (unsigned long long)st.n_steps);
+    /* the viewer's frame array in page-locked memory: the same call, the march stores its pixels into the array itself */
+    void *locked = NULL;
+    const size_t bytes = (size_t)W * H * 4 * sizeof(float);
+    if (sdfhip_host_alloc(bytes, &locked) != SDFHIP_OK) { fprintf(stderr, "host_alloc: %s\n", sdfhip_last_error()); return 9; }
+    memset(locked, 0xA5, bytes);
+    rc = sdfhip_render(scene, &info, W, H, SDFHIP_KERNEL_AUTO, (float *)locked, NULL);
+    if (rc != SDFHIP_OK) { fprintf(stderr, "render (page-locked): %s\n", sdfhip_last_error()); return 10; }
+    if (memcmp(locked, frame, bytes) != 0) { fprintf(stderr, "the page-locked frame differs\n"); return 11; }
+    if (sdfhip_host_release(locked) != SDFHIP_OK) { fprintf(stderr, "host_release: %s\n", sdfhip_last_error()); return 12; }
+    printf("page-locked frame identical\n");
     FILE *f = fopen(argv[4], "wb");
     if (!f || fwrite(frame, sizeof(float), (size_t)W * H * 4, f) != (size_t)W * H * 4) return 8;
     fclose(f);

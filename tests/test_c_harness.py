@@ -42,3 +42,4 @@ def test_c_caller_renders_the_oracle_frame(tmp_path, sb, oracle_mod, scenes):
     ref, cnt = oracle_mod.render(scenes["sphere_d4"].Structs, scenes["sphere_d4"].Values, cam.State, 200, 120)
     assert_frames_identical(frame, ref, "C harness")
     assert f"{int(cnt[0])} node reads, {int(cnt[1])} samples, {int(cnt[2])} steps" in out.stdout
+    assert "page-locked frame identical" in out.stdout            # sdfhip_host_alloc + the same sdfhip_render, from C
