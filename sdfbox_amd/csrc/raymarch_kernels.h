@@ -1064,6 +1064,19 @@ struct PtHit {
     uint32_t v0, v1, pid, steps;     // cursor values; path = pixel * spp + sample (pixel = row * width + x of the LOCAL rows); the segment's steps
     float ux, uy, uz, T;             // incoming direction, throughput
 };
+// the hit queues are written once and read once, a level later: streamed past the caches (nt), so that the L2 lines they
+// would take stay with the grid cells the bounce rays look up
+__device__ __forceinline__ void nt_store(float4 *p, const float4 &v)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(p));
+}
+__device__ __forceinline__ float4 nt_load(const float4 *p)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 template <class CursorT>
 __device__ __forceinline__ void pt_push(const RenderParams &P, uint32_t queue, uint32_t q, bool hit, uint32_t lane,
                                         float px, float py, float pz, float prox, const CursorT &c, uint32_t pid, uint32_t steps,
@@ -1081,11 +1094,11 @@ __device__ __forceinline__ void pt_push(const RenderParams &P, uint32_t queue, u
     if (hit && base + rank < P.pt_cap) {
         const size_t total = (size_t)HIT_QUEUES * P.pt_cap, i = (size_t)q * P.pt_cap + base + rank;
         float4 *Q = P.pt_q[queue];
-        Q[i] = make_float4(px, py, pz, prox);
+        nt_store(&Q[i], make_float4(px, py, pz, prox));
         const int4 k = c.pack();
-        Q[total + i] = make_float4(__int_as_float(k.x), __int_as_float(k.y), __int_as_float(k.z), __int_as_float(k.w));
-        Q[2 * total + i] = make_float4(__uint_as_float(c.v0), __uint_as_float(c.v1), __uint_as_float(pid), __uint_as_float(steps));
-        Q[3 * total + i] = make_float4(ux, uy, uz, T);
+        nt_store(&Q[total + i], make_float4(__int_as_float(k.x), __int_as_float(k.y), __int_as_float(k.z), __int_as_float(k.w)));
+        nt_store(&Q[2 * total + i], make_float4(__uint_as_float(c.v0), __uint_as_float(c.v1), __uint_as_float(pid), __uint_as_float(steps)));
+        nt_store(&Q[3 * total + i], make_float4(ux, uy, uz, T));
     }
 }
 
@@ -1139,8 +1152,8 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_pt_primary(RenderP
         if (COUNT) cl += c.loads;
         if (live) {
             const size_t o = (size_t)s * npx + lidx;
-            P.pt_t[o] = escaped ? 1.0f : 0.0f;                // the camera ray's throughput is 1
-            P.pt_n[o] = (uint32_t)r.n;                        // no vertex yet
+            __builtin_nontemporal_store(escaped ? 1.0f : 0.0f, &P.pt_t[o]);   // the camera ray's throughput is 1
+            __builtin_nontemporal_store((uint32_t)r.n, &P.pt_n[o]);           // no vertex yet
         }
         pt_push(P, 0, q, live && !escaped, lane, r.px, r.py, r.pz, r.prox, c, (uint32_t)lidx * P.pt_spp + s, (uint32_t)r.n,
                 r.dx, r.dy, r.dz, 1.0f);
@@ -1178,7 +1191,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
         bool next = false, escaped = false;       // a next segment was marched; it escaped
         if (have) {
             const size_t e = (size_t)q * P.pt_cap + i;
-            const float4 a = Q[e], k = Q[total + e], v = Q[2 * total + e], d = Q[3 * total + e];
+            const float4 a = nt_load(&Q[e]), k = nt_load(&Q[total + e]), v = nt_load(&Q[2 * total + e]), d = nt_load(&Q[3 * total + e]);
             r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w;
             c.unpack(make_int4(__float_as_int(k.x), __float_as_int(k.y), __float_as_int(k.z), __float_as_int(k.w)),
                      CursorT::units_shift(P.top_level + (CUR == CUR_STACK_SPLIT ? P.fine_bits : 0)));
@@ -1210,8 +1223,8 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
                 shadow_steps = (uint32_t)r.n;
                 if (lit) e_light = T * (P.pt_albedo * (angle / (dist * dist) * I.k_strength));
             }
-            P.pt_e[(size_t)b * P.pt_spp * npx + o] = e_light;
-            uint32_t nsteps = (P.pt_n[o] & 0xFFFFu) + shadow_steps;
+            __builtin_nontemporal_store(e_light, &P.pt_e[(size_t)b * P.pt_spp * npx + o]);
+            uint32_t nsteps = (__builtin_nontemporal_load(&P.pt_n[o]) & 0xFFFFu) + shadow_steps;
             if (b < P.pt_bounces) {
                 // diffuse bounce (o_pixel_pt): the normal facing the incoming ray, a direction by rejection in the cube
                 if (dot3(n0, n1, n2, ux, uy, uz) > 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
@@ -1239,9 +1252,9 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
                 next = true;
                 escaped = pt_march<COUNT>(P, I, r, c, cn, cs);
                 nsteps += (uint32_t)r.n;
-                if (escaped) P.pt_t[o] = T;
+                if (escaped) __builtin_nontemporal_store(T, &P.pt_t[o]);
             }
-            P.pt_n[o] = nsteps | ((b + 1u) << 16);
+            __builtin_nontemporal_store(nsteps | ((b + 1u) << 16), &P.pt_n[o]);
             if (COUNT) cl += c.loads;
         }
         pt_push(P, qout, blockIdx.x & (HIT_QUEUES - 1u), have && next && !escaped, lane, r.px, r.py, r.pz, r.prox, c, pid, 0u, ux, uy, uz, T);
@@ -1262,13 +1275,13 @@ __global__ __launch_bounds__(256) void k_pt_resolve(RenderParams P)
         uint32_t steps = 0;
         for (uint32_t s = 0; s < P.pt_spp; s++) {
             const size_t o = (size_t)s * npx + pix;
-            const uint32_t n = P.pt_n[o], nv = n >> 16;
+            const uint32_t n = __builtin_nontemporal_load(&P.pt_n[o]), nv = n >> 16;
             steps += n & 0xFFFFu;
             for (uint32_t b = 0; b < nv; b++) {
-                const float e = P.pt_e[(size_t)b * P.pt_spp * npx + o];
+                const float e = __builtin_nontemporal_load(&P.pt_e[(size_t)b * P.pt_spp * npx + o]);
                 acc0 += e; acc1 += e; acc2 += e;
             }
-            const float T = P.pt_t[o];
+            const float T = __builtin_nontemporal_load(&P.pt_t[o]);
             acc0 = __builtin_fmaf(T, 0.005f, acc0); acc1 = __builtin_fmaf(T, 0.01f, acc1); acc2 = __builtin_fmaf(T, 0.2f, acc2);
         }
         const float inv = (float)P.pt_spp;
