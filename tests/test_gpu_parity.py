@@ -286,6 +286,33 @@ def test_path_traced_mode(sb, oracle_mod, scenes, gpu_scenes, kernel):
         gpu_scenes["sphere_d4"].DrawPath(make_camera("default", 8, 8), 8, 8, flags=sb.FLAG_COMPACT)
 
 
+@pytest.mark.parametrize("blocks,order", [("0", "1"), ("1", "1"), ("2", "1"), ("2", "0"), ("3", "1"), ("4", "1"), ("4", "0")])
+def test_path_traced_mode_through_every_scatter_grid(sb, oracle_mod, scenes, blocks, order):
+    # The bounce levels of the path-traced pipeline read a split grid of their own (SDFHIP_SCATTER_GRID: the levels inside a block,
+    # 0 = the scene's grid; SDFHIP_SCATTER_ORDER: blocks stored sub-cube by sub-cube or in x-y-z order).  Whatever the grid, the frame
+    # is the oracle's.  (The knobs are read when the scatter grid is built: a handle of its own per setting.)
+    od = scenes["torus_d6"]
+    W, H = 61, 37
+    cam = make_camera("rotated", W, H)
+    pt = sb.PathTrace(spp=8, max_bounces=3)
+    ref, cnt = oracle_mod.render_pt(od.Structs, od.Values, cam.State, W, H, spp=pt.spp, max_bounces=pt.max_bounces, seed=pt.seed,
+                                    albedo=pt.albedo, nthreads=8)
+    prev = {k: os.environ.get(k) for k in ("SDFHIP_SCATTER_GRID", "SDFHIP_SCATTER_ORDER")}
+    os.environ["SDFHIP_SCATTER_GRID"] = blocks; os.environ["SDFHIP_SCATTER_ORDER"] = order
+    try:
+        with sb.Scene(od) as sc:
+            img, st = sc.DrawPath(cam, W, H, pt, flags=sb.FLAG_COUNT, want_stats=True)
+            assert_frames_identical(img, ref, f"scatter grid {blocks} order {order}, counting")
+            assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
+            assert_frames_identical(sc.DrawPath(cam, W, H, pt), ref, f"scatter grid {blocks} order {order}")
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_path_traced_config5_full_size(sb, oracle_mod, dragon):
     # BASELINE config 5: 3840x2160, 16 spp, 3 bounces, seed 0x5DFB0C5 on the dragon stand-in.
     # Size-independent properties + the oracle on sampled rows.
