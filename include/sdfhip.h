@@ -319,7 +319,7 @@ typedef struct sdfhip_pathtrace {
 /* The bounce levels of the path-traced pipeline read a second split grid of the scene's cells, with larger blocks (+0.83 GB for
  * the depth-9 bench scene).  sdfhip_scene_prepare_path builds it at load time (allocations, kernels and two
  * stream synchronisations on the scene's own stream); without the call the first path-traced render builds it before its clock
- * starts.  Environment, read then: SDFHIP_SCATTER_GRID=0 no second grid, 1..4 the levels of its blocks (default 3);
+ * starts.  Environment, read then: SDFHIP_SCATTER_GRID=0 no second grid, 1..4 the levels of its blocks (default 4: 16^3 cells; 3 for trees of depth < 6);
  * SDFHIP_SCATTER_ORDER=0 blocks in x-y-z order (default: 2x2x2 sub-cubes, one cache line each).  sdfhip_scene_top_grid counts its
  * bytes once it exists.  sdfhip_render_path returns SDFHIP_ERR_NOMEM, not a wrong image, if a hit ever found no room in its queue
  * (their capacity is the worst case of every sub-queue, so this is a check, not a limit). */
