@@ -554,14 +554,20 @@ __global__ __launch_bounds__(256) void k_deinterleave_sparse2(const ShareTable S
             const uint32_t slot = reinterpret_cast<const uint32_t *>(src + L.off_bases)[ft] + (uint32_t)__popcll(m & ((1ull << bit) - 1ull));
             if (slot < L.capacity) a = reinterpret_cast<const float *>(src + L.off_floats)[slot];
         }
-        if (MODE == OUT_RGBA32F) reinterpret_cast<float4 *>(frame)[i] = wire_expand(a, code);
+        // (the frame is written once and read by somebody else: past the caches -- the lines stay with the grid cells of the groups
+        // that march meanwhile; 4K, one rank 0.364 -> 0.351 ms per frame, four ranks 0.388 -> 0.382)
+        if (MODE == OUT_RGBA32F) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const float4 v = wire_expand(a, code);
+            __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(frame) + i);
+        }
         else {
             const float4 v = wire_expand(a, code);
             uint32_t q;
             if (MODE == OUT_HEAT8) q = heat8(v.w);
             else if (code > 140u) q = sky8 | alpha8(v.w);
             else { const uint32_t g = gamma8(a); q = g | (g << 8) | (g << 16) | alpha8(v.w); }
-            reinterpret_cast<uint32_t *>(frame)[i] = q;
+            __builtin_nontemporal_store(q, reinterpret_cast<uint32_t *>(frame) + i);
         }
     }
 }
