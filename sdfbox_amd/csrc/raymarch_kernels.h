@@ -1057,13 +1057,27 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
 // =====================================================================================
 __device__ __forceinline__ uint32_t *pt_count(const RenderParams &P, uint32_t queue, uint32_t q) { return P.pt_ctl + ((size_t)queue * HIT_QUEUES + q) * 32u; }
 
-// a path's state at a surface hit, four 16-byte records (SoA over the queue: record r of entry i at [r * total + i])
-struct PtHit {
-    float px, py, pz, prox;          // where the march ended, its last sample
-    int32_t ax, ay, az; uint32_t s;  // cursor
-    uint32_t v0, v1, pid, steps;     // cursor values; path = pixel * spp + sample (pixel = row * width + x of the LOCAL rows); the segment's steps
-    float ux, uy, uz, T;             // incoming direction, throughput
-};
+// a path's state at a surface hit, three 16-byte records (SoA over the queue: record r of entry i at [r * total + i]):
+//   {pos, prox}   where the march ended, its last sample
+//   {cursor coordinates and level in two words (pt_pack_cursor), the cursor's two value words}
+//   {path = pixel * spp + sample (pixel = row * width + x of the LOCAL rows), incoming direction}
+// The throughput is not stored: it is albedo multiplied level times onto 1, in that order, and the next level does just that.
+// (Round 2's entry had a fourth record: the cursor in four words, the throughput, and a step count nobody read.)
+constexpr uint32_t PT_RECORDS = 3;
+// (ax, ay, az, s) of CursorFT::pack() -- coordinates below 2^LM = 4096 or the root mark on all three, s = LM - level | FLAT_BIT -- in 64 bits
+__device__ __forceinline__ uint2 pt_pack_cursor(const int4 &k)
+{
+    const bool fresh = k.x == 0x40000000;
+    const uint32_t x = fresh ? 0u : (uint32_t)k.x, y = fresh ? 0u : (uint32_t)k.y, z = fresh ? 0u : (uint32_t)k.z, s = (uint32_t)k.w;
+    return make_uint2(x | (y << 13) | (z << 26), (z >> 6) | ((s & 31u) << 7) | ((s >> 31) << 12) | ((fresh ? 1u : 0u) << 13));
+}
+__device__ __forceinline__ int4 pt_unpack_cursor(const uint2 &w)
+{
+    const bool fresh = ((w.y >> 13) & 1u) != 0u;
+    const int32_t x = (int32_t)(w.x & 0x1FFFu), y = (int32_t)((w.x >> 13) & 0x1FFFu), z = (int32_t)((w.x >> 26) | ((w.y & 0x7Fu) << 6));
+    const uint32_t s = ((w.y >> 7) & 31u) | (((w.y >> 12) & 1u) << 31);
+    return make_int4(fresh ? 0x40000000 : x, fresh ? 0x40000000 : y, fresh ? 0x40000000 : z, (int32_t)s);
+}
 // the hit queues are written once and read once, a level later: streamed past the caches (nt), so that the L2 lines they
 // would take stay with the grid cells the bounce rays look up
 __device__ __forceinline__ void nt_store(float4 *p, const float4 &v)
@@ -1079,8 +1093,8 @@ __device__ __forceinline__ float4 nt_load(const float4 *p)
 }
 template <class CursorT>
 __device__ __forceinline__ void pt_push(const RenderParams &P, uint32_t queue, uint32_t q, bool hit, uint32_t lane,
-                                        float px, float py, float pz, float prox, const CursorT &c, uint32_t pid, uint32_t steps,
-                                        float ux, float uy, float uz, float T)
+                                        float px, float py, float pz, float prox, const CursorT &c, uint32_t pid,
+                                        float ux, float uy, float uz)
 {
     const unsigned long long hits = __ballot(hit);
     if (!hits) return;
@@ -1095,10 +1109,9 @@ __device__ __forceinline__ void pt_push(const RenderParams &P, uint32_t queue, u
         const size_t total = (size_t)HIT_QUEUES * P.pt_cap, i = (size_t)q * P.pt_cap + base + rank;
         float4 *Q = P.pt_q[queue];
         nt_store(&Q[i], make_float4(px, py, pz, prox));
-        const int4 k = c.pack();
-        nt_store(&Q[total + i], make_float4(__int_as_float(k.x), __int_as_float(k.y), __int_as_float(k.z), __int_as_float(k.w)));
-        nt_store(&Q[2 * total + i], make_float4(__uint_as_float(c.v0), __uint_as_float(c.v1), __uint_as_float(pid), __uint_as_float(steps)));
-        nt_store(&Q[3 * total + i], make_float4(ux, uy, uz, T));
+        const uint2 k = pt_pack_cursor(c.pack());
+        nt_store(&Q[total + i], make_float4(__uint_as_float(k.x), __uint_as_float(k.y), __uint_as_float(c.v0), __uint_as_float(c.v1)));
+        nt_store(&Q[2 * total + i], make_float4(__uint_as_float(pid), ux, uy, uz));
     }
 }
 
@@ -1155,8 +1168,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_pt_primary(RenderP
             __builtin_nontemporal_store(escaped ? 1.0f : 0.0f, &P.pt_t[o]);   // the camera ray's throughput is 1
             __builtin_nontemporal_store((uint32_t)r.n, &P.pt_n[o]);           // no vertex yet
         }
-        pt_push(P, 0, q, live && !escaped, lane, r.px, r.py, r.pz, r.prox, c, (uint32_t)lidx * P.pt_spp + s, (uint32_t)r.n,
-                r.dx, r.dy, r.dz, 1.0f);
+        pt_push(P, 0, q, live && !escaped, lane, r.px, r.py, r.pz, r.prox, c, (uint32_t)lidx * P.pt_spp + s, r.dx, r.dy, r.dz);
     }
     if (COUNT) flush_counters(P, cn, cs, 0, 0, cl);
 }
@@ -1191,12 +1203,14 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
         bool next = false, escaped = false;       // a next segment was marched; it escaped
         if (have) {
             const size_t e = (size_t)q * P.pt_cap + i;
-            const float4 a = nt_load(&Q[e]), k = nt_load(&Q[total + e]), v = nt_load(&Q[2 * total + e]), d = nt_load(&Q[3 * total + e]);
+            const float4 a = nt_load(&Q[e]), k = nt_load(&Q[total + e]), d = nt_load(&Q[2 * total + e]);
             r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w;
-            c.unpack(make_int4(__float_as_int(k.x), __float_as_int(k.y), __float_as_int(k.z), __float_as_int(k.w)),
+            c.unpack(pt_unpack_cursor(make_uint2(__float_as_uint(k.x), __float_as_uint(k.y))),
                      CursorT::units_shift(P.top_level + (CUR == CUR_STACK_SPLIT ? P.fine_bits : 0)));
-            c.v0 = __float_as_uint(v.x); c.v1 = __float_as_uint(v.y); pid = __float_as_uint(v.z);
-            ux = d.x; uy = d.y; uz = d.z; T = d.w;
+            c.v0 = __float_as_uint(k.z); c.v1 = __float_as_uint(k.w); pid = __float_as_uint(d.x);
+            ux = d.y; uy = d.z; uz = d.w;
+            T = 1.0f;
+            for (uint32_t lv = 0; lv < b; lv++) T *= P.pt_albedo;     // what the levels before this one multiplied onto 1, in their order
             const uint32_t pix = pid / P.pt_spp, s = pid - pix * P.pt_spp;
             const size_t o = (size_t)s * npx + pix;
             // shade (Compute.hlsl:205-213)
@@ -1257,7 +1271,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
             __builtin_nontemporal_store(nsteps | ((b + 1u) << 16), &P.pt_n[o]);
             if (COUNT) cl += c.loads;
         }
-        pt_push(P, qout, blockIdx.x & (HIT_QUEUES - 1u), have && next && !escaped, lane, r.px, r.py, r.pz, r.prox, c, pid, 0u, ux, uy, uz, T);
+        pt_push(P, qout, blockIdx.x & (HIT_QUEUES - 1u), have && next && !escaped, lane, r.px, r.py, r.pz, r.prox, c, pid, ux, uy, uz);
     }
     if (COUNT) flush_counters(P, cn, cs, 0, cr, cl);
 }

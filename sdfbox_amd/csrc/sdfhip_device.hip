@@ -1363,7 +1363,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
         if (npaths >= ((size_t)1 << 32))
             return fail(SDFHIP_ERR_ARG, "render_path: %zu paths (pixels x spp) exceed the 32-bit path index", npaths);
         P.pt_cap = (uint32_t)((((size_t)grid.x + HIT_QUEUES - 1) / HIT_QUEUES) * 64 * pt->spp + 8192);
-        const size_t qbytes = (size_t)4 * 16 * HIT_QUEUES * P.pt_cap;                 // one hit queue
+        const size_t qbytes = (size_t)PT_RECORDS * 16 * HIT_QUEUES * P.pt_cap;        // one hit queue
         const size_t ebytes = (size_t)(pt->max_bounces + 1) * npaths * 4, tbytes = npaths * 4;
         int rcs = get_pt_scratch(s, st, 2 * qbytes + ebytes + 2 * tbytes, &sc);
         if (rcs != SDFHIP_OK) return rcs;
