@@ -369,15 +369,8 @@ done:
  *   adds throughput * albedo * angle / dist^2 * (exp2(strength) - 1) when lit; then it
  *   bounces: dir = normalize(n' + u), n' = the normal facing the incoming ray, u uniform
  *   on the unit sphere (rejection in the cube, at most 8 tries), pos += n' * 4 * margin,
- *   throughput *= albedo.  The cursor (index, box) carries over from a segment into the
- *   shading step and the shadow march at its end, as it does between the primary and the
- *   shadow march in the shader; the NEXT segment starts from the root again (round 3: until
- *   then it continued with the cursor the shadow march had left, which made every vertex's
- *   shadow ray and bounce ray one chain -- now they are two independent rays from the hit,
- *   and the HIP pipeline marches the shadow rays of a level in a pass of their own).  The
- *   cursor decides no distance: it changes the node counters, and a pixel only where a
- *   position falls exactly on a cell face (the reference's descent then depends on where it
- *   starts).
+ *   throughput *= albedo.  The cursor (index, box) carries over between segments, as it
+ *   does between the primary and the shadow march in the shader.
  * RNG: PCG hash chained over (seed + pixel, sample, bounce, draw); uniform = top 24 bits
  * * 2^-24.  No transcendental function anywhere, so parity stays bit-exact.
  * out = mean radiance (r, g, b), alpha = march steps of all segments and samples. */
@@ -496,10 +489,6 @@ O_INLINE void o_pixel_pt(const o_scene *sc, const o_info *inf, float k, uint32_t
             float off = margin * 4.0f;
             px = fmaf(n0, off, px); py = fmaf(n1, off, py); pz = fmaf(n2, off, pz);
             T *= albedo;
-            /* the bounce segment starts from the root (see above: the shadow ray and the bounce ray are independent) */
-            t.index = 0;
-            t.box.lx = t.box.ly = t.box.lz = 0.0f;
-            t.box.scale = 1.0f;
         }
     }
     float inv = (float)spp;

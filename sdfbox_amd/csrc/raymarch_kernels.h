@@ -999,7 +999,6 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
                     b++;
                     prox = 1.0f;
                     it = 0;
-                    c.reset(root);              // the bounce segment starts from the root (o_pixel_pt)
                     continue;                   // the new segment starts with its loop-header checks
                 }
             }
@@ -1179,7 +1178,6 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
 {
     typedef typename ScatterCursorOf<CUR, COUNT>::type CursorT;
     const uint32_t lane = threadIdx.x, b = P.pt_level, qin = b & 1u, qout = qin ^ 1u;
-    const NodeRec root = P.nodes[0];
     FrameInfo I = P.frames[0];
     asm volatile("" : "+s"(I.margin), "+s"(I.margin2), "+s"(I.limit));
     const float margin = I.margin;
@@ -1266,8 +1264,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
                 // the next segment
                 r.dx = ux; r.dy = uy; r.dz = uz; r.prox = 1.0f; r.n = 0; r.phase = PH_PRIMARY;
                 next = true;
-                c.reset(root);                                // the bounce segment starts from the root (o_pixel_pt)
-                escaped = pt_march<COUNT, true>(P, I, r, c, cn, cs);
+                escaped = pt_march<COUNT>(P, I, r, c, cn, cs);
                 nsteps += (uint32_t)r.n;
                 if (escaped) __builtin_nontemporal_store(T, &P.pt_t[o]);
             }
