@@ -31,7 +31,13 @@ def main():
     tag = sys.argv[1]
     src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
     os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
-    for f in glob.glob(f"{src}/stats/*/*_kernel_stats.csv"):
+    # gpurun merges a call's files into gpurun_out/ and keeps those of earlier calls (rocprofv3 names them by process id): of every
+    # pass take the NEWEST file only -- the others belong to earlier builds
+    def newest(pattern):
+        files = glob.glob(pattern)
+        return max(files, key=os.path.getmtime) if files else None
+    f = newest(f"{src}/stats/*/*_kernel_stats.csv")
+    if f:
         shutil.copy(f, os.path.join(REPO, "profiles", f"{tag}_kernel_stats.csv"))
     bench = None
     try:
@@ -41,7 +47,7 @@ def main():
     kernels = collections.defaultdict(dict)
     per_frame = collections.defaultdict(float)        # counter -> sum over the frame's kernels, per frame
     FIRST = ("k_march", "k_pt_primary", "k_plain", "k_compact", "k_path")   # one launch of these per frame (or per batch of frames)
-    for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
+    for f in [g for g in (newest(f"{d}/*/*_counter_collection.csv") for d in sorted(glob.glob(f"{src}/pmc_*")) if os.path.isdir(d)) if g]:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
