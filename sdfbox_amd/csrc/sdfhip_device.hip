@@ -1013,14 +1013,16 @@ static void ensure_scatter_grid(sdfhip_scene *s)
     const char *env = getenv("SDFHIP_SCATTER_GRID");
     // blocks of 8^FB fine cells; 0 = off.  Default 16^3-cell blocks (64 KB each) for trees of depth 6 and more: cfg-5 21.9 ms
     // against 22.3 with 8^3 (and 24.6 with 4^3) for 1.00 instead of 0.83 GB at depth 9, on a 288 GB device
-    const int FB = env ? atoi(env) : ((int)s->depth >= 6 ? 4 : 3);
-    if (FB >= 1 && FB <= 4 && (int)s->depth - FB >= 1 && (int)s->depth - FB <= MAX_TOP_LEVEL &&
-        !(s->fine_bits && s->top_level == (int)s->depth - FB)) {
+    // (without the variable, blocks that do not fit the memory share fall back to the next smaller size)
+    for (int FB = env ? atoi(env) : ((int)s->depth >= 6 ? 4 : 3); FB >= 1; FB = env ? 0 : FB - 1) {
+        if (!(FB <= 4 && (int)s->depth - FB >= 1 && (int)s->depth - FB <= MAX_TOP_LEVEL)) continue;
+        if (s->fine_bits && s->top_level == (int)s->depth - FB) return;            // the scene's own grid is that grid
         uint64_t fbytes = 0;
         s->fine2_order = (FB >= 2 && !(getenv("SDFHIP_SCATTER_ORDER") && atoi(getenv("SDFHIP_SCATTER_ORDER")) == 0)) ? 1 : 0;
         if (build_split_grid(s, (int)s->depth - FB, FB, s->fine2_order, s->total_mem / 32, &s->d_top2, &s->d_fine2, &fbytes)) {
             s->top2_level = (int)s->depth - FB; s->fine2_bits = FB;
             s->top2_bytes = ((uint64_t)sizeof(TopCell) << (3 * s->top2_level)) + fbytes;
+            return;
         }
     }
 }
