@@ -4,10 +4,10 @@
 A "step" is one frame of the workload: every rank ray-marches its row bands of
 the frame (scene and camera already resident in HBM), the band buffers are
 gathered to rank 0 over RCCL and put back in row order.  At N=1 a step is the
-ray-march kernel alone.  Consecutive frames are double-buffered on separate HIP
-streams (frames in flight), as a renderer would: the long tail of one frame (a
-few 100-140-step pixels) overlaps the body of the next.  Prints ONE JSON line
-on rank 0.
+ray-march kernel alone.  Consecutive frames go to separate HIP streams round
+robin (six frames in flight by default), as a renderer would keep them: the
+long tail of one frame (a few 100-140-step pixels) overlaps the body of the
+next ones.  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--compact", type=int, default=-1, help="wavefront ray compaction: 1 on, 0 off, -1 default")
     ap.add_argument("--band-rows", type=int, default=16)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="HIP streams / buffers used round-robin (0 = default: 2).  Unsharded: frames in flight.  "
+                    help="HIP streams / buffers used round-robin (0 = default: 6; 2 for --spp / --compact).  Unsharded: frames in flight.  "
                          "Sharded: groups of --gather-every frames in flight")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="sharded runs: frames per gather (fewer, larger messages; one collective launch per "
@@ -201,9 +201,12 @@ def main():
     G = (args.gather_every if args.gather_every > 0 else (8 if world >= 8 else 4)) if sharded else 1
     if pt is not None or compact:
         G = 1 if not sharded else G            # those kernels render one frame per launch
-    # in flight: 2 frames on one GPU; 4 groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4
-    # frames per launch needs 4 launches in flight to fill the chip -- 0.039 -> 0.024 ms per frame at 8 ranks)
-    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (4 if sharded else 2)
+    # in flight: 6 frames on one GPU (the long tail of a frame's last waves under the body of the next ones: 1080p 0.163 ms with one
+    # frame in flight, 0.0903 with two or four, 0.0889 / 0.0885 / 0.0893 / 0.0892 with five / six / eight / twelve -- and 0.115 with
+    # three, reproducibly: two of three streams then share a hardware queue); 2 for the path-traced mode (its buffers are gigabytes
+    # per stream and its levels fill the chip); 4 groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4 frames per
+    # launch needs 4 launches in flight to fill the chip -- 0.039 -> 0.024 ms per frame at 8 ranks)
+    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (4 if sharded else 2 if (pt is not None or compact) else 6)
 
     # rank 0 also assembles the frame (de-interleave + wire expansion of every rank's rows), so it
     # renders a smaller share: --rank0-weight, or measured here before anything is timed
