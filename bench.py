@@ -56,6 +56,12 @@ def parse():
                     help="run the sharded path (bands + gather + de-interleave) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time target of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--configs", default="auto", choices=["auto", "all", "none"],
+                    help="the other single-GPU BASELINE configurations timed in the same process, behind the headline: cfg-3 (4K, "
+                         "compaction off and on), cfg-5 (4K, 16 spp), cfg-2 on the depth-10 scene -> the line's `configs` block.  "
+                         "auto: when the command is the headline's (1 GPU, 1920x1080, default scene and kernel); all: always; none")
+    ap.add_argument("--configs-scale", type=int, default=1,
+                    help="tests only: the `configs` block on frames 1/N the size and the deeper scene at --depth + 1 (no PMC pass matches)")
     ap.add_argument("--display", action="store_true",
                     help="fuse SdfBox's display pass (DisplayFrag.hlsl) into the epilogue: RGBA8 frames, 4x fewer "
                          "bytes stored and gathered (SURVEY 8f N2); the headline metric is measured without it")
@@ -641,16 +647,15 @@ def main():
         if sharded:
             mode += ":sharded"                         # other kernels instances (wire pixels, bands): no PMC pass of its own
         # ... and of the same grid (SDFHIP_TOP_GRID_LEVEL / _SPLIT change it): "grid9" dense, "grid8+blocks" split
-        lvl, gbytes = scene.top_grid_level, scene.top_grid_bytes
-        mode += f":grid{lvl}" + ("+blocks" if lvl and gbytes > (16 << (3 * lvl)) and pt is None else "")
+        mode += grid_suffix(scene, pt)
         pmc = load_pmc(f"{W}x{H}:{scene_name}:{mode}") if world == 1 else None
         roof = roofline(sec_per_step, own_bytes_rank, ref_bytes_rank, pmc, copy_gbs)
         # what the fraction divides by, so that it can be recomputed from profiles/: per_frame / time_ms / peak.  kernel_ms is
         # the HIP-event time around one frame's launches on their stream (k_march; overlapping the other frame in
         # flight), and frac_over_kernel_ms the same fraction over that longer time
         roof.update({"time_ms": round(sec_per_step * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch,
-                     "frac_over_kernel_ms": round(roof["frac"] * sec_per_step * 1e3 * frames_per_launch / kernel_ms, 4)
-                     if kernel_ms > 0 and roof["frac"] is not None else None})
+                     "kernel_ms_is": "average HIP-event time around one launch on its stream; with several frames in flight the launches overlap, "
+                                     "so this is longer than time_ms (the steady-state time per frame, which the fractions divide by)"})
         out = {
             "metric": "Mray/s (primary rays; frame W*H / time per frame)",
             "value": round(W * H * max(1, args.spp) / sec_per_step / 1e6, 2),
@@ -710,6 +715,14 @@ def main():
         }
         if check_ok is not None:
             out["config"]["assembled_frame_equals_whole_frame_render"] = check_ok
+        headline = (world == 1 and not sharded and (W, H) == (1920, 1080) and args.depth == 9 and not args.asdf and pt is None and not compact
+                    and not args.display and not args.one_kernel and not args.shadow_queue and not args.tile_order and args.orbit == 0
+                    and args.kernel == "auto")
+        if args.configs == "all" or (args.configs == "auto" and headline):
+            # (the headline's buffers are not needed any more: the path-traced configuration wants 30 GB of queues)
+            local = send = frame = gathered = None
+            torch.cuda.empty_cache()
+            out["configs"] = run_configs(sb, torch, scene, scene_name, copy_gbs, args.configs_scale, args.depth)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(od, cam, W, H, args.cpu_seconds)
         sys.stdout.flush()
@@ -844,7 +857,7 @@ def main_single_process(args, json_fd):
     ref_bytes = 8 * st.n_nodes + 8 * st.n_samples + px_bytes * W * H
     own_bytes = 16 * st.n_loads + px_bytes * W * H
     roof = roofline(sec_per_step, own_bytes, ref_bytes, None, measured_copy_bandwidth())
-    roof.update({"time_ms": round(sec_per_step * 1e3, 4), "note": "whole-node figure over the steady-state time per frame; no PMC pass exists for a multi-device run"})
+    roof.update({"time_ms": round(sec_per_step * 1e3, 4), "note": "no PMC pass exists for a multi-device run: no fraction, only the demand figures"})
     n_st = max(1, len(stats_seen))
     out = {
         "metric": "Mray/s (primary rays; frame W*H / time per frame)",
@@ -1043,20 +1056,24 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
     frames in flight the per-launch durations overlap), from the rocprofv3 counters of THIS build and workload
     (profiles/hbm_traffic.json; the PMC passes serialise launches: one frame in flight while they count, which changes times,
     not counts):
+      valu         issued VALU wave instructions per frame (SQ_INSTS_VALU) / time against the chip's SPEC issue rate, 1 228.8 G
+                   wave64 instructions per second (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles); `frac_of_measured_ceiling` beside it:
+                   against the rate of the cheapest instruction as measured on this chip (2.35 cycles, scripts/micro/valu_mix.hip)
       hbm_frac     HBM bytes per frame (2 x FETCH_SIZE + WRITE_SIZE, separate passes, the guide's gfx950 correction) / time
                    / 8 TB/s -- what BASELINE's "% of HBM roofline" asks; hbm_frac_of_measured_copy: the same over the
                    box's own device-to-device copy rate
-      valu_busy    SQ_ACTIVE_INST_VALU (quad-cycles a SIMD's VALU was executing) x 4 / (1024 SIMDs x 2.4 GHz x time): the
-                   measured utilisation of the vector pipes -- near 1 means the frame is bound by its VALU instructions
-      valu         issued VALU wave instructions per frame (SQ_INSTS_VALU) against the ceiling of the cheapest instruction
-                   (peak = measured 2.35 cycles; peak_spec = 2 cycles beside it)
-    `frac` is the larger of hbm-traffic and valu (both measured quantities against hard ceilings, <= 1) and `bound` names it.
-    Without a PMC pass of this build the only figure left is `algorithmic`: the bytes this kernel's own algorithm asks for per
-    frame (16 or 32 B per grid cell a LANE loads, the pixel store; counted by the counting build) -- a demand on the memory
-    system, not on HBM: the lanes of a wave mostly ask for the same few cells, which L1 serves once.  The reference
-    algorithm's bytes (8 B per node visit of find(), Compute.hlsl:88-108) are the work-equivalent rate: the
-    kernel does not perform those loads (one grid lookup replaces up to nine node visits).  Where that demand exceeds
-    8 TB/s, `frac` is null (`demand_over_hbm_peak` holds the ratio)."""
+      valu_busy    SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x 2.4 GHz x time).  NOT a utilisation: the counter charges every VALU
+                   instruction one quad-cycle whatever it costs, so this is the instruction count again, priced at 4 cycles
+    `frac` is the larger of valu (of spec) and hbm_frac -- both measured quantities against hard ceilings, <= 1 -- and `bound`
+    names it.  `pmc_stale` = true: the committed PMC pass was measured on other kernel sources (or there is none); then no
+    fraction is reported, only `demand`.
+    `demand`: the bytes this kernel's own algorithm asks of the MEMORY SYSTEM per frame (16 B per grid cell a LANE loads, the
+    pixel store; counted by the counting build) and the bytes the REFERENCE algorithm would read for the same pixels (SURVEY.md
+    8d: 8 B per node visit of find(), Compute.hlsl:88-108, 8 B per sample, the store), each over 8 TB/s x time.  Both ratios
+    exceed 1 on the bench frames: they are not fractions of any roof.  The kernel does not perform the reference's loads (one
+    lookup in a grid built at upload replaces the descent: 1.1 loads per step instead of 8.2), and of its own loads the lanes of
+    a wave mostly ask for the same few cells, which L1 and L2 serve (77 % / 72 % hits at 1080p): SURVEY 8d's algorithmic-bytes
+    roofline does not describe this design, the counters above do."""
     cands = {}
     traffic = None
     dropped = pmc.get("dropped") if isinstance(pmc, dict) else None
@@ -1070,39 +1087,139 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
         if copy_gbs:
             hbm_frac_copy = round(traffic / sec_per_frame / 1e9 / copy_gbs, 4)
         if pmc.get("valu_insts_per_frame"):
-            cands["valu"] = {"achieved": pmc["valu_insts_per_frame"] / sec_per_frame / 1e9, "peak": round(VALU_PEAK_GINSTR, 1),
-                             "peak_is": "measured: the cheapest VALU instruction, 2.35 cycles per wave64 instruction (scripts/micro/valu_mix.hip)",
-                             "peak_spec": round(VALU_PEAK_SPEC_GINSTR, 1), "unit": "G wave-instr/s", "per_frame": int(pmc["valu_insts_per_frame"])}
-            cands["valu"]["frac_of_spec"] = round(cands["valu"]["achieved"] / VALU_PEAK_SPEC_GINSTR, 4)
+            ach = pmc["valu_insts_per_frame"] / sec_per_frame / 1e9
+            cands["valu"] = {"achieved": ach, "peak": round(VALU_PEAK_SPEC_GINSTR, 1),
+                             "peak_is": "spec: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
+                             "measured_ceiling": round(VALU_PEAK_GINSTR, 1),
+                             "measured_ceiling_is": "the cheapest VALU instruction on this chip, 2.35 cycles (scripts/micro/valu_mix.hip)",
+                             "frac_of_measured_ceiling": round(ach / VALU_PEAK_GINSTR, 4),
+                             "unit": "G wave-instr/s", "per_frame": int(pmc["valu_insts_per_frame"])}
         if pmc.get("valu_active_quad_cycles_per_frame"):
             valu_busy = round(pmc["valu_active_quad_cycles_per_frame"] * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9 * sec_per_frame), 4)
-    measured = bool(cands)
-    if not measured:
-        cands["hbm-algorithmic"] = {"achieved": own_bytes / sec_per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": int(own_bytes)}
     for c in cands.values():
         c["frac"] = round(c["achieved"] / c["peak"], 4)
         c["achieved"] = round(c["achieved"], 1)
-    name = max(cands, key=lambda k: cands[k]["frac"])
-    b = cands[name]
-    if not measured and b["frac"] > 1.0:
-        # a demand above 8 TB/s is served by L1 / L2, not by HBM: it is not a fraction of any roof, so none is reported
-        b["demand_over_hbm_peak"] = b["frac"]
-        b["frac"] = None
+    if cands:
+        name = max(cands, key=lambda k: cands[k]["frac"])
+        b = cands[name]
+    else:
+        name, b = None, {"achieved": None, "peak": None, "unit": None, "frac": None}
+    own_over, ref_over = own_bytes / sec_per_frame / 1e9 / HBM_PEAK_GBS, ref_bytes / sec_per_frame / 1e9 / HBM_PEAK_GBS
     return {
-        "bound": "hbm" if name.startswith("hbm") else "valu",
+        "bound": None if name is None else ("hbm" if name.startswith("hbm") else "valu"),
         "binding": name,
         "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"],
-        "frac_is_measured_against_a_ceiling": measured,
-        "hbm_frac": hbm_frac, "hbm_frac_of_measured_copy": hbm_frac_copy, "valu_busy": valu_busy,
+        "pmc_stale": not cands,
+        "hbm_frac": hbm_frac, "hbm_frac_of_measured_copy": hbm_frac_copy,
+        "valu_frac_of_spec": cands["valu"]["frac"] if "valu" in cands else None,
+        "valu_frac_of_measured_ceiling": cands["valu"]["frac_of_measured_ceiling"] if "valu" in cands else None,
+        "valu_busy": valu_busy,
+        "valu_busy_is": "SQ_ACTIVE_INST_VALU x 4 cycles over the SIMD-cycles of the frame: every instruction is charged one quad-cycle, "
+                        "so this is the instruction count at 4 cycles each, not a measured utilisation",
         "traffic": traffic,
         "traffic_source": ({"profile": pmc.get("profile"), "kernel_source_sha": pmc.get("kernel_source_sha"),
                             "frames_in_flight_while_counting": 1} if pmc else
                            (dropped or "no PMC pass of this build and workload under profiles/ (scripts/profile.sh)")),
         "candidates": cands,
-        "algorithmic": {"own_bytes_per_frame": int(own_bytes), "own_gbs": round(own_bytes / sec_per_frame / 1e9, 1),
-                        "reference_bytes_per_frame": int(ref_bytes), "reference_gbs": round(ref_bytes / sec_per_frame / 1e9, 1)},
+        "demand": {"own_bytes_per_frame": int(own_bytes), "own_demand_over_hbm_peak": round(own_over, 3),
+                   "reference_bytes_per_frame": int(ref_bytes), "reference_demand_over_hbm_peak": round(ref_over, 3),
+                   "note": "requests to the memory system over 8 TB/s x time, NOT roofline fractions: the lookup grid built at upload replaces "
+                           "the reference's descent and L1 / L2 serve most of the kernel's own loads (see roofline() in bench.py)"},
         "measured_copy_gbs": copy_gbs,
     }
+
+
+def bench_camera(sb, W, H):
+    """SURVEY.md 8d cfg-2's camera"""
+    cam = sb.Logic(W, H)
+    cam.Position = (0.5, 0.5, -0.35)
+    cam.Heading = (-0.2, 0.35)            # (X = pitch, Y = yaw), Logic.cs:53
+    return cam
+
+
+def grid_suffix(scene, pt=None):
+    """The part of a PMC key that names the scene's grid: "grid9" dense, "grid8+blocks" split (SDFHIP_TOP_GRID_LEVEL / _SPLIT change it)"""
+    lvl, gbytes = scene.top_grid_level, scene.top_grid_bytes
+    return f":grid{lvl}" + ("+blocks" if lvl and gbytes > (16 << (3 * lvl)) and pt is None else "")
+
+
+def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9):
+    """BASELINE.json's other single-GPU configurations, timed in this process behind the headline: the same
+    clock (host time around `steps` frames, synchronised on both sides, frames in flight on their own streams), the HIP-event
+    time of a launch beside it, and the counter fractions from the committed PMC pass of the SAME command line
+    (profiles/hbm_traffic.json -> profiles/<tag>_pmc.json, formulas in profiles/README.md) when it was measured on this build's
+    kernel sources -- else pmc_stale and no fraction."""
+    out = {}
+    suffix9 = grid_suffix(scene)                      # (before the path-traced mode adds its second grid to the byte count)
+
+    def measure(name, sc, sname, W, H, mode, suffix, flags=0, pt=None, steps=60, warmup=12, nbuf=6, note=None):
+        cam = bench_camera(sb, W, H)
+        bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+        streams = [torch.cuda.Stream() for _ in range(nbuf)]
+
+        def launch(k):
+            s = streams[k % nbuf].cuda_stream
+            if pt is not None:
+                sc.DrawPathDevice(cam, W, H, bufs[k % nbuf].data_ptr(), pt=pt, flags=flags, stream=s)
+            else:
+                sc.DrawDevice(cam, W, H, bufs[k % nbuf].data_ptr(), flags=flags, stream=s)
+        for k in range(warmup):
+            launch(k)
+        torch.cuda.synchronize()
+        ev = []
+        t0 = time.perf_counter()
+        for k in range(steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(streams[k % nbuf])
+            launch(k)
+            e1.record(streams[k % nbuf])
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / steps
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        spp = pt.spp if pt is not None else 1
+        key = f"{W}x{H}:{sname}:{mode}{suffix}"
+        pmc = load_pmc(key)
+        stale = "dropped" in pmc
+        e = {"workload": f"{W}x{H}, {sname}, " + (f"path trace {spp} spp, 3 diffuse bounces" if pt is not None else
+                                                   "primary-ray sphere trace + shadow march") + (", " + note if note else ""),
+             "ms_per_step": round(sec * 1e3, 4), "value": round(W * H * spp / sec / 1e6, 2), "unit": "Mray/s",
+             "steps": steps, "warmup": warmup, "frames_in_flight": nbuf, "kernel_ms": round(kernel_ms, 4),
+             "pmc_key": key, "pmc_stale": stale,
+             "hbm_frac": None, "valu_frac_of_spec": None, "traffic": None, "valu_insts_per_frame": None,
+             "profile": None if stale else pmc.get("profile"), "kernel_source_sha": kernel_source_hash()}
+        if stale:
+            e["pmc_dropped"] = pmc["dropped"]
+        else:
+            e["traffic"] = int(pmc["hbm_bytes_per_frame"])
+            e["hbm_frac"] = round(e["traffic"] / sec / 1e9 / HBM_PEAK_GBS, 4)
+            e["hbm_frac_of_measured_copy"] = round(e["traffic"] / sec / 1e9 / copy_gbs, 4) if copy_gbs else None
+            if pmc.get("valu_insts_per_frame"):
+                e["valu_insts_per_frame"] = int(pmc["valu_insts_per_frame"])
+                e["valu_frac_of_spec"] = round(pmc["valu_insts_per_frame"] / sec / 1e9 / VALU_PEAK_SPEC_GINSTR, 4)
+            e["bound"] = "hbm" if (e["hbm_frac"] or 0) >= (e["valu_frac_of_spec"] or 0) else "valu"
+        out[name] = e
+        del bufs, streams
+        torch.cuda.empty_cache()
+
+    W4, H4, W2, H2 = 3840 // scale, 2160 // scale, 1920 // scale, 1080 // scale
+    measure("cfg3_4k", scene, scene_name, W4, H4, "default", suffix9,
+            note="BASELINE cfg-3's frame with compaction OFF (the default kernel: faster than either form of compaction)")
+    measure("cfg3_4k_compact", scene, scene_name, W4, H4, "compact", suffix9, flags=sb.FLAG_COMPACT, steps=20, warmup=4, nbuf=2,
+            note="BASELINE cfg-3 as named: wavefront ray compaction ON (persistent waves, ballot / prefix lane refill: k_compact)")
+    pt = sb.PathTrace(spp=16)
+    sb._lib.check(sb._lib.lib.sdfhip_scene_prepare_path(scene._h))       # the bounce levels' grid, at load time
+    measure("cfg5_4k_spp16", scene, scene_name, W4, H4, "spp16", grid_suffix(scene, pt), pt=pt, steps=6, warmup=2, nbuf=2,
+            note="BASELINE cfg-5 on one GPU")
+    # cfg-2 at the reference application's default depth (Model.MaxDepth = 10, SdfBox/Model.cs:18)
+    t0 = time.time()
+    od10 = sb.dragon_standin(depth + 1, nthreads=max(1, min(32, os.cpu_count() or 1)))
+    t_gen = time.time() - t0
+    with sb.Scene(od10, device=scene.device) as sc10:
+        measure("cfg2_depth10", sc10, f"dragon_standin_d{depth + 1}", W2, H2, "default", grid_suffix(sc10),
+                note=f"N={od10.Length} nodes, {od10.nbytes / 1e6:.0f} MB, built in {t_gen:.1f} s")
+    del od10
+    return out
 
 
 def measured_copy_bandwidth(nbytes=1 << 30, reps=10):

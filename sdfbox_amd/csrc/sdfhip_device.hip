@@ -627,6 +627,8 @@ struct sdfhip_scene {
         uint32_t *ctl;               // hit fill counts (two sets), then the compact kernel's tile queues
         uint32_t launches;           // two-kernel launch pairs so far: its parity selects the set of fill counts
         uint64_t last_use;           // the handle's render count when this scratch was last handed out (the oldest idle one is recycled)
+        hipEvent_t idle;             // the library's own event behind the last launch that used this scratch: "is it idle?" never asks the
+                                     // caller's stream handle, which may have been destroyed since
         char *pt_buf;                // path-traced pipeline: two hit queues, then the per-path results
         size_t pt_bytes;
         // SDFHIP_FLAG_TILE_ORDER: the wave-iterations of every tile of the last frame rendered on this stream, the launch order
@@ -713,6 +715,7 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
             if (s->scratch[i].ord_class) (void)hipFree(s->scratch[i].ord_class);
             if (s->scratch[i].ord_perm) (void)hipFree(s->scratch[i].ord_perm);
             if (s->scratch[i].ctl) (void)hipFree(s->scratch[i].ctl);
+            if (s->scratch[i].idle) (void)hipEventDestroy(s->scratch[i].idle);
         }
         if (s->d_frame) (void)hipFree(s->d_frame);
         for (int b = 0; b < sdfhip_scene::HOST_BANDS; b++) {
@@ -988,6 +991,11 @@ extern "C" int sdfhip_scene_top_grid(const sdfhip_scene *s, int32_t *level, uint
     return SDFHIP_OK;
 }
 
+bool sdfhip::scene_has_full_depth_grid(const sdfhip_scene *s)
+{
+    return s && s->stack_ok && s->d_top && (s->fine_bits || (uint32_t)s->top_level >= s->depth);     // render_impl's `two`
+}
+
 extern "C" int sdfhip_scene_info(const sdfhip_scene *s, uint32_t *n, uint32_t *depth,
                                  int *stack_kernel_ok, int *device)
 {
@@ -1053,7 +1061,9 @@ int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::S
         // order is dropped by the geometry / camera check or is simply a valid order of the same tiles.)
         int best = -1;
         for (int i = 0; i < s->n_scratch; i++) {
-            if (hipStreamQuery(s->scratch[i].stream) != hipSuccess) { (void)hipGetLastError(); continue; }
+            // (the slot's own event, not hipStreamQuery on its stream: a host that makes a stream per frame destroys them, and a
+            // stale handle must not be handed back to HIP)
+            if (hipEventQuery(s->scratch[i].idle) != hipSuccess) { (void)hipGetLastError(); continue; }
             if (best < 0 || s->scratch[i].last_use < s->scratch[best].last_use) best = i;
         }
         if (best < 0)
@@ -1066,11 +1076,12 @@ int get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_scene::S
     }
     if (!sc) {
         sc = &s->scratch[s->n_scratch];
-        sc->stream = st; sc->hit_buf = nullptr; sc->records = 0; sc->ctl = nullptr; sc->launches = 0; sc->pt_buf = nullptr; sc->pt_bytes = 0;
+        sc->stream = st; sc->hit_buf = nullptr; sc->records = 0; sc->ctl = nullptr; sc->launches = 0; sc->pt_buf = nullptr; sc->pt_bytes = 0; sc->idle = nullptr;
         sc->ord_cost = nullptr; sc->ord_class = nullptr; sc->ord_perm = nullptr; sc->ord_tiles = sc->ord_blocks = 0; sc->ord_valid = false; memset(sc->ord_sig, 0, sizeof sc->ord_sig);
         const size_t ctl_bytes = (sdfhip_scene::CTL_HIT_WORDS + sdfhip_scene::CTL_QUEUE_WORDS + sdfhip_scene::CTL_PT_WORDS +
                                   sdfhip_scene::CTL_COUNTER_WORDS) * sizeof(uint32_t);
-        HIP_TRY(hipMalloc((void **)&sc->ctl, ctl_bytes));
+        HIP_TRY(hipEventCreateWithFlags(&sc->idle, hipEventDisableTiming));
+        { const hipError_t em = hipMalloc((void **)&sc->ctl, ctl_bytes); if (em != hipSuccess) { (void)hipEventDestroy(sc->idle); return fail(SDFHIP_ERR_DEVICE, "hipMalloc(scratch) failed: %s", hipGetErrorString(em)); } }
         // zeroed IN the stream that will use it: a hipMemset on the null stream is not ordered against a non-blocking
         // stream (the first frame on a new scratch would, now and then, have met counters that were not zero yet)
         HIP_TRY(hipMemsetAsync(sc->ctl, 0, ctl_bytes, st));
@@ -1398,6 +1409,7 @@ int render_impl(sdfhip_scene *s, const sdfhip_info *info, uint32_t width, uint32
     else if (cur == CUR_STACK)      { if (count) launch_pair<CUR_STACK, true>(compact, bt, grid, st, P); else launch_pair<CUR_STACK, false>(compact, bt, grid, st, P); }
     else                            { if (count) launch_pair<CUR_GENERIC, true>(compact, bt, grid, st, P); else launch_pair<CUR_GENERIC, false>(compact, bt, grid, st, P); }
     HIP_TRY(hipGetLastError());
+    if (sc) HIP_TRY(hipEventRecord(sc->idle, st));        // this stream's scratch is busy until here
     if (stats) {
         HIP_TRY(hipEventRecord(s->ev1, st));
         HIP_TRY(hipEventSynchronize(s->ev1));

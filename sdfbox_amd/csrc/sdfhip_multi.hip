@@ -58,6 +58,7 @@ struct Rccl {
     void *handle = nullptr;
     int (*CommInitAll)(void **, int, const int *) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -75,6 +76,7 @@ struct Rccl {
         if (!handle) return false;
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(handle, "ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(handle, "ncclCommAbort"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(handle, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(handle, "ncclGroupEnd"));
         Send = reinterpret_cast<decltype(Send)>(dlsym(handle, "ncclSend"));
@@ -150,9 +152,11 @@ struct Worker {
 struct RankBuf {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_sent = nullptr;
-    uint8_t *d_share = nullptr;            // on the rank's device: what it renders (sparse share, or dense RGBA32F bands)
+    uint8_t *d_share = nullptr;            // on the rank's device: the sparse share it renders (its header word 0 is a counter that runs on
+                                           // from launch to launch: nothing else may ever be written into this buffer)
+    uint8_t *d_bands = nullptr;            // on the rank's device: dense bands (path-traced mode, scenes without a full-depth grid)
     uint8_t *d_gather = nullptr;           // on rank 0's device: where rank r > 0's share lands (sparse mode)
-    size_t share_cap = 0, gather_cap = 0;  // bytes allocated
+    size_t share_cap = 0, bands_cap = 0, gather_cap = 0;  // bytes allocated
     uint32_t count_base = 0;               // the share's counter before this slot's launch (it is never zeroed, see sdfhip_render_sparse_device)
     uint32_t sent = 0;                     // floats copied with this slot's share
 };
@@ -163,12 +167,13 @@ struct Slot {
     hipEvent_t ev_rx = nullptr, ev_done = nullptr, ev_t0 = nullptr;
     uint8_t *d_frames = nullptr;           // rank 0's device: the assembled frames (when the caller gave no buffer)
     size_t frames_cap = 0;
-    uint8_t *d_dense = nullptr;            // rank 0's device: [world] dense shares (path-traced mode)
+    uint8_t *d_dense = nullptr;            // rank 0's device: [world] dense shares (path-traced mode, scenes without a full-depth grid)
     size_t dense_cap = 0;
+    uint32_t dense_px = 16;                // bytes per pixel of this submission's dense shares (4 with the display pass)
     uint32_t *h_counts = nullptr;          // pinned, [MAX_RANKS]: the shares' counters as the assembly kernel found them
     uint32_t last_used[MAX_RANKS] = { 0 };
     void *out = nullptr;                   // where this submission's frames go (the caller's buffer or d_frames)
-    bool busy = false, path = false, dirty = false;   // dirty: a submission failed half-way: the shares' counters are re-zeroed before the next one
+    bool busy = false, path = false, dirty = false;   // path: dense shares (see d_dense); dirty: a submission failed half-way: the shares' counters are re-zeroed before the next one
     uint32_t n_frames = 0, width = 0, height = 0, flags = 0;
     std::chrono::steady_clock::time_point t_submit;
 };
@@ -220,6 +225,9 @@ struct sdfhip_multi {
     float rank0_weight = 1.0f;
     uint32_t est[MAX_RANKS];               // floats to send with a rank's next share (0: not measured yet, send all)
     bool use_rccl = false, rccl_self = false;
+    bool dense_only = false;               // a device's scene has no full-depth grid (depth > 12, inconsistent links, no memory for the grid):
+                                           // the default kernel cannot write sparse shares there, so every frame gathers dense bands
+    bool broken = false;                   // RCCL transport: a submission failed between its receives and its sends; only sdfhip_multi_free is left
     Rccl rccl;
     void *comms[MAX_RANKS];
     uint64_t resends = 0;
@@ -228,6 +236,7 @@ struct sdfhip_multi {
     struct Job {
         sdfhip_multi *m; uint32_t slot; const sdfhip_info *infos; uint32_t n_frames, width, height, flags, capacity;
         const sdfhip_pathtrace *pt;
+        bool dense;                         // dense bands instead of sparse shares (pt, or dense_only)
         // upload
         const int32_t *structs; const uint8_t *values; uint32_t n_nodes;
     } job;
@@ -287,12 +296,12 @@ int rank_submit(void *arg, uint32_t r)
     const Layout &L = m->lay;
     if (L.bands[r].empty()) { B.sent = 0; return SDFHIP_OK; }              // more ranks than bands: nothing to do
     M_TRY(hipEventRecord(B.ev_start, B.stream));
-    if (J.pt) {
-        // dense RGBA32F bands; rank 0 renders straight into its place in the gathered array
-        const size_t share = (size_t)L.rows_per_rank * L.width * 16;
+    if (J.dense) {
+        // dense bands (RGBA32F, or RGBA8 through the display pass); rank 0 renders straight into its place in the gathered array
+        const size_t share = (size_t)J.n_frames * L.rows_per_rank * L.width * S.dense_px;
         uint8_t *dst = S.d_dense + (size_t)r * share;
-        uint8_t *out = r == 0 ? dst : B.d_share;
-        int rc = sdfhip_render_bands_device(m->scenes[r], J.infos, 1, J.pt, L.width, L.height, L.band_rows, L.bands[r].data(),
+        uint8_t *out = r == 0 ? dst : B.d_bands;
+        int rc = sdfhip_render_bands_device(m->scenes[r], J.infos, J.n_frames, J.pt, L.width, L.height, L.band_rows, L.bands[r].data(),
                                             (uint32_t)L.bands[r].size(), L.rows_per_rank, J.flags, reinterpret_cast<float *>(out),
                                             B.stream, nullptr);
         if (rc != SDFHIP_OK) return rc;
@@ -361,7 +370,7 @@ int prepare_slot(sdfhip_multi *m, Slot &S, uint32_t n_frames, bool path, bool in
         RankBuf &B = S.rb[r];
         DevGuard g(m->devices[r]);
         if (path) {
-            if (r > 0) { int rc = grow(&B.d_share, &B.share_cap, (size_t)L.rows_per_rank * L.width * 16, B.stream); if (rc) return rc; }
+            if (r > 0) { int rc = grow(&B.d_bands, &B.bands_cap, (size_t)n_frames * L.rows_per_rank * L.width * frame_px_bytes, B.stream); if (rc) return rc; }
         } else {
             const ShareShape sh = share_shape(m, n_frames);
             const uint8_t *before = B.d_share;
@@ -379,7 +388,7 @@ int prepare_slot(sdfhip_multi *m, Slot &S, uint32_t n_frames, bool path, bool in
         }
     }
     DevGuard g0(m->devices[0]);
-    if (path) { int rc = grow(&S.d_dense, &S.dense_cap, (size_t)m->n * L.rows_per_rank * L.width * 16, S.rb[0].stream); if (rc) return rc; }
+    if (path) { int rc = grow(&S.d_dense, &S.dense_cap, (size_t)m->n * n_frames * L.rows_per_rank * L.width * frame_px_bytes, S.rb[0].stream); if (rc) return rc; }
     if (internal_frames) { int rc = grow(&S.d_frames, &S.frames_cap, (size_t)n_frames * L.width * L.height * frame_px_bytes, S.rb[0].stream); if (rc) return rc; }
     S.dirty = false;
     return SDFHIP_OK;
@@ -397,7 +406,7 @@ int assemble(sdfhip_multi *m, Slot &S, int only_rank)
     const uint8_t *owner = (L.weight < 1.0f && m->n > 1) ? L.owner.data() : nullptr;
     if (S.path)
         return sdfhip_deinterleave_bands_device(m->devices[0], S.d_dense, S.out, L.width, L.height, L.band_rows, m->n, L.rows_per_rank,
-                                                L.owner.data(), 16, 1, st);
+                                                L.owner.data(), S.dense_px, S.n_frames, st);
     const void *shares[MAX_RANKS];
     for (uint32_t r = 0; r < m->n; r++) shares[r] = (r == 0 && !m->rccl_self) ? S.rb[0].d_share : S.rb[r].d_gather;
     const ShareShape sh = share_shape(m, S.n_frames);
@@ -417,7 +426,7 @@ int post_receives(sdfhip_multi *m, Slot &S)
     for (uint32_t r = 1; r < m->n; r++) {
         if (L.bands[r].empty()) continue;
         if (S.path) {
-            const size_t share = (size_t)L.rows_per_rank * L.width * 16;
+            const size_t share = (size_t)S.n_frames * L.rows_per_rank * L.width * S.dense_px;
             if ((e = m->rccl.Recv(S.d_dense + (size_t)r * share, share, NCCL_UINT8, (int)r, m->comms[0], S.rx_stream)) != 0) return nccl_fail(m, e, "ncclRecv");
         } else {
             const ShareShape sh = share_shape(m, S.n_frames);
@@ -428,6 +437,25 @@ int post_receives(sdfhip_multi *m, Slot &S)
     if ((e = m->rccl.GroupEnd()) != 0) return nccl_fail(m, e, "ncclGroupEnd");
     M_TRY(hipEventRecord(S.ev_rx, S.rx_stream));
     return SDFHIP_OK;
+}
+
+// A submission (or the wait for one) failed half-way: whatever was issued is drained, the slot is free again and marked so
+// that the shares' counters are re-zeroed before its next use.  With the RCCL transport receives may be outstanding whose
+// sends were never issued; they cannot be taken back, so the handle refuses further work (sdfhip_multi_free aborts the comms).
+int abort_slot(sdfhip_multi *m, Slot &S, int rc)
+{
+    char msg[256];
+    strncpy(msg, sdfhip_last_error(), sizeof msg - 1); msg[sizeof msg - 1] = 0;
+    if (m->use_rccl && m->n > 1) m->broken = true;
+    else {
+        for (uint32_t r = 0; r < m->n; r++) {
+            DevGuard g(m->devices[r]);
+            if (S.rb[r].stream) (void)hipStreamSynchronize(S.rb[r].stream);
+        }
+        (void)hipGetLastError();
+    }
+    S.busy = false; S.dirty = true;
+    return fail(rc, "%s", msg);
 }
 
 int submit_locked(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint32_t n_frames, const sdfhip_pathtrace *pt,
@@ -441,6 +469,7 @@ int submit_locked(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint
         return fail(SDFHIP_ERR_ARG, "multi_submit: flags %#x are not available across devices", flags);
     if (pt && (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG)))
         return fail(SDFHIP_ERR_ARG, "multi_submit: the display pass is not available in path-traced mode");
+    if (m->broken) return fail(SDFHIP_ERR_DEVICE, "multi_submit: an earlier submission failed with RCCL receives outstanding; free this handle and create a new one");
     Slot &S = m->slots[slot];
     if (S.busy) return fail(SDFHIP_ERR_ARG, "multi_submit: slot %u is in flight (sdfhip_multi_wait it first)", slot);
     const uint32_t frame_bands = (height + m->band_rows - 1) / m->band_rows;
@@ -454,37 +483,34 @@ int submit_locked(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint
         for (uint32_t r = 0; r < MAX_RANKS; r++) m->est[r] = 0;
     }
     const bool display = (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG)) != 0;
-    int rc = prepare_slot(m, S, n_frames, pt != nullptr, d_out == nullptr, display ? 4 : 16);
+    const bool dense = pt != nullptr || m->dense_only;
+    int rc = prepare_slot(m, S, n_frames, dense, d_out == nullptr, display ? 4 : 16);
     if (rc != SDFHIP_OK) return rc;
     S.out = d_out ? d_out : S.d_frames;
-    S.path = pt != nullptr; S.n_frames = n_frames; S.width = width; S.height = height; S.flags = flags;
+    S.path = dense; S.dense_px = display ? 4u : 16u; S.n_frames = n_frames; S.width = width; S.height = height; S.flags = flags;
     S.t_submit = std::chrono::steady_clock::now();
     m->job.m = m; m->job.slot = slot; m->job.infos = infos; m->job.n_frames = n_frames; m->job.width = width; m->job.height = height;
-    m->job.flags = flags & ~(uint32_t)(SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG);   // the display pass runs where the frame is assembled
-    m->job.pt = pt;
+    // sparse shares: the display pass runs where the frame is assembled; dense bands: where they are rendered
+    m->job.flags = dense ? flags : flags & ~(uint32_t)(SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG);
+    m->job.pt = pt; m->job.dense = dense;
     S.dirty = true;                                   // until everything below has been issued
     rc = post_receives(m, S);
-    if (rc != SDFHIP_OK) return rc;
-    rc = on_all_ranks(m, rank_submit);
-    if (rc != SDFHIP_OK) return rc;
-    rc = assemble(m, S, -1);
-    if (rc != SDFHIP_OK) return rc;
-    S.dirty = false;
-    {
+    if (rc == SDFHIP_OK) rc = on_all_ranks(m, rank_submit);
+    if (rc == SDFHIP_OK) rc = assemble(m, S, -1);
+    if (rc == SDFHIP_OK) {
         DevGuard g0(m->devices[0]);
-        M_TRY(hipEventRecord(S.ev_done, S.rb[0].stream));
+        const hipError_t e = hipEventRecord(S.ev_done, S.rb[0].stream);
+        if (e != hipSuccess) rc = fail(SDFHIP_ERR_DEVICE, "multi: hipEventRecord failed: %s", hipGetErrorString(e));
     }
+    if (rc != SDFHIP_OK) return abort_slot(m, S, rc);
+    S.dirty = false;
     S.busy = true;
     return SDFHIP_OK;
 }
 
-int wait_locked(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_stats *stats)
+int wait_body(sdfhip_multi *m, Slot &S, uint32_t &resent)
 {
-    if (slot >= MAX_SLOTS) return fail(SDFHIP_ERR_ARG, "multi_wait: slot %u of %u", slot, MAX_SLOTS);
-    Slot &S = m->slots[slot];
-    if (!S.busy) return fail(SDFHIP_ERR_ARG, "multi_wait: nothing was submitted to slot %u", slot);
     const Layout &L = m->lay;
-    uint32_t resent = 0;
     {
         DevGuard g0(m->devices[0]);
         M_TRY(hipEventSynchronize(S.ev_done));
@@ -519,6 +545,18 @@ int wait_locked(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_st
             S.last_used[r] = used;
         }
     }
+    return SDFHIP_OK;
+}
+
+int wait_locked(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_stats *stats)
+{
+    if (slot >= MAX_SLOTS) return fail(SDFHIP_ERR_ARG, "multi_wait: slot %u of %u", slot, MAX_SLOTS);
+    Slot &S = m->slots[slot];
+    if (!S.busy) return fail(SDFHIP_ERR_ARG, "multi_wait: nothing was submitted to slot %u", slot);
+    const Layout &L = m->lay;
+    uint32_t resent = 0;
+    const int rcw = wait_body(m, S, resent);
+    if (rcw != SDFHIP_OK) return abort_slot(m, S, rcw);
     m->resends += resent;
     S.busy = false;
     if (d_frames) *d_frames = S.out;
@@ -538,7 +576,7 @@ int wait_locked(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_st
                 stats->floats_used[r] = S.last_used[r];
                 if (r > 0) stats->gathered_bytes += sh.fixed + (uint64_t)S.rb[r].sent * 4;
             } else if (r > 0) {
-                stats->gathered_bytes += (uint64_t)L.rows_per_rank * L.width * 16;
+                stats->gathered_bytes += (uint64_t)S.n_frames * L.rows_per_rank * L.width * S.dense_px;
             }
         }
     }
@@ -565,6 +603,7 @@ extern "C" int sdfhip_multi_free(sdfhip_multi *m)
             DevGuard g(m->devices[r]);
             if (B.stream) (void)hipStreamSynchronize(B.stream);
             if (B.d_share) (void)hipFree(B.d_share);
+            if (B.d_bands) (void)hipFree(B.d_bands);
             if (B.ev_start) (void)hipEventDestroy(B.ev_start);
             if (B.ev_sent) (void)hipEventDestroy(B.ev_sent);
             if (B.stream) (void)hipStreamDestroy(B.stream);
@@ -580,7 +619,8 @@ extern "C" int sdfhip_multi_free(sdfhip_multi *m)
         if (S.ev_t0) (void)hipEventDestroy(S.ev_t0);
     }
     if (m->use_rccl)
-        for (uint32_t r = 0; r < m->n; r++) if (m->comms[r]) (void)m->rccl.CommDestroy(m->comms[r]);
+        for (uint32_t r = 0; r < m->n; r++)
+            if (m->comms[r]) (void)((m->broken && m->rccl.CommAbort) ? m->rccl.CommAbort(m->comms[r]) : m->rccl.CommDestroy(m->comms[r]));
     for (uint32_t r = 0; r < m->n; r++) if (m->scenes[r]) (void)sdfhip_scene_free(m->scenes[r]);
     delete m;
     return SDFHIP_OK;
@@ -647,6 +687,9 @@ extern "C" int sdfhip_multi_create(const int *devices, uint32_t n_devices, const
     m->job.structs = structs; m->job.values = values; m->job.n_nodes = n;
     int rc = on_all_ranks(m, rank_upload);
     if (rc != SDFHIP_OK) return bail(rc);
+    // sparse shares come from the default kernel, which needs a grid as deep as the tree; a scene without one (deeper than 12
+    // levels, inconsistent links, or no memory for the grid on some device) is gathered as dense bands instead
+    for (uint32_t r = 0; r < n_devices; r++) if (!scene_has_full_depth_grid(m->scenes[r])) m->dense_only = true;
     // transport of the gather
     const char *tr = getenv("SDFHIP_MULTI_TRANSPORT");
     if (tr && strcmp(tr, "rccl") == 0) {

@@ -261,8 +261,12 @@ class MultiScene:
     def Draw(self, state, width, height, flags=0, pt=None, want_stats=False, out=None):
         """One frame across the devices to a host array: (H, W, 4) float32, or uint8 with FLAG_DISPLAY[_DEBUG]."""
         display = bool(flags & (_lib.FLAG_DISPLAY | _lib.FLAG_DISPLAY_DEBUG))
+        want = np.uint8 if display else np.float32
         if out is None:
-            out = np.empty((int(height), int(width), 4), dtype=np.uint8 if display else np.float32)
+            out = np.empty((int(height), int(width), 4), dtype=want)
+        elif not isinstance(out, np.ndarray) or out.shape != (int(height), int(width), 4) or out.dtype != want or \
+                not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError(f"MultiScene.Draw: out must be a writeable C-contiguous {np.dtype(want).name} array of shape (height, width, 4)")
         st = MultiStats()
         info = state if isinstance(state, Info) else state.State
         if pt is not None:

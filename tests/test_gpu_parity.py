@@ -889,6 +889,30 @@ def test_a_stream_per_frame_and_counters_per_stream(sb, oracle_mod, scenes):
         assert (stats.n_nodes, stats.n_samples, stats.n_steps, stats.n_shadow_rays) == tuple(int(c) for c in cnt)
 
 
+def test_streams_created_and_destroyed_by_the_host(sb, oracle_mod, scenes):
+    # A host that really destroys its per-frame streams (hipStreamCreate / hipStreamDestroy, not torch's pooled streams): the
+    # handle's scratch slots must never hand a destroyed stream back to HIP -- idleness is asked of the library's own events --
+    # and the 17th, 18th, ... stream must find a slot.
+    import ctypes
+    import torch
+    hip = ctypes.CDLL("libamdhip64.so")
+    od = scenes["torus_d6"]
+    W, H = 160, 120
+    cam = make_camera("rotated", W, H)
+    ref, _ = oracle_mod.render(od.Structs, od.Values, cam.State, W, H, nthreads=8)
+    with sb.Scene(od) as sc:
+        buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        for k in range(48):
+            st = ctypes.c_void_p()
+            assert hip.hipStreamCreate(ctypes.byref(st)) == 0
+            flags = (sb.KERNEL_STACK | sb.FLAG_TILE_ORDER, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.FLAG_COUNT)[k % 3]
+            sc.DrawDevice(cam, W, H, buf.data_ptr(), flags=flags, stream=st.value)
+            assert hip.hipStreamSynchronize(st) == 0
+            assert_frames_identical(buf.cpu().numpy(), ref, f"frame {k} on a stream of its own")
+            assert hip.hipStreamDestroy(st) == 0
+
+
 def test_every_path_hits_and_the_scatter_grid_is_prepared(sb, oracle_mod, scenes):
     # the path-traced pipeline's hit queues hold the worst case: a camera inside the solid, every camera ray a hit at its first
     # step; sdfhip_scene_prepare_path builds the bounce levels' grid ahead of the first path-traced render (same pixels either way)

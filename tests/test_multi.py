@@ -149,6 +149,71 @@ def test_multi_display_pass_and_path_traced_mode(sb, oracle_mod, scenes):
         assert_frames_identical(ms.Draw(cam, W, H, pt=pt), ref, "path-traced frame, weighted deal")
 
 
+@pytest.mark.gpu
+def test_multi_path_traced_frame_then_ordinary_frames_on_one_handle(sb, oracle_mod, scenes):
+    # A viewer that toggles path tracing: sdfhip_multi_render_path, then sdfhip_multi_render on the same slot.  The dense bands of the
+    # path-traced frame once went into the ranks' sparse-share buffers and overwrote the shares' running slot counters: the next
+    # ordinary frame lost every lit pixel of the ranks > 0.  Both kinds of share have their own buffers now.
+    od = scenes["torus_d6"]
+    W, H = 160, 96
+    cam = make_camera("rotated", W, H)
+    ref, _ = oracle_mod.render(od.Structs, od.Values, cam.State, W, H, nthreads=8)
+    pt = sb.PathTrace(spp=2)
+    ref_pt, _ = oracle_mod.render_pt(od.Structs, od.Values, cam.State, W, H, spp=pt.spp, max_bounces=pt.max_bounces, seed=pt.seed,
+                                     albedo=pt.albedo, nthreads=8)
+    for devices in ([0, 0], [0, 0, 0]):
+        with sb.MultiScene(od, devices) as ms:
+            assert_frames_identical(ms.Draw(cam, W, H), ref, "ordinary frame first")            # (the shares' counters have run on)
+            for k in range(2):
+                assert_frames_identical(ms.Draw(cam, W, H, pt=pt), ref_pt, f"path-traced frame {k}")
+                img, st = ms.Draw(cam, W, H, want_stats=True)
+                assert_frames_identical(img, ref, f"ordinary frame right after a path-traced one ({k})")
+                assert st.resends == 0
+                assert_frames_identical(ms.Draw(cam, W, H), ref, f"the frame after that ({k})")
+            # the same through the slots: a path-traced submission between two groups on one slot
+            ms.Submit(1, [cam, cam], W, H); ms.Wait(1)
+            ms.Submit(1, cam, W, H, pt=pt); ms.Wait(1)
+            ms.Submit(1, [cam, cam], W, H)
+            ptr, st = ms.Wait(1, want_stats=True)
+            assert st.resends == 0
+            assert_frames_identical(ms.Draw(cam, W, H), ref, "after the slots")
+        with pytest.raises(ValueError):
+            with sb.MultiScene(od, devices) as ms:
+                ms.Draw(cam, W, H, out=np.empty((H, W, 3), dtype=np.float32))                    # a wrong array is refused, not overrun
+
+
+@pytest.mark.gpu
+def test_multi_scene_without_a_full_depth_grid_gathers_dense_bands(sb, oracle_mod, scenes):
+    # sparse shares come from the default kernel, which needs a grid as deep as the tree.  A tree with inconsistent parent
+    # links (legal input: the shader just follows them) or deeper than 12 levels is rendered by the generic kernel on one
+    # device -- and across devices as dense bands, bit for bit the same frame.
+    od = scenes["sphere_d4"]
+    s = od.Structs.copy()
+    s[9:17, 0] = 2                                     # the block of node 1 claims node 2 as its parent
+    bad = sb.OctData(s, od.Values)
+    W, H = 120, 88
+    cam = make_camera("default", W, H)
+    ref, _ = oracle_mod.render(s, od.Values, cam.State, W, H)
+    with sb.Scene(bad) as one, sb.MultiScene(bad, [0, 0, 0]) as ms:
+        assert not one.stack_kernel_ok
+        assert_frames_identical(ms.Draw(cam, W, H), ref, "inconsistent tree over three ranks")
+        ms.configure(band_rows=8, rank0_weight=0.5)
+        img, st = ms.Draw(cam, W, H, want_stats=True)
+        assert_frames_identical(img, ref, "inconsistent tree, weighted deal")
+        assert st.gathered_bytes > 0
+        for dbg in (False, True):
+            assert (ms.Draw(cam, W, H, flags=sb.FLAG_DISPLAY_DEBUG if dbg else sb.FLAG_DISPLAY) == one.DrawDisplay(cam, W, H, debug=dbg)).all()
+        ms.Submit(2, [cam, make_camera("rotated", W, H)], W, H)          # a group of two frames, dense
+        ptr = ms.Wait(2)
+        import torch
+        frames = torch.empty((2, H, W, 4), dtype=torch.float32, device="cuda")
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(ctypes.c_void_p(frames.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(frames.numel() * 4), 3) == 0
+        assert_frames_identical(frames[0].cpu().numpy(), ref, "group frame 0")
+        ref2, _ = oracle_mod.render(s, od.Values, make_camera("rotated", W, H).State, W, H)
+        assert_frames_identical(frames[1].cpu().numpy(), ref2, "group frame 1")
+
+
 @pytest.fixture(scope="module")
 def dragon(sb):
     od = sb.dragon_standin(9)
