@@ -85,8 +85,8 @@ def parse():
                     help="sharded runs: rank 0's share of the frame as a fraction of a peer's share "
                          "(0 = measure at start-up so that render + assembly on rank 0 takes as long as a peer's render)")
     ap.add_argument("--sparse-cap-scale", type=float, default=1.25,
-                    help="sparse wire shares: capacity = this x the lit pixels measured before the timed region (a value "
-                         "below 1 forces overflows, to exercise the dense resend)")
+                    help="sparse shares: the floats that travel with a share = this x the lit pixels measured before the timed region (a value "
+                         "below 1 forces tails to be sent again)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 (or --devices) through the library's own multi-device entry points (sdfhip_multi_*: one process, one "
                          "host thread and stream per device, peer copies or RCCL inside the library) instead of one process per GPU "
@@ -96,12 +96,9 @@ def parse():
     ap.add_argument("--multi-mode", default="groups", choices=["groups", "frame"],
                     help="--single-process: 'groups' = groups of --gather-every frames, four groups in flight (throughput); "
                          "'frame' = one frame at a time across all devices, launch to completion (what a viewer waits for)")
-    ap.add_argument("--wire", type=int, default=3,
-                    help="sharded runs: what the ranks send.  3 = sparse shares written by the march kernel itself (per 8x8 tile "
-                         "a mask, the code bytes and the non-zero grey levels; the floats that travel are measured before the timed "
-                         "region, a longer tail is sent again), 2 = the same format made by three compaction kernels from dense wire "
-                         "shares (round 2's form), 1 = 5-byte wire pixels, 0 = RGBA32F pixels.  Rank 0 expands 1-3 to the same "
-                         "RGBA32F frame, bit for bit")
+    ap.add_argument("--lab", action="store_true",
+                    help="load the experiments flavour of the library (libsdfhip_lab.so, include/sdfhip_experimental.h): needed by the A/B "
+                         "forms --one-kernel and --shadow-queue")
     return ap.parse_args()
 
 
@@ -129,10 +126,10 @@ def main():
     import torch
     import torch.distributed as dist
 
-    import sdfbox_amd as sb
-    from sdfbox_amd.tiles import (BandLayout, deinterleave, deinterleave_share, deinterleave_sparse, deinterleave_sparse2, render_bands,
-                                  render_bands_batch, render_sparse2, sparse2_bytes, sparse2_floats_offset, sparse_count, sparse_headers,
-                                  sparse_share_bytes, wire_compact, wire_shape)
+    sb = load_package(args)
+    BandLayout, deinterleave, deinterleave_sparse2, render_bands, render_bands_batch, render_sparse2, sparse2_bytes, sparse2_floats_offset = (
+        sb.tiles.BandLayout, sb.tiles.deinterleave, sb.tiles.deinterleave_sparse2, sb.tiles.render_bands, sb.tiles.render_bands_batch,
+        sb.tiles.render_sparse2, sb.tiles.sparse2_bytes, sb.tiles.sparse2_floats_offset)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
@@ -183,20 +180,14 @@ def main():
         (sb.FLAG_TILE_ORDER if args.tile_order else 0)
     px_shape, px_dtype, px_bytes = ((), torch.int32, 4) if args.display else ((4,), torch.float32, 16)
     pt = sb.PathTrace(spp=args.spp) if args.spp > 0 else None
-    # what travels in the gather: the frame's own pixels, or 5-byte wire pixels that rank 0 expands
-    # to the RGBA32F frame while it restores row order (lossless; sdfbox_amd/tiles.py)
-    wire = sharded and args.wire >= 1 and not args.display and pt is None and not compact
-    # 3: the march kernel writes the sparse share itself (sdfhip_render_sparse_device) -- where the scene has a full-depth grid
-    sparse2 = wire and args.wire == 3 and scene.top_grid_level > 0 and scene.stack_kernel_ok
-    if sparse2:
-        wire = False
-    sparse = wire and args.wire >= 2       # ... compacted before the gather: most of the float plane is zeros (sky)
-    wpx_dtype, wpx_bytes = (torch.uint8, 5) if wire else (px_dtype, px_bytes)
+    # what travels in the gather: the sparse shares the march kernel writes itself (sdfhip_render_sparse_device) wherever the scene
+    # has a grid as deep as the tree and the frame is the default kernel's; else the frame's own pixels (path-traced mode, display
+    # pass, compaction, trees without such a grid)
+    sparse2 = sharded and not args.display and pt is None and not compact and not args.one_kernel and not args.shadow_queue and \
+        scene.top_grid_level > 0 and scene.stack_kernel_ok
 
-    def share_shape(rows):                 # one frame-share of `rows` rows as it is rendered and gathered
-        return wire_shape(rows, W) if wire else (rows, W) + px_shape
-    if wire:
-        flags |= sb.FLAG_WIRE
+    def share_shape(rows):                 # one dense frame-share of `rows` rows as it is rendered and gathered
+        return (rows, W) + px_shape
     if pt is not None and (args.display or compact):
         raise SystemExit("--spp excludes --display and --compact")
 
@@ -218,15 +209,15 @@ def main():
     # renders a smaller share: --rank0-weight, or measured here before anything is timed
     w0 = args.rank0_weight if world > 1 else 1.0
     if sharded and world > 1 and w0 <= 0:
-        w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, share_shape, wpx_dtype, wpx_bytes,
-                                  rank, nccl, pt, compact, G, nbuf, sparse, sparse2)
+        w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, share_shape, px_dtype, px_bytes,
+                                  rank, nccl, pt, compact, G, nbuf, sparse2)
     if (H + args.band_rows - 1) // args.band_rows > 512 or w0 > 0.98:
         w0 = 1.0
     layout = BandLayout(H, world, args.band_rows, w0)
     streams = [torch.cuda.Stream() for _ in range(nbuf)]                       # one per group in flight
     main = torch.cuda.current_stream().cuda_stream
     rows_local = layout.rows_per_rank if sharded else H
-    local = [torch.zeros((G,) + share_shape(rows_local), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)] if not sparse2 else None
+    local = [torch.zeros((G,) + share_shape(rows_local), dtype=px_dtype, device="cuda") for _ in range(nbuf)] if not sparse2 else None
     gathered = frame = None
     # sparse2: a share holds the G frames of a group and room for every float; what travels is its fixed part and the first
     # `s2_send` floats (measured now, x --sparse-cap-scale); a share that needed more sends the tail again, point to point
@@ -251,7 +242,7 @@ def main():
             s2["gath"] = [torch.zeros((world, s2["bytes"]), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
             s2["counts"] = [torch.zeros(world, dtype=torch.int32).pin_memory() for _ in range(nbuf)]
             s2["bases"] = [[0] * world for _ in range(nbuf)]
-    if sharded and world > 1 and (sparse or sparse2):
+    if sharded and world > 1 and sparse2:
         # the point-to-point path of a resend, used once before anything is timed: the first send / recv between two ranks sets
         # their channel up (with NCCL: hundreds of milliseconds), and the first overflow of a run may come inside the timed region
         probe = torch.zeros(1, dtype=torch.int32, device="cuda" if nccl else "cpu")
@@ -262,49 +253,17 @@ def main():
             dist.send(probe, dst=0)
         if nccl:
             torch.cuda.synchronize()
-    send = local                                    # what the gather carries
-    cap = 0
-    overflow = torch.zeros(1, dtype=torch.int32, device="cuda")
-    if sparse:
-        # capacity of the packed float array: this rank's lit pixels per frame-share, the maximum over the
-        # ranks (a control-plane all-reduce before anything is timed), plus a quarter
-        full_cap = rows_local * W
-        probe = torch.zeros((G, sparse_share_bytes(rows_local, W, full_cap)), dtype=torch.uint8, device="cuda")
-        render_bands_batch(scene, [cam] * G, W, layout, rank, local[0].data_ptr(), flags=flags, stream=main)
-        wire_compact(device, local[0].data_ptr(), probe.data_ptr(), W, rows_local, G, full_cap, stream=main)
-        counts, _ = sparse_count(probe, rows_local, W, full_cap)
-        need = torch.tensor([max(counts)], dtype=torch.int64, device="cuda" if nccl else "cpu")
-        if world > 1:
-            dist.all_reduce(need, op=dist.ReduceOp.MAX)
-        cap = min(full_cap, max(1024, (int(int(need.item()) * args.sparse_cap_scale) + 1023) // 1024 * 1024))
-        del probe
-        send = [torch.zeros((G, sparse_share_bytes(rows_local, W, cap)), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-    # A share that overflows that capacity says so in its header.  Every rank copies the headers of its own shares
-    # to pinned memory behind the compaction (rank 0 also those of the gathered shares, behind the gather), and when
-    # a group's buffers are about to be reused -- groups later, so nothing waits -- a rank whose share overflowed
-    # sends the dense wire share as well, point to point, and rank 0 writes it over that rank's rows.
     resent = 0
-    hdr_own = hdr_all = hdr_ev = dense_rx = None
-    if sparse:
-        hdr_own = [torch.zeros((G, 8), dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
-        hdr_ev = [torch.cuda.Event() for _ in range(nbuf)]
-        if rank == 0:
-            hdr_all = [torch.zeros((world, G, 8), dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
     if sharded and rank == 0:
         if not sparse2:
-            gathered = [torch.zeros((world,) + tuple(send[0].shape), dtype=send[0].dtype, device="cuda") for _ in range(nbuf)]
+            gathered = [torch.zeros((world,) + tuple(local[0].shape), dtype=local[0].dtype, device="cuda") for _ in range(nbuf)]
         frame = [torch.zeros((G, H, W) + px_shape, dtype=px_dtype, device="cuda") for _ in range(nbuf)]
 
     def s2_ptrs(slot):                     # rank 0 reads its own share where it rendered it
         return [s2["share"][slot].data_ptr()] + [s2["gath"][slot][r].data_ptr() for r in range(1, world)]
 
     def assemble(slot, st):
-        if sparse:
-            deinterleave_sparse(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, cap, stream=st,
-                                frames=G, overflow_ptr=overflow.data_ptr())
-        else:
-            deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=st,
-                         pixel_bytes=wpx_bytes, frames=G)
+        deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=st, pixel_bytes=px_bytes, frames=G)
 
     def render(buf, st, stats=None, fl=None, c=None):
         f = flags if fl is None else fl
@@ -324,7 +283,6 @@ def main():
     def finish(slot):
         """Complete the gather issued from group buffer `slot`; rank 0 puts the rows of its G frames
         back in order."""
-        nonlocal resent, dense_rx
         w, pending[slot] = pending[slot], None
         if w is None:
             return
@@ -335,50 +293,10 @@ def main():
             with torch.cuda.stream(st):
                 w.wait()                              # the group's stream waits for its gather
                 if rank == 0:
-                    if sparse:
-                        hdr_all[slot].copy_(sparse_headers(gathered[slot], rows_local, W, cap), non_blocking=True)
-                        hdr_ev[slot].record(st)
                     assemble(slot, st.cuda_stream)
         elif rank == 0:                               # gloo rehearsal: through host buffers
             gathered[slot].copy_(torch.stack(w).cuda())
-            if sparse:
-                hdr_all[slot].copy_(sparse_headers(gathered[slot], rows_local, W, cap))
             assemble(slot, main)
-        if not sparse:
-            return
-        # dense resend of overflowed shares (normally none)
-        if rank == 0:
-            if nccl:
-                hdr_ev[slot].synchronize()
-            over = hdr_all[slot].view(torch.int32)[:, :, 1].any(dim=1).tolist()
-            for r in range(world):
-                if not over[r]:
-                    continue
-                resent += 1
-                if r == 0:
-                    src = local[slot]
-                else:
-                    if dense_rx is None:
-                        dense_rx = torch.zeros_like(local[slot])
-                    src = dense_rx
-                    if nccl:
-                        with torch.cuda.stream(st):
-                            dist.recv(src, src=r)
-                    else:
-                        host = torch.empty(local[slot].shape, dtype=local[slot].dtype)
-                        dist.recv(host, src=r)
-                        src.copy_(host)
-                with torch.cuda.stream(st):
-                    deinterleave_share(device, src.data_ptr(), frame[slot].data_ptr(), W, layout, r,
-                                       stream=(st.cuda_stream if nccl else main), pixel_bytes=5, frames=G)
-        else:
-            hdr_ev[slot].synchronize()
-            if bool(hdr_own[slot].view(torch.int32)[:, 1].any()):
-                if nccl:
-                    with torch.cuda.stream(st):
-                        dist.send(local[slot], dst=0)
-                else:
-                    dist.send(local[slot].cpu(), dst=0)
 
     def finish_sparse2(slot, w, st):
         """the gather of sparse2 shares: rank 0 expands them; a share whose floats did not all travel sends the tail again"""
@@ -486,20 +404,14 @@ def main():
                 pending[slot] = glist if rank == 0 else True
                 finish(slot)
             return
-        if sparse:                                    # three small launches behind the render, on its stream
-            wire_compact(device, local[slot].data_ptr(), send[slot].data_ptr(), W, rows_local, G, cap, stream=s.cuda_stream)
-            if rank != 0:                             # this rank's own overflow flags, for finish()
-                with torch.cuda.stream(s):
-                    hdr_own[slot].copy_(sparse_headers(send[slot], rows_local, W, cap), non_blocking=True)
-                    hdr_ev[slot].record(s)
         # one collective for the whole group (a partial last group is gathered whole, too)
         if nccl:
             glist = list(gathered[slot].unbind(0)) if rank == 0 else None
             with torch.cuda.stream(s):                # the collective orders itself behind this stream's renders
-                pending[slot] = dist.gather(send[slot], glist, dst=0, async_op=True)
+                pending[slot] = dist.gather(local[slot], glist, dst=0, async_op=True)
         else:
             s.synchronize()
-            host = send[slot].cpu()
+            host = local[slot].cpu()
             glist = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
             dist.gather(host, glist, dst=0)
             pending[slot] = glist if rank == 0 else True
@@ -523,10 +435,10 @@ def main():
     my_pixels = len(layout.rows_of(rank)) * W if sharded else W * H
     # the bytes the REFERENCE algorithm reads and writes for these pixels (Compute.hlsl:88-108: entry +
     # ascents + descents, 8 B of topology each; 8 B of values per sample; the pixel store)
-    ref_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + wpx_bytes * my_pixels
+    ref_bytes_rank = 8 * st.n_nodes + 8 * st.n_samples + px_bytes * my_pixels
     # the bytes THIS kernel's own algorithm moves: 16 B per grid cell / node record a lane loads, the pixel store, and
     # under --shadow-queue 64 B written and 64 B read per shadow ray queued between the two kernels
-    own_bytes_rank = 16 * st.n_loads + 128 * st.n_hits + wpx_bytes * my_pixels
+    own_bytes_rank = 16 * st.n_loads + 128 * st.n_hits + px_bytes * my_pixels
     counters = torch.tensor([st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays, st.n_loads, st.n_hits], dtype=torch.float64)
     kernel_used = st.kernel_used
 
@@ -627,7 +539,7 @@ def main():
                 if pt is not None:
                     scene.DrawPathDevice(cams[c], W, H, ref.data_ptr(), pt=pt, flags=flags, stream=main)
                 else:
-                    scene.DrawDevice(cams[c], W, H, ref.data_ptr(), flags=flags & ~sb.FLAG_WIRE, stream=main)
+                    scene.DrawDevice(cams[c], W, H, ref.data_ptr(), flags=flags, stream=main)
                 torch.cuda.synchronize()
                 refs[c] = ref
             return refs[c]
@@ -645,7 +557,7 @@ def main():
         if args.one_kernel and not compact:
             mode = "one-kernel" if mode == "default" else mode + ":one-kernel"     # k_plain / k_path: other kernels, other counters
         if sharded:
-            mode += ":sharded"                         # other kernels instances (wire pixels, bands): no PMC pass of its own
+            mode += ":sharded"                         # other kernel instances (sparse shares, bands): no PMC pass of its own
         # ... and of the same grid (SDFHIP_TOP_GRID_LEVEL / _SPLIT change it): "grid9" dense, "grid8+blocks" split
         mode += grid_suffix(scene, pt)
         pmc = load_pmc(f"{W}x{H}:{scene_name}:{mode}") if world == 1 else None
@@ -696,11 +608,8 @@ def main():
                                f" + gather to rank 0 ({args.backend})",
                 "frames_in_flight": nbuf * G,
                 "frames_per_gather": G if sharded else None,
-                "gather_pixel_bytes": (round(s2["prefix"] / (rows_local * W * G), 3) if sparse2 else
-                                       round(send[0].shape[1] / (rows_local * W), 3) if sparse else wpx_bytes) if sharded else None,
-                "gather_format": ("sparse shares written by the march kernel" if sparse2 else "sparse wire" if sparse else
-                                  "wire" if wire else "frame pixels") if sharded else None,
-                "sparse_shares_resent_dense": resent if sparse else None,
+                "gather_pixel_bytes": (round(s2["prefix"] / (rows_local * W * G), 3) if sparse2 else px_bytes) if sharded else None,
+                "gather_format": ("sparse shares written by the march kernel" if sparse2 else "frame pixels") if sharded else None,
                 "float_tails_sent_again": resent if sparse2 else None,
                 "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
                 "gstep_per_s": round(float(counters[2]) / sec_per_step / 1e9, 3),
@@ -733,6 +642,17 @@ def main():
         dist.destroy_process_group()
 
 
+def load_package(args):
+    """sdfbox_amd against the product library, or -- for the A/B forms -- against the experiments flavour"""
+    if args.lab or args.one_kernel or args.shadow_queue:
+        if not args.lab:
+            raise SystemExit("--one-kernel / --shadow-queue are A/B forms of the experiments build: add --lab")
+        import sdfbox_amd.lab
+        return sdfbox_amd.lab.load()
+    import sdfbox_amd
+    return sdfbox_amd
+
+
 def main_single_process(args, json_fd):
     """`--single-process`: the N-device frame behind the library's one call (sdfhip_multi_submit / _wait): one process, one
     host thread and one stream per device inside libsdfhip.so, sparse shares written by the march kernel, pushed into
@@ -741,7 +661,7 @@ def main_single_process(args, json_fd):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
-    import sdfbox_amd as sb
+    sb = load_package(args)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
@@ -898,47 +818,43 @@ def main_single_process(args, json_fd):
     ms.close()
 
 
-def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_shape, wpx_dtype, wpx_bytes, rank, nccl, pt, compact,
-                         G, nbuf, sparse, sparse2=False):
-    """Rank 0 also assembles the frame (de-interleave and wire expansion of all ranks' rows), so an
+def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_shape, px_dtype, px_bytes, rank, nccl, pt, compact,
+                         G, nbuf, sparse2=False):
+    """Rank 0 also assembles the frame (de-interleave, or the expansion of all ranks' sparse shares), so an
     even deal makes it the slowest rank.  Before anything is timed, rank 0 tries layouts that give it
     0.3 .. 1.0 of a peer's share: for each it times its own work (render + assembly) and the largest
     peer share (rank 1's, which it can render itself: the scene is replicated), and every rank then
     receives the weight with the smallest max of the two."""
     import torch
     import torch.distributed as dist
-    from sdfbox_amd.tiles import (BandLayout, deinterleave, deinterleave_sparse2, render_bands, render_bands_batch, render_sparse2,
-                                  sparse2_bytes, sparse_share_bytes, wire_compact)
+    T = sb.tiles
     w = torch.ones(1, dtype=torch.float64)
     if rank == 0:
         streams = [torch.cuda.Stream() for _ in range(nbuf)]
-        full_shape, full_dtype = ((), torch.int32) if wpx_bytes == 4 else ((4,), torch.float32)
+        full_shape, full_dtype = ((), torch.int32) if px_bytes == 4 else ((4,), torch.float32)
         frame = torch.zeros((G, H, W) + full_shape, dtype=full_dtype, device="cuda")
         n = 3 if pt is not None else 16
 
-        def work(lay, r, local, gathered, packed):
+        def work(lay, r, local, gathered):
             def one(k):
                 s = streams[k % nbuf].cuda_stream
                 if sparse2:          # the march kernel writes the share; rank 0 expands `world` of them (its own stands in for the peers')
                     share = local[k % nbuf]
                     with torch.cuda.stream(streams[k % nbuf]):
                         share[:4].zero_()
-                    render_sparse2(scene, [cam] * G, W, lay, r, share.data_ptr(), lay.rows_per_rank * W * G, 0, flags=flags, stream=s)
+                    T.render_sparse2(scene, [cam] * G, W, lay, r, share.data_ptr(), lay.rows_per_rank * W * G, 0, flags=flags, stream=s)
                     if r == 0:
-                        deinterleave_sparse2(torch.cuda.current_device(), [share.data_ptr()] * world, frame.data_ptr(), W, lay,
-                                             lay.rows_per_rank * W * G, frames=G, stream=s)
+                        T.deinterleave_sparse2(torch.cuda.current_device(), [share.data_ptr()] * world, frame.data_ptr(), W, lay,
+                                               lay.rows_per_rank * W * G, frames=G, stream=s)
                     return
                 if pt is None and not compact:
-                    render_bands_batch(scene, [cam] * G, W, lay, r, local[k % nbuf].data_ptr(), flags=flags, stream=s)
+                    T.render_bands_batch(scene, [cam] * G, W, lay, r, local[k % nbuf].data_ptr(), flags=flags, stream=s)
                 else:
                     for f in range(G):
-                        render_bands(scene, cam, W, lay, r, local[k % nbuf][f].data_ptr(), flags=flags, stream=s, pt=pt)
-                if sparse:           # every rank compacts its shares (the capacity does not change the cost)
-                    wire_compact(torch.cuda.current_device(), local[k % nbuf].data_ptr(), packed.data_ptr(), W, lay.rows_per_rank, G,
-                                 lay.rows_per_rank * W // 4, stream=s)
-                if r == 0:           # (assembling dense wire shares costs the same as assembling sparse ones)
-                    deinterleave(torch.cuda.current_device(), gathered.data_ptr(), frame.data_ptr(), W, lay,
-                                 stream=s, pixel_bytes=wpx_bytes, frames=G)
+                        T.render_bands(scene, cam, W, lay, r, local[k % nbuf][f].data_ptr(), flags=flags, stream=s, pt=pt)
+                if r == 0:
+                    T.deinterleave(torch.cuda.current_device(), gathered.data_ptr(), frame.data_ptr(), W, lay,
+                                   stream=s, pixel_bytes=px_bytes, frames=G)
             best = 1e9
             for _ in range(2):
                 one(0); torch.cuda.synchronize()
@@ -951,18 +867,16 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
 
         tried = []
         for cand in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3):
-            lay = BandLayout(H, world, band_rows, cand)
+            lay = T.BandLayout(H, world, band_rows, cand)
             if sparse2:
-                local = [torch.zeros(sparse2_bytes(lay.rows_per_rank, W, G, lay.rows_per_rank * W * G), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+                local = [torch.zeros(T.sparse2_bytes(lay.rows_per_rank, W, G, lay.rows_per_rank * W * G), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
                 gathered = torch.zeros(1, dtype=torch.uint8, device="cuda")
             else:
-                local = [torch.zeros((G,) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda") for _ in range(nbuf)]
-                gathered = torch.zeros((world, G) + share_shape(lay.rows_per_rank), dtype=wpx_dtype, device="cuda")
-            packed = torch.zeros(G * sparse_share_bytes(lay.rows_per_rank, W, lay.rows_per_rank * W // 4) if sparse else 1,
-                                 dtype=torch.uint8, device="cuda")
-            t0, t1 = work(lay, 0, local, gathered, packed), work(lay, 1, local, gathered, packed)
+                local = [torch.zeros((G,) + share_shape(lay.rows_per_rank), dtype=px_dtype, device="cuda") for _ in range(nbuf)]
+                gathered = torch.zeros((world, G) + share_shape(lay.rows_per_rank), dtype=px_dtype, device="cuda")
+            t0, t1 = work(lay, 0, local, gathered), work(lay, 1, local, gathered)
             tried.append((max(t0, t1), cand, t0, t1))
-            del local, gathered, packed
+            del local, gathered
             if t0 <= t1:                               # rank 0 is no longer the slowest: a smaller share only loads the peers
                 break
         _, best, t0, t1 = min(tried)
@@ -1009,10 +923,14 @@ def orbit_cameras(sb, W, H, n, step_deg=1.0):
     return out
 
 
+# the kernel sources of the frame's pipeline (device code only: host-side edits do not change what the counters measured)
+KERNEL_SOURCES = ("raymarch_device.h", "raymarch_kernels.h", "upload_kernels.h", "tile_order_kernels.h")
+
+
 def kernel_source_hash():
     """What the PMC figures in profiles/hbm_traffic.json were measured on (scripts/summarise_profile.py)."""
     h = hashlib.sha256()
-    for f in ("raymarch_device.h", "raymarch_kernels.h", "sdfhip_device.hip"):
+    for f in KERNEL_SOURCES:
         with open(os.path.join(REPO, "sdfbox_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

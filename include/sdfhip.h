@@ -66,51 +66,29 @@ typedef struct sdfhip_octdata {
 /* Opaque scene handle: the octree resident in one GPU's HBM. */
 typedef struct sdfhip_scene sdfhip_scene;
 
-/* Render flags. */
+/* Render flags.  (A scene handle keeps scratch memory per stream that renders on it, 16 at a time; a 17th stream takes over the
+ * least recently used scratch whose work has drained.)  Any other bit is refused with SDFHIP_ERR_ARG: the A/B knobs of the
+ * measured-and-dropped kernel forms exist in the experiments build only (include/sdfhip_experimental.h, libsdfhip_lab.so). */
 enum {
-    SDFHIP_KERNEL_AUTO = 0,       /* cursor-stack kernel when the tree allows, else generic */
-    SDFHIP_KERNEL_GENERIC = 1,    /* one thread per pixel, loads as Compute.hlsl does      */
-    SDFHIP_KERNEL_STACK = 2,      /* ancestor stack in LDS, fused 16-B node records        */
+    SDFHIP_KERNEL_AUTO = 0,       /* the default: a grid lookup per find() wherever the tree allows, else the shader's own traversal */
+    SDFHIP_KERNEL_GENERIC = 1,    /* one thread per pixel, follows parent / children links through memory as Compute.hlsl does */
+    SDFHIP_KERNEL_STACK = 2,      /* integer cell coordinates and the lookup grids (needs a consistent tree of depth <= 12)   */
     SDFHIP_KERNEL_MASK = 0xF,
-    SDFHIP_FLAG_COMPACT = 0x10,   /* persistent waves, ballot/prefix refill of finished lanes */
+    SDFHIP_FLAG_COMPACT = 0x10,   /* BASELINE cfg-3's wavefront ray compaction: persistent waves, ballot/prefix refill of finished
+                                     lanes.  Bit-identical, and slower than the default on every frame measured */
     SDFHIP_FLAG_COUNT = 0x20,     /* also count algorithmic node/sample reads (slower)     */
     SDFHIP_FLAG_DISPLAY = 0x40,   /* fused display pass: output is RGBA8, gamma 1/2.2 (DisplayFrag.hlsl:24) */
     SDFHIP_FLAG_DISPLAY_DEBUG = 0x80, /* fused display pass, debug heat map w/140 (DisplayFrag.hlsl:21-22) */
-    /* (a scene handle keeps scratch memory per stream that renders on it, 16 at a time; a 17th stream takes over the least
-     * recently used scratch whose stream has drained) */
-    SDFHIP_FLAG_TILE_ORDER = 0x100000, /* for a viewer that renders one frame at a time: launch this frame's 8x8 tiles in
+    SDFHIP_FLAG_TILE_ORDER = 0x100000 /* for a viewer that renders one frame at a time: launch this frame's 8x8 tiles in
                                      descending order of the march iterations they (or a tile within two of them) took in the
                                      last frame rendered with the same geometry on the same stream; the order is made on the
                                      device behind every such frame whose camera block differs from the one the order in use
                                      came from (two small kernels, 13 us; a camera at rest pays once).  The first frame of a
                                      geometry, frames of a batch and frames of more than 65 536 tiles take the default order.
                                      A frame alone ends when its longest wave does, so the tiles that were expensive a moment
-                                     ago go first: 0.174 -> 0.133 ms per 1080p frame with the camera at rest, 0.170 -> 0.146
-                                     with a quarter of a degree between frames, 0.188 -> 0.148 with one degree.  Not for
-                                     frames in flight on several streams (0.090 -> 0.095 ms per frame with a fixed camera,
-                                     0.093 -> 0.109 with a moving one: the ordering kernels sit between a stream's frames), and
-                                     no gain at 4K (16 rounds of workgroups: the tail is short and neighbouring tiles no longer
-                                     run together), hence the limit.  Never changes a pixel. */
-    SDFHIP_FLAG_WIRE = 0x10000,   /* device-resident entry points only: 5-byte wire pixels for the
-                                     tile gather (see sdfhip_deinterleave_device), lossless */
-    /* tuning knobs for A/B measurements (0 = the default): bits 8..11 blockIdx -> tile
-     * order of the plain kernel (1 row-major, 2 one slab per XCD), bits 12..15 workgroup
-     * size (1 = 64, 2 = 128, 3 = 256 threads).  Results never depend on them. */
-    SDFHIP_TUNE_ORDER_SHIFT = 8,
-    SDFHIP_TUNE_BLOCK_SHIFT = 12,
-    /* A/B knob: render with the one-kernel form (a lane state machine that shades in place) where the
-     * default is k_march (primary march, shading, shadow march as three wave-converged loops).
-     * Same pixels, same counters. */
-    SDFHIP_TUNE_ONE_KERNEL = 0x20000,
-    /* measurement variant of the cursor-stack kernel when the scene's top grid has level <= 3
-     * (SDFHIP_TOP_GRID_LEVEL=3 at upload): every workgroup stages the grid in LDS */
-    SDFHIP_TUNE_LDS_TOP = 0x40000,
-    /* A/B knob: k_march appends its shadow rays to a queue that a second kernel (k_shadow) marches 64 to a
-     * wave, where by default every wave marches its own shadow rays after the shading step */
-    SDFHIP_TUNE_SHADOW_QUEUE = 0x80000,
-    /* A/B knob: the default kernel reads the 16-byte cells of a split grid (8 value bytes, decoded in every non-flat
-     * sample) where by default it reads the grid's 32-byte cells with pre-decoded corners.  Same pixels. */
-    SDFHIP_TUNE_BYTE_CELLS = 0x200000
+                                     ago go first: 0.174 -> 0.133 ms per 1080p frame with the camera at rest, 0.188 -> 0.148
+                                     with one degree between frames.  Not for frames in flight on several streams (the ordering
+                                     kernels sit between a stream's frames).  Never changes a pixel. */
 };
 
 /* Per-call statistics (all optional: pass NULL). */
@@ -128,9 +106,8 @@ typedef struct sdfhip_stats {
     uint64_t n_loads;       /* with SDFHIP_FLAG_COUNT: 16-byte node records / */
                             /* grid cells the kernels themselves loaded (one  */
                             /* per lane and load): their own algorithmic reads */
-    uint64_t n_hits;        /* with SDFHIP_FLAG_COUNT: pixels queued from the */
-                            /* primary-march kernel to the shading kernel     */
-                            /* (48-byte records written and read once)        */
+    uint64_t n_hits;        /* (experiments build, queued-shadow A/B form: pixels */
+                            /* queued between its two kernels; else 0)         */
 } sdfhip_stats;
 
 /* ---- errors ------------------------------------------------------------ */
@@ -371,18 +348,10 @@ SDFHIP_API int sdfhip_render_batch_device(sdfhip_scene *scene, const sdfhip_info
                                           uint32_t flags, float *d_rgba_out, void *stream,
                                           sdfhip_stats *stats);
 
-/* Rank-0 helper for the tile gather: scatter `world` compact band buffers back into
- * row order.  One gather may carry several frames (fewer, larger messages):
- * d_gathered is [world][frames][rows_per_rank][width] pixels, d_frame is
- * [frames][height][width].  pixel_bytes = 16 (RGBA32F) or 4 (RGBA8): both sides hold
- * such pixels.  pixel_bytes = 5: d_gathered holds the wire buffers that
- * SDFHIP_FLAG_WIRE renders make.  Every pixel Compute.hlsl writes is (a, a, a, n) with
- * n <= 140 steps, or the sky constant (0.005, 0.01, 0.2, n) with n <= 100, so a frame
- * of nrows_out x width pixels travels as nrows_out*width floats (the bits of a)
- * followed by nrows_out*width bytes (n, or 255 - n for a sky pixel) -- 5 instead of 16
- * bytes per pixel over xGMI (nrows_out*width must be a multiple of 4) -- and d_frame
- * receives the RGBA32F frame, bit for bit what a render without the flag writes.
- * Asynchronous on `stream`. */
+/* Rank-0 helper for the tile gather of DENSE bands (the path-traced mode; scenes without a full-depth grid): scatter `world`
+ * compact band buffers back into row order.  One gather may carry several frames (fewer, larger messages):
+ * d_gathered is [world][frames][rows_per_rank][width] pixels, d_frame is [frames][height][width].
+ * pixel_bytes = 16 (RGBA32F) or 4 (RGBA8): both sides hold such pixels.  Asynchronous on `stream`. */
 SDFHIP_API int sdfhip_deinterleave_device(int device, const void *d_gathered, void *d_frame,
                                           uint32_t width, uint32_t height,
                                           uint32_t band_rows, uint32_t world,
@@ -407,39 +376,6 @@ SDFHIP_API int sdfhip_deinterleave_bands_device(int device, const void *d_gather
                                                 uint32_t width, uint32_t height, uint32_t band_rows,
                                                 uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
                                                 uint32_t pixel_bytes, uint32_t frames, void *stream);
-
-/* Sparse wire format: what the ranks put on xGMI when most of a frame is sky.  A frame-share in the
- * wire format of SDFHIP_FLAG_WIRE (rows x width pixels, rows a multiple of 8) is compacted on its own
- * GPU -- the code bytes stay; of the float plane only the values with any bit set, packed in tile
- * order behind a 64-bit mask and a slot index per 8x8 tile -- gathered, and expanded by rank 0 while it
- * restores row order.  `capacity` = float slots per frame-share; a share with more lit pixels sets the
- * overflow word (then the frame is not complete: choose the capacity from a measured maximum, or
- * rows * width to be safe).  Lossless within the capacity; 1.2 bytes per pixel + 4 per lit pixel.
- *   sdfhip_wire_sparse_bytes            bytes of one sparse frame-share
- *   sdfhip_wire_compact_device          d_wire [frames] dense wire shares -> d_sparse [frames] sparse shares
- *   sdfhip_deinterleave_sparse_device   like sdfhip_deinterleave[_bands]_device (owner may be NULL: round
- *                                       robin) for [world][frames] sparse shares; *d_overflow (device word,
- *                                       may be NULL) is OR-ed with 1 when a share overflowed */
-SDFHIP_API uint64_t sdfhip_wire_sparse_bytes(uint32_t width, uint32_t rows, uint32_t capacity);
-/* Recovery when a sparse share overflowed its capacity: byte offset, within a sparse share, of its 16-byte
- * header {uint32 lit pixels, uint32 overflowed, 0, 0} -- the sender reads word 1 of its own shares and rank 0
- * that of the gathered ones, and the rank concerned sends the share again in the dense wire format
- * (point to point: no other rank takes part), which rank 0 writes over that rank's rows with
- *   sdfhip_deinterleave_share_device   like sdfhip_deinterleave[_bands]_device, but d_share holds the
- *                                      [frames] buffers of ONE rank (`rank`) and only its rows are written
- * (owner may be NULL: round robin). */
-SDFHIP_API uint64_t sdfhip_wire_sparse_head_offset(uint32_t width, uint32_t rows, uint32_t capacity);
-SDFHIP_API int sdfhip_deinterleave_share_device(int device, const void *d_share, void *d_frame,
-                                                uint32_t width, uint32_t height, uint32_t band_rows,
-                                                uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
-                                                uint32_t rank, uint32_t pixel_bytes, uint32_t frames, void *stream);
-SDFHIP_API int sdfhip_wire_compact_device(int device, const void *d_wire, void *d_sparse, uint32_t width,
-                                          uint32_t rows, uint32_t frames, uint32_t capacity, void *stream);
-SDFHIP_API int sdfhip_deinterleave_sparse_device(int device, const void *d_gathered, void *d_frame,
-                                                 uint32_t width, uint32_t height, uint32_t band_rows,
-                                                 uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
-                                                 uint32_t capacity, uint32_t frames, uint32_t *d_overflow,
-                                                 void *stream);
 
 /* ---- sparse wire shares written by the march kernel itself ------------------------------------------------------------
  * A wave of the default kernel renders one 8x8 tile, which is the unit of the sparse wire format: at its end it holds the tile's
@@ -515,27 +451,6 @@ SDFHIP_API int sdfhip_multi_submit(sdfhip_multi *m, uint32_t slot, const sdfhip_
 SDFHIP_API int sdfhip_multi_submit_path(sdfhip_multi *m, uint32_t slot, const sdfhip_info *info, const sdfhip_pathtrace *pt,
                                         uint32_t width, uint32_t height, uint32_t flags, void *d_frame_out);
 SDFHIP_API int sdfhip_multi_wait(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_stats *stats);
-/* Test hook: how many packed floats the next share of every device carries (normally 1.25 x what its last share used; 0 = all
- * of them): a small value forces the float tail of the next shares to be sent again (sdfhip_multi_stats.resends). */
-SDFHIP_API int sdfhip_multi_debug_floats_sent(sdfhip_multi *m, uint32_t floats);
-
-/* Experiment hook (scripts/ab_tile_order.py): the primary-march kernel of the following single-frame renders
- * on this scene takes workgroup b's tile from d_perm[b] (device array, one entry per workgroup of its grid =
- * 8 * ceil(tiles_y / 8) * tiles_x with 8x8 tiles; entries >= the tile count idle) and writes the march
- * iterations of every tile's wave to d_cost[tile] (device array): the primary loop's in the low byte, the
- * shadow loop's in the high byte.  NULL switches either off. */
-SDFHIP_API int sdfhip_debug_tile_order(sdfhip_scene *scene, const uint32_t *d_perm, uint16_t *d_cost);
-
-/* Diagnostics: after a SDFHIP_FLAG_COUNT render of the default kernel on `stream` (the stream argument of the
- * sdfhip_render_device call that made it; synchronises with it), how many lane-steps sampled which kind of cell: out6 = {flat leaf at or above the grid's coarse level, flat leaf below it, non-flat at or above the coarse level,
- * non-flat as deep as the grid, non-flat in between, non-flat with the position outside the cube (or NaN)}.  What the
- * layout of the grid's cells is tuned by. */
-SDFHIP_API int sdfhip_debug_step_classes(sdfhip_scene *scene, void *stream, uint64_t *out6);
-
-/* Test hook: the kernel's R8_UNorm decode of bytes 0..255 (256 floats to the
- * host), checked exhaustively against byte/255.0f. */
-SDFHIP_API int sdfhip_debug_unorm_table(int device, float *out256);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,4 @@
-"""Emit the loops of one kernel as hipcc builds them: compiles sdfhip_device.hip to gfx950 assembly (device only) and prints every
+"""Emit the loops of one kernel as hipcc builds them: compiles render.hip to gfx950 assembly (device only) and prints every
 "Depth=1" loop of the kernel (header block to the block after its last one) with static instruction counts.
 Usage: python scripts/isa_listing.py [mangled-kernel-name]   (default: k_march<CUR_STACK_SPLIT, false, OUT_RGBA32F, false>, the bench
 frame's kernel: loop 1 = primary march, loop 2 = shadow march)
@@ -16,7 +16,7 @@ KERNEL = sys.argv[1] if len(sys.argv) > 1 else "_ZN6sdfhip7k_marchILi3ELb0ELi0EL
 with tempfile.TemporaryDirectory() as tmp:
     out = os.path.join(tmp, "dev.s")
     subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
-                    "-fvisibility=hidden", "--offload-device-only", "-S", "sdfhip_device.hip", "-o", out],
+                    "-fvisibility=hidden", "--offload-device-only", "-S", "render.hip", "-o", out],
                    cwd=CSRC, check=True, stderr=subprocess.DEVNULL)
     text = open(out).read().splitlines()
 

@@ -16,10 +16,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_source_hash():
-    h = hashlib.sha256()
-    for f in ("raymarch_device.h", "raymarch_kernels.h", "sdfhip_device.hip"):
-        h.update(open(os.path.join(REPO, "sdfbox_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    sys.path.insert(0, REPO)
+    import bench                       # one definition of "the kernel sources": bench.KERNEL_SOURCES
+    return bench.kernel_source_hash()
 
 
 def short(name):

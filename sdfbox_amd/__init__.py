@@ -4,7 +4,7 @@ fields behind SdfBox's frame boundary.  The compute lives in libsdfhip.so
 mirror of the reference's interface for that path: OctData (.asdf), Logic
 (camera -> Info), Scene.Draw (Program.Draw's compute pass).
 """
-from . import _lib
+from . import _lib, tiles
 from ._lib import (FLAG_COMPACT, FLAG_COUNT, FLAG_DISPLAY, FLAG_DISPLAY_DEBUG, FLAG_TILE_ORDER, FLAG_WIRE, KERNEL_AUTO, KERNEL_GENERIC, KERNEL_STACK, TUNE_ONE_KERNEL, TUNE_SHADOW_QUEUE, Info,
                    MultiStats, PathTrace, SdfHipError, Stats)
 from .logic import Logic

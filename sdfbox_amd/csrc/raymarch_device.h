@@ -42,14 +42,20 @@ struct FrameInfo {
 };
 constexpr int MAX_BATCH = 8;   // frames one k_plain launch can render (grid.y)
 constexpr int MAX_BAND_LIST = 512;   // bands one launch can be handed as an explicit list
+constexpr int INLINE_BAND_LIST = 64; // ... of which this many travel in the kernel arguments; a longer list is read from device memory
 
 struct TopCell { uint32_t level, v0, v1; int32_t children; };   // a cell of the top grid, see below (cursor-stack kernels)
 // the grid as find() sees it: dense cells of level `level`; for a split grid, blocks of 8^fine_bits finer cells
 // fine_order 1: within a block the cells are stored 2x2x2 sub-cube by sub-cube (the 8 cells of a sub-cube share a 128-byte
 // line), not in x-y-z order: for the kernels whose every lookup is a cache miss (fine_cell_index)
-// d4 / recs: the same grid again as a dense array of 4-byte words + 64-byte sample records of the non-flat leaves, for the
-// default kernel's loop (CursorFF below), or null
-struct GridRef { const TopCell *top; const TopCell *fine; int level; int fine_bits; int fine_order; const uint32_t *d4 = nullptr; const uint4 *recs = nullptr; };
+// (experiments build: d4 / recs = the same grid again as a dense array of 4-byte words + 64-byte sample records of the non-flat
+// leaves, for the default kernel's loop through CursorFF, lab_device.h; or null)
+struct GridRef {
+    const TopCell *top; const TopCell *fine; int level; int fine_bits; int fine_order;
+#ifdef SDFHIP_EXPERIMENTS
+    const uint32_t *d4 = nullptr; const uint4 *recs = nullptr;
+#endif
+};
 __host__ __device__ __forceinline__ uint32_t fine_cell_index(uint32_t x, uint32_t y, uint32_t z, int FB, int order)
 {
     if (order == 0) return x | (y << FB) | (z << (2 * FB));
@@ -68,16 +74,19 @@ struct RenderParams {
     int32_t fine_bits;
     int32_t fine_order;        // see GridRef
     const TopCell *fine;
+#ifdef SDFHIP_EXPERIMENTS
     const uint32_t *d4;        // the grid as 4-byte words (CursorFF): a flat leaf's distance, or where a non-flat leaf's sample record is; or null
     const uint4 *recs;         // ... the records, biased by the words' tag (see find_sample_ff)
+#endif
     float4 *out;               // compact rows: nrows_out x width
     uint32_t width, height;    // full frame
     uint32_t band_rows, band_first, band_stride, nrows_out;
     // n_band_list != 0: local band i is band band_list[i] of the frame (an explicit list instead of
-    // every band_stride-th band: layouts that give the ranks unequal shares).  Read-only, so the
-    // kernels index it in the kernel-argument segment.
+    // every band_stride-th band: layouts that give the ranks unequal shares).  Up to INLINE_BAND_LIST bands travel
+    // in the kernel arguments (read-only: the kernels index them there); a longer list is in device memory at band_ptr.
     uint32_t n_band_list;
-    uint16_t band_list[MAX_BAND_LIST];
+    uint16_t band_list[INLINE_BAND_LIST];
+    const uint16_t *band_ptr;
     uint32_t tiles_x, tiles_y, n_tiles;   // 8x8 (compact) or 16x16 (plain) tiles of the local rows
     // frames[f]: camera of frame f of a batched launch (k_plain: f = blockIdx.y, output at
     // out + f * nrows_out * width pixels; the other kernels render frames[0] only).  A rank's
@@ -88,9 +97,11 @@ struct RenderParams {
     FrameInfo frames[MAX_BATCH];
     unsigned long long *counters;  // [0] nodes [1] samples [2] steps [3] shadow rays [4] records / cells loaded [5] queued hits (COUNT builds)
     uint32_t *queue;           // tile queue head (compact kernels)
+#ifdef SDFHIP_EXPERIMENTS
     uint32_t tile_order;       // k_plain: blockIdx -> tile mapping (tuning knob, flags bits 8..11)
+#endif
     // fused display pass (DisplayFrag.hlsl): out_mode 0 = RGBA32F frame, 1 = gamma RGBA8,
-    // 2 = step-count heat map RGBA8 (`out` aliased as one uint32 per pixel), 3 = wire pixels of the
+    // 2 = step-count heat map RGBA8 (`out` aliased as one uint32 per pixel), 3 (experiments build) = wire pixels of round 1's
     // tile gather (per frame a float plane and a byte plane, 5 bytes per pixel)
     uint32_t out_mode;         // 4: the sparse wire share of sdfhip_render_sparse_device (`out` = the share of all frames of the launch)
     uint32_t sparse_cap;       // ... and the float slots it holds
@@ -99,7 +110,8 @@ struct RenderParams {
     // path-traced mode (k_path): samples per pixel, diffuse bounces, RNG seed, albedo
     uint32_t pt_spp, pt_bounces, pt_seed;
     float pt_albedo;
-    // two-kernel pipeline (k_march -> k_shadow, raymarch_kernels.h): the pixels whose primary march ended on
+#ifdef SDFHIP_EXPERIMENTS
+    // two-kernel A/B form (k_march -> k_shadow, lab_kernels.h): the pixels whose primary march ended on
     // the surface facing the light, as records {position, prox | cursor | pixel, steps, values | direction to the
     // light, Lambert term} in HIT_QUEUES queues per frame
     // of the launch: arrays [n_frames][HIT_QUEUES][hit_cap]; hit_ctl = two sets of [MAX_BATCH][HIT_QUEUES] fill
@@ -110,6 +122,7 @@ struct RenderParams {
     float4 *hit_d;                 // direction to the light, Lambert term
     uint32_t *hit_ctl;
     uint32_t hit_cap, hit_set;
+#endif
     // path-traced mode as a pipeline of kernels (k_pt_primary -> k_pt_bounce x (bounces + 1) -> k_pt_resolve):
     // two hit queues used alternately (a level's kernel reads one and fills the other), HIT_QUEUES sub-queues of
     // pt_cap entries each, an entry = four 16-byte records; per-path results [sample][pixel] that k_pt_resolve sums
@@ -712,127 +725,6 @@ __device__ __forceinline__ uint32_t flat_cell_distance_bits(uint32_t byte, uint3
     return __float_as_uint((unorm8((float)byte) - 0.25f) * scale * 2.0f);
 }
 
-// ---- the default kernel's cursor: a dense grid of 4-byte words + sample records with pre-decoded corners -----------------
-// What bounds the march are the VALU pipes and the vector-memory address path (TA) together: the frame
-// takes as long as its VALU instructions take to issue, and a load instruction costs the TA one tag lookup per cache line its
-// lanes touch.  A third of the wave-iterations pay the 44 instructions of a non-flat sample: the exact R8_UNorm decode of 8
-// bytes (8 v_cvt_f32_ubyte + 4 v_pk_mul + 4 v_pk_fma), the differences t1 - t0 of the x-lerps, and the cell's local
-// coordinates from its level (masks, conversions, 2^-k) -- all functions of the LEAF alone; and 83 % of the lane-steps are in
-// flat leaves, which need 4 bytes: the distance.  So the grid exists a second time, in the form the loop wants:
-//   d4     one 32-bit word per cell of the tree's deepest level (dense: 8^F words, 0.54 GB at F = 9): the distance a flat leaf
-//          returns, or -- a word that is no distance: as a float it is >= 2 -- TAG + the index, in 16-byte units, of the
-//          leaf's sample record.  find() is ONE 4-byte load for every flat step (no coarse / fine levels, no shifts);
-//   recs   per non-flat leaf (one per LEAF: the cells of a large leaf share it) 64 bytes: q0 = {-ax 2^-k, -ay 2^-k, -az 2^-k, 2^-k}
-//          (a = the leaf's lower corner in the grid's units, 2^k its width), q1 = {t0, t4, t2, t6}, q2 = {t1 - t0, t5 - t4,
-//          t3 - t2, t7 - t6} (t_i = unorm8(byte i), the differences rounded as lerp() rounds them).
-// The local coordinates are d = sat(fma(u, 2^-k, -a 2^-k)): (u - a) 2^-k without a rounding of its own wherever its value
-// matters (inside the cell u - a is exact; outside the cube both saturate the same way), so sat((u - a) * inv) bit for bit.
-// The sample: three fmas, 2 + 1 packed fmas and a packed subtraction for the x- and y-lerps, the z-lerp, and
-// (v - 0.25) * (2 scale) with 2 scale = 2^(1 - F) / 2^-k from the exponent of q0.w: 14 instructions for every non-flat
-// leaf of any level, ONE block of code.  (Two earlier forms, both measured slower than the byte cells: 32-byte cells for the
-// full-depth leaves only -- the waves near the surface hold full-depth leaves AND the non-flat level-8 leaves next to them, so
-// both the new and the old sample ran; and 64-byte cells for every cell of a split grid's blocks -- 19 % fewer VALU
-// instructions, but three 16-byte loads per lane that is inside a block: 1.7 x the tag lookups, and the waves waited.)
-// The cursor shrinks to the coordinates of the last lookup: the loop keeps no bytes and no s; the shading step's gradient --
-// once per wave -- and the on-a-face rule (rare) look the leaf up again in the 16-byte cells every other kernel reads.
-constexpr uint32_t D4_TAG = 0x40000000u;       // 2.0f: no leaf returns a distance of 2 or more (at most 1.5 cell widths <= 1.5)
-struct CursorFF {
-    struct Pos { float prox; };
-    static constexpr int32_t ROOT_MARK = 0x40000000;
-    int32_t ax, ay, az;      // the cell coordinates of the last lookup in units of 2^-(LM - sh), or the root mark
-    uint32_t sh;             // wave-uniform
-    uint32_t loads;
-    __device__ __forceinline__ void reset(const NodeRec &) { ax = ay = az = ROOT_MARK; sh = 0; }
-};
-// the 16-byte cell {LM - level | FLAT_BIT, bytes / distance, .} the cursor sits in (coordinates in the grid's own units)
-__device__ __forceinline__ uint4 cell_at(const GridRef &g, int32_t Dx, int32_t Dy, int32_t Dz)
-{
-    const int FB = g.fine_bits;                                     // 0: a dense grid as deep as the tree
-    uint4 e = reinterpret_cast<const uint4 *>(g.top)[top_index((uint32_t)Dx >> FB, (uint32_t)Dy >> FB, (uint32_t)Dz >> FB, g.level)];
-    if (FB && e.x == 15u) {
-        const uint32_t m = (1u << FB) - 1u;
-        e = reinterpret_cast<const uint4 *>(g.fine)[e.w + fine_cell_index((uint32_t)Dx & m, (uint32_t)Dy & m, (uint32_t)Dz & m, FB, 0)];
-    }
-    return e;
-}
-__device__ __forceinline__ Cell cell_of(const CursorFF &c, const GridRef &g, const NodeRec *__restrict__ nodes)
-{
-    Cell k;
-    const bool fresh = c.ax == CursorFF::ROOT_MARK;                 // never looked up: the root box and the root's values
-    const uint4 e = fresh ? make_uint4((uint32_t)LM, nodes[0].z, nodes[0].w, 0u) : cell_at(g, c.ax, c.ay, c.az);
-    const uint32_t s = e.x & 15u;
-    const float q = 1.0f / 4096.0f;
-    const int32_t keep = (int32_t)(0xFFFFFFFFu << s);
-    const int32_t x = (int32_t)((uint32_t)c.ax << c.sh) & keep, y = (int32_t)((uint32_t)c.ay << c.sh) & keep, z = (int32_t)((uint32_t)c.az << c.sh) & keep;
-    k.lx = fresh ? 0.0f : (float)x * q; k.ly = fresh ? 0.0f : (float)y * q; k.lz = fresh ? 0.0f : (float)z * q;
-    k.scale = __uint_as_float((127u - LM + s) << 23);
-    k.inv = __uint_as_float((127u + LM - s) << 23);
-    k.v0 = e.y; k.v1 = (e.x & FLAT_BIT) ? e.y : e.z;
-    return k;
-}
-// find() and the sample that follows it, in one piece (nothing but the distance leaves it)
-template <bool FRESH>
-__device__ __forceinline__ float find_sample_ff(CursorFF &c, const GridRef &g, float px, float py, float pz)
-{
-    const int F = g.level + g.fine_bits, sh = LM - F;
-    const float unit = __uint_as_float((uint32_t)(127 + F) << 23), top = unit - 1.0f;      // 2^F, and the last cell
-    const float ux = px * unit, uy = py * unit, uz = pz * unit;
-    const float fm = __builtin_fminf(__builtin_fminf(__builtin_amdgcn_fractf(ux), __builtin_amdgcn_fractf(uy)), __builtin_amdgcn_fractf(uz));
-    int32_t Dx, Dy, Dz;
-    if (FRESH || __ballot(fm == 0.0f) == 0ull) {
-        Dx = cvt_floor(__builtin_amdgcn_fmed3f(ux, 0.0f, top)); Dy = cvt_floor(__builtin_amdgcn_fmed3f(uy, 0.0f, top));
-        Dz = cvt_floor(__builtin_amdgcn_fmed3f(uz, 0.0f, top));
-    } else {                                                        // a lane on a cell face: the reference's rule (find_units)
-        float tx, ty, tz, qx, qy, qz;
-        Dx = axis_a(px, tx, qx); Dy = axis_a(py, ty, qy); Dz = axis_a(pz, tz, qz);
-        const bool fresh = c.ax == CursorFF::ROOT_MARK;
-        int s = LM;
-        if (!fresh) s = (int)(cell_at(g, c.ax, c.ay, c.az).x & 15u);
-        bool moved;
-        on_face_choice(fresh ? c.ax : (int32_t)((uint32_t)c.ax << c.sh), fresh ? c.ay : (int32_t)((uint32_t)c.ay << c.sh),
-                       fresh ? c.az : (int32_t)((uint32_t)c.az << c.sh), s, Dx, Dy, Dz, tx == qx, ty == qy, tz == qz, moved);
-        Dx = min(max(Dx, 0), 4095) >> sh; Dy = min(max(Dy, 0), 4095) >> sh; Dz = min(max(Dz, 0), 4095) >> sh;
-    }
-    c.sh = (uint32_t)sh; c.ax = Dx; c.ay = Dy; c.az = Dz;
-    c.loads++;
-    const uint32_t w = g.d4[top_index((uint32_t)Dx, (uint32_t)Dy, (uint32_t)Dz, F)];
-    if (!(__uint_as_float(w) >= 2.0f)) return __uint_as_float(w);     // a flat leaf: its distance
-    c.loads++;
-    // (whole 16-byte loads, each kept as ONE register tuple: constrained word by word the compiler shuffles the words back
-    // into pairs for the packed fmas)
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 *cellp = reinterpret_cast<const u32x4 *>(g.recs) + (size_t)w;   // (g.recs is biased by the tag: no subtraction here)
-    u32x4 q0 = cellp[0], q1 = cellp[1], q2 = cellp[2];
-    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));                   // all three in flight together
-    const float inv = __uint_as_float(q0.w);
-    const float dx = sat(__builtin_fmaf(ux, inv, __uint_as_float(q0.x)));
-    const float dy = sat(__builtin_fmaf(uy, inv, __uint_as_float(q0.y)));
-    const float dz = sat(__builtin_fmaf(uz, inv, __uint_as_float(q0.z)));
-    const float topL = __builtin_fmaf(dx, __uint_as_float(q2.x), __uint_as_float(q1.x));
-    const float topH = __builtin_fmaf(dx, __uint_as_float(q2.y), __uint_as_float(q1.y));
-    const float botL = __builtin_fmaf(dx, __uint_as_float(q2.z), __uint_as_float(q1.z));
-    const float botH = __builtin_fmaf(dx, __uint_as_float(q2.w), __uint_as_float(q1.w));
-    const float loadL = __builtin_fmaf(dy, botL - topL, topL);
-    const float loadH = __builtin_fmaf(dy, botH - topH, topH);
-    // 2 * scale = 2^(1 - level) = 2^(1 - F) / 2^-k: exponents subtract, (127 + 1 - F) - (127 - k) + 127 (multiplying by scale and then
-    // by 2 rounds nowhere)
-    const float scale2 = __uint_as_float(((uint32_t)(255 - F) << 23) - q0.w);
-    return (lerp(loadL, loadH, dz) - 0.25f) * scale2;
-}
-__device__ __forceinline__ uint32_t find(CursorFF &c, const NodeRec *__restrict__, const GridRef &g, uint32_t, int32_t *__restrict__,
-                                         uint32_t, float px, float py, float pz, CursorFF::Pos &u)
-{
-    u.prox = find_sample_ff<false>(c, g, px, py, pz);
-    return 0;
-}
-__device__ __forceinline__ uint32_t find_fresh(CursorFF &c, const NodeRec *__restrict__, const GridRef &g, uint32_t, int32_t *__restrict__,
-                                               uint32_t, float px, float py, float pz, CursorFF::Pos &u)
-{
-    u.prox = find_sample_ff<true>(c, g, px, py, pz);
-    return 0;
-}
-__device__ __forceinline__ float sample_after_find(const CursorFF &, const CursorFF::Pos &u, float, float, float) { return u.prox; }
-
 __device__ __forceinline__ uint32_t find(CursorS &c, const NodeRec *__restrict__ nodes, const GridRef &g,
                                          uint32_t, int32_t *__restrict__ stack, uint32_t stride, float px, float py, float pz,
                                          Scaled &u)
@@ -958,3 +850,7 @@ __device__ __forceinline__ void ray_f(const FrameInfo &I, float fx, float fy, fl
 }
 
 }  // namespace sdfhip
+
+#ifdef SDFHIP_EXPERIMENTS
+#include "lab_device.h"
+#endif

@@ -34,21 +34,29 @@ constexpr int MAX_STACK = LM;          // the shader's own descent limit (Comput
 #define PLAIN_WAVES_PER_SIMD 8          // <= 64 VGPRs: 8 waves per SIMD (2nd launch-bound = waves per SIMD)
 #endif
 
-// cursor kinds of the kernels: generic, cursor stack, cursor stack with a top grid as deep as the tree
-// CUR_DENSE4: the default kernel through the grid's second form, 4-byte words + sample records (CursorFF, raymarch_device.h)
+// cursor kinds of the kernels: generic, cursor stack, cursor stack with a top grid as deep as the tree (dense, or split)
+// (experiments build: CUR_DENSE4, the default kernel through the grid's second form, CursorFF in lab_device.h)
 enum { CUR_GENERIC = 0, CUR_STACK = 1, CUR_STACK_FULL = 2, CUR_STACK_SPLIT = 3, CUR_DENSE4 = 4 };
 template <int CUR, bool COUNT> struct CursorOf { typedef CursorG type; };
 template <bool COUNT> struct CursorOf<CUR_STACK, COUNT> { typedef CursorS type; };
 template <bool COUNT> struct CursorOf<CUR_STACK_FULL, COUNT> { typedef CursorFT<COUNT, false> type; };
 template <bool COUNT> struct CursorOf<CUR_STACK_SPLIT, COUNT> { typedef CursorFT<COUNT, true> type; };
-template <> struct CursorOf<CUR_DENSE4, false> { typedef CursorFF type; };
-// the cell a cursor sits in, for the gradient: most cursors carry its bytes; CursorFF looks them up again
+// the grid a launch's find() reads
+__device__ __forceinline__ GridRef grid_of(const RenderParams &P, const TopCell *top = nullptr)
+{
+#ifdef SDFHIP_EXPERIMENTS
+    return GridRef{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order, P.d4, P.recs};
+#else
+    return GridRef{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order};
+#endif
+}
+// the cell a cursor sits in, for the gradient: the cursors carry its bytes (CursorFF looks them up again)
 template <class CursorT>
 __device__ __forceinline__ Cell cell_of(const CursorT &c, const RenderParams &) { return c.cell(); }
-__device__ __forceinline__ Cell cell_of(const CursorFF &c, const RenderParams &P)
-{
-    return cell_of(c, GridRef{P.top, P.fine, P.top_level, P.fine_bits, P.fine_order, P.d4, P.recs}, P.nodes);
-}
+#ifdef SDFHIP_EXPERIMENTS
+template <> struct CursorOf<CUR_DENSE4, false> { typedef CursorFF type; };
+__device__ __forceinline__ Cell cell_of(const CursorFF &c, const RenderParams &P) { return cell_of(c, grid_of(P), P.nodes); }
+#endif
 // the bounce kernels of the path tracer may read a split grid whose blocks are stored sub-cube by sub-cube (GridRef::fine_order)
 template <int CUR, bool COUNT> struct ScatterCursorOf { typedef typename CursorOf<CUR, COUNT>::type type; };
 template <bool COUNT> struct ScatterCursorOf<CUR_STACK_SPLIT, COUNT> { typedef CursorFT<COUNT, true, true> type; };
@@ -66,7 +74,11 @@ struct RayState {
 __device__ __forceinline__ uint32_t global_row(const RenderParams &P, uint32_t yl)
 {
     const uint32_t band = yl / P.band_rows, within = yl - band * P.band_rows;
-    if (P.n_band_list) return band < P.n_band_list ? P.band_list[band] * P.band_rows + within : 0xFFFFFFFFu;
+    if (P.n_band_list) {
+        if (band >= P.n_band_list) return 0xFFFFFFFFu;
+        const uint32_t b = P.n_band_list <= (uint32_t)INLINE_BAND_LIST ? P.band_list[band] : P.band_ptr[band];
+        return b * P.band_rows + within;
+    }
     return (P.band_first + band * P.band_stride) * P.band_rows + within;
 }
 
@@ -252,7 +264,7 @@ __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const Fram
 {
     typename CursorT::Pos u;
     // top: the top grid somewhere else than P.top (the workgroup's LDS copy, k_plain<..., LDSTOP>)
-    const GridRef g{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order, P.d4, P.recs};
+    const GridRef g = grid_of(P, top);
     uint32_t reads = FRESH ? find_fresh(c, P.nodes, g, P.n_nodes, stack, stride, r.px, r.py, r.pz, u)
                            : find(c, P.nodes, g, P.n_nodes, stack, stride, r.px, r.py, r.pz, u);
     r.prox = sample_after_find(c, u, r.px, r.py, r.pz);
@@ -268,6 +280,13 @@ __device__ __forceinline__ uint32_t march_step(const RenderParams &P, const Fram
 // [0] flat leaf of the coarse level or above  [1] flat leaf inside a fine block (or, dense grid: below level 8)
 // [2] non-flat, coarse  [3] non-flat, as deep as the grid (k = 0)  [4] non-flat below the coarse level but not at the
 // grid's full depth  [5] non-flat steps whose position is outside the cube or NaN
+// (experiments build only; the product's counting kernels carry empty stand-ins)
+#ifndef SDFHIP_EXPERIMENTS
+struct StepClasses {};
+template <class CursorT>
+__device__ __forceinline__ void classify_step(StepClasses &, const CursorT &, const RenderParams &, float, float, float) {}
+__device__ __forceinline__ void flush_classes(const RenderParams &, StepClasses &) {}
+#else
 struct StepClasses { unsigned long long n[6] = {0, 0, 0, 0, 0, 0}; };
 template <class CursorT>
 __device__ __forceinline__ void classify_step(StepClasses &, const CursorT &, const RenderParams &, float, float, float) {}
@@ -289,6 +308,7 @@ __device__ __forceinline__ void flush_classes(const RenderParams &P, StepClasses
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(&P.counters[6 + i], v);
     }
 }
+#endif
 
 // loads: 16-byte node records / grid cells the kernel itself loaded (the cursor counts them); hits: shadow rays queued for k_shadow
 __device__ __forceinline__ void flush_counters(const RenderParams &P, unsigned long long nodes,
@@ -334,12 +354,17 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
     // any grid size).
     const uint32_t nb = gridDim.x, bid = blockIdx.x;
     uint32_t tile;
+#ifdef SDFHIP_EXPERIMENTS
     if (P.tile_order == 2) {          // one contiguous slab of tiles per XCD (load-imbalanced: kept for A/B runs)
         const uint32_t q = nb >> 3, rem = nb & 7u, xcd = bid & 7u;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
     } else if (P.tile_order == 1) {   // dispatch order = row-major tile order
         tile = bid;
-    } else {                          // default: XCD k renders tile rows k, k+8, ... (grid padded to 8*ceil(tiles_y/8) rows)
+    } else
+#else
+    (void)nb;
+#endif
+    {                                 // default: XCD k renders tile rows k, k+8, ... (grid padded to 8*ceil(tiles_y/8) rows)
         // tiles_y is rarely a multiple of 8: the first tiles_y % 8 labels get one tile row more.  A rank's
         // share of a sharded frame has few tile rows (17 at 8 ranks: 3 for label 0, 2 for the others), so
         // in a batched launch frame f shifts the labels by f * (tiles_y % 8): the extra rows go to
@@ -518,6 +543,7 @@ __device__ __forceinline__ uint32_t tile_of_block(const RenderParams &P, uint32_
     const uint32_t row = r * 8 + xcd;
     return row < P.tiles_y ? row * P.tiles_x + cx : 0xFFFFFFFFu;
 }
+#ifdef SDFHIP_EXPERIMENTS
 // Fill count of queue q of frame f, one 128-byte line each, in two sets: a launch pair uses set
 // P.hit_set, and its k_shadow zeroes the other set for the next pair on this scratch -- nothing else
 // touches that set meanwhile (launches that share a scratch run in stream order), so the queues are
@@ -527,6 +553,7 @@ __device__ __forceinline__ uint32_t *hit_count(const RenderParams &P, uint32_t s
 {
     return P.hit_ctl + (((size_t)set * MAX_BATCH + f) * HIT_QUEUES + q) * 32u;
 }
+#endif
 
 // The shadow march of Compute.hlsl:214-230 for a lane whose RayState holds the shading step's results (pos, dir, prox,
 // dist; n = 0).  Every exit is black (:223, :229) except the one that reaches the light (:215-219): returns that.
@@ -663,6 +690,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
         if (COUNT) { flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, 0u); flush_classes(P, classes); }
         return;
     }
+#ifdef SDFHIP_EXPERIMENTS
     if constexpr (QUEUE) {
     const unsigned long long hits = __ballot(shadow);
     if (hits) {
@@ -681,54 +709,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     }
     if (COUNT) flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, shadow ? 1u : 0u);
     }
-}
-
-// One lane per queued shadow ray; a wave takes 64 consecutive records of one queue at a time (chunks are
-// numbered over the frame's queues: a wave-wide scan of the 64 fill counts, once per wave).
-template <int CUR, bool COUNT, int MODE>
-__global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shadow(RenderParams P)
-{
-    typedef typename CursorOf<CUR, COUNT>::type CursorT;
-    const uint32_t f = blockIdx.y, lane = threadIdx.x;
-    FrameInfo I = P.frames[f];
-    asm volatile("" : "+s"(I.margin));
-    const PixelSink<MODE> dst(P, f);
-    // chunks of queue `lane`, and their running sum over the queues (inclusive scan across the wave)
-    const uint32_t fill = min(*hit_count(P, P.hit_set, f, lane), P.hit_cap);
-    if (blockIdx.x == 0 && f == 0)                       // empty the other set -- every frame of it -- for the next launch pair
-        for (uint32_t ff = 0; ff < (uint32_t)MAX_BATCH; ff++) *hit_count(P, P.hit_set ^ 1u, ff, lane) = 0u;
-    const uint32_t chunks = (fill + 63u) >> 6;
-    uint32_t incl = chunks;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    unsigned long long cn = 0, cs = 0, ct = 0, cl = 0;
-    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
-        // queue of chunk t = the number of queues whose inclusive sum is <= t
-        const uint32_t q = (uint32_t)__popcll(__ballot(incl <= t));
-        const uint32_t q_incl = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)q), q_chunks = (uint32_t)__builtin_amdgcn_readlane((int)chunks, (int)q);
-        const uint32_t q_fill = (uint32_t)__builtin_amdgcn_readlane((int)fill, (int)q);
-        const uint32_t i = (t - (q_incl - q_chunks)) * 64u + lane;
-        if (i < q_fill) {
-            const size_t slot = ((size_t)f * HIT_QUEUES + q) * P.hit_cap + i;
-            const float4 a = P.hit_a[slot], d = P.hit_d[slot];
-            const int4 b = P.hit_b[slot];
-            const uint4 e = P.hit_c[slot];
-            RayState r;
-            CursorT c;
-            r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w; r.dx = d.x; r.dy = d.y; r.dz = d.z; r.angle = d.w;
-            r.base = (int)e.y; r.n = 0; r.phase = PH_SHADOW;          // i stays, j starts
-            c.unpack(b, CursorT::units_shift(P.top_level + (CUR == CUR_STACK_SPLIT ? P.fine_bits : 0)));
-            c.v0 = e.z; c.v1 = e.w; c.loads = 0;
-            const size_t lidx = e.x;
-            const float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;      // Compute.hlsl:212
-            r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
-            const bool lit = shadow_march<COUNT>(P, I, r, c, cn, cs);
-            if (lit) dst.grey(lidx, r.angle / (r.dist * r.dist) * I.k_strength, (float)(r.base + r.n));
-            else dst.black(lidx, (float)(r.base + r.n));
-            if (COUNT) { ct += (unsigned long long)(r.base + r.n); cl += c.loads; }
-        }
-    }
-    if (COUNT) flush_counters(P, cn, cs, ct, 0, cl);
+#endif
 }
 
 // ---- persistent waves with lane refill and state batching (wavefront ray compaction) --
@@ -1013,7 +994,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
             }
             // ---- one march step of the segment or of the shadow ray -----------------------
             typename CursorT::Pos u;
-            uint32_t reads = find(c, P.nodes, GridRef{P.top, P.fine, P.top_level, P.fine_bits, P.fine_order}, P.n_nodes, stack, 64, mx, my, mz, u);
+            uint32_t reads = find(c, P.nodes, grid_of(P), P.n_nodes, stack, 64, mx, my, mz, u);
             prox = sample_after_find(c, u, mx, my, mz);
             if (COUNT) { cn += reads; cs += 1; }
             const float st = shadow ? prox + margin : prox;

@@ -465,8 +465,8 @@ int submit_locked(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint
     if (!infos || n_frames == 0 || n_frames > MAX_GROUP || width == 0 || height == 0)
         return fail(SDFHIP_ERR_ARG, "multi_submit: null argument, zero-sized frame or n_frames outside 1..%u", MAX_GROUP);
     if (pt && n_frames != 1) return fail(SDFHIP_ERR_ARG, "multi_submit: the path-traced mode renders one frame per submission");
-    if (flags & (SDFHIP_FLAG_WIRE | SDFHIP_FLAG_COMPACT | SDFHIP_FLAG_COUNT | SDFHIP_TUNE_ONE_KERNEL | SDFHIP_TUNE_SHADOW_QUEUE | SDFHIP_TUNE_LDS_TOP))
-        return fail(SDFHIP_ERR_ARG, "multi_submit: flags %#x are not available across devices", flags);
+    if (flags & ~(uint32_t)(SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG | SDFHIP_FLAG_TILE_ORDER))
+        return fail(SDFHIP_ERR_ARG, "multi_submit: flags %#x are not available across devices (0, SDFHIP_FLAG_DISPLAY[_DEBUG], SDFHIP_FLAG_TILE_ORDER)", flags);
     if (pt && (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG)))
         return fail(SDFHIP_ERR_ARG, "multi_submit: the display pass is not available in path-traced mode");
     if (m->broken) return fail(SDFHIP_ERR_DEVICE, "multi_submit: an earlier submission failed with RCCL receives outstanding; free this handle and create a new one");
@@ -718,6 +718,8 @@ extern "C" int sdfhip_multi_configure(sdfhip_multi *m, uint32_t band_rows, float
     return SDFHIP_OK;
 }
 
+#ifdef SDFHIP_EXPERIMENTS
+#include "../../include/sdfhip_experimental.h"
 extern "C" int sdfhip_multi_debug_floats_sent(sdfhip_multi *m, uint32_t floats)
 {
     if (!m) return fail(SDFHIP_ERR_ARG, "multi_debug_floats_sent: null handle");
@@ -725,6 +727,7 @@ extern "C" int sdfhip_multi_debug_floats_sent(sdfhip_multi *m, uint32_t floats)
     for (uint32_t r = 0; r < MAX_RANKS; r++) m->est[r] = floats;
     return SDFHIP_OK;
 }
+#endif
 
 extern "C" int sdfhip_multi_info(const sdfhip_multi *m, uint32_t *n_devices, int *devices, uint32_t *band_rows, float *rank0_weight, int *transport)
 {

@@ -214,6 +214,7 @@ class Scene:
     def step_classes(self, stream=None):
         """After a FLAG_COUNT DrawDevice on `stream`: lane-steps by the kind of cell they sampled
         (sdfhip_debug_step_classes)."""
+        _lib.need_lab("Scene.step_classes")
         out = (ctypes.c_uint64 * 6)()
         check(lib.sdfhip_debug_step_classes(self._h, ctypes.c_void_p(int(stream)) if stream else None, out))
         return dict(zip(("flat_coarse", "flat_fine", "nonflat_coarse", "nonflat_full_depth", "nonflat_between", "nonflat_outside"),
@@ -296,6 +297,7 @@ class MultiScene:
         return (p.value, st) if want_stats else p.value
 
     def debug_floats_sent(self, floats):
+        _lib.need_lab("MultiScene.debug_floats_sent")
         check(lib.sdfhip_multi_debug_floats_sent(self._h, int(floats)))
 
 
@@ -306,6 +308,7 @@ def device_count():
 
 
 def unorm_table(device=0):
+    _lib.need_lab("unorm_table")
     out = np.empty(256, dtype=np.float32)
     check(lib.sdfhip_debug_unorm_table(int(device), out.ctypes.data))
     return out

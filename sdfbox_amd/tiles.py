@@ -29,7 +29,7 @@ as well, point to point, and rank 0 writes it over that rank's rows
 """
 import ctypes
 
-from ._lib import check, lib
+from ._lib import check, lib, need_lab
 
 
 class BandLayout:
@@ -151,11 +151,13 @@ def deinterleave(device, gathered_ptr, frame_ptr, width, layout, stream=None, pi
 
 def sparse_share_bytes(rows, width, capacity):
     """Bytes of one frame-share in the sparse wire format."""
+    need_lab("sparse_share_bytes")
     return int(lib.sdfhip_wire_sparse_bytes(int(width), int(rows), int(capacity)))
 
 
 def wire_compact(device, wire_ptr, sparse_ptr, width, rows, frames, capacity, stream=None):
     """[frames] dense wire shares (FLAG_WIRE renders) -> [frames] sparse shares, on `stream`."""
+    need_lab("wire_compact")
     check(lib.sdfhip_wire_compact_device(int(device), ctypes.c_void_p(int(wire_ptr)), ctypes.c_void_p(int(sparse_ptr)),
                                          int(width), int(rows), int(frames), int(capacity),
                                          ctypes.c_void_p(int(stream)) if stream else None))
@@ -163,6 +165,7 @@ def wire_compact(device, wire_ptr, sparse_ptr, width, rows, frames, capacity, st
 
 def sparse_head_offset(rows, width, capacity):
     """Byte offset of a sparse share's header {uint32 lit pixels, uint32 overflowed, 0, 0}."""
+    need_lab("sparse_head_offset")
     return int(lib.sdfhip_wire_sparse_head_offset(int(width), int(rows), int(capacity)))
 
 
@@ -177,6 +180,7 @@ def deinterleave_share(device, share_ptr, frame_ptr, width, layout, rank, stream
     """Rank 0: write ONE rank's buffers ([frames] x rows_per_rank x width pixels; pixel_bytes as for
     `deinterleave`) over that rank's rows of the frames: the dense resend of a share whose sparse form
     overflowed its capacity."""
+    need_lab("deinterleave_share")
     owner = (ctypes.c_uint8 * layout.n_bands)(*layout.owner) if layout.weighted else None
     check(lib.sdfhip_deinterleave_share_device(int(device), ctypes.c_void_p(int(share_ptr)), ctypes.c_void_p(int(frame_ptr)),
                                                int(width), layout.height, layout.band_rows, layout.world,
@@ -199,6 +203,7 @@ def deinterleave_sparse(device, gathered_ptr, frame_ptr, width, layout, capacity
     """Rank 0: gathered sparse shares (world x frames x sparse_share_bytes) -> frames x height x width
     RGBA32F.  overflow_ptr: a device int32 that is OR-ed with 1 if a share had more lit pixels than
     `capacity` (the frame is then incomplete)."""
+    need_lab("deinterleave_sparse")
     owner = (ctypes.c_uint8 * layout.n_bands)(*layout.owner) if layout.weighted else None
     check(lib.sdfhip_deinterleave_sparse_device(int(device), ctypes.c_void_p(int(gathered_ptr)),
                                                 ctypes.c_void_p(int(frame_ptr)), int(width), layout.height,

@@ -62,5 +62,7 @@ def oracle_mod():
 
 
 @pytest.fixture(scope="session")
-def scenes(sb):
-    return {"sphere_d4": sb.sphere_d4(), "torus_d6": sb.torus_d6()}
+def scenes():
+    # (host arrays: the same for both flavours of the library -- test files that run on both override `sb` per module)
+    import sdfbox_amd
+    return {"sphere_d4": sdfbox_amd.sphere_d4(), "torus_d6": sdfbox_amd.torus_d6()}

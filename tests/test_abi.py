@@ -10,33 +10,57 @@ import pytest
 from conftest import REPO
 
 
-def declared_symbols():
-    text = open(os.path.join(REPO, "include", "sdfhip.h")).read()
+def declared_symbols(header="sdfhip.h"):
+    text = open(os.path.join(REPO, "include", header)).read()
     return sorted(set(re.findall(r"SDFHIP_API[^;]*?\b(sdfhip_\w+)\s*\(", text)))
 
 
-def test_every_declared_symbol_is_exported(sb):
+def exported_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("sdfhip_")})
+
+
+def test_the_product_exports_exactly_its_header(sb):
+    # libsdfhip.so == include/sdfhip.h, symbol for symbol: the laboratory (A/B kernel forms, superseded gather formats, test
+    # hooks) is a library of its own
     names = declared_symbols()
-    assert len(names) >= 17
-    for n in names:
-        assert hasattr(sb._lib.lib, n), f"{n} declared in include/sdfhip.h but not exported"
+    assert len(names) >= 40
+    assert exported_symbols(sb._lib.LIB_PATH) == names
+    assert os.path.basename(sb._lib.LIB_PATH) == "libsdfhip.so" and not sb._lib.EXPERIMENTS
     # and the Python binding covers exactly the declared set
     assert sorted(sb._lib.EXPORTED_SYMBOLS) == names
+    for n in names:
+        assert hasattr(sb._lib.lib, n)
 
 
-def test_flag_constants_match_the_header(sb):
-    # every SDFHIP_FLAG_* / SDFHIP_TUNE_* / SDFHIP_KERNEL_* enumerator of include/sdfhip.h that the Python mirror names has the
-    # header's value, and no two render flags share a bit
-    text = open(os.path.join(REPO, "include", "sdfhip.h")).read()
-    header = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"\bSDFHIP_((?:FLAG|TUNE|KERNEL)_\w+)\s*=\s*(0x[0-9A-Fa-f]+|\d+)", text)}
-    assert {"FLAG_COMPACT", "FLAG_COUNT", "FLAG_DISPLAY", "FLAG_WIRE", "FLAG_TILE_ORDER", "TUNE_ONE_KERNEL", "TUNE_SHADOW_QUEUE"} <= set(header)
+def test_the_experiments_build_exports_both_headers(sb):
+    lab = declared_symbols("sdfhip_experimental.h")
+    assert 8 <= len(lab) <= 12 and not set(lab) & set(declared_symbols())
+    assert exported_symbols(sb._lib.LAB_LIB_PATH) == sorted(declared_symbols() + lab)
+    assert sorted(sb._lib.EXPERIMENTAL_SYMBOLS) == lab
+    import sdfbox_amd.lab
+    sbx = sdfbox_amd.lab.load()
+    assert sbx._lib.EXPERIMENTS and sbx.Info is sb.Info and sbx._lib.lib is not sb._lib.lib      # one set of ctypes classes, two libraries
+
+
+def test_flag_constants_match_the_headers(sb):
+    # every SDFHIP_FLAG_* / SDFHIP_TUNE_* / SDFHIP_KERNEL_* enumerator of the two headers that the Python mirror names has the
+    # header's value, no two render flags share a bit, and the product's header carries no A/B knob
+    def enums(header):
+        text = open(os.path.join(REPO, "include", header)).read()
+        return {m.group(1): int(m.group(2), 0) for m in re.finditer(r"\bSDFHIP_((?:FLAG|TUNE|KERNEL)_\w+)\s*=\s*(0x[0-9A-Fa-f]+|\d+)", text)}
+    product, lab = enums("sdfhip.h"), enums("sdfhip_experimental.h")
+    assert {"FLAG_COMPACT", "FLAG_COUNT", "FLAG_DISPLAY", "FLAG_DISPLAY_DEBUG", "FLAG_TILE_ORDER", "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_STACK", "KERNEL_MASK"} == set(product)
+    assert {"FLAG_WIRE", "TUNE_ONE_KERNEL", "TUNE_SHADOW_QUEUE", "TUNE_LDS_TOP", "TUNE_BYTE_CELLS", "TUNE_ORDER_SHIFT", "TUNE_BLOCK_SHIFT"} == set(lab)
+    header = dict(product, **lab)
     L = sb._lib
     seen = 0
     for name, value in header.items():
         if hasattr(L, name):
             assert getattr(L, name) == value, name
             seen += 1
-    assert seen >= 10
+    assert seen >= 14
     bits = [v for k, v in header.items() if k.startswith(("FLAG_", "TUNE_")) and not k.endswith("_SHIFT")]
     assert len(bits) == len(set(bits)) and all(v & (v - 1) == 0 for v in bits)      # single, distinct bits
 

@@ -51,9 +51,9 @@ def test_bench_gpus_n_starts_its_own_ranks():
     j = run_bench("--gpus", 2, "--backend", "gloo", "--steps", 8, "--warmup", 4, "--depth", 6, "--size", "640x360", "--check")
     assert j["n_gpus"] == 2 and j["config"]["assembled_frame_equals_whole_frame_render"] is True
     assert j["config"]["gather_format"] == "sparse shares written by the march kernel"
-    # round 2's form (dense wire shares compacted by three kernels before the gather) stays as --wire 2
-    j = run_bench("--gpus", 2, "--backend", "gloo", "--steps", 8, "--warmup", 4, "--depth", 6, "--size", "640x360", "--check", "--wire", 2)
-    assert j["config"]["assembled_frame_equals_whole_frame_render"] is True and j["config"]["gather_format"] == "sparse wire"
+    # the display pass travels as the frame's own RGBA8 pixels
+    j = run_bench("--gpus", 2, "--backend", "gloo", "--steps", 8, "--warmup", 4, "--depth", 6, "--size", "640x360", "--check", "--display")
+    assert j["config"]["assembled_frame_equals_whole_frame_render"] is True and j["config"]["gather_format"] == "frame pixels"
 
 
 @pytest.mark.gpu
@@ -73,10 +73,6 @@ def test_cfg4_frame_two_ranks_moving_camera_and_dense_resend():
                   "--orbit", 16, "--sparse-cap-scale", 0.2, "--no-cpu-baseline")
     assert j["n_gpus"] == 2 and j["config"]["assembled_frame_equals_whole_frame_render"] is True
     assert j["config"]["float_tails_sent_again"] > 0
-    # ... and round 2's form: overflowed sparse wire shares come again dense
-    j = run_bench("--gpus", 2, "--backend", "gloo", "--check", "--size", "3840x2160", "--steps", 8, "--warmup", 4,
-                  "--orbit", 16, "--sparse-cap-scale", 0.2, "--no-cpu-baseline", "--wire", 2)
-    assert j["config"]["assembled_frame_equals_whole_frame_render"] is True and j["config"]["sparse_shares_resent_dense"] > 0
 
 
 @pytest.mark.gpu
@@ -133,6 +129,16 @@ def test_committed_pmc_passes_belong_to_this_build():
         assert key in t, key
         assert t[key]["kernel_source_sha"] == here, f"{key}: measured on {t[key]['kernel_source_sha']}, the tree is {here}: re-profile"
         assert "dropped" not in bench.load_pmc(key)
+
+
+@pytest.mark.gpu
+def test_bench_ab_forms_need_the_experiments_flavour():
+    # --one-kernel / --shadow-queue are A/B forms of libsdfhip_lab.so: `--lab` loads it; without it bench.py says so
+    j = run_bench("--lab", "--one-kernel", "--steps", 3, "--warmup", 1, "--depth", 6, "--size", "320x200", "--no-cpu-baseline")
+    assert "one kernel" in j["config"]["kernel"]
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--shadow-queue", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert out.returncode != 0 and "--lab" in (out.stderr + out.stdout)
 
 
 def test_roofline_reports_only_measured_fractions():

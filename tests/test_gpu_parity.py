@@ -13,11 +13,44 @@ from conftest import CAMERAS, GOLDEN, assert_frames_identical, bits_equal, make_
 
 pytestmark = pytest.mark.gpu
 
+# Every test of this file runs on BOTH flavours of the library: the product (libsdfhip.so, include/sdfhip.h) and the experiments
+# build (libsdfhip_lab.so, include/sdfhip_experimental.h: the same sources + the A/B kernel forms and superseded gather formats).
 # "stack" = the default: k_march (primary march, shading, shadow march as wave-converged loops) wherever the scene has a full-depth or split
-# grid (every test scene of depth <= 12 does); "stack+one" = the one-kernel form of the same traversal;
-# "stack+queue" = k_march queues its shadow rays for k_shadow (the A/B knob SDFHIP_TUNE_SHADOW_QUEUE)
-# "stack+bytes" = the default kernel reading the 16-byte cells of a split grid where it would read the 32-byte pre-decoded ones
-ALL_VARIANTS = ["generic", "stack", "stack+one", "stack+queue", "stack+bytes", "generic+compact", "stack+compact"]
+# grid (every test scene of depth <= 12 does); "generic" = the shader's own traversal; "+compact" = BASELINE cfg-3's wavefront ray compaction.
+# Experiments build only: "stack+one" = round 1's one-kernel form of the same traversal; "stack+queue" = k_march queues its shadow
+# rays for k_shadow (SDFHIP_TUNE_SHADOW_QUEUE); "stack+bytes" = SDFHIP_TUNE_BYTE_CELLS (a no-op unless SDFHIP_SAMPLE_RECORDS=1 built the
+# grid's second form)
+PRODUCT_VARIANTS = ["generic", "stack", "generic+compact", "stack+compact"]
+LAB_VARIANTS = ["stack+one", "stack+queue", "stack+bytes"]
+ALL_VARIANTS = PRODUCT_VARIANTS + LAB_VARIANTS
+
+
+@pytest.fixture(scope="module", params=["product", "lab"])
+def sb(request):
+    import sdfbox_amd
+    if request.param == "product":
+        return sdfbox_amd
+    import sdfbox_amd.lab
+    return sdfbox_amd.lab.load()
+
+
+def variants_of(sb):
+    return ALL_VARIANTS if sb._lib.EXPERIMENTS else PRODUCT_VARIANTS
+
+
+def skip_unless_offered(sb, variant):
+    if variant in LAB_VARIANTS and not sb._lib.EXPERIMENTS:
+        pytest.skip("an A/B form of the experiments build")
+
+
+def ab(sb, *flags):
+    """the A/B forms' flags where the library offers them"""
+    return tuple(flags) if sb._lib.EXPERIMENTS else ()
+
+
+def lab_only(sb):
+    if not sb._lib.EXPERIMENTS:
+        pytest.skip("include/sdfhip_experimental.h: the experiments build only")
 
 
 def flags_of(sb, name):
@@ -35,19 +68,35 @@ def gpu_scenes(sb, scenes):
 
 
 def test_native_library_is_the_one_in_tree(sb):
-    # the driver records which .so the process loaded: it must be sdfbox_amd/libsdfhip.so
+    # the driver records which .so the process loaded: it must be sdfbox_amd/libsdfhip.so (and, for the A/B forms, libsdfhip_lab.so)
     with open("/proc/self/maps") as f:
         maps = f.read()
-    assert sb._lib.LIB_PATH in maps
+    assert sb._lib.LIB_PATH in maps and os.path.dirname(sb._lib.LIB_PATH).endswith("sdfbox_amd")
+    assert os.path.basename(sb._lib.LIB_PATH) == ("libsdfhip_lab.so" if sb._lib.EXPERIMENTS else "libsdfhip.so")
+
+
+def test_product_refuses_the_experiments_flags(sb, gpu_scenes):
+    # the A/B knobs exist in the experiments build only: the product says so instead of silently rendering the default
+    if sb._lib.EXPERIMENTS:
+        pytest.skip("the product flavour's behaviour")
+    cam = make_camera("default", 32, 32)
+    for fl in (sb.TUNE_ONE_KERNEL, sb.TUNE_SHADOW_QUEUE, sb.FLAG_WIRE, sb._lib.TUNE_LDS_TOP, sb._lib.TUNE_BYTE_CELLS, 1 << 8, 2 << 12):
+        with pytest.raises(sb.SdfHipError) as e:
+            gpu_scenes["sphere_d4"].Draw(cam, 32, 32, fl)
+        assert e.value.code == sb._lib.ERR_ARG and "experimental" in str(e.value)
+    for name in sb._lib.EXPERIMENTAL_SYMBOLS:
+        assert not hasattr(sb._lib.lib, name), name
 
 
 def test_unorm_table(sb, oracle_mod):
+    lab_only(sb)
     # the kernel's reciprocal + fma fix-up decode == byte / 255.0f for all 256 bytes
     assert bits_equal(sb.unorm_table(0), oracle_mod.unorm_table()).all()
 
 
 @pytest.mark.parametrize("variant", ALL_VARIANTS)
 def test_golden_frames(sb, gpu_scenes, variant):
+    skip_unless_offered(sb, variant)
     g = np.load(os.path.join(GOLDEN, "frames.npz"))
     for sname, scene in gpu_scenes.items():
         for cname in CAMERAS:
@@ -62,6 +111,7 @@ def test_golden_frames(sb, gpu_scenes, variant):
 @pytest.mark.parametrize("variant", ALL_VARIANTS)
 @pytest.mark.parametrize("size", [(256, 256), (200, 120), (1, 1), (7, 3), (17, 33), (129, 65)])
 def test_against_oracle_cfg1_and_ragged_sizes(sb, oracle_mod, scenes, gpu_scenes, variant, size):
+    skip_unless_offered(sb, variant)
     # cfg-1 (256x256 sphere_d4, default camera) plus frames that do not fill whole
     # 8x8 / 16x16 tiles; the kernels must neither skip nor write outside W x H
     W, H = size
@@ -74,6 +124,7 @@ def test_against_oracle_cfg1_and_ragged_sizes(sb, oracle_mod, scenes, gpu_scenes
 
 
 def test_tuning_knobs_never_change_results(sb, gpu_scenes):
+    lab_only(sb)
     # blockIdx -> tile order (bits 8..11) and workgroup size (bits 12..15) are pure speed knobs
     scene = gpu_scenes["torus_d6"]
     cam = make_camera("rotated", 333, 211)
@@ -106,7 +157,7 @@ def test_camera_edge_cases(sb, oracle_mod, scenes, gpu_scenes):
     c = sb.Logic(W, H); c.State.screen_size[0] = 640.0; c.State.screen_size[1] = 480.0; cams.append(("screen_size != frame size", c))
     for what, cam in cams:
         ref, cnt = oracle_mod.render(od.Structs, od.Values, cam.State, W, H, nthreads=8)
-        for variant in ALL_VARIANTS:
+        for variant in variants_of(sb):
             img, st = scene.Draw(cam, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
             assert_frames_identical(img, ref, f"{what} / {variant}")
             assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), what
@@ -135,7 +186,7 @@ def test_degenerate_and_deep_trees(sb, oracle_mod):
     ref, cnt = oracle_mod.render(od.Structs, od.Values, cam.State, W, H)
     with sb.Scene(od) as sc:
         assert sc.stack_kernel_ok and sc.depth == 0
-        for variant in ALL_VARIANTS:
+        for variant in variants_of(sb):
             assert_frames_identical(sc.Draw(cam, W, H, flags_of(sb, variant)), ref, f"single leaf / {variant}")
     # depth 12: still within the shader's 12-descent limit -> stack kernel allowed
     s, v = _chain_tree(12)
@@ -144,7 +195,7 @@ def test_degenerate_and_deep_trees(sb, oracle_mod):
     ref, cnt = oracle_mod.render(s, v, cam2.State, W, H)
     with sb.Scene(od) as sc:
         assert sc.stack_kernel_ok and sc.depth == 12
-        for variant in ALL_VARIANTS:
+        for variant in variants_of(sb):
             img, st = sc.Draw(cam2, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
             assert_frames_identical(img, ref, f"depth 12 / {variant}")
             assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
@@ -242,7 +293,7 @@ def test_band_rendering_reassembles_the_frame(sb, gpu_scenes):
     # the multi-GPU sharding, all ranks played by one GPU: each rank's bands into a compact
     # buffer, "gathered" side by side, de-interleaved by the rank-0 kernel
     import torch
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands
+    BandLayout, deinterleave, render_bands = (sb.tiles.BandLayout, sb.tiles.deinterleave, sb.tiles.render_bands)
     scene = gpu_scenes["torus_d6"]
     for (W, H, world, band_rows, variant) in [(160, 100, 3, 16, "stack"), (90, 77, 4, 8, "stack+compact"),
                                              (64, 64, 8, 16, "generic"), (70, 50, 2, 24, "generic+compact")]:
@@ -342,6 +393,7 @@ def assert_display_close(got, ref, what):
 
 @pytest.mark.parametrize("variant", ALL_VARIANTS)
 def test_fused_display_pass(sb, oracle_mod, scenes, gpu_scenes, variant):
+    skip_unless_offered(sb, variant)
     # N2: DisplayFrag.hlsl fused into the epilogue -- gamma RGBA8 and the debug heat map
     for sname in ("sphere_d4", "torus_d6"):
         for cname, (W, H) in (("default", (200, 120)), ("rotated", (97, 61)), ("closeup", (64, 64))):
@@ -360,7 +412,7 @@ def test_fused_display_pass(sb, oracle_mod, scenes, gpu_scenes, variant):
 
 def test_display_bands_reassemble(sb, gpu_scenes):
     import torch
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands
+    BandLayout, deinterleave, render_bands = (sb.tiles.BandLayout, sb.tiles.deinterleave, sb.tiles.render_bands)
     scene = gpu_scenes["torus_d6"]
     W, H, world = 150, 90, 3
     cam = make_camera("rotated", W, H)
@@ -379,7 +431,7 @@ def test_display_bands_reassemble(sb, gpu_scenes):
 def test_batched_launch_renders_each_camera(sb, gpu_scenes):
     # several frames in one launch (grid.y = frame): each with its own camera block, bands included
     import torch
-    from sdfbox_amd.tiles import BandLayout
+    BandLayout = sb.tiles.BandLayout
     scene = gpu_scenes["torus_d6"]
     W, H = 150, 90
     cams = [make_camera(n, W, H) for n in ("default", "rotated", "closeup")]
@@ -417,7 +469,7 @@ def test_batched_launch_renders_each_camera(sb, gpu_scenes):
 def test_grouped_gather_deinterleave(sb, gpu_scenes):
     # one gather may carry several frames: gathered [world][frames][rows][W] -> [frames][H][W]
     import torch
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands
+    BandLayout, deinterleave, render_bands = (sb.tiles.BandLayout, sb.tiles.deinterleave, sb.tiles.render_bands)
     scene = gpu_scenes["sphere_d4"]
     W, H, world, G = 120, 70, 3, 3
     lay = BandLayout(H, world, 16)
@@ -436,11 +488,12 @@ def test_grouped_gather_deinterleave(sb, gpu_scenes):
 
 
 def test_wire_pixels_expand_to_the_same_frame(sb, gpu_scenes):
+    lab_only(sb)
     # the gather's 5-byte wire format (FLAG_WIRE) is lossless: ranks render wire pixels, rank 0's
     # de-interleave expands them, and the frame is the direct RGBA32F render bit for bit --
     # sky, lit, shadowed and back-facing pixels, single and batched launches, both kernels
     import torch
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch, wire_shape
+    BandLayout, deinterleave, render_bands, render_bands_batch, wire_shape = (sb.tiles.BandLayout, sb.tiles.deinterleave, sb.tiles.render_bands, sb.tiles.render_bands_batch, sb.tiles.wire_shape)
     stream = torch.cuda.current_stream().cuda_stream
     for name, (W, H, world, band_rows) in [("sphere_d4", (128, 96, 1, 96)), ("torus_d6", (150, 90, 3, 16)),
                                            ("torus_d6", (97, 61, 4, 8))]:
@@ -493,7 +546,7 @@ def test_weighted_band_layouts_reassemble_the_frame(sb, gpu_scenes):
     # on the render side, an owner table on the de-interleave side; all pixel formats, batched
     # launches and the path-traced mode
     import torch
-    from sdfbox_amd.tiles import BandLayout, deinterleave, render_bands, render_bands_batch, wire_shape
+    BandLayout, deinterleave, render_bands, render_bands_batch, wire_shape = (sb.tiles.BandLayout, sb.tiles.deinterleave, sb.tiles.render_bands, sb.tiles.render_bands_batch, sb.tiles.wire_shape)
     scene = gpu_scenes["torus_d6"]
     stream = torch.cuda.current_stream().cuda_stream
     for (W, H, world, band_rows, w0) in [(160, 100, 3, 8, 0.5), (90, 77, 4, 16, 0.8), (64, 200, 8, 8, 0.775), (70, 50, 2, 24, 0.9)]:
@@ -502,7 +555,7 @@ def test_weighted_band_layouts_reassemble_the_frame(sb, gpu_scenes):
         cams = [make_camera(n, W, H) for n in ("rotated", "closeup")]
         full = [torch.from_numpy(scene.Draw(c, W, H)).cuda() for c in cams]
         # RGBA32F and wire pixels, one launch per frame and one per group
-        for pb, fl in ((16, 0), (5, sb.FLAG_WIRE)):
+        for pb, fl in ((16, 0), (5, sb.FLAG_WIRE)) if sb._lib.EXPERIMENTS else ((16, 0),):
             if pb == 16:
                 gathered = torch.zeros((world, 2, lay.rows_per_rank, W, 4), dtype=torch.float32, device="cuda")
             else:
@@ -575,11 +628,11 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
                     if lv is None:       # the default for shallow trees: as deep as the tree (every leaf in the grid)
                         assert scene.top_grid_level == scene.depth
                     for c, (ref, cnt) in zip((cam, ongrid), refs):
-                        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL, sb.KERNEL_STACK | sb.FLAG_COMPACT):
+                        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT) + ((sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL,) if sb._lib.EXPERIMENTS else ()):
                             img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
                             assert_frames_identical(img, ref, f"top grid {lv}")
                             assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), lv
-                        if 0 < scene.top_grid_level <= 3 and scene.top_grid_level < scene.depth:
+                        if sb._lib.EXPERIMENTS and 0 < scene.top_grid_level <= 3 and scene.top_grid_level < scene.depth:
                             # the measurement variant that stages the top grid in LDS (64- and 256-thread workgroups)
                             for block in (0, 3):
                                 img = scene.Draw(c, W, H, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL | sb._lib.TUNE_LDS_TOP | (block << 12))
@@ -598,12 +651,13 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
                     with sb.Scene(od) as scene:
                         assert scene.top_grid_level == int(sp) and scene.top_grid_bytes >= 16 << (3 * int(sp))
                         for c, (ref, cnt) in zip((cam, ongrid), refs):
-                            for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL, sb.KERNEL_STACK | sb.FLAG_COMPACT):
+                            for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT) + ((sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL,) if sb._lib.EXPERIMENTS else ()):
                                 img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
                                 assert_frames_identical(img, ref, f"split grid {sp}")
                                 assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), sp
                                 assert_frames_identical(scene.Draw(c, W, H, flags), ref, f"split grid {sp}, not counting")
-                                assert_frames_identical(scene.Draw(c, W, H, flags | sb._lib.TUNE_BYTE_CELLS), ref, f"split grid {sp}, byte cells")
+                                if sb._lib.EXPERIMENTS:
+                                    assert_frames_identical(scene.Draw(c, W, H, flags | sb._lib.TUNE_BYTE_CELLS), ref, f"split grid {sp}, byte cells")
                             pimg = scene.DrawPath(c, W, H, pt=sb.PathTrace(spp=2))
                             pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
                             assert_frames_identical(pimg, pref, f"split grid {sp}, path-traced")
@@ -622,12 +676,12 @@ def od_depth(sb, od):
 
 
 def test_sparse_wire_format_is_lossless_within_its_capacity(sb, gpu_scenes):
+    lab_only(sb)
     # dense wire shares compacted on the rendering side (codes + per-tile mask and slot index + packed
     # non-zero floats), expanded by the rank-0 kernel: the same frame bit for bit; too small a
     # capacity is reported, never silent
     import torch
-    from sdfbox_amd.tiles import (BandLayout, deinterleave_sparse, render_bands_batch, sparse_count, sparse_share_bytes,
-                                  wire_compact, wire_shape)
+    BandLayout, deinterleave_sparse, render_bands_batch, sparse_count, sparse_share_bytes, wire_compact, wire_shape = (sb.tiles.BandLayout, sb.tiles.deinterleave_sparse, sb.tiles.render_bands_batch, sb.tiles.sparse_count, sb.tiles.sparse_share_bytes, sb.tiles.wire_compact, sb.tiles.wire_shape)
     stream = torch.cuda.current_stream().cuda_stream
     scene = gpu_scenes["torus_d6"]
     for (W, H, world, band_rows, w0) in [(160, 96, 1, 96, 1.0), (150, 90, 3, 16, 1.0), (97, 61, 4, 8, 0.6), (64, 200, 8, 8, 0.5)]:
@@ -678,10 +732,11 @@ def test_sparse_wire_format_is_lossless_within_its_capacity(sb, gpu_scenes):
 
 
 def test_sparse_wire_format_on_random_shares(sb):
+    lab_only(sb)
     # the format itself, fed with arbitrary wire shares (any float bit pattern: NaNs, -0.0, denormals;
     # any legal code byte; ragged widths): expanding the sparse form equals expanding the dense form
     import torch
-    from sdfbox_amd.tiles import BandLayout, deinterleave, deinterleave_sparse, sparse_count, sparse_share_bytes, wire_compact, wire_shape
+    BandLayout, deinterleave, deinterleave_sparse, sparse_count, sparse_share_bytes, wire_compact, wire_shape = (sb.tiles.BandLayout, sb.tiles.deinterleave, sb.tiles.deinterleave_sparse, sb.tiles.sparse_count, sb.tiles.sparse_share_bytes, sb.tiles.wire_compact, sb.tiles.wire_shape)
     stream = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cpu").manual_seed(5)
     for (W, H, world, band_rows, frames, p_lit) in [(61, 40, 1, 8, 2, 0.3), (200, 64, 2, 16, 3, 0.05), (33, 96, 4, 8, 1, 0.9), (128, 24, 3, 8, 2, 0.0)]:
@@ -737,12 +792,13 @@ def test_two_handles_render_concurrently(sb, oracle_mod, scenes):
 
 
 def test_tile_order_hook_permutes_work_not_results(sb, oracle_mod, scenes):
+    lab_only(sb)
     # sdfhip_debug_tile_order (the experiment hook of scripts/ab_tile_order.py and wave_iterations.py): workgroups take their
     # tiles from a permutation -- the frame must not change -- and the kernel reports every tile's wave-iterations: the longest
     # primary march of the tile in the low byte, the longest shadow march in the high byte
     import ctypes
     import torch
-    from sdfbox_amd._lib import lib, check
+    lib, check = sb._lib.lib, sb._lib.check
     od = scenes["torus_d6"]
     W, H = 200, 120                                 # 25 x 15 tiles; the grid has 8 * ceil(15 / 8) * 25 = 400 workgroups
     cam = make_camera("closeup", W, H)
@@ -818,8 +874,9 @@ def test_tile_order_flag_changes_no_pixel(sb, oracle_mod, scenes, split):
                 draw(("closeup", "rotated", "default")[k % 3], 200, 120, stream=streams[k & 1])
             draw("closeup", 200, 120, flags=F | sb.FLAG_COUNT)
             draw("rotated", 200, 120, flags=F | sb.FLAG_COUNT)
-            draw("closeup", 200, 120, flags=F | sb.TUNE_SHADOW_QUEUE)
-            draw("rotated", 200, 120, flags=F | sb.TUNE_SHADOW_QUEUE)
+            if sb._lib.EXPERIMENTS:
+                draw("closeup", 200, 120, flags=F | sb.TUNE_SHADOW_QUEUE)
+                draw("rotated", 200, 120, flags=F | sb.TUNE_SHADOW_QUEUE)
             # bands of a frame (what a rank of the sharded pipeline renders): rows 16..31, 48..63, ... twice, then the other ranks' bands
             W, H = 200, 128
             whole = ref("closeup", W, H)[0]
@@ -850,7 +907,7 @@ def test_frames_in_flight_on_one_handle_do_not_share_scratch(sb, oracle_mod, sce
         cams.append(c)
     refs = [oracle_mod.render(od.Structs, od.Values, c.State, W, H, nthreads=8)[0] for c in cams]
     streams = [torch.cuda.Stream() for _ in cams]
-    for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb._lib.TUNE_SHADOW_QUEUE, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL):
+    for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.FLAG_TILE_ORDER) + ab(sb, sb.KERNEL_STACK | sb._lib.TUNE_SHADOW_QUEUE, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL):
         bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
         for rep in range(8):                       # keep every stream busy so that the launches really overlap
             for c, b, st in zip(cams, bufs, streams):
@@ -873,7 +930,7 @@ def test_a_stream_per_frame_and_counters_per_stream(sb, oracle_mod, scenes):
         buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
         for k in range(40):
             st = torch.cuda.Stream()
-            flags = (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_TILE_ORDER, sb.KERNEL_STACK | sb._lib.TUNE_SHADOW_QUEUE, sb.KERNEL_STACK | sb.FLAG_COMPACT)[k % 4]
+            flags = (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_TILE_ORDER, sb.KERNEL_STACK | (sb._lib.TUNE_SHADOW_QUEUE if sb._lib.EXPERIMENTS else sb.FLAG_COUNT), sb.KERNEL_STACK | sb.FLAG_COMPACT)[k % 4]
             sc.DrawDevice(cam, W, H, buf.data_ptr(), flags=flags, stream=st.cuda_stream)
             st.synchronize()
             assert_frames_identical(buf.cpu().numpy(), ref, f"frame {k} on its own new stream")
@@ -943,7 +1000,7 @@ def test_first_frame_on_a_fresh_handle(sb, oracle_mod, scenes):
     cam = make_camera("closeup", 256, 192)
     ref, _ = oracle_mod.render(od.Structs, od.Values, cam.State, 256, 192, nthreads=8)
     for rep in range(2):        # (one handle per flag would do: the cause -- a memset on the null stream -- is gone by construction)
-        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb._lib.TUNE_SHADOW_QUEUE, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.FLAG_COUNT):
+        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.FLAG_COUNT) + ab(sb, sb.KERNEL_STACK | sb._lib.TUNE_SHADOW_QUEUE):
             with sb.Scene(od) as sc:
                 assert_frames_identical(sc.Draw(cam, 256, 192, flags), ref, f"first frame, flags {flags:#x}, handle {rep}")
 
@@ -968,11 +1025,11 @@ def test_full_size_properties(sb, oracle_mod, dragon, size, view):
     else:
         cam.Position = (0.5, 0.5, 0.02)                                 # the object fills the frame
     imgs, stats = {}, {}
-    for variant in ALL_VARIANTS:
+    for variant in variants_of(sb):
         imgs[variant], stats[variant] = sc.Draw(cam, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
     base = imgs["generic"]
     # (1) every kernel variant produces the same bits, and the same algorithmic counters
-    for variant in ALL_VARIANTS[1:]:
+    for variant in variants_of(sb)[1:]:
         assert_frames_identical(imgs[variant], base, f"{variant} vs generic at {W}x{H}")
         for f in ("n_nodes", "n_samples", "n_steps", "n_shadow_rays"):
             assert getattr(stats[variant], f) == getattr(stats["generic"], f)
@@ -1095,18 +1152,19 @@ def test_nan_coordinates_select_the_low_cells(sb, oracle_mod):
     with sb.Scene(od) as sc:
         for ci, cam in enumerate(cams):
             ref, cnt = oracle_mod.render(s, v, cam.State, W, H, nthreads=4)
-            for variant in ALL_VARIANTS:
+            for variant in variants_of(sb):
                 img, st = sc.Draw(cam, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
                 assert_frames_identical(img, ref, f"NaN camera {ci} {variant}")
                 assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(x) for x in cnt), (ci, variant)
                 assert_frames_identical(sc.Draw(cam, W, H, flags_of(sb, variant)), ref, f"NaN camera {ci} {variant}, not counting")
             pref, _ = oracle_mod.render_pt(s, v, cam.State, W, H, spp=2, nthreads=4)
-            for fl in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL, sb.KERNEL_GENERIC):
+            for fl in (sb.KERNEL_STACK, sb.KERNEL_GENERIC) + ab(sb, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL):
                 assert_frames_identical(sc.DrawPath(cam, W, H, pt=sb.PathTrace(spp=2), flags=fl), pref, f"NaN camera {ci} path-traced {fl:#x}")
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SDFHIP_FUZZ_SEEDS", "4"))))
 def test_pre_decoded_cells_of_split_grids(sb, oracle_mod, seed):
+    lab_only(sb)
     # SDFHIP_SAMPLE_RECORDS=1 (an experiment, measured slower: DESIGN.md section 4.3): the default kernel reads the grid's second form,
     # one 4-byte word per cell of the deepest level + 64-byte sample records with pre-decoded corners (CursorFF).  Random trees with
     # random bytes -- non-flat leaves at every level -- behind dense grids and split grids with blocks of 1 to 4 levels, cameras
@@ -1205,7 +1263,7 @@ def test_fuzz_random_trees_and_on_grid_cameras(sb, oracle_mod, seed):
         assert sc.stack_kernel_ok
         for ci, cam in enumerate(cams):
             ref, cnt = oracle_mod.render(s, v, cam.State, W, H, nthreads=8)
-            for variant in ALL_VARIANTS:
+            for variant in variants_of(sb):
                 img, st = sc.Draw(cam, W, H, flags_of(sb, variant) | sb.FLAG_COUNT, want_stats=True)
                 assert_frames_identical(img, ref, f"seed {seed} cam {ci} {variant}")
                 assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), (seed, ci, variant)

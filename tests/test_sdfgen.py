@@ -167,8 +167,8 @@ def test_mesh_scale_import_and_render(sb, oracle_mod, tmp_path, depth):
     with sb.Scene(back) as sc:
         assert sc.stack_kernel_ok and sc.depth == depth and sc.top_grid_level > 0
         img, stt = sc.Draw(cam, W, H, sb.FLAG_COUNT, want_stats=True)
-        img2 = sc.Draw(cam, W, H, sb.TUNE_ONE_KERNEL)
-        img3 = sc.Draw(cam, W, H, sb.TUNE_SHADOW_QUEUE)
+        img2 = sc.Draw(cam, W, H, sb.KERNEL_GENERIC)          # the shader's own traversal, and the compaction kernel, beside the default
+        img3 = sc.Draw(cam, W, H, sb.FLAG_COMPACT)
     assert ((img.view(np.uint32) == img2.view(np.uint32)) | (np.isnan(img) & np.isnan(img2))).all()
     assert ((img.view(np.uint32) == img3.view(np.uint32)) | (np.isnan(img) & np.isnan(img3))).all()
     assert int(img[..., 3].astype(np.float64).sum()) == stt.n_steps

@@ -98,7 +98,7 @@ def test_wire_pixels_are_lossless_on_oracle_frames(oracle_mod, scenes):
 
 
 def numpy_deinterleave(gathered, layout):
-    """Mirror of k_deinterleave (sdfhip_device.hip) in numpy."""
+    """Mirror of k_deinterleave (gather_kernels.h) in numpy."""
     W = gathered.shape[2]
     frame = np.zeros((layout.height, W, 4), dtype=np.float32)
     for y in range(layout.height):
@@ -162,7 +162,8 @@ def test_sparse_share_size_arithmetic():
     # the byte layout of a sparse wire share (codes, per-tile masks and slot indices, header, floats), from the
     # host side of the library: sizes are 16-byte multiples, grow by 4 bytes per slot, and beat the dense 5 bytes
     # per pixel whenever at most ~90 % of the pixels are lit
-    from sdfbox_amd.tiles import sparse_share_bytes
+    import sdfbox_amd.lab                           # round 2's format: the experiments build (include/sdfhip_experimental.h)
+    sparse_share_bytes = sdfbox_amd.lab.load().tiles.sparse_share_bytes
     for rows, W in [(8, 8), (16, 61), (144, 1920), (1088, 3840)]:
         tiles = ((W + 7) // 8) * (rows // 8)
         up = lambda v: (v + 15) & ~15
