@@ -36,7 +36,9 @@ def build_native():
     return NATIVE_PATH
 
 
-VARIANTS = {"unfused": "-DO_UNFUSED", "lerp_mathcs": "-DO_LERP_MATHCS", "sampler8": "-DO_SAMPLER8", "rsqrt1ulp": "-DO_RSQRT1ULP"}
+VARIANTS = {"unfused": "-DO_UNFUSED", "lerp_mathcs": "-DO_LERP_MATHCS", "sampler8": "-DO_SAMPLER8", "rsqrt1ulp": "-DO_RSQRT1ULP",
+            # what a D3D11 GPU may really run: 8-bit bilinear weights in the texture unit AND mads that are not fused
+            "sampler8_unfused": "-DO_SAMPLER8 -DO_UNFUSED"}
 
 
 def build_variant(name):
@@ -45,7 +47,7 @@ def build_variant(name):
     src = os.path.join(_HERE, "sdf_oracle.c")
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
         subprocess.check_call(["gcc", "-O2", "-march=x86-64-v2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c11",
-                               VARIANTS[name], "-shared", "-o", path, src, os.path.join(_HERE, "sdfgen_oracle.c"), "-lm", "-lpthread"])
+                               *VARIANTS[name].split(), "-shared", "-o", path, src, os.path.join(_HERE, "sdfgen_oracle.c"), "-lm", "-lpthread"])
     return path
 
 

@@ -33,11 +33,11 @@ def frames(sb, oracle_mod):
     od = sb.sphere_d4()
     cam = sb.Logic(256, 256)
     out["cfg1"] = {v: oracle_mod.render(od.Structs, od.Values, cam.State, 256, 256, nthreads=8, native=v)[0]
-                   for v in (False, "unfused", "lerp_mathcs", "sampler8", "rsqrt1ulp")}
+                   for v in (False, "unfused", "lerp_mathcs", "sampler8", "rsqrt1ulp", "sampler8_unfused")}
     od = sb.dragon_standin(9, nthreads=8)
     cam = sb.Logic(1920, 1080); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
     out["bench"] = {v: oracle_mod.render(od.Structs, od.Values, cam.State, 1920, 1080, nthreads=8, native=v)[0]
-                    for v in (False, "unfused", "lerp_mathcs", "sampler8", "rsqrt1ulp")}
+                    for v in (False, "unfused", "lerp_mathcs", "sampler8", "rsqrt1ulp", "sampler8_unfused")}
     return out
 
 
@@ -84,3 +84,17 @@ def test_exact_vs_one_ulp_reciprocal_square_roots(frames):
     assert c1["statement"] == 1.0
     assert 0.995 <= b["statement"] < 0.999
     assert b["alpha_equal"] >= 0.9999 and b["rgb_1/255"] >= 0.99999
+
+
+def test_fp32_fused_vs_8_bit_weights_and_unfused_mads_together(frames):
+    # the reading a real D3D11 GPU may run: the texture unit's 8-bit bilinear weights AND separately rounded mads, both at once
+    c1, b = parity(frames["cfg1"][False], frames["cfg1"]["sampler8_unfused"]), parity(frames["bench"][False], frames["bench"]["sampler8_unfused"])
+    s1, sb_ = parity(frames["cfg1"]["sampler8"], frames["cfg1"]["sampler8_unfused"]), parity(frames["bench"]["sampler8"], frames["bench"]["sampler8_unfused"])
+    print("fp32 fused vs 8-bit weights + unfused:", c1, b)
+    print("8-bit weights: fused vs unfused:", s1, sb_)
+    # Measured: against the contract the combination sits where the 8-bit sampler alone sits -- cfg-1 0.4282 (alone: 0.4283),
+    # bench frame 0.95497 (alone: 0.95500) -- the sampler dominates; and between the two 8-bit readings, fusing or not moves
+    # 0.05 % of the pixels by the statement (cfg-1 0.99950, bench frame 0.99944; 46 % / 96 % stay bit-identical).
+    assert 0.35 <= c1["statement"] <= 0.55 and 0.94 <= b["statement"] <= 0.97
+    assert c1["rgb_1/255"] >= 0.998 and b["rgb_1/255"] >= 0.9995 and b["alpha_equal"] >= 0.998
+    assert s1["statement"] >= 0.99 and 0.99 <= sb_["statement"] <= 1.0
