@@ -134,6 +134,16 @@ struct RenderParams {
     float *pt_e;                    // [bounces + 1][spp][pixels]
     float *pt_t;                    // [spp][pixels]
     uint32_t *pt_n;                 // [spp][pixels]
+#ifdef SDFHIP_EXPERIMENTS
+    // A/B (measured: no gain, profiles/r04_cfg5_sort_ab.txt): bounce levels with pt_sort_bits = R > 0: before a level's kernel its queue entries are ordered by the key
+    // (Morton code of the hit's region, 2^R regions per axis) << 3 | octant of the OUTGOING direction -- the rays a wave marches
+    // start in the same part of the scene and head the same way (k_pt_key, k_pt_scatter): pt_key[entry] = the key, pt_perm[slot] =
+    // the entry a lane takes, pt_hist = the keys' counts, then their running slots ([keys + 1]: the last word is the entry total)
+    uint16_t *pt_key;
+    uint32_t *pt_perm;
+    uint32_t *pt_hist;
+    uint32_t pt_sort_bits;
+#endif
     // k_march, optional: tile_perm[b] = the tile workgroup b renders (a permutation of the default order: the
     // previous frame's expensive tiles first); tile_cost[tile] = march iterations the tile's wave ran
     const uint32_t *tile_perm;

@@ -1154,6 +1154,163 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_pt_primary(RenderP
     if (COUNT) flush_counters(P, cn, cs, 0, 0, cl);
 }
 
+// chunk t of 64 entries of queue `queue` -> (sub-queue, first entry, fill): the bounce kernel's numbering (a wave-wide scan of the fills)
+struct PtChunks {
+    uint32_t fill, chunks, incl, nchunks;
+    __device__ __forceinline__ PtChunks(const RenderParams &P, uint32_t queue, uint32_t lane)
+    {
+        fill = min(*pt_count(P, queue, lane), P.pt_cap);
+        chunks = (fill + 63u) >> 6;
+        incl = chunks;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+        nchunks = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    // the entry lane `lane` takes of chunk t: its index in the queue's arrays, or 0xFFFFFFFF
+    __device__ __forceinline__ uint32_t entry(const RenderParams &P, uint32_t t, uint32_t lane) const
+    {
+        const uint32_t q = (uint32_t)__popcll(__ballot(incl <= t));
+        const uint32_t q_incl = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)q), q_chunks = (uint32_t)__builtin_amdgcn_readlane((int)chunks, (int)q);
+        const uint32_t q_fill = (uint32_t)__builtin_amdgcn_readlane((int)fill, (int)q);
+        const uint32_t i = (t - (q_incl - q_chunks)) * 64u + lane;
+        return i < q_fill ? q * P.pt_cap + i : 0xFFFFFFFFu;
+    }
+};
+
+#ifdef SDFHIP_EXPERIMENTS
+// ---- LABORATORY (experiments build): the bounce levels' queue entries ordered by (region of the hit, octant of the outgoing direction) ----
+// MEASURED: NO GAIN (profiles/r04_cfg5_sort_ab.txt): the camera level's queue is already in screen-tile order, which
+// no key of this kind beats (level 0: 9.5 -> 10.6 ms ordered), and the deeper levels gain 0.5 ms of 13 for 0.7 ms of key + scatter:
+// what the bounce rays fetch is decided where they END, which no order of their starts can know.  Kept as a bit-identical A/B
+// (SDFHIP_PT_SORT=R, SDFHIP_PT_SORT_FROM=first level).
+// The bounce levels are bound by the 64-byte sectors their incoherent rays fetch.  The queues hold the hits in
+// the order the waves of the level before pushed them; here a level's entries get a KEY -- where the ray starts and which way it
+// will go: the bounce direction is a function of the entry alone (the hit's normal from its cursor's cell, the counter-based RNG) --
+// and a permutation that orders them by it, so that the 64 rays of a wave, and the waves in flight, walk the same blocks of the
+// grid.  The entries stay where they are (a gathered read through the permutation); results do not depend on the order of the
+// queue (every path writes its own slots of pt_e / pt_t / pt_n), so the frame is bit for bit the unsorted pipeline's.
+//   k_pt_key      one lane per entry: the key -> pt_key[entry], counts per key -> pt_hist (an LDS histogram per workgroup)
+//   k_pt_scan     one workgroup: exclusive prefix of the counts -> the keys' first slots; pt_hist[keys] = the entry total
+//   k_pt_scatter  the same entry -> workgroup map again: a workgroup claims its share of every key's slots with ONE atomic per key
+//                 and hands them to its entries through LDS counters -> pt_perm[slot] = entry
+constexpr int PT_SORT_MAX_BITS = 3;                       // 8^3 regions x 8 octants = 4096 keys: two 16 KB LDS arrays
+constexpr int PT_SORT_THREADS = 256;
+__device__ __forceinline__ uint32_t pt_morton3(uint32_t x, uint32_t y, uint32_t z, int bits)
+{
+    uint32_t m = 0;
+    for (int b = 0; b < bits; b++) m |= (((x >> b) & 1u) | (((y >> b) & 1u) << 1) | (((z >> b) & 1u) << 2)) << (3 * b);
+    return m;
+}
+template <int CUR>
+__global__ __launch_bounds__(PT_SORT_THREADS) void k_pt_key(RenderParams P)
+{
+    typedef typename ScatterCursorOf<CUR, false>::type CursorT;
+    __shared__ uint32_t hist[8u << (3 * PT_SORT_MAX_BITS)];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = P.pt_level, qin = b & 1u;
+    const int R = (int)P.pt_sort_bits;
+    const uint32_t nkeys = 8u << (3 * R);
+    for (uint32_t k = tid; k < nkeys; k += PT_SORT_THREADS) hist[k] = 0u;
+    __syncthreads();
+    const FrameInfo &I = P.frames[0];
+    const size_t total = (size_t)HIT_QUEUES * P.pt_cap;
+    const float4 *Q = P.pt_q[qin];
+    const PtChunks C(P, qin, lane);
+    constexpr uint32_t WAVES = PT_SORT_THREADS / 64;
+    for (uint32_t t = blockIdx.x * WAVES + wave; t < C.nchunks; t += gridDim.x * WAVES) {
+        const uint32_t e = C.entry(P, t, lane);
+        if (e == 0xFFFFFFFFu) continue;
+        const float4 a = nt_load(&Q[e]), k = nt_load(&Q[total + e]), d = nt_load(&Q[2 * total + e]);
+        // the vertex's normal and outgoing direction, as k_pt_bounce computes them (only their signs are used here)
+        CursorT c;
+        c.unpack(pt_unpack_cursor(make_uint2(__float_as_uint(k.x), __float_as_uint(k.y))),
+                 CursorT::units_shift(P.top_level + (CUR == CUR_STACK_SPLIT ? P.fine_bits : 0)));
+        c.v0 = __float_as_uint(k.z); c.v1 = __float_as_uint(k.w);
+        float lx = I.lightx - a.x, ly = I.lighty - a.y, lz = I.lightz - a.z;
+        const float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+        const float px = __builtin_fmaf(lx * rl, I.margin, a.x), py = __builtin_fmaf(ly * rl, I.margin, a.y), pz = __builtin_fmaf(lz * rl, I.margin, a.z);
+        uint32_t octant = 0;
+        if (b < P.pt_bounces) {
+            float g0, g1, g2;
+            gradient(c.cell(), px, py, pz, g0, g1, g2);
+            const float rg = 1.0f / sqrtf(dot3(g0, g1, g2, g0, g1, g2));
+            float n0 = g0 * rg, n1 = g1 * rg, n2 = g2 * rg;
+            if (dot3(n0, n1, n2, d.y, d.z, d.w) > 0.0f) { n0 = -n0; n1 = -n1; n2 = -n2; }
+            const uint32_t pid = __float_as_uint(d.x), pix = pid / P.pt_spp, s = pid - pix * P.pt_spp;
+            const uint32_t y_l = pix / P.width, x_l = pix - y_l * P.width;
+            const uint32_t p = global_row(P, y_l) * P.width + x_l;
+            float u0 = n0, u1 = n1, u2 = n2, qq1 = 1.0f;
+            for (uint32_t a2 = 0; a2 < 8; a2++) {
+                const float c0 = rnd(P.pt_seed, p, s, b + 1, 3 * a2) * 2.0f - 1.0f;
+                const float c1 = rnd(P.pt_seed, p, s, b + 1, 3 * a2 + 1) * 2.0f - 1.0f;
+                const float c2 = rnd(P.pt_seed, p, s, b + 1, 3 * a2 + 2) * 2.0f - 1.0f;
+                const float qq = dot3(c0, c1, c2, c0, c1, c2);
+                if (qq <= 1.0f && qq > 1e-12f) { u0 = c0; u1 = c1; u2 = c2; qq1 = qq; break; }
+            }
+            const float ru = 1.0f / sqrtf(qq1);
+            const float d0 = __builtin_fmaf(u0, ru, n0), d1 = __builtin_fmaf(u1, ru, n1), d2 = __builtin_fmaf(u2, ru, n2);
+            octant = (d0 < 0.0f ? 1u : 0u) | (d1 < 0.0f ? 2u : 0u) | (d2 < 0.0f ? 4u : 0u);
+        }
+        const float scale = (float)(1u << R), top = scale - 1.0f;
+        const uint32_t rx = (uint32_t)__builtin_amdgcn_fmed3f(px * scale, 0.0f, top), ry = (uint32_t)__builtin_amdgcn_fmed3f(py * scale, 0.0f, top),
+                       rz = (uint32_t)__builtin_amdgcn_fmed3f(pz * scale, 0.0f, top);
+        const uint32_t key = (pt_morton3(rx, ry, rz, R) << 3) | octant;
+        P.pt_key[e] = (uint16_t)key;
+        atomicAdd(&hist[key], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < nkeys; k += PT_SORT_THREADS) { const uint32_t v = hist[k]; if (v) atomicAdd(&P.pt_hist[k], v); }
+}
+
+// exclusive prefix of the keys' counts in place (one workgroup); the entry total goes to pt_hist[nkeys]
+template <int = 0>      // (a template so that the header may be included by several translation units)
+__global__ __launch_bounds__(1024) void k_pt_scan(uint32_t *__restrict__ v, uint32_t n)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n + 1023u) / 1024u, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += v[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {
+        const uint32_t add = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t x = v[i]; v[i] = run; run += x; }
+    if (threadIdx.x == 1023u) v[n] = part[1023];
+}
+
+template <int = 0>
+__global__ __launch_bounds__(PT_SORT_THREADS) void k_pt_scatter(RenderParams P)
+{
+    __shared__ uint32_t cnt[8u << (3 * PT_SORT_MAX_BITS)], base[8u << (3 * PT_SORT_MAX_BITS)];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, qin = P.pt_level & 1u;
+    const uint32_t nkeys = 8u << (3 * P.pt_sort_bits);
+    for (uint32_t k = tid; k < nkeys; k += PT_SORT_THREADS) cnt[k] = 0u;
+    __syncthreads();
+    const PtChunks C(P, qin, lane);
+    constexpr uint32_t WAVES = PT_SORT_THREADS / 64;
+    for (uint32_t t = blockIdx.x * WAVES + wave; t < C.nchunks; t += gridDim.x * WAVES) {       // this workgroup's entries by key
+        const uint32_t e = C.entry(P, t, lane);
+        if (e != 0xFFFFFFFFu) atomicAdd(&cnt[P.pt_key[e]], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < nkeys; k += PT_SORT_THREADS) {                                     // its share of every key's slots
+        const uint32_t v = cnt[k];
+        base[k] = v ? atomicAdd(&P.pt_hist[k], v) : 0u;
+        cnt[k] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t t = blockIdx.x * WAVES + wave; t < C.nchunks; t += gridDim.x * WAVES) {
+        const uint32_t e = C.entry(P, t, lane);
+        if (e == 0xFFFFFFFFu) continue;
+        const uint32_t key = P.pt_key[e];
+        P.pt_perm[base[key] + atomicAdd(&cnt[key], 1u)] = e;
+    }
+}
+#endif
+
 template <int CUR, bool COUNT>
 __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderParams P)
 {
@@ -1163,19 +1320,24 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
     asm volatile("" : "+s"(I.margin), "+s"(I.margin2), "+s"(I.limit));
     const float margin = I.margin;
     const size_t npx = (size_t)P.nrows_out * P.width, total = (size_t)HIT_QUEUES * P.pt_cap;
-    const uint32_t fill = min(*pt_count(P, qin, lane), P.pt_cap);
-    const uint32_t chunks = (fill + 63u) >> 6;
-    uint32_t incl = chunks;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
-    const uint32_t nchunks = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const PtChunks C(P, qin, lane);
+#ifdef SDFHIP_EXPERIMENTS
+    // ordered (P.pt_sort_bits, an A/B): chunk t = slots 64 t .. of the permutation; else the queue's own chunks
+    const uint32_t n_sorted = P.pt_sort_bits ? P.pt_hist[8u << (3 * P.pt_sort_bits)] : 0u;
+    const uint32_t nchunks = P.pt_sort_bits ? (n_sorted + 63u) >> 6 : C.nchunks;
+#else
+    const uint32_t nchunks = C.nchunks;
+#endif
     unsigned long long cn = 0, cs = 0, cr = 0, cl = 0;
     const float4 *Q = P.pt_q[qin];
     for (uint32_t t = blockIdx.x; t < nchunks; t += gridDim.x) {
-        const uint32_t q = (uint32_t)__popcll(__ballot(incl <= t));
-        const uint32_t q_incl = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)q), q_chunks = (uint32_t)__builtin_amdgcn_readlane((int)chunks, (int)q);
-        const uint32_t q_fill = (uint32_t)__builtin_amdgcn_readlane((int)fill, (int)q);
-        const uint32_t i = (t - (q_incl - q_chunks)) * 64u + lane;
-        const bool have = i < q_fill;
+        uint32_t e32;
+#ifdef SDFHIP_EXPERIMENTS
+        if (P.pt_sort_bits) { const uint32_t slot = t * 64u + lane; e32 = slot < n_sorted ? P.pt_perm[slot] : 0xFFFFFFFFu; }
+        else
+#endif
+        e32 = C.entry(P, t, lane);
+        const bool have = e32 != 0xFFFFFFFFu;
         RayState r;
         CursorT c;
         c.loads = 0;
@@ -1183,7 +1345,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
         float ux = 0, uy = 0, uz = 1, T = 0;
         bool next = false, escaped = false;       // a next segment was marched; it escaped
         if (have) {
-            const size_t e = (size_t)q * P.pt_cap + i;
+            const size_t e = e32;
             const float4 a = nt_load(&Q[e]), k = nt_load(&Q[total + e]), d = nt_load(&Q[2 * total + e]);
             r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w;
             c.unpack(pt_unpack_cursor(make_uint2(__float_as_uint(k.x), __float_as_uint(k.y))),

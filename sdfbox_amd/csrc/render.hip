@@ -220,19 +220,36 @@ int launch_pt_pipeline(sdfhip_scene *s, dim3 grid, hipStream_t st, RenderParams 
     if ((e = hipMemsetAsync(P.pt_ctl, 0, sdfhip_scene::CTL_PT_WORDS * sizeof(uint32_t), st)) != hipSuccess)
         return fail(SDFHIP_ERR_DEVICE, "render_path: hipMemsetAsync failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL((k_pt_primary<CUR, COUNT>), grid, dim3(64), 0, st, P);
+#ifdef SDFHIP_EXPERIMENTS
+    uint32_t pt_sort_from = 0;                          // SDFHIP_PT_SORT_FROM=b: only the levels from b on are ordered
+    if (const char *env = getenv("SDFHIP_PT_SORT_FROM")) pt_sort_from = (uint32_t)atoi(env);
+#endif
     for (uint32_t b = 0; b <= P.pt_bounces; b++) {
         P.pt_level = b;
         // the queue this level fills was drained by the level before it
         if (b > 0 && (e = hipMemsetAsync(P.pt_ctl + (size_t)((b & 1u) ^ 1u) * HIT_QUEUES * 32, 0, HIT_QUEUES * 32 * sizeof(uint32_t), st)) != hipSuccess)
             return fail(SDFHIP_ERR_DEVICE, "render_path: hipMemsetAsync failed: %s", hipGetErrorString(e));
+        RenderParams Pb = P;                            // the level's parameters
         if (s->d_top2) {
             // incoherent rays: the same cells through the split grid (the cursor does not depend on the grid it was filled from)
-            RenderParams P2 = P;
-            P2.top = s->d_top2; P2.top_level = s->top2_level; P2.fine = s->d_fine2; P2.fine_bits = s->fine2_bits; P2.fine_order = s->fine2_order;
-            hipLaunchKernelGGL((k_pt_bounce<CUR_STACK_SPLIT, COUNT>), dim3(resident), dim3(64), 0, st, P2);
-        } else {
-            hipLaunchKernelGGL((k_pt_bounce<CUR, COUNT>), dim3(resident), dim3(64), 0, st, P);
+            Pb.top = s->d_top2; Pb.top_level = s->top2_level; Pb.fine = s->d_fine2; Pb.fine_bits = s->fine2_bits; Pb.fine_order = s->fine2_order;
         }
+#ifdef SDFHIP_EXPERIMENTS
+        // A/B: the level's entries in the order of (region of the hit, octant of the outgoing direction): see k_pt_key
+        if (b < pt_sort_from) Pb.pt_sort_bits = 0;
+        if (Pb.pt_sort_bits) {
+            const uint32_t nkeys = 8u << (3 * Pb.pt_sort_bits);
+            const dim3 sort_grid((uint32_t)s->cu_count * 4u);
+            if ((e = hipMemsetAsync(Pb.pt_hist, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st)) != hipSuccess)
+                return fail(SDFHIP_ERR_DEVICE, "render_path: hipMemsetAsync failed: %s", hipGetErrorString(e));
+            if (s->d_top2) hipLaunchKernelGGL((k_pt_key<CUR_STACK_SPLIT>), sort_grid, dim3(PT_SORT_THREADS), 0, st, Pb);
+            else           hipLaunchKernelGGL((k_pt_key<CUR>), sort_grid, dim3(PT_SORT_THREADS), 0, st, Pb);
+            hipLaunchKernelGGL((k_pt_scan<0>), dim3(1), dim3(1024), 0, st, Pb.pt_hist, nkeys);
+            hipLaunchKernelGGL((k_pt_scatter<0>), sort_grid, dim3(PT_SORT_THREADS), 0, st, Pb);
+        }
+#endif
+        if (s->d_top2) hipLaunchKernelGGL((k_pt_bounce<CUR_STACK_SPLIT, COUNT>), dim3(resident), dim3(64), 0, st, Pb);
+        else           hipLaunchKernelGGL((k_pt_bounce<CUR, COUNT>), dim3(resident), dim3(64), 0, st, Pb);
     }
     const size_t npx = (size_t)P.nrows_out * P.width;
     const uint32_t rb = (uint32_t)((npx + 255) / 256 < 4096 ? (npx + 255) / 256 : 4096);
@@ -258,10 +275,27 @@ int launch_path(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &pla
     P.pt_cap = (uint32_t)((((size_t)grid.x + HIT_QUEUES - 1) / HIT_QUEUES) * 64 * c.pt->spp + 8192);
     const size_t qbytes = (size_t)PT_RECORDS * 16 * HIT_QUEUES * P.pt_cap;        // one hit queue
     const size_t ebytes = (size_t)(c.pt->max_bounces + 1) * npaths * 4, tbytes = npaths * 4;
+    size_t sort_bytes = 0;
+#ifdef SDFHIP_EXPERIMENTS
+    // SDFHIP_PT_SORT=R (1..3): the bounce levels take their entries in the order of a key (k_pt_key): an A/B, measured without gain
+    uint32_t sort_bits = 0;
+    if (const char *env = getenv("SDFHIP_PT_SORT")) { const int v = atoi(env); if (v >= 1 && v <= PT_SORT_MAX_BITS) sort_bits = (uint32_t)v; }
+    const size_t n_entries = (size_t)HIT_QUEUES * P.pt_cap;
+    sort_bytes = sort_bits ? n_entries * 6 + (((size_t)8 << (3 * PT_SORT_MAX_BITS)) + 64) * 4 : 0;
+#endif
     sdfhip_scene::Scratch *sc = nullptr;
-    int rcs = get_pt_scratch(s, st, 2 * qbytes + ebytes + 2 * tbytes, &sc);
+    int rcs = get_pt_scratch(s, st, 2 * qbytes + ebytes + 2 * tbytes + sort_bytes, &sc);
     if (rcs != SDFHIP_OK) return rcs;
     plan.sc = sc;
+#ifdef SDFHIP_EXPERIMENTS
+    if (sort_bits) {
+        char *base = sc->pt_buf + 2 * qbytes + ebytes + 2 * tbytes;
+        P.pt_perm = reinterpret_cast<uint32_t *>(base);
+        P.pt_hist = reinterpret_cast<uint32_t *>(base + n_entries * 4);
+        P.pt_key = reinterpret_cast<uint16_t *>(base + n_entries * 4 + (((size_t)8 << (3 * PT_SORT_MAX_BITS)) + 64) * 4);
+        P.pt_sort_bits = sort_bits;
+    }
+#endif
     P.pt_q[0] = reinterpret_cast<float4 *>(sc->pt_buf);
     P.pt_q[1] = reinterpret_cast<float4 *>(sc->pt_buf + qbytes);
     P.pt_e = reinterpret_cast<float *>(sc->pt_buf + 2 * qbytes);

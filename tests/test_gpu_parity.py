@@ -364,6 +364,35 @@ def test_path_traced_mode_through_every_scatter_grid(sb, oracle_mod, scenes, blo
                 os.environ[k] = v
 
 
+def test_path_traced_bounce_levels_ordered_by_key(sb, oracle_mod, scenes):
+    # A/B of the experiments build (SDFHIP_PT_SORT=R, profiles/r04_cfg5_sort_ab.txt: measured without gain): before every bounce
+    # level its queue entries are ordered by (region of the hit, octant of the outgoing direction) and read through a permutation.
+    # A path's results do not depend on where its entry sits in a queue: every ordering must give the oracle's frame, counters included
+    lab_only(sb)
+    W, H = 96, 72
+    prev = {k: os.environ.get(k) for k in ("SDFHIP_PT_SORT", "SDFHIP_PT_SORT_FROM")}
+    try:
+        for sname, cname in (("torus_d6", "rotated"), ("sphere_d4", "closeup")):
+            od = scenes[sname]
+            cam = make_camera(cname, W, H)
+            pt = sb.PathTrace(spp=5, max_bounces=3)
+            ref, cnt = oracle_mod.render_pt(od.Structs, od.Values, cam.State, W, H, spp=pt.spp, max_bounces=pt.max_bounces, seed=pt.seed,
+                                            albedo=pt.albedo, nthreads=8)
+            with sb.Scene(od) as sc:
+                for bits, first in (("1", "0"), ("2", "0"), ("3", "0"), ("3", "1"), ("2", "2"), ("9", "0")):     # (9: out of range = off)
+                    os.environ["SDFHIP_PT_SORT"], os.environ["SDFHIP_PT_SORT_FROM"] = bits, first
+                    img, st = sc.DrawPath(cam, W, H, pt, flags=sb.FLAG_COUNT, want_stats=True)
+                    assert_frames_identical(img, ref, f"{sname}: bounce levels ordered with {bits} region bits from level {first}")
+                    assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
+                    assert_frames_identical(sc.DrawPath(cam, W, H, pt), ref, "not counting")
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_path_traced_config5_full_size(sb, oracle_mod, dragon):
     # BASELINE config 5: 3840x2160, 16 spp, 3 bounces, seed 0x5DFB0C5 on the dragon stand-in.
     # Size-independent properties + the oracle on sampled rows.
