@@ -146,6 +146,12 @@ def main():
     nccl = args.backend == "nccl"
 
     W, H = (int(v) for v in args.size.lower().split("x"))
+    # who really takes part (the line says so: a scaling curve is only one if the ranks sit on different GPUs)
+    bus_ids = [sb.device_pci_bus_id(device)]
+    if sharded and world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, bus_ids[0])
+        bus_ids = got
 
     # ---- scene: built on the host, resident in HBM before anything is timed ----------
     t0 = time.time()
@@ -606,6 +612,10 @@ def main():
                                ("round-robin" if not layout.weighted else
                                 f"dealt by weight (rank 0: {layout.rank0_weight:.3f} of a peer's share)") +
                                f" + gather to rank 0 ({args.backend})",
+                "ranks_seen": dist.get_world_size() if sharded else 1,
+                "pci_bus_ids": bus_ids, "distinct_gpus": len(set(bus_ids)),
+                "transport": (("RCCL through torch.distributed (backend nccl)" if nccl else "gloo through host buffers (a rehearsal, not a performance mode)")
+                              if sharded else None),
                 "frames_in_flight": nbuf * G,
                 "frames_per_gather": G if sharded else None,
                 "gather_pixel_bytes": (round(s2["prefix"] / (rows_local * W * G), 3) if sparse2 else px_bytes) if sharded else None,
@@ -679,7 +689,8 @@ def main_single_process(args, json_fd):
         scene_name = f"dragon_standin_d{args.depth}"
     t_gen = time.time() - t0
     torch.cuda.set_device(devices[0])
-    ms = sb.MultiScene(od, devices)
+    ms = sb.MultiScene(od, devices)                  # (create runs sdfhip_multi_selftest: a link that does not deliver fails here)
+    links = ms.selftest()
     if args.band_rows != 16 or args.rank0_weight > 0:
         ms.configure(band_rows=args.band_rows, rank0_weight=args.rank0_weight if args.rank0_weight > 0 else 1.0)
     cam = sb.Logic(W, H)
@@ -796,6 +807,9 @@ def main_single_process(args, json_fd):
                         "camera (0.5,0.5,-0.35) yaw 0.35 pitch -0.2" + (f", moving 1 degree per frame ({len(cams)} cameras)" if args.orbit > 0 else ""),
             "parallelism": f"single process, devices {devices} through sdfhip_multi_submit/_wait (one host thread + stream per device, "
                            f"{args.band_rows}-row bands, sparse shares written by the march kernel, gather by {ms.transport} into device {devices[0]})",
+            "ranks_seen": len(links), "pci_bus_ids": [l["pci_bus_id"] for l in links], "distinct_gpus": len({l["pci_bus_id"] for l in links}),
+            "transport": "RCCL ncclSend / ncclRecv inside the library" if ms.transport == "rccl" else "hipMemcpyPeerAsync on the senders' streams",
+            "links": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in l.items()} for l in links],
             "measures": ("one frame at a time across all devices, submit to completion: the viewer's latency (strong scaling of ONE frame)"
                          if frame_mode else
                          f"throughput of groups: {G} frames per launch and gather, {nslots} groups in flight ({G * nslots} frames in flight)"),

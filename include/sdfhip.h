@@ -228,6 +228,8 @@ SDFHIP_API float sdfhip_camera_mouse_wheel(float m_speed, float wheel_delta);
 /* ---- device ------------------------------------------------------------ */
 
 SDFHIP_API int sdfhip_device_count(int *count);
+/* The PCI bus id of a device ("0000:c1:00.0"; out holds at least 16 bytes): what tells two ranks of a multi-GPU run apart. */
+SDFHIP_API int sdfhip_device_pci_bus_id(int device, char *out, uint32_t len);
 
 /* Replaces: OctData.StructBuffer() + OctData.ValueTexture(),
  * SdfBox/Program.cs:543-572, bound at Program.cs:147-152: copies the scene to
@@ -436,6 +438,19 @@ typedef struct sdfhip_multi_stats {
 } sdfhip_multi_stats;
 SDFHIP_API int sdfhip_multi_create(const int *devices, uint32_t n_devices, const int32_t *structs, const uint8_t *values,
                                    uint32_t n, sdfhip_multi **out);
+/* First contact with the node's links.  Per device r > 0: can it reach devices[0]'s memory (hipDeviceCanAccessPeer), and does a
+ * 1 MB pattern pushed the way the gather pushes shares -- hipMemcpyPeerAsync on r's stream, or ncclSend / ncclRecv in a group with
+ * the RCCL transport -- arrive in devices[0]'s memory intact (read back and compared on the host)?  sdfhip_multi_create runs it and
+ * fails with SDFHIP_ERR_DEVICE naming the pair, instead of leaving a link problem to surface as a wrong frame; callable again at
+ * any time no slot is in flight.  links (may be NULL): n_devices entries. */
+typedef struct sdfhip_multi_link {
+    int32_t device;             /* devices[r]                                                        */
+    int32_t peer_access;        /* 1: devices[r] writes devices[0]'s memory directly (xGMI / PCIe P2P); 0: the copy is staged; -1: same device */
+    uint32_t ok;                /* the pattern arrived                                               */
+    float push_ms;              /* HIP-event time of the 1 MB push on the sender's stream            */
+    char pci_bus_id[16];        /* "0000:c1:00.0"                                                    */
+} sdfhip_multi_link;
+SDFHIP_API int sdfhip_multi_selftest(sdfhip_multi *m, sdfhip_multi_link *links);
 SDFHIP_API int sdfhip_multi_free(sdfhip_multi *m);
 /* band height (a multiple of 8; default 16, or SDFHIP_MULTI_BAND_ROWS) and the share of devices[0], which also assembles
  * the frame, as a fraction of a peer's (default 1, or SDFHIP_MULTI_RANK0_WEIGHT); no slot may be in flight */

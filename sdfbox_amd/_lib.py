@@ -46,7 +46,7 @@ SHAPE_SPHERE, SHAPE_TORUS, SHAPE_GYROID = 0, 1, 2
 if __name__ != "sdfbox_amd._lib":
     # the package imported a second time against another flavour of the library (sdfbox_amd.lab.load()): both flavours share ONE
     # set of ctypes classes, so that a camera, a PathTrace or a Stats object made with either package is accepted by both
-    from sdfbox_amd._lib import COctData, CPoints, Info, MultiStats, PathTrace, SdfGenStats, SdfHipError, Stats   # noqa: F401
+    from sdfbox_amd._lib import COctData, CPoints, Info, MultiLink, MultiStats, PathTrace, SdfGenStats, SdfHipError, Stats   # noqa: F401
 else:
     class Info(ctypes.Structure):
         """The 112-byte `Info` cbuffer (Logic.cs:407-420)."""
@@ -117,6 +117,11 @@ else:
         ]
 
 
+    class MultiLink(ctypes.Structure):
+        _fields_ = [("device", ctypes.c_int32), ("peer_access", ctypes.c_int32), ("ok", ctypes.c_uint32), ("push_ms", ctypes.c_float),
+                    ("pci_bus_id", ctypes.c_char * 16)]
+
+
     class MultiStats(ctypes.Structure):
         _fields_ = [
             ("total_ms", ctypes.c_float), ("n_devices", ctypes.c_uint32), ("resends", ctypes.c_uint32), ("pad_", ctypes.c_uint32),
@@ -152,6 +157,8 @@ _SIG = {
     "sdfhip_info_set_heading": (None, [_c.POINTER(Info), _c.c_float, _c.c_float]),
     "sdfhip_info_set_position": (None, [_c.POINTER(Info), _c.c_float, _c.c_float, _c.c_float]),
     "sdfhip_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
+    "sdfhip_device_pci_bus_id": (_c.c_int, [_c.c_int, _c.c_char_p, _c.c_uint32]),
+    "sdfhip_multi_selftest": (_c.c_int, [_vp, _c.POINTER(MultiLink)]),
     "sdfhip_scene_upload": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.POINTER(_vp)]),
     "sdfhip_scene_free": (_c.c_int, [_vp]),
     "sdfhip_scene_info": (_c.c_int, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint32),

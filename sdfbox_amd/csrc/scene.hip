@@ -27,6 +27,14 @@ extern "C" int sdfhip_device_count(int *count)
     return SDFHIP_OK;
 }
 
+extern "C" int sdfhip_device_pci_bus_id(int device, char *out, uint32_t len)
+{
+    if (!out || len < 16) return fail(SDFHIP_ERR_ARG, "device_pci_bus_id: the buffer must hold 16 bytes");
+    out[0] = 0;
+    HIP_TRY(hipDeviceGetPCIBusId(out, (int)len, device));
+    return SDFHIP_OK;
+}
+
 extern "C" int sdfhip_scene_free(sdfhip_scene *s)
 {
     if (!s) return SDFHIP_OK;

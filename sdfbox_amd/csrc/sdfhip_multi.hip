@@ -30,6 +30,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
@@ -173,6 +174,7 @@ struct Slot {
     uint32_t *h_counts = nullptr;          // pinned, [MAX_RANKS]: the shares' counters as the assembly kernel found them
     uint32_t last_used[MAX_RANKS] = { 0 };
     void *out = nullptr;                   // where this submission's frames go (the caller's buffer or d_frames)
+    bool timed = false;                    // this submission recorded the ranks' start events
     bool busy = false, path = false, dirty = false;   // path: dense shares (see d_dense); dirty: a submission failed half-way: the shares' counters are re-zeroed before the next one
     uint32_t n_frames = 0, width = 0, height = 0, flags = 0;
     std::chrono::steady_clock::time_point t_submit;
@@ -237,6 +239,7 @@ struct sdfhip_multi {
         sdfhip_multi *m; uint32_t slot; const sdfhip_info *infos; uint32_t n_frames, width, height, flags, capacity;
         const sdfhip_pathtrace *pt;
         bool dense;                         // dense bands instead of sparse shares (pt, or dense_only)
+        bool timed;                         // per-rank start events (sdfhip_multi_stats.rank_ms): one API call per rank that a frame alone can do without
         // upload
         const int32_t *structs; const uint8_t *values; uint32_t n_nodes;
     } job;
@@ -295,7 +298,7 @@ int rank_submit(void *arg, uint32_t r)
     DevGuard g(m->devices[r]);
     const Layout &L = m->lay;
     if (L.bands[r].empty()) { B.sent = 0; return SDFHIP_OK; }              // more ranks than bands: nothing to do
-    M_TRY(hipEventRecord(B.ev_start, B.stream));
+    if (J.timed) M_TRY(hipEventRecord(B.ev_start, B.stream));
     if (J.dense) {
         // dense bands (RGBA32F, or RGBA8 through the display pass); rank 0 renders straight into its place in the gathered array
         const size_t share = (size_t)J.n_frames * L.rows_per_rank * L.width * S.dense_px;
@@ -459,7 +462,7 @@ int abort_slot(sdfhip_multi *m, Slot &S, int rc)
 }
 
 int submit_locked(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint32_t n_frames, const sdfhip_pathtrace *pt,
-                  uint32_t width, uint32_t height, uint32_t flags, void *d_out)
+                  uint32_t width, uint32_t height, uint32_t flags, void *d_out, bool timed = true)
 {
     if (slot >= MAX_SLOTS) return fail(SDFHIP_ERR_ARG, "multi_submit: slot %u of %u", slot, MAX_SLOTS);
     if (!infos || n_frames == 0 || n_frames > MAX_GROUP || width == 0 || height == 0)
@@ -492,7 +495,8 @@ int submit_locked(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint
     m->job.m = m; m->job.slot = slot; m->job.infos = infos; m->job.n_frames = n_frames; m->job.width = width; m->job.height = height;
     // sparse shares: the display pass runs where the frame is assembled; dense bands: where they are rendered
     m->job.flags = dense ? flags : flags & ~(uint32_t)(SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG);
-    m->job.pt = pt; m->job.dense = dense;
+    m->job.pt = pt; m->job.dense = dense; m->job.timed = timed;
+    S.timed = timed;
     S.dirty = true;                                   // until everything below has been issued
     rc = post_receives(m, S);
     if (rc == SDFHIP_OK) rc = on_all_ranks(m, rank_submit);
@@ -500,7 +504,7 @@ int submit_locked(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint
     if (rc == SDFHIP_OK) {
         DevGuard g0(m->devices[0]);
         const hipError_t e = hipEventRecord(S.ev_done, S.rb[0].stream);
-        if (e != hipSuccess) rc = fail(SDFHIP_ERR_DEVICE, "multi: hipEventRecord failed: %s", hipGetErrorString(e));
+        if (e != hipSuccess) rc = fail(SDFHIP_ERR_DEVICE, "multi: queueing the frame's completion failed: %s", hipGetErrorString(e));
     }
     if (rc != SDFHIP_OK) return abort_slot(m, S, rc);
     S.dirty = false;
@@ -569,7 +573,7 @@ int wait_locked(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_st
             if (L.bands[r].empty()) continue;
             DevGuard g(m->devices[r]);
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, S.rb[r].ev_start, S.rb[r].ev_sent) == hipSuccess) stats->rank_ms[r] = ms;
+            if (S.timed && hipEventElapsedTime(&ms, S.rb[r].ev_start, S.rb[r].ev_sent) == hipSuccess) stats->rank_ms[r] = ms;
             (void)hipGetLastError();
             if (!S.path) {
                 const ShareShape sh = share_shape(m, S.n_frames);
@@ -702,8 +706,105 @@ extern "C" int sdfhip_multi_create(const int *devices, uint32_t n_devices, const
             m->use_rccl = true;
         }
     }
+    // first contact with the links, before any frame depends on them
+    rc = sdfhip_multi_selftest(m, nullptr);
+    if (rc != SDFHIP_OK) return bail(rc);
     *out = m;
     return SDFHIP_OK;
+}
+
+extern "C" int sdfhip_multi_selftest(sdfhip_multi *m, sdfhip_multi_link *links)
+{
+    if (!m) return fail(SDFHIP_ERR_ARG, "multi_selftest: null handle");
+    std::lock_guard<std::mutex> lk(m->lock);
+    for (uint32_t k = 0; k < MAX_SLOTS; k++)
+        if (m->slots[k].busy) return fail(SDFHIP_ERR_ARG, "multi_selftest: slot %u is in flight", k);
+    if (m->broken) return fail(SDFHIP_ERR_DEVICE, "multi_selftest: the handle's RCCL transport is in an undefined state");
+    constexpr size_t BYTES = 1u << 20;
+    std::vector<uint8_t> pattern(BYTES), back(BYTES);
+    Slot &S = m->slots[0];
+    uint8_t *d_rx = nullptr;
+    { DevGuard g0(m->devices[0]); M_TRY(hipMalloc((void **)&d_rx, BYTES)); }
+    int rc = SDFHIP_OK;
+    char first[256] = { 0 };
+    for (uint32_t r = 0; r < m->n; r++) {
+        sdfhip_multi_link L;
+        memset(&L, 0, sizeof L);
+        L.device = m->devices[r];
+        (void)hipDeviceGetPCIBusId(L.pci_bus_id, (int)sizeof L.pci_bus_id, m->devices[r]);
+        (void)hipGetLastError();
+        L.ok = 1; L.peer_access = -1;
+        if (r > 0 || m->rccl_self) {
+            if (m->devices[r] != m->devices[0]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, m->devices[r], m->devices[0]) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+                L.peer_access = can ? 1 : 0;
+            }
+            for (size_t i = 0; i < BYTES; i++) pattern[i] = (uint8_t)((i * 2654435761u + r * 97u + (i >> 11)) >> 7);
+            uint8_t *d_tx = nullptr;
+            hipError_t e = hipSuccess;
+            int ne = 0;
+            float ms = 0.0f;
+            {
+                DevGuard g(m->devices[r]);
+                RankBuf &B = S.rb[r];
+                if ((e = hipMalloc((void **)&d_tx, BYTES)) == hipSuccess &&
+                    (e = hipMemcpyAsync(d_tx, pattern.data(), BYTES, hipMemcpyHostToDevice, B.stream)) == hipSuccess) {
+                    { DevGuard g0(m->devices[0]); e = hipMemsetAsync(d_rx, 0, BYTES, S.rb[0].stream); if (e == hipSuccess) e = hipStreamSynchronize(S.rb[0].stream); }
+                    if (e == hipSuccess) e = hipEventRecord(B.ev_start, B.stream);
+                    if (e == hipSuccess) {
+                        if (m->use_rccl) {
+                            // the gather's own pattern: the receive on devices[0]'s receive stream, the send on the rank's stream, each in a group
+                            // (one group for both when the rank IS devices[0]: the self test of one-GPU boxes)
+                            DevGuard g0(m->devices[0]);
+                            if (r == 0) {
+                                ne = m->rccl.GroupStart();
+                                if (!ne) ne = m->rccl.Send(d_tx, BYTES, NCCL_UINT8, 0, m->comms[0], B.stream);
+                                if (!ne) ne = m->rccl.Recv(d_rx, BYTES, NCCL_UINT8, 0, m->comms[0], B.stream);
+                                if (!ne) ne = m->rccl.GroupEnd();
+                            } else {
+                                ne = m->rccl.GroupStart();
+                                if (!ne) ne = m->rccl.Recv(d_rx, BYTES, NCCL_UINT8, (int)r, m->comms[0], S.rx_stream);
+                                if (!ne) ne = m->rccl.GroupEnd();
+                                DevGuard gr(m->devices[r]);
+                                if (!ne) ne = m->rccl.GroupStart();
+                                if (!ne) ne = m->rccl.Send(d_tx, BYTES, NCCL_UINT8, 0, m->comms[r], B.stream);
+                                if (!ne) ne = m->rccl.GroupEnd();
+                            }
+                        } else {
+                            e = push(d_rx, m->devices[0], d_tx, m->devices[r], BYTES, B.stream);
+                        }
+                    }
+                    if (e == hipSuccess && !ne) e = hipEventRecord(B.ev_sent, B.stream);
+                    if (e == hipSuccess && !ne) e = hipStreamSynchronize(B.stream);
+                    if (e == hipSuccess && !ne) { (void)hipEventElapsedTime(&ms, B.ev_start, B.ev_sent); (void)hipGetLastError(); }
+                }
+                if (d_tx) (void)hipFree(d_tx);
+            }
+            if (e == hipSuccess && !ne) {
+                DevGuard g0(m->devices[0]);
+                if (m->use_rccl && r > 0) e = hipStreamSynchronize(S.rx_stream);
+                if (e == hipSuccess) e = hipMemcpy(back.data(), d_rx, BYTES, hipMemcpyDeviceToHost);
+            }
+            L.push_ms = ms;
+            L.ok = (e == hipSuccess && !ne && memcmp(back.data(), pattern.data(), BYTES) == 0) ? 1u : 0u;
+            if (!L.ok && rc == SDFHIP_OK) {
+                size_t bad = 0;
+                while (bad < BYTES && back[bad] == pattern[bad]) bad++;
+                rc = SDFHIP_ERR_DEVICE;
+                snprintf(first, sizeof first, "multi_selftest: device %d (%s) -> device %d by %s: %s", m->devices[r], L.pci_bus_id, m->devices[0],
+                         m->use_rccl ? "ncclSend / ncclRecv" : (L.peer_access == 1 ? "hipMemcpyPeerAsync over a peer link" : "hipMemcpyPeerAsync (staged: no peer access)"),
+                         e != hipSuccess ? hipGetErrorString(e) : ne ? (m->rccl.GetErrorString ? m->rccl.GetErrorString(ne) : "RCCL error") :
+                         bad < BYTES ? "the pattern arrived damaged" : "?");
+                if (e == hipSuccess && !ne && bad < BYTES) { const size_t l = strlen(first); snprintf(first + l, sizeof first - l, " (first wrong byte at %zu of %zu)", bad, BYTES); }
+                (void)hipGetLastError();
+                if (m->use_rccl && (e != hipSuccess || ne)) m->broken = true;
+            }
+        }
+        if (links) links[r] = L;
+    }
+    { DevGuard g0(m->devices[0]); (void)hipFree(d_rx); }
+    return rc == SDFHIP_OK ? SDFHIP_OK : fail(rc, "%s", first);
 }
 
 extern "C" int sdfhip_multi_configure(sdfhip_multi *m, uint32_t band_rows, float rank0_weight)
@@ -769,7 +870,10 @@ static int multi_render_host(sdfhip_multi *m, const sdfhip_info *info, const sdf
     if (!m || !info || !out) return fail(SDFHIP_ERR_ARG, "multi_render: null argument");
     std::lock_guard<std::mutex> lk(m->lock);
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = submit_locked(m, 0, info, 1, pt, width, height, flags, nullptr);
+    // (per-rank start events only when somebody asked for statistics.  The copy to the host array is issued AFTER the wait: queued
+    // behind the assembly in its stream -- one wait for both -- a copy into pageable memory made the call slower, 0.072 -> 0.082 ms
+    // for a 64x64 frame: the runtime stages it with the host waiting inside the copy call)
+    int rc = submit_locked(m, 0, info, 1, pt, width, height, flags, nullptr, stats != nullptr);
     if (rc != SDFHIP_OK) return rc;
     void *d = nullptr;
     rc = wait_locked(m, 0, &d, stats);

@@ -253,6 +253,15 @@ class MultiScene:
     def configure(self, band_rows=16, rank0_weight=1.0):
         check(lib.sdfhip_multi_configure(self._h, int(band_rows), float(rank0_weight)))
 
+    def selftest(self):
+        """First contact with the node's links (sdfhip_multi_selftest; create runs it too): per device its PCI bus id, whether it
+        reaches devices[0]'s memory directly, and whether a 1 MB pattern pushed the gather's way arrived intact.  Raises
+        SdfHipError naming the pair when one did not."""
+        links = (_lib.MultiLink * len(self.devices))()
+        check(lib.sdfhip_multi_selftest(self._h, links))
+        return [{"device": l.device, "pci_bus_id": l.pci_bus_id.decode(), "peer_access": l.peer_access, "ok": bool(l.ok), "push_ms": l.push_ms}
+                for l in links]
+
     @property
     def transport(self):
         t = ctypes.c_int()
@@ -269,13 +278,13 @@ class MultiScene:
                 not out.flags.c_contiguous or not out.flags.writeable:
             raise ValueError(f"MultiScene.Draw: out must be a writeable C-contiguous {np.dtype(want).name} array of shape (height, width, 4)")
         st = MultiStats()
+        stp = ctypes.byref(st) if want_stats else None             # (statistics cost an event per rank: only when asked for)
         info = state if isinstance(state, Info) else state.State
         if pt is not None:
             check(lib.sdfhip_multi_render_path(self._h, ctypes.byref(info), ctypes.byref(pt), int(width), int(height), int(flags),
-                                               out.ctypes.data, ctypes.byref(st)))
+                                               out.ctypes.data, stp))
         else:
-            check(lib.sdfhip_multi_render(self._h, ctypes.byref(info), int(width), int(height), int(flags), out.ctypes.data,
-                                          ctypes.byref(st)))
+            check(lib.sdfhip_multi_render(self._h, ctypes.byref(info), int(width), int(height), int(flags), out.ctypes.data, stp))
         return (out, st) if want_stats else out
 
     def Submit(self, slot, states, width, height, flags=0, out_ptr=None, pt=None):
@@ -299,6 +308,12 @@ class MultiScene:
     def debug_floats_sent(self, floats):
         _lib.need_lab("MultiScene.debug_floats_sent")
         check(lib.sdfhip_multi_debug_floats_sent(self._h, int(floats)))
+
+
+def device_pci_bus_id(device=0):
+    out = ctypes.create_string_buffer(32)
+    check(lib.sdfhip_device_pci_bus_id(int(device), out, 32))
+    return out.value.decode()
 
 
 def device_count():

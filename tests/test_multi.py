@@ -143,6 +143,23 @@ def test_multi_frame_equals_the_oracle_and_one_device(sb, oracle_mod, scenes, de
 
 
 @pytest.mark.gpu
+def test_multi_selftest_reports_every_link(sb, scenes):
+    # sdfhip_multi_selftest (create runs it; callable again): per device its PCI bus id, peer access into devices[0], and a 1 MB
+    # pattern pushed the gather's way and read back from devices[0]
+    with sb.MultiScene(scenes["sphere_d4"], [0, 0, 0]) as ms:
+        links = ms.selftest()
+        assert [l["device"] for l in links] == [0, 0, 0] and all(l["ok"] for l in links)
+        assert len({l["pci_bus_id"] for l in links}) == 1 and links[0]["pci_bus_id"] == sb.device_pci_bus_id(0) and ":" in links[0]["pci_bus_id"]
+        assert all(l["peer_access"] == -1 for l in links)                  # the same device: nothing to reach
+        assert links[1]["push_ms"] > 0 and links[0]["push_ms"] == 0
+        ms.Submit(0, make_camera("default", 64, 64), 64, 64)
+        with pytest.raises(sb.SdfHipError):                                # not while a slot is in flight
+            ms.selftest()
+        ms.Wait(0)
+        assert all(l["ok"] for l in ms.selftest())
+
+
+@pytest.mark.gpu
 def test_multi_display_pass_and_path_traced_mode(sb, oracle_mod, scenes):
     od = scenes["torus_d6"]
     W, H = 160, 96
@@ -298,6 +315,8 @@ def test_multi_rccl_transport_on_one_device(sb, oracle_mod, scenes):
         "ref, _ = oracle.render(od.Structs, od.Values, cam.State, W, H, nthreads=8)\n"
         "with sb.MultiScene(od, [0]) as ms:\n"
         "    assert ms.transport == 'rccl', ms.transport\n"
+        "    links = ms.selftest()\n"
+        "    assert links[0]['ok'] and links[0]['push_ms'] > 0, links        # the pattern went through ncclSend / ncclRecv\n"
         "    for k in range(3):\n"
         "        img = ms.Draw(cam, W, H)\n"
         "        assert bits_equal(img, ref).all(), k\n"
