@@ -5,9 +5,15 @@ import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import sdfbox_amd as sb
 import oracle
+import os
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 bad = 0
 for case in range(n_cases):
+    # every third case: the sibling-block kernels on every level below the root (by default only levels of 16 384 nodes and more)
+    if case % 3 == 0:
+        os.environ["SDFHIP_GEN_WIDE"] = "8"
+    else:
+        os.environ.pop("SDFHIP_GEN_WIDE", None)
     rng = np.random.default_rng(5000 + case)
     n = int(rng.choice([50, 300, 2000, 20000]))
     kind = int(rng.integers(4))

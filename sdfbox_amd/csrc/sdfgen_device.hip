@@ -1,5 +1,6 @@
 // Point cloud -> ASDF on the GPU: SdfGen's builder (SdfGen/dllmain.cpp:67-207,295-319),
-// level-synchronous instead of recursive: sixteen lanes per octree node, several workgroups per node on the first levels.
+// level-synchronous instead of recursive: a wavefront per block of eight siblings (which share one candidate list), several
+// workgroups per node on the first levels.
 //
 // What the reference does per node (construct, dllmain.cpp:163-190), and where it is here:
 //   centerValue = distance from the cell centre to the nearest candidate   k_center_*
@@ -8,8 +9,8 @@
 //   corner i    = signed distance to the nearest *surviving* point, unless  k_corners_*
 //                 inherited from the parent (child i inherits corner i)
 //   split       = centerValue < 2 * scale && depth < MaxDepth               k_corners_*
-// (levels of fewer than 4 096 nodes: k_center_seg_min / _seg_count, k_corners_seg / _fin -- several workgroups per node;
-//  the others: k_center_sub / k_corners_sub -- four nodes per wavefront)
+// (levels of fewer than 16 384 nodes: k_center_seg_min / _seg_count, k_corners_seg / _fin -- several workgroups per node;
+//  the others: k_center_sib / k_corners_sib -- a wavefront per sibling block, the shared list staged through LDS)
 //   children    = 8 new nodes whose candidates are this node's `possible`   k_children
 // The recursion becomes a loop over levels; the reference's node order (children blocks
 // appended in depth-first pre-order) is restored afterwards, still on the GPU, from subtree
@@ -31,6 +32,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <sys/mman.h>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -290,12 +292,7 @@ __global__ __launch_bounds__(256) void k_corners_fin(GenParams P, LevelArrays L,
     if (i == 0) L.split[node] = (L.center_value[node] < P.scale * 2 && P.depth < P.max_depth) ? 1u : 0u;
 }
 
-// ---- several nodes per wavefront --------------------------------------------------------------------
-// On the deepest levels a node's candidate list is short (tens of entries): with one wavefront per node most lanes
-// of k_center / k_corners idle through the list, and the eight 6-step butterfly reductions of k_corners cost more
-// than the list itself.  Here G = 16 lanes work on a node and a wavefront takes 64 / G nodes: the same arithmetic
-// per candidate and the same tie-breaking (earliest list position), so the same bytes.
-constexpr int SUB_UNROLL = 4;
+// minimum over the G lanes of a group (ties: the earlier list position)
 template <int G> __device__ __forceinline__ Best sub_min(Best b)
 {
     for (int off = G / 2; off > 0; off >>= 1) {
@@ -307,72 +304,91 @@ template <int G> __device__ __forceinline__ Best sub_min(Best b)
     return b;
 }
 
-template <int G>
-__global__ __launch_bounds__(64) void k_center_sub(GenParams P, LevelArrays L, const Cand *__restrict__ cand,
-                                                   uint32_t n_nodes, uint32_t *err)
+// ---- a wavefront per sibling block --------------------------------------------------------------------
+// The eight children of a node share ONE candidate list (construct passes `possible` to all of them, dllmain.cpp:183-189; here
+// cand_off / cand_cnt of the eight are equal).  A wavefront takes a whole sibling block: it brings the list into LDS once, 64
+// entries per load instruction, fully coalesced and SIB_CH / 64 loads in flight per lane, and eight lanes per child walk it
+// there -- where the sixteen-lanes-per-node form asks L1 for every entry once per child and waits for it.  A short list (the
+// deepest levels: ~100 entries) stays in LDS for both passes of the centre kernel.  The epilogue is lane-parallel: a butterfly
+// that exchanges halves (4 + 2 + 1 candidates per lane instead of 8 x 3) leaves lane j of a child with the nearest survivor of
+// corner j, and the lane computes that corner's value alone (the other form computes all eight on every lane).
+// Same arithmetic per candidate, same tie-breaking (earliest list position), same stable order of the survivors: same bytes.
+constexpr int SIB_CH = 256;                               // list entries per LDS chunk (4 KB per wavefront)
+
+__global__ __launch_bounds__(64) void k_center_sib(GenParams P, LevelArrays L, const Cand *__restrict__ cand, uint32_t n_nodes, uint32_t *err)
 {
-    const uint32_t tid = threadIdx.x, sub = tid % G, node = blockIdx.x * (64 / G) + tid / G;
-    const bool have = node < n_nodes;
+    __shared__ Cand buf[SIB_CH];
+    const uint32_t lane = threadIdx.x, j = lane & 7u, node = blockIdx.x * 8u + (lane >> 3);      // n_nodes is a multiple of 8 below the root
+    if (blockIdx.x * 8u >= n_nodes) return;
     const float h = 0.5f * P.scale;
-    float cx = 0, cy = 0, cz = 0;
-    uint32_t off = 0, cnt = 0;
-    if (have) {
-        transform(P, L.px[node] + h, L.py[node] + h, L.pz[node] + h, cx, cy, cz);
-        off = L.cand_off[node]; cnt = L.cand_cnt[node];
-    }
-    // (both passes take SUB_UNROLL list entries per lane at a time, loaded before the first is used; the order of the
-    // comparisons, and with it the tie-breaking, is the list's)
+    float cx, cy, cz;
+    transform(P, L.px[node] + h, L.py[node] + h, L.pz[node] + h, cx, cy, cz);
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.cand_off[node]), cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.cand_cnt[node]);
     Best b{INFINITY, 0xFFFFFFFFu};
-    for (uint32_t k0 = sub; k0 < cnt; k0 += SUB_UNROLL * G) {
-        Cand e[SUB_UNROLL];
-#pragma unroll
-        for (int u = 0; u < SUB_UNROLL; u++) e[u] = k0 + u * G < cnt ? cand[off + k0 + u * G] : make_float4(0, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < SUB_UNROLL; u++) {
-            const uint32_t k = k0 + u * G;
-            if (k < cnt) {
-                float d = lensq(e[u].x - cx, e[u].y - cy, e[u].z - cz);
-                if (d < b.d) { b.d = d; b.k = k; }
-            }
+    for (uint32_t k0 = 0; k0 < cnt; k0 += SIB_CH) {
+        const uint32_t n = min((uint32_t)SIB_CH, cnt - k0);
+        if (k0) __syncthreads();                         // the chunk before has been read
+        for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+        __syncthreads();
+        for (uint32_t t = j; t < n; t += 8u) {
+            const Cand e = buf[t];
+            const float d = lensq(e.x - cx, e.y - cy, e.z - cz);
+            if (d < b.d) { b.d = d; b.k = k0 + t; }
         }
     }
-    b = sub_min<G>(b);
+    b = sub_min<8>(b);
     const bool bad = b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d);      // "Did not find" / "NaN distance"
     const float center_value = bad ? 0.0f : sqrtf(b.d) / P.gs;
     float r = center_value + 0.866025404f * P.scale;     // GetPossible, dllmain.cpp:151-162
     r *= P.gs;
     r *= r;
     uint32_t count = 0;
-    if (!bad)
-        for (uint32_t k0 = sub; k0 < cnt; k0 += SUB_UNROLL * G) {
-            Cand e[SUB_UNROLL];
-#pragma unroll
-            for (int u = 0; u < SUB_UNROLL; u++) e[u] = k0 + u * G < cnt ? cand[off + k0 + u * G] : make_float4(0, 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < SUB_UNROLL; u++)
-                if (k0 + u * G < cnt && lensq(e[u].x - cx, e[u].y - cy, e[u].z - cz) < r) count++;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += SIB_CH) {
+        const uint32_t n = min((uint32_t)SIB_CH, cnt - k0);
+        if (cnt > (uint32_t)SIB_CH) {                    // (a list of one chunk is still there)
+            __syncthreads();
+            for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+            __syncthreads();
         }
-    for (int o = G / 2; o > 0; o >>= 1) count += __shfl_xor(count, o);
-    if (have && sub == 0) {
+        if (!bad)
+            for (uint32_t t = j; t < n; t += 8u) {
+                const Cand e = buf[t];
+                if (lensq(e.x - cx, e.y - cy, e.z - cz) < r) count++;
+            }
+    }
+    for (int o = 4; o > 0; o >>= 1) count += __shfl_xor(count, o);
+    if (j == 0) {
         if (bad) atomicExch(err, 2u);
         L.center_value[node] = center_value; L.pcount[node] = bad ? 0u : count;
     }
 }
 
-template <int G>
-__global__ __launch_bounds__(64) void k_corners_sub(GenParams P, LevelArrays L, const Cand *__restrict__ cand,
+// one step of the epilogue's butterfly: of 2 n candidates a lane keeps the n whose corner has this bit as the lane has it, and
+// takes its partner's candidates for the same corners
+template <int N>
+__device__ __forceinline__ void halve(const Best (&in)[2 * N], Best (&out)[N], bool upper, int off)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const Best mine = upper ? in[i + N] : in[i], send = upper ? in[i] : in[i + N];
+        Best o;
+        o.d = __shfl_xor(send.d, off);
+        o.k = (uint32_t)__shfl_xor((int)send.k, off);
+        out[i] = better(o, mine) ? o : mine;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_corners_sib(GenParams P, LevelArrays L, const Cand *__restrict__ cand,
                                                     const uint32_t *__restrict__ poff, Cand *__restrict__ possible,
                                                     uint32_t n_nodes, uint32_t *err)
 {
-    const uint32_t tid = threadIdx.x, sub = tid % G, grp = tid / G, node = blockIdx.x * (64 / G) + grp;
-    const bool have = node < n_nodes;
-    float px = 0, py = 0, pz = 0, center_value = 0;
-    uint32_t off = 0, cnt = 0, out = 0;
-    int slot = -1;
-    if (have) {
-        px = L.px[node]; py = L.py[node]; pz = L.pz[node]; center_value = L.center_value[node];
-        off = L.cand_off[node]; cnt = L.cand_cnt[node]; out = poff[node]; slot = L.slot[node];
-    }
+    __shared__ Cand buf[SIB_CH];
+    const uint32_t lane = threadIdx.x, s = lane >> 3, j = lane & 7u, node = blockIdx.x * 8u + s;
+    if (blockIdx.x * 8u >= n_nodes) return;
+    const float px = L.px[node], py = L.py[node], pz = L.pz[node], center_value = L.center_value[node];
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.cand_off[node]), cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.cand_cnt[node]);
+    const uint32_t out = poff[node];
+    const int slot = L.slot[node];
     const float h = 0.5f * P.scale;
     float cx, cy, cz;
     transform(P, px + h, py + h, pz + h, cx, cy, cz);
@@ -387,62 +403,59 @@ __global__ __launch_bounds__(64) void k_corners_sub(GenParams P, LevelArrays L, 
     Best best[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) best[i] = Best{INFINITY, 0xFFFFFFFFu};
-    // the groups of a wavefront walk their lists together, chunk by chunk, until the longest is done
-    uint32_t longest = cnt;
-    for (int o = 32; o >= G; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
     uint32_t base = 0;
-    for (uint32_t k0 = 0; k0 < longest; k0 += G) {
-        const uint32_t k = k0 + sub;
-        bool keep = false;
-        Cand vi = make_float4(0, 0, 0, 0);
-        float vx = 0, vy = 0, vz = 0;
-        if (k < cnt) {
-            vi = cand[off + k];
-            vx = vi.x; vy = vi.y; vz = vi.z;
-            keep = lensq(vx - cx, vy - cy, vz - cz) < r;
-        }
-        const unsigned long long m = __ballot(keep);
-        const uint32_t gm = (uint32_t)(m >> (G * grp)) & ((1u << G) - 1u);            // this group's survivors of the chunk
-        if (keep) {
-            possible[out + base + (uint32_t)__popc(gm & ((1u << sub) - 1u))] = vi;       // stable: list order
+    for (uint32_t k0 = 0; k0 < cnt; k0 += SIB_CH) {
+        const uint32_t n = min((uint32_t)SIB_CH, cnt - k0);
+        if (k0) __syncthreads();
+        for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < n; t0 += 8u) {        // eight entries per child and round, in list order
+            const uint32_t t = t0 + j;
+            const Cand vi = buf[t < n ? t : 0u];
+            const float vx = vi.x, vy = vi.y, vz = vi.z;
+            const bool keep = t < n && lensq(vx - cx, vy - cy, vz - cz) < r;
+            const unsigned long long m = __ballot(keep);
+            const uint32_t gm = (uint32_t)(m >> (8u * s)) & 0xFFu;                   // this child's survivors of the round
+            if (keep) {
+                possible[out + base + (uint32_t)__popc(gm & ((1u << j) - 1u))] = vi;    // stable: list order
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                float d = lensq(vx - qx[i], vy - qy[i], vz - qz[i]);
-                if (d < best[i].d) { best[i].d = d; best[i].k = k; }
+                for (int i = 0; i < 8; i++) {
+                    float d = lensq(vx - qx[i], vy - qy[i], vz - qz[i]);
+                    if (d < best[i].d) { best[i].d = d; best[i].k = k0 + t; }
+                }
             }
+            base += (uint32_t)__popc(gm);
         }
-        base += (uint32_t)__popc(gm);
     }
-    float myval = 0.0f;                                  // lane i < 8 of the group ends up holding corner i
-    bool bad_any = false;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        Best b = sub_min<G>(best[i]);
-        float val;
-        if (i == slot) {
-            val = have ? L.inherit[node] : 0.0f;         // n[i] = vals[insert][i], dllmain.cpp:181
-        } else if (b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d)) {
-            bad_any = true;
-            val = 0.0f;
-        } else {                                         // DistanceAt, dllmain.cpp:119-149
-            const float *v = P.verts + 6 * (size_t)__float_as_uint(cand[off + b.k].w);
-            float md = sqrtf(b.d);
-            const float ex = qx[i] - v[0], ey = qy[i] - v[1], ez = qz[i] - v[2];      // p - closest.Position
-            if ((double)md < 0.015) {
-                const float nl = sqrtf(lensq(v[3], v[4], v[5]));
-                md = (v[3] / nl) * ex + (v[4] / nl) * ey + (v[5] / nl) * ez;
-            } else if (v[3] * (v[0] - qx[i]) + v[4] * (v[1] - qy[i]) + v[5] * (v[2] - qz[i]) > 0) {   // Inside
-                md *= -1;
-            }
-            val = md / P.gs;
+    // lane j of a child ends up with corner j's nearest survivor
+    Best b4[4], b2[2], b1[1];
+    halve<4>(best, b4, (j & 4u) != 0u, 4);
+    halve<2>(b4, b2, (j & 2u) != 0u, 2);
+    halve<1>(b2, b1, (j & 1u) != 0u, 1);
+    const Best b = b1[0];
+    const int i = (int)j;
+    float q0, q1, q2;
+    transform(P, px + (float)(i % 2) * P.scale, py + (float)((i / 2) % 2) * P.scale, pz + (float)((i / 2 / 2) % 2) * P.scale, q0, q1, q2);
+    float val;
+    if (i == slot) {
+        val = L.inherit[node];                           // n[i] = vals[insert][i], dllmain.cpp:181
+    } else if (b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d)) {
+        atomicExch(err, 2u);
+        val = 0.0f;
+    } else {                                             // DistanceAt, dllmain.cpp:119-149
+        const float *v = P.verts + 6 * (size_t)__float_as_uint(cand[off + b.k].w);
+        float md = sqrtf(b.d);
+        const float ex = q0 - v[0], ey = q1 - v[1], ez = q2 - v[2];      // p - closest.Position
+        if ((double)md < 0.015) {
+            const float nl = sqrtf(lensq(v[3], v[4], v[5]));
+            md = (v[3] / nl) * ex + (v[4] / nl) * ey + (v[5] / nl) * ez;
+        } else if (v[3] * (v[0] - q0) + v[4] * (v[1] - q1) + v[5] * (v[2] - q2) > 0) {   // Inside
+            md *= -1;
         }
-        if ((int)sub == i) myval = val;
+        val = md / P.gs;
     }
-    if (have) {
-        if (bad_any && sub == 0) atomicExch(err, 2u);
-        if (sub < 8) L.vals[8 * (size_t)node + sub] = myval;
-        if (sub == 0) L.split[node] = (center_value < P.scale * 2 && P.depth < P.max_depth) ? 1u : 0u;
-    }
+    L.vals[8 * (size_t)node + j] = val;
+    if (j == 0) L.split[node] = (center_value < P.scale * 2 && P.depth < P.max_depth) ? 1u : 0u;
 }
 
 // the 8 children of every split node (construct's push_back loop + the arguments of its recursion)
@@ -575,11 +588,48 @@ namespace {
 // Bump allocator over a few large hipMalloc chunks.  reset() makes the memory reusable; work on
 // the (single, in-order) stream that still reads the old contents was launched before whatever
 // is launched to overwrite them, so no synchronisation is needed.
+// The arenas' chunks outlive a build: they go back to a per-process pool (by device) instead of to hipFree, and the next build
+// takes them from there.  On this stack the first hipMalloc after a build had freed its ~10 GB took 340 ms -- every build after
+// the first one in a process: 31 ms became 370 -- and a build's own allocations are 5 ms of it.  The pool keeps at most
+// POOL_MAX_BYTES per device (what a depth-10 build of a million points needs); SDFHIP_GEN_POOL=0 turns it off.
+struct ChunkPool {
+    struct Item { int device; char *base; size_t size; };
+    std::mutex mu;
+    std::vector<Item> items;
+    size_t held = 0;
+    static constexpr size_t POOL_MAX_BYTES = (size_t)24 << 30;
+    static bool enabled() { const char *e = getenv("SDFHIP_GEN_POOL"); return !(e && atoi(e) == 0); }
+    char *take(int device, size_t want, size_t *size_out)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t best = items.size();
+        for (size_t i = 0; i < items.size(); i++)        // the smallest chunk that fits, and no more than twice as large
+            if (items[i].device == device && items[i].size >= want && items[i].size <= 2 * want + ((size_t)64 << 20) &&
+                (best == items.size() || items[i].size < items[best].size)) best = i;
+        if (best == items.size()) return nullptr;
+        char *p = items[best].base;
+        *size_out = items[best].size;
+        held -= items[best].size;
+        items.erase(items.begin() + (long)best);
+        return p;
+    }
+    void give(int device, char *base, size_t size)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (enabled() && held + size <= POOL_MAX_BYTES) { items.push_back(Item{device, base, size}); held += size; return; }
+        }
+        (void)hipFree(base);
+    }
+};
+ChunkPool g_pool;
+
 struct Arena {
     struct Chunk { char *base; size_t size, used; };
     std::vector<Chunk> chunks;
     size_t grow;
-    explicit Arena(size_t grow) : grow(grow) {}
+    int device = 0;
+    explicit Arena(size_t grow) : grow(grow) { (void)hipGetDevice(&device); }
     Arena(const Arena &) = delete;
     Arena &operator=(const Arena &) = delete;
     void *take(size_t bytes)
@@ -588,16 +638,21 @@ struct Arena {
         if (bytes == 0) bytes = 256;
         for (auto &c : chunks)
             if (c.size - c.used >= bytes) { void *p = c.base + c.used; c.used += bytes; return p; }
-        const size_t size = bytes > grow ? bytes : grow;
-        void *p = nullptr;
-        if (hipMalloc(&p, size) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        size_t size = bytes > grow ? bytes : grow;
+        void *p = ChunkPool::enabled() ? g_pool.take(device, size, &size) : nullptr;
+        if (!p) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (hipMalloc(&p, size) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > 5.0f && getenv("SDFHIP_GEN_LEVELS")) fprintf(stderr, "sdfgen: hipMalloc(%zu MB) took %.1f ms\n", size >> 20, ms);
+        }
         chunks.push_back(Chunk{ (char *)p, size, bytes });
         grow = grow < ((size_t)1 << 30) ? grow * 2 : grow;
         return p;
     }
     template <class T> T *alloc(size_t n) { return (T *)take(n * sizeof(T)); }
     void reset() { for (auto &c : chunks) c.used = 0; }
-    ~Arena() { for (auto &c : chunks) (void)hipFree(c.base); }
+    ~Arena() { for (auto &c : chunks) g_pool.give(device, c.base, c.size); }
 };
 
 // scratch: arrays only the level itself and k_children read; keep: what the final ordering needs
@@ -623,7 +678,7 @@ bool scan_u32(Arena &scratch, const uint32_t *in, uint32_t *out, uint32_t n, uns
     return true;
 }
 
-constexpr uint32_t WIDE_LEVEL = 4096;
+constexpr uint32_t WIDE_LEVEL = 16384;
 struct KeptLevel { LevelArrays L; uint32_t n; uint32_t *cnt, *rank; int32_t *index; };
 
 }  // namespace
@@ -696,19 +751,23 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
         uint32_t n_nodes = 1;
         size_t total_nodes = 0;
         unsigned long long cand_entries = n;
+        // (SDFHIP_GEN_WIDE=n: the sibling-block form from n nodes on -- tests set 8 to run small trees through it)
+        const uint32_t wide_level = getenv("SDFHIP_GEN_WIDE") ? (uint32_t)atoi(getenv("SDFHIP_GEN_WIDE")) : WIDE_LEVEL;
+        const bool level_timing = getenv("SDFHIP_GEN_LEVELS") != nullptr;      // debug aid: nodes, entries and time of every level on stderr
         for (int lvl = 0;; lvl++) {
+            auto tl = std::chrono::steady_clock::now();
             Arena &mine = scratch[lvl & 1], &other = scratch[(lvl + 1) & 1];
             P.depth = lvl;
             P.scale = ldexpf(1.0f, -lvl);                 // powf(0.5, depth)
             uint32_t *poff = mine.alloc<uint32_t>(n_nodes);
             if (!poff) return GEN_NOMEM();
-            const bool wide = n_nodes >= WIDE_LEVEL;      // enough nodes to fill the GPU with one wavefront each
-            // wide levels: 16 lanes per node, four nodes per wavefront -- whatever the lists' lengths: the passes over a list are
-            // chains of dependent gathers (index -> position), and four lists per wave keep four times as many of them in flight
-            // (1 M-point knot: depth 9 in 40 ms instead of 56, depth 10 in 58 instead of 90; scripts/sdfgen_short_list.py)
-            // narrow levels: a node's list over S workgroups, so that the level still fills the chip (k_center_seg_min, ...)
-            SegArrays A{ nullptr, nullptr, nullptr, wide ? 0u : (WIDE_LEVEL + n_nodes - 1) / n_nodes };
-            if (wide) hipLaunchKernelGGL(k_center_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
+            // which form: a wavefront per sibling block (k_center_sib / k_corners_sib) where that fills the chip -- 16 384 nodes = 2 048
+            // wavefronts and more; below the root a level's nodes come in blocks of eight -- else a node's list over S workgroups of
+            // 1 024 threads (k_center_seg_min, ...).  (1 M-point knot, depth 10: level 5, 10 776 nodes with lists of 50 000: 2.9 ms
+            // in segments, 3.9 by sibling blocks; level 6, 37 896 nodes: 4.7 against 1.9)
+            const bool wide = n_nodes >= wide_level && lvl >= 1 && (n_nodes & 7u) == 0;
+            SegArrays A{ nullptr, nullptr, nullptr, wide ? 0u : (4096u + n_nodes - 1) / n_nodes };           // segments per node: ~4 096 workgroups per level
+            if (wide) hipLaunchKernelGGL(k_center_sib, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
             else {
                 A.best = mine.alloc<unsigned long long>(n_nodes); A.corner = mine.alloc<unsigned long long>(8 * (size_t)n_nodes);
                 A.count = mine.alloc<uint32_t>((size_t)n_nodes * A.S);
@@ -727,7 +786,7 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             Cand *possible = lists[(lvl + 1) & 1].alloc<Cand>((size_t)total);
             if (!possible) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory for %llu candidate entries", total);
             cand_entries += total;
-            if (wide) hipLaunchKernelGGL(k_corners_sub<16>, dim3((n_nodes + 3) / 4), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            if (wide) hipLaunchKernelGGL(k_corners_sib, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
             else {
                 hipLaunchKernelGGL(k_corners_seg, dim3(n_nodes * A.S), dim3(1024), 0, 0, P, L, A, cand, poff, possible, n_nodes);
                 hipLaunchKernelGGL(k_corners_fin, dim3((8 * n_nodes + 255) / 256), dim3(256), 0, 0, P, L, A, cand, n_nodes, d_err);
@@ -737,6 +796,11 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             GEN_TRY(hipMemcpy(&back.n_split, d_total, sizeof back.n_split, hipMemcpyDeviceToHost));
             GEN_TRY(hipMemcpy(&back.err, d_err, sizeof back.err, hipMemcpyDeviceToHost));
             if (back.err) return fail(SDFHIP_ERR_ARG, "sdfgen: a cell at depth %d has no candidate point left (the reference throws \"Did not find\")", lvl);
+            if (level_timing) {
+                (void)hipDeviceSynchronize();
+                fprintf(stderr, "sdfgen: level %2d: %9u nodes, %11llu entries kept for the next level, %8.3f ms\n", lvl, n_nodes, total,
+                        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tl).count());
+            }
             levels.push_back(KeptLevel{ L, n_nodes, nullptr, nullptr, nullptr });
             total_nodes += n_nodes;
             const unsigned long long n_split = back.n_split;

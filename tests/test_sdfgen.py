@@ -114,8 +114,14 @@ def test_oracle_structure_and_inheritance(oracle_mod):
 
 # ---- the HIP builder -----------------------------------------------------------------------------
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["default", "sibling blocks everywhere"])
 @pytest.mark.parametrize("cloud,depth", [("sphere20k", 4), ("sphere20k", 6), ("torus", 5), ("torus", 7), ("two", 5)])
-def test_gpu_builder_equals_oracle(sb, oracle_mod, cloud, depth):
+def test_gpu_builder_equals_oracle(sb, oracle_mod, cloud, depth, form, monkeypatch):
+    # two kernel forms per level: several 1 024-thread workgroups per node (levels of fewer than 16 384 nodes) and a wavefront per
+    # block of eight siblings, their shared list staged through LDS (the others); SDFHIP_GEN_WIDE=8 takes even the smallest
+    # levels below the root through the second
+    if form != "default":
+        monkeypatch.setenv("SDFHIP_GEN_WIDE", "8")
     v = {"sphere20k": fib_sphere(20000), "torus": torus_cloud(30000),
          "two": np.concatenate([fib_sphere(4000, 0.3, (-0.2, 0.1, 0.0)), fib_sphere(3000, 0.25, (0.35, -0.1, 0.2))])}[cloud]
     o = oracle_mod.sdfgen(v, depth)
