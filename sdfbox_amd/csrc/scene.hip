@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 
 using namespace sdfhip;
 
@@ -181,10 +182,27 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
     {   // validation (sdfhip_octdata_validate's verdicts, on the device: see k_validate)
         uint32_t *d_verdict = s->d_verdict, verdict[2] = { 0u, 0u };
         if ((e = hipMemsetAsync(d_verdict, 0, sizeof verdict, s->stream)) != hipSuccess) return bail(e, "hipMemset(verdict)");
-        hipLaunchKernelGGL(k_validate, dim3((n + 255u) / 256u), dim3(256), 0, s->stream, (const int2 *)d_s, n, d_verdict);
+        // (scratch: the allocation of the fused records, 16 bytes per node, not written before k_fuse)
+        Jump *ja = reinterpret_cast<Jump *>(s->alloc), *jb = ja + n;
+        const dim3 vg((n + 255u) / 256u), vb(256);
+        hipLaunchKernelGGL(k_validate_init, vg, vb, 0, s->stream, (const int2 *)d_s, n, d_verdict, ja);
+        for (int round = 0; round < 3; round++) { hipLaunchKernelGGL((k_validate_jump<false>), vg, vb, 0, s->stream, ja, jb, n, d_verdict); std::swap(ja, jb); }
+        hipLaunchKernelGGL((k_validate_jump<true>), vg, vb, 0, s->stream, ja, jb, n, d_verdict);
+        std::swap(ja, jb);
         if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_validate launch");
         if ((e = hipMemcpyAsync(verdict, d_verdict, sizeof verdict, hipMemcpyDeviceToHost, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(verdict)");
         if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail(e, "k_validate");
+        if ((verdict[0] & 4u) && !(verdict[0] & 1u)) {
+            // chains of more than 16 links: three more rounds reach 128; what is open after those is a cycle or longer than 64 links
+            if ((e = hipMemsetAsync(d_verdict, 0, sizeof verdict, s->stream)) != hipSuccess) return bail(e, "hipMemset(verdict)");
+            const uint32_t keep = verdict[0] & 3u;
+            for (int round = 0; round < 2; round++) { hipLaunchKernelGGL((k_validate_jump<false>), vg, vb, 0, s->stream, ja, jb, n, d_verdict); std::swap(ja, jb); }
+            hipLaunchKernelGGL((k_validate_jump<true>), vg, vb, 0, s->stream, ja, jb, n, d_verdict);
+            if ((e = hipGetLastError()) != hipSuccess) return bail(e, "k_validate launch");
+            if ((e = hipMemcpyAsync(verdict, d_verdict, sizeof verdict, hipMemcpyDeviceToHost, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(verdict)");
+            if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail(e, "k_validate");
+            verdict[0] = keep | (verdict[0] & 1u) | ((verdict[0] & 4u) ? 1u : 0u);      // still open: endless or too long
+        }
         if (verdict[0] & 1u) {                          // a bad link: the host function finds it again and says which
             if (!resident) { (void)hipFree(d_s); (void)hipFree(d_v); }
             d_s = d_v = nullptr;

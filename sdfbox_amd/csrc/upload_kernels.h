@@ -79,18 +79,29 @@ __global__ void k_fine_blocks(const NodeRec *__restrict__ nodes, const uint32_t 
 }
 
 // sdfhip_octdata_validate (asdf_io.cpp) on the device, for the upload: the arrays are on their way to HBM anyway (8 ms for
-// 451 MB) and the host's single-threaded pass over 28 M nodes takes 110 ms.  One thread per node; the same verdicts:
+// 451 MB) and the host's single-threaded pass over 28 M nodes takes 110 ms.  The same verdicts:
 //   bad          a link out of range, or a parent chain of more than 64 links / a cycle (the host function then names the node)
 //   inconsistent the root has a parent, a node's children block is block 0 or does not point back at it
 //   depth        the most links from a node to the root among the nodes the root reaches (every link of the chain is mirrored by
 //                its parent's children block): the host function's walk down from the root
-// Reads nothing through a link it has not range-checked.
-__global__ __launch_bounds__(256) void k_validate(const int2 *__restrict__ structs, uint32_t n, uint32_t *__restrict__ verdict)
+// Every node's chain to the root by POINTER JUMPING (round 4; until then every thread walked its own chain link by link: <= 9
+// dependent loads per node, 5.0 ms for 28 M nodes): k_validate_init checks a node's own links and writes {where my chain has got
+// to, how many links that is, are they all mirrored}; a round of k_validate_jump doubles every chain's reach by appending the
+// chain of the node it has got to (A -> B -> A: two buffers, no race).  Four rounds resolve chains of up to 16 links -- every
+// tree the shader can descend -- and the last of them reduces the verdicts; chains still unresolved then get three more rounds
+// (128 links), and what is unresolved after those is longer than 64 links or a cycle: bad.  Reads nothing through a link that
+// has not been range-checked.
+struct Jump { int32_t at; uint32_t info; };              // at: the node the chain has reached (-1: its end); info: links | ok << 8
+constexpr uint32_t JUMP_OK = 0x100u, JUMP_LINKS = 0xFFu;
+
+__global__ __launch_bounds__(256) void k_validate_init(const int2 *__restrict__ structs, uint32_t n, uint32_t *__restrict__ verdict,
+                                                       Jump *__restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     const int2 me = valid ? structs[i] : make_int2(-1, -1);
     bool bad = false, inconsistent = false;
+    Jump jmp{-1, 0u};
     if (valid) {
         if (me.x >= 0 && (uint32_t)me.x >= n) bad = true;
         if (me.y >= 0 && (uint64_t)(uint32_t)me.y + 8u > (uint64_t)n) bad = true;
@@ -100,28 +111,49 @@ __global__ __launch_bounds__(256) void k_validate(const int2 *__restrict__ struc
             for (int k = 0; k < 8; k++)
                 if (structs[(uint32_t)me.y + (uint32_t)k].x != (int32_t)i) inconsistent = true;
         }
+        if (me.x < 0) {
+            jmp.info = i == 0 ? JUMP_OK : 0u;            // a chain must end at node 0
+        } else if ((uint32_t)me.x < n) {
+            const int2 up = structs[(uint32_t)me.x];
+            const bool mirrored = up.y >= 0 && i >= (uint32_t)up.y && i - (uint32_t)up.y < 8u;
+            jmp.at = me.x; jmp.info = 1u | (mirrored && !bad ? JUMP_OK : 0u);
+        }                                                // (a parent out of range: this thread has said `bad`; the chain is not attached)
+        out[i] = jmp;
     }
-    uint32_t links = 0;
-    bool attached = valid && !bad;
-    if (attached) {
-        uint32_t j = i;
-        int32_t p = me.x;
-        while (p >= 0) {
-            if ((uint32_t)p >= n) { attached = false; break; }            // that node's own thread reports the bad link
-            const int2 up = structs[(uint32_t)p];
-            if (!(up.y >= 0 && j >= (uint32_t)up.y && j - (uint32_t)up.y < 8u)) attached = false;
-            j = (uint32_t)p; p = up.x;
-            if (++links > 64u) { bad = true; attached = false; break; }
-        }
-        if (j != 0u) attached = false;
-    }
-    // one atomic per wave and verdict
-    uint32_t m = attached ? links : 0u;
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
     const uint32_t flags = (__ballot(bad) ? 1u : 0u) | (__ballot(inconsistent) ? 2u : 0u);
-    if ((threadIdx.x & 63u) == 0) {
-        if (flags) atomicOr(&verdict[0], flags);
-        if (m) atomicMax(&verdict[1], m);
+    if ((threadIdx.x & 63u) == 0 && flags) atomicOr(&verdict[0], flags);
+}
+
+// LAST: also the verdicts of the resolved chains (more than 64 links: bad; the deepest attached node) and, in verdict[0] bit 2,
+// whether any chain is still on its way
+template <bool LAST>
+__global__ __launch_bounds__(256) void k_validate_jump(const Jump *__restrict__ in, Jump *__restrict__ out, uint32_t n, uint32_t *__restrict__ verdict)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Jump a{-1, 0u};
+    if (i < n) {
+        a = in[i];
+        if (a.at >= 0) {
+            const Jump t = in[(uint32_t)a.at];
+            const uint32_t links = min((a.info & JUMP_LINKS) + (t.info & JUMP_LINKS), JUMP_LINKS);
+            a.info = links | (a.info & t.info & JUMP_OK);
+            a.at = t.at;
+        }
+        out[i] = a;
+    }
+    if (LAST) {
+        const bool open = i < n && a.at >= 0;
+        const uint32_t links = a.info & JUMP_LINKS;
+        const bool bad = i < n && !open && links > 64u;
+        uint32_t m = (i < n && !open && !bad && (a.info & JUMP_OK)) ? links : 0u;
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        const uint32_t flags = (__ballot(bad) ? 1u : 0u) | (__ballot(open) ? 4u : 0u);
+        // (a wave adds its maximum only when it would raise the word: 440 000 atomic maxima on one address serialise at ~90 per
+        // microsecond -- that, not the chain walks, was most of the old kernel's 5 ms)
+        if ((threadIdx.x & 63u) == 0) {
+            if (flags) atomicOr(&verdict[0], flags);
+            if (m > *reinterpret_cast<volatile uint32_t *>(&verdict[1])) atomicMax(&verdict[1], m);
+        }
     }
 }
 

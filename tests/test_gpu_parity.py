@@ -267,6 +267,15 @@ def test_upload_validates_on_the_device_like_the_host_function(sb):
     for k in range(60):
         s[N + k, 0] = (N + k - 1) if k else 0
     cases.append(("a 60-link chain (allowed; nothing reaches it)", s))
+    for links in (16, 17, 63, 64, 65, 128, 129):        # round the limits of the pointer jumping's two stages (16 links, 128) and of the rule (64)
+        s = np.concatenate([od.Structs, np.full((links, 2), -1, np.int32)])
+        for k in range(links):
+            s[N + k, 0] = (N + k - 1) if k else 0
+        cases.append((f"a {links}-link chain", s))
+    for depth in (13, 16, 17, 40, 64):                  # consistent trees deeper than the first four rounds resolve: the depth must come out
+        cases.append((f"a consistent chain tree of depth {depth}", _chain_tree(depth)[0]))
+    s = _chain_tree(30)[0]; s[1 + 8 * 20, 0] = 5        # ... and one whose chain is broken in the middle: everything below is unattached
+    cases.append(("a deep chain tree with a false parent link half-way", s))
     assert rng is not None
     for name, s in cases:
         s = np.ascontiguousarray(s, dtype=np.int32)
