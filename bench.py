@@ -1151,6 +1151,18 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9):
         measure("cfg2_depth10", sc10, f"dragon_standin_d{depth + 1}", W2, H2, "default", grid_suffix(sc10),
                 note=f"N={od10.Length} nodes, {od10.nbytes / 1e6:.0f} MB, built in {t_gen:.1f} s")
     del od10
+    # ... and on a MESH-derived scene at that depth: the reference's import flow (Program.cs:613-650: .ply -> SdfGen(depth 10) -> upload)
+    # on a 1 M-point cloud (a torus-knot tube: no mesh ships with the reference), the tree built by the GPU builder and never
+    # leaving HBM (sdfhip_sdfgen_scene)
+    if scale == 1:
+        pts = sb.knot_point_cloud(1_000_000)
+        sb.Scene.FromPoints(pts[:2000], 3).close()                       # (module load)
+        t0 = time.time()
+        scm, stg = sb.Scene.FromPoints(pts, depth + 1, device=scene.device, want_stats=True)
+        t_build = time.time() - t0
+        with scm:
+            measure("cfg2_mesh_knot_d10", scm, f"knot_d{depth + 1}.asdf", W2, H2, "default", grid_suffix(scm),
+                    note=f"1 M-point cloud -> sdfhip_sdfgen_scene: N={scm.Length} nodes in {t_build * 1e3:.0f} ms wall ({stg.total_ms:.0f} ms in the library)")
     return out
 
 

@@ -1,26 +1,25 @@
 #!/bin/bash
 # The round's bench lines (GPU box, via gpurun): gpurun_out/bench_lines/<tag>_<name>.json -> copy to profiles/bench_lines/
-R=${1:-r03}; O=gpurun_out/bench_lines; mkdir -p $O
+R=${1:-r04}; O=gpurun_out/bench_lines; mkdir -p $O
 run() { n=$1; shift; python bench.py "$@" > $O/${R}_$n.json 2> $O/${R}_$n.err || echo "$n failed"; }
 run 1080p_default
 run 1080p_driver_style --steps 20 --warmup 5
 run 1080p_one_frame_in_flight --no-cpu-baseline --frames-in-flight 1
-run 1080p_shadow_queue --no-cpu-baseline --shadow-queue
-run 1080p_shadow_queue_single --no-cpu-baseline --shadow-queue --frames-in-flight 1
-run 1080p_one_kernel --no-cpu-baseline --one-kernel
-run 1080p_one_kernel_single --no-cpu-baseline --one-kernel --frames-in-flight 1
+run 1080p_shadow_queue --no-cpu-baseline --lab --shadow-queue
+run 1080p_shadow_queue_single --no-cpu-baseline --lab --shadow-queue --frames-in-flight 1
+run 1080p_one_kernel --no-cpu-baseline --lab --one-kernel
+run 1080p_one_kernel_single --no-cpu-baseline --lab --one-kernel --frames-in-flight 1
 run 1080p_display --no-cpu-baseline --display
 run 1080p_depth10 --no-cpu-baseline --depth 10
 run 1080p_compact --no-cpu-baseline --compact 1
 run 1080p_orbit --no-cpu-baseline --orbit 90
 run 4k_default --no-cpu-baseline --size 3840x2160
-run 4k_shadow_queue --no-cpu-baseline --size 3840x2160 --shadow-queue
-run 4k_one_kernel --no-cpu-baseline --size 3840x2160 --one-kernel
+run 4k_shadow_queue --no-cpu-baseline --size 3840x2160 --lab --shadow-queue
+run 4k_one_kernel --no-cpu-baseline --size 3840x2160 --lab --one-kernel
 run 4k_compact --no-cpu-baseline --size 3840x2160 --compact 1
 run cfg5_4k_spp16 --no-cpu-baseline --size 3840x2160 --spp 16 --steps 8 --warmup 2
-run cfg5_4k_spp16_one_kernel --no-cpu-baseline --size 3840x2160 --spp 16 --steps 8 --warmup 2 --one-kernel
+run cfg5_4k_spp16_one_kernel --no-cpu-baseline --size 3840x2160 --spp 16 --steps 8 --warmup 2 --lab --one-kernel
 run sharded_1rank_nccl_4k --no-cpu-baseline --exercise-gather --check --size 3840x2160
-run sharded_1rank_nccl_4k_wire2 --no-cpu-baseline --exercise-gather --check --size 3840x2160 --wire 2
 run sharded_2rank_gloo_1080p --no-cpu-baseline --gpus 2 --backend gloo --check --steps 40 --warmup 8
 # the library's own multi-device entry points (sdfhip_multi_*), the ranks played by the one GPU
 run multi_4k_groups_1rank --single-process --devices 0 --size 3840x2160 --check --steps 64 --warmup 16
@@ -39,7 +38,7 @@ import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
     r = d["roofline"]
-    print(sys.argv[1].split("/")[-1], d["value"], "Mray/s", d["ms_per_step"], "ms/step, latency", d["latency_ms"], "frac", r["frac"], r["binding"], "hbm_frac", r.get("hbm_frac"), "valu_busy", r.get("valu_busy"))
+    print(sys.argv[1].split("/")[-1], d["value"], "Mray/s", d["ms_per_step"], "ms/step, latency", d["latency_ms"], "frac", r["frac"], r["binding"], "hbm_frac", r.get("hbm_frac"), "valu of spec", r.get("valu_frac_of_spec"))
 except Exception as e: print(sys.argv[1], "unreadable", e)
 PY
 done

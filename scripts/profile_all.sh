@@ -1,11 +1,11 @@
 #!/bin/bash
 # Every configuration whose PMC figures bench.py reports (profiles/hbm_traffic.json): run on the GPU box via gpurun,
 # then `python scripts/summarise_all.py <round>` here.   bash scripts/profile_all.sh r02
-R=${1:-r02}
+R=${1:-r04}
 bash scripts/profile.sh ${R}_1080p                                  && \
-bash scripts/profile.sh ${R}_1080p_onekernel --one-kernel           && \
-bash scripts/profile.sh ${R}_1080p_queue --shadow-queue             && \
-bash scripts/profile.sh ${R}_4k_queue --size 3840x2160 --shadow-queue && \
+bash scripts/profile.sh ${R}_1080p_onekernel --lab --one-kernel           && \
+bash scripts/profile.sh ${R}_1080p_queue --lab --shadow-queue             && \
+bash scripts/profile.sh ${R}_4k_queue --size 3840x2160 --lab --shadow-queue && \
 bash scripts/profile.sh ${R}_4k --size 3840x2160                    && \
 bash scripts/profile.sh ${R}_4k_compact --size 3840x2160 --compact 1 && \
 bash scripts/profile.sh ${R}_1080p_display --display                && \

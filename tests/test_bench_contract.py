@@ -125,7 +125,7 @@ def test_committed_pmc_passes_belong_to_this_build():
     here = bench.kernel_source_hash()
     for key in ("1920x1080:dragon_standin_d9:default:grid8+blocks", "3840x2160:dragon_standin_d9:default:grid8+blocks",
                 "3840x2160:dragon_standin_d9:compact:grid8+blocks", "3840x2160:dragon_standin_d9:spp16:grid8",
-                "1920x1080:dragon_standin_d10:default:grid8+blocks"):
+                "1920x1080:dragon_standin_d10:default:grid8+blocks", "1920x1080:knot_d10.asdf:default:grid7+blocks"):
         assert key in t, key
         assert t[key]["kernel_source_sha"] == here, f"{key}: measured on {t[key]['kernel_source_sha']}, the tree is {here}: re-profile"
         assert "dropped" not in bench.load_pmc(key)
