@@ -108,6 +108,11 @@ template <int BT> __device__ __forceinline__ Best node_min(Best b, Best *sh)
 // floats the bit patterns order as the values do, and equal distances go to the earlier position: the same winner as the
 // strict `<` scan -- and the `possible` list stays in list order: segment s writes behind the survivors of the segments
 // before it (their counts are known from the centre pass).
+constexpr uint32_t SEG_BT = 256;   // threads of a workgroup of the segment kernels: four wavefronts -- five workgroups share a CU, where one of
+                                   // sixteen wavefronts had it alone and nothing covered its chains of dependent loads (10 us a workgroup)
+constexpr uint32_t SEG_U = 4;      // entries a thread has in flight per trip: a trip takes SEG_U x SEG_BT = 1 024 list entries
+constexpr uint32_t SEG_W = SEG_BT / 64;
+static_assert(SEG_U * SEG_BT == 1024, "segment_of cuts lists into whole trips of 1 024 entries");
 struct SegArrays {
     unsigned long long *best;      // per node: the candidate nearest to the cell centre
     unsigned long long *corner;    // 8 per node: ... to every corner, among the survivors
@@ -122,9 +127,9 @@ __device__ __forceinline__ void segment_of(uint32_t cnt, uint32_t S, uint32_t s,
     lo = min(cnt, s * len); hi = min(cnt, lo + len);
 }
 
-__global__ __launch_bounds__(1024) void k_center_seg_min(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand, uint32_t n_nodes)
+__global__ __launch_bounds__(SEG_BT) void k_center_seg_min(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand, uint32_t n_nodes)
 {
-    __shared__ Best sh[16];
+    __shared__ Best sh[SEG_W];
     const uint32_t node = blockIdx.x / A.S, s = blockIdx.x % A.S, tid = threadIdx.x;
     if (node >= n_nodes) return;
     const float h = 0.5f * P.scale;
@@ -134,19 +139,25 @@ __global__ __launch_bounds__(1024) void k_center_seg_min(GenParams P, LevelArray
     uint32_t lo, hi;
     segment_of(cnt, A.S, s, lo, hi);
     Best b{INFINITY, 0xFFFFFFFFu};
-    for (uint32_t k = lo + tid; k < hi; k += 1024u) {
-        const Cand v = cand[off + k];
-        float d = lensq(v.x - cx, v.y - cy, v.z - cz);
-        if (d < b.d) { b.d = d; b.k = k; }
+    for (uint32_t k0 = lo + tid; k0 < hi; k0 += SEG_U * SEG_BT) {
+        Cand v[SEG_U];                                   // SEG_U loads in flight per thread: one per trip left the passes waiting
+#pragma unroll                                           // for a single load's latency (1.6 TB/s out of L2)
+        for (uint32_t u = 0; u < SEG_U; u++) v[u] = cand[off + min(k0 + u * SEG_BT, hi - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < SEG_U; u++) {
+            const uint32_t k = k0 + u * SEG_BT;
+            float d = lensq(v[u].x - cx, v[u].y - cy, v[u].z - cz);
+            if (k < hi && d < b.d) { b.d = d; b.k = k; }
+        }
     }
-    b = node_min<1024>(b, sh);
+    b = node_min<SEG_BT>(b, sh);
     if (tid == 0 && b.k != 0xFFFFFFFFu) atomicMin(&A.best[node], pack_best(b));
 }
 
-__global__ __launch_bounds__(1024) void k_center_seg_count(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand,
+__global__ __launch_bounds__(SEG_BT) void k_center_seg_count(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand,
                                                            uint32_t n_nodes, uint32_t *err)
 {
-    __shared__ uint32_t shc[16];
+    __shared__ uint32_t shc[SEG_W];
     const uint32_t node = blockIdx.x / A.S, s = blockIdx.x % A.S, tid = threadIdx.x;
     if (node >= n_nodes) return;
     const Best b = unpack_best(A.best[node]);
@@ -168,28 +179,32 @@ __global__ __launch_bounds__(1024) void k_center_seg_count(GenParams P, LevelArr
     r *= P.gs;
     r *= r;
     uint32_t count = 0;
-    for (uint32_t k = lo + tid; k < hi; k += 1024u) {
-        const Cand v = cand[off + k];
-        if (lensq(v.x - cx, v.y - cy, v.z - cz) < r) count++;
+    for (uint32_t k0 = lo + tid; k0 < hi; k0 += SEG_U * SEG_BT) {
+        Cand v[SEG_U];
+#pragma unroll
+        for (uint32_t u = 0; u < SEG_U; u++) v[u] = cand[off + min(k0 + u * SEG_BT, hi - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < SEG_U; u++)
+            if (k0 + u * SEG_BT < hi && lensq(v[u].x - cx, v[u].y - cy, v[u].z - cz) < r) count++;
     }
     for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
     if ((tid & 63u) == 0) shc[tid >> 6] = count;
     __syncthreads();
     if (tid == 0) {
         count = 0;
-        for (int w = 0; w < 16; w++) count += shc[w];
+        for (uint32_t w = 0; w < SEG_W; w++) count += shc[w];
         A.count[blockIdx.x] = count;
         if (count) atomicAdd(&L.pcount[node], count);
         if (s == 0) L.center_value[node] = center_value;
     }
 }
 
-__global__ __launch_bounds__(1024) void k_corners_seg(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand,
+__global__ __launch_bounds__(SEG_BT) void k_corners_seg(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand,
                                                       const uint32_t *__restrict__ poff, Cand *__restrict__ possible, uint32_t n_nodes)
 {
-    __shared__ Best sh[16];
-    __shared__ uint32_t kept[2][16];                     // survivors per wavefront, double-buffered over chunks
-    __shared__ uint32_t ahead[16];
+    __shared__ Best sh[SEG_W * 8];
+    __shared__ uint32_t kept[2][SEG_U][SEG_W];              // survivors per wavefront and chunk, double-buffered over trips
+    __shared__ uint32_t ahead[SEG_W];
     const uint32_t node = blockIdx.x / A.S, s = blockIdx.x % A.S, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (node >= n_nodes) return;
     const Best c = unpack_best(A.best[node]);
@@ -213,46 +228,62 @@ __global__ __launch_bounds__(1024) void k_corners_seg(GenParams P, LevelArrays L
     const uint32_t off = L.cand_off[node], cnt = L.cand_cnt[node];
     uint32_t lo, hi;
     segment_of(cnt, A.S, s, lo, hi);
+    if (lo >= hi) return;                                // (the whole workgroup: a short list leaves most segments empty)
     // where this segment's survivors go: behind those of the segments before it
     uint32_t before_seg = 0;
-    for (uint32_t j = tid; j < s; j += 1024u) before_seg += A.count[node * A.S + j];
+    for (uint32_t j = tid; j < s; j += SEG_BT) before_seg += A.count[node * A.S + j];
     for (int o = 32; o > 0; o >>= 1) before_seg += __shfl_xor(before_seg, o);
     if (lane == 0) ahead[wave] = before_seg;
     __syncthreads();
     before_seg = 0;
-    for (int w = 0; w < 16; w++) before_seg += ahead[w];
+    for (uint32_t w = 0; w < SEG_W; w++) before_seg += ahead[w];
     const uint32_t out = poff[node] + before_seg;
     uint32_t base = 0, flip = 0;
-    for (uint32_t k0 = lo; k0 < hi; k0 += 1024u, flip ^= 1u) {
-        const uint32_t k = k0 + tid;
-        bool keep = false;
-        Cand vi = make_float4(0, 0, 0, 0);
-        float vx = 0, vy = 0, vz = 0;
-        if (k < hi) {
-            vi = cand[off + k];
-            vx = vi.x; vy = vi.y; vz = vi.z;
-            keep = lensq(vx - cx, vy - cy, vz - cz) < r;
-        }
-        const unsigned long long m = __ballot(keep);
-        uint32_t before = 0, all = 0;
-        if (lane == 0) kept[flip][wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        for (uint32_t w = 0; w < 16; w++) { const uint32_t n = kept[flip][w]; before += w < wave ? n : 0u; all += n; }
-        if (keep) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            possible[out + base + before + rank] = vi;
+    for (uint32_t k0 = lo; k0 < hi; k0 += SEG_U * SEG_BT, flip ^= 1u) {
+        // SEG_U entries per thread and trip: their loads are in flight together, and one barrier serves them all
+        Cand vi[SEG_U];
+        bool keep[SEG_U];
+        unsigned long long m[SEG_U];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                float d = lensq(vx - qx[i], vy - qy[i], vz - qz[i]);
-                if (d < best[i].d) { best[i].d = d; best[i].k = k; }
-            }
+        for (uint32_t u = 0; u < SEG_U; u++) vi[u] = cand[off + min(k0 + u * SEG_BT + tid, hi - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < SEG_U; u++) {
+            keep[u] = k0 + u * SEG_BT + tid < hi && lensq(vi[u].x - cx, vi[u].y - cy, vi[u].z - cz) < r;
+            m[u] = __ballot(keep[u]);
+            if (lane == 0) kept[flip][u][wave] = (uint32_t)__popcll(m[u]);
         }
-        base += all;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < SEG_U; u++) {           // the survivors stay in list order: chunk by chunk, wavefront by wavefront
+            uint32_t before = 0, all = 0;
+            for (uint32_t w = 0; w < SEG_W; w++) { const uint32_t n = kept[flip][u][w]; before += w < wave ? n : 0u; all += n; }
+            if (keep[u]) {
+                const uint32_t k = k0 + u * SEG_BT + tid;
+                const float vx = vi[u].x, vy = vi[u].y, vz = vi[u].z;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
+                possible[out + base + before + rank] = vi[u];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float d = lensq(vx - qx[i], vy - qy[i], vz - qz[i]);
+                    if (d < best[i].d) { best[i].d = d; best[i].k = k; }
+                }
+            }
+            base += all;
+        }
     }
+    // the eight minima of the workgroup with ONE barrier: every wavefront leaves its own in LDS, thread i of the first eight
+    // takes corner i over the wavefronts (eight reductions one after the other, two barriers each, were most of what a
+    // workgroup with little to do cost: 17 us)
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const Best b = node_min<1024>(best[i], sh);
-        if (tid == 0 && b.k != 0xFFFFFFFFu) atomicMin(&A.corner[8 * (size_t)node + i], pack_best(b));
+        const Best b = wave_min(best[i]);
+        if (lane == 0) sh[wave * 8 + i] = b;
+    }
+    __syncthreads();
+    if (tid < 8u) {
+        Best b = sh[tid];
+        for (uint32_t w = 1; w < SEG_W; w++) if (better(sh[w * 8 + tid], b)) b = sh[w * 8 + tid];
+        if (b.k != 0xFFFFFFFFu) atomicMin(&A.corner[8 * (size_t)node + tid], pack_best(b));
     }
 }
 
@@ -476,6 +507,14 @@ __global__ void k_children(LevelArrays L, LevelArrays N, const uint32_t *__restr
     N.cand_cnt[c] = L.pcount[node];
 }
 
+// the root: construct(all, 0, 0, -1, 0)
+__global__ void k_root(LevelArrays L, uint32_t n_points)
+{
+    L.px[0] = L.py[0] = L.pz[0] = L.inherit[0] = 0.0f;
+    L.slot[0] = L.parent[0] = -1;
+    L.cand_off[0] = 0; L.cand_cnt[0] = n_points;
+}
+
 // the root's list: every point, in input order
 __global__ void k_cand_init(Cand *p, const float *__restrict__ verts, uint32_t n)
 {
@@ -504,8 +543,12 @@ __global__ __launch_bounds__(SCAN_CHUNK) void k_scan_sums(const uint32_t *__rest
     const uint32_t s = block_sum(i < n ? in[i] : 0u, wsum);
     if (threadIdx.x == 0) sums[blockIdx.x] = s;
 }
+// What the host waits for at the two points of a level where it must know a total before it can go on (the size of the next
+// lists; the number of nodes of the next level, and whether a cell ran out of candidates): written by the scan's last thread
+// straight into page-locked host memory -- one stream synchronisation per point instead of a blocking copy per word.
+struct Report { unsigned long long total; uint32_t err, pad; };
 __global__ __launch_bounds__(SCAN_CHUNK) void k_scan_apply(const uint32_t *__restrict__ in, const uint32_t *__restrict__ sums,
-                                                            uint32_t *__restrict__ out, uint32_t n, unsigned long long *total)
+                                                            uint32_t *__restrict__ out, uint32_t n, const uint32_t *err, Report *report)
 {
     __shared__ uint32_t wsum[SCAN_CHUNK / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -527,7 +570,7 @@ __global__ __launch_bounds__(SCAN_CHUNK) void k_scan_apply(const uint32_t *__res
     uint32_t woff = 0;
     for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
     if (i < n) out[i] = (uint32_t)(before + woff + x - v);
-    if (i == n - 1) *total = before + woff + x;
+    if (i == n - 1) { report->total = before + woff + x; report->err = *err; }
 }
 
 // ---- the reference's node order, on the GPU ------------------------------------------------------
@@ -668,13 +711,13 @@ bool alloc_level(Arena &scratch, Arena &keep, LevelArrays &L, size_t n)
            L.center_value && L.pcount && L.vals && L.split && L.block_of;
 }
 
-bool scan_u32(Arena &scratch, const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *d_total)
+bool scan_u32(Arena &scratch, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_err, sdfhip::Report *report)
 {
     const uint32_t chunks = (n + sdfhip::SCAN_CHUNK - 1) / sdfhip::SCAN_CHUNK;
     uint32_t *sums = scratch.alloc<uint32_t>(chunks);
     if (!sums) return false;
     hipLaunchKernelGGL(sdfhip::k_scan_sums, dim3(chunks), dim3(sdfhip::SCAN_CHUNK), 0, 0, in, sums, n);
-    hipLaunchKernelGGL(sdfhip::k_scan_apply, dim3(chunks), dim3(sdfhip::SCAN_CHUNK), 0, 0, in, sums, out, n, d_total);
+    hipLaunchKernelGGL(sdfhip::k_scan_apply, dim3(chunks), dim3(sdfhip::SCAN_CHUNK), 0, 0, in, sums, out, n, d_err, report);
     return true;
 }
 
@@ -730,9 +773,11 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
               lists[2] = { Arena((size_t)64 << 20), Arena((size_t)64 << 20) };
         float *d_verts = keep.alloc<float>(6 * (size_t)n);
         uint32_t *d_err = keep.alloc<uint32_t>(1);
-        unsigned long long *d_total = keep.alloc<unsigned long long>(1);
+        // (page-locked and mapped; one per host thread, kept for the life of the process: allocating one costs as much as a level)
+        static thread_local Report *report = nullptr;
+        if (!report) GEN_TRY(hipHostMalloc((void **)&report, sizeof(Report), hipHostMallocPortable | hipHostMallocMapped));
         Cand *cand = lists[0].alloc<Cand>(n);
-        if (!d_verts || !d_err || !d_total || !cand) return GEN_NOMEM();
+        if (!d_verts || !d_err || !cand) return GEN_NOMEM();
         GEN_TRY(hipMemcpy(d_verts, verts6, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
         GEN_TRY(hipMemset(d_err, 0, sizeof(uint32_t)));
         hipLaunchKernelGGL(k_cand_init, dim3(1024), dim3(256), 0, 0, cand, (const float *)d_verts, n);
@@ -740,19 +785,14 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
 
         LevelArrays L;
         if (!alloc_level(scratch[0], keep, L, 1)) return GEN_NOMEM();
-        {   // the root: construct(all, 0, 0, -1, 0)
-            const float z = 0.0f; const int32_t m1 = -1; const uint32_t zero = 0;
-            GEN_TRY(hipMemcpy(L.px, &z, 4, hipMemcpyHostToDevice)); GEN_TRY(hipMemcpy(L.py, &z, 4, hipMemcpyHostToDevice));
-            GEN_TRY(hipMemcpy(L.pz, &z, 4, hipMemcpyHostToDevice)); GEN_TRY(hipMemcpy(L.inherit, &z, 4, hipMemcpyHostToDevice));
-            GEN_TRY(hipMemcpy(L.slot, &m1, 4, hipMemcpyHostToDevice)); GEN_TRY(hipMemcpy(L.parent, &m1, 4, hipMemcpyHostToDevice));
-            GEN_TRY(hipMemcpy(L.cand_off, &zero, 4, hipMemcpyHostToDevice)); GEN_TRY(hipMemcpy(L.cand_cnt, &n, 4, hipMemcpyHostToDevice));
-        }
+        hipLaunchKernelGGL(k_root, dim3(1), dim3(1), 0, 0, L, n);
         std::vector<KeptLevel> levels;
         uint32_t n_nodes = 1;
         size_t total_nodes = 0;
         unsigned long long cand_entries = n;
         // (SDFHIP_GEN_WIDE=n: the sibling-block form from n nodes on -- tests set 8 to run small trees through it)
         const uint32_t wide_level = getenv("SDFHIP_GEN_WIDE") ? (uint32_t)atoi(getenv("SDFHIP_GEN_WIDE")) : WIDE_LEVEL;
+        const uint32_t seg_target = getenv("SDFHIP_GEN_SEGS") ? (uint32_t)max(1, atoi(getenv("SDFHIP_GEN_SEGS"))) : 4096u;
         const bool level_timing = getenv("SDFHIP_GEN_LEVELS") != nullptr;      // debug aid: nodes, entries and time of every level on stderr
         for (int lvl = 0;; lvl++) {
             auto tl = std::chrono::steady_clock::now();
@@ -766,7 +806,7 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             // 1 024 threads (k_center_seg_min, ...).  (1 M-point knot, depth 10: level 5, 10 776 nodes with lists of 50 000: 2.9 ms
             // in segments, 3.9 by sibling blocks; level 6, 37 896 nodes: 4.7 against 1.9)
             const bool wide = n_nodes >= wide_level && lvl >= 1 && (n_nodes & 7u) == 0;
-            SegArrays A{ nullptr, nullptr, nullptr, wide ? 0u : (4096u + n_nodes - 1) / n_nodes };           // segments per node: ~4 096 workgroups per level
+            SegArrays A{ nullptr, nullptr, nullptr, wide ? 0u : (seg_target + n_nodes - 1) / n_nodes };      // segments per node: ~4 096 workgroups per level
             if (wide) hipLaunchKernelGGL(k_center_sib, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
             else {
                 A.best = mine.alloc<unsigned long long>(n_nodes); A.corner = mine.alloc<unsigned long long>(8 * (size_t)n_nodes);
@@ -775,12 +815,12 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
                 GEN_TRY(hipMemsetAsync(A.best, 0xFF, (size_t)n_nodes * 8, 0));
                 GEN_TRY(hipMemsetAsync(A.corner, 0xFF, (size_t)n_nodes * 64, 0));
                 GEN_TRY(hipMemsetAsync(L.pcount, 0, (size_t)n_nodes * 4, 0));
-                hipLaunchKernelGGL(k_center_seg_min, dim3(n_nodes * A.S), dim3(1024), 0, 0, P, L, A, cand, n_nodes);
-                hipLaunchKernelGGL(k_center_seg_count, dim3(n_nodes * A.S), dim3(1024), 0, 0, P, L, A, cand, n_nodes, d_err);
+                hipLaunchKernelGGL(k_center_seg_min, dim3(n_nodes * A.S), dim3(SEG_BT), 0, 0, P, L, A, cand, n_nodes);
+                hipLaunchKernelGGL(k_center_seg_count, dim3(n_nodes * A.S), dim3(SEG_BT), 0, 0, P, L, A, cand, n_nodes, d_err);
             }
-            if (!scan_u32(mine, L.pcount, poff, n_nodes, d_total)) return GEN_NOMEM();
-            unsigned long long total = 0;
-            GEN_TRY(hipMemcpy(&total, d_total, sizeof total, hipMemcpyDeviceToHost));
+            if (!scan_u32(mine, L.pcount, poff, n_nodes, d_err, report)) return GEN_NOMEM();
+            GEN_TRY(hipStreamSynchronize(0));
+            const unsigned long long total = ((volatile Report *)report)->total;
             if (total > 0xFFFFFFF0ull) return fail(SDFHIP_ERR_NOMEM, "sdfgen: candidate lists of level %d exceed 2^32 entries", lvl);
             lists[(lvl + 1) & 1].reset();                 // the lists of level lvl-1: dead since k_children of lvl-1
             Cand *possible = lists[(lvl + 1) & 1].alloc<Cand>((size_t)total);
@@ -788,13 +828,14 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             cand_entries += total;
             if (wide) hipLaunchKernelGGL(k_corners_sib, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
             else {
-                hipLaunchKernelGGL(k_corners_seg, dim3(n_nodes * A.S), dim3(1024), 0, 0, P, L, A, cand, poff, possible, n_nodes);
+                hipLaunchKernelGGL(k_corners_seg, dim3(n_nodes * A.S), dim3(SEG_BT), 0, 0, P, L, A, cand, poff, possible, n_nodes);
                 hipLaunchKernelGGL(k_corners_fin, dim3((8 * n_nodes + 255) / 256), dim3(256), 0, 0, P, L, A, cand, n_nodes, d_err);
             }
-            if (!scan_u32(mine, L.split, L.block_of, n_nodes, d_total)) return GEN_NOMEM();
+            if (!scan_u32(mine, L.split, L.block_of, n_nodes, d_err, report)) return GEN_NOMEM();
+            GEN_TRY(hipStreamSynchronize(0));
             struct { unsigned long long n_split; uint32_t err; } back;
-            GEN_TRY(hipMemcpy(&back.n_split, d_total, sizeof back.n_split, hipMemcpyDeviceToHost));
-            GEN_TRY(hipMemcpy(&back.err, d_err, sizeof back.err, hipMemcpyDeviceToHost));
+            back.n_split = ((volatile Report *)report)->total;
+            back.err = ((volatile Report *)report)->err;
             if (back.err) return fail(SDFHIP_ERR_ARG, "sdfgen: a cell at depth %d has no candidate point left (the reference throws \"Did not find\")", lvl);
             if (level_timing) {
                 (void)hipDeviceSynchronize();
