@@ -139,10 +139,17 @@ __global__ __launch_bounds__(SEG_BT) void k_center_seg_min(GenParams P, LevelArr
     uint32_t lo, hi;
     segment_of(cnt, A.S, s, lo, hi);
     Best b{INFINITY, 0xFFFFFFFFu};
+    // SEG_U loads in flight per thread (one per trip left the passes waiting for a single load's latency: 1.6 TB/s out of L2),
+    // and the next trip's are issued before this trip's entries are looked at
+    Cand nx[SEG_U];
+    if (lo < hi) {
+#pragma unroll
+        for (uint32_t u = 0; u < SEG_U; u++) nx[u] = cand[off + min(lo + tid + u * SEG_BT, hi - 1u)];
+    }
     for (uint32_t k0 = lo + tid; k0 < hi; k0 += SEG_U * SEG_BT) {
-        Cand v[SEG_U];                                   // SEG_U loads in flight per thread: one per trip left the passes waiting
-#pragma unroll                                           // for a single load's latency (1.6 TB/s out of L2)
-        for (uint32_t u = 0; u < SEG_U; u++) v[u] = cand[off + min(k0 + u * SEG_BT, hi - 1u)];
+        Cand v[SEG_U];
+#pragma unroll
+        for (uint32_t u = 0; u < SEG_U; u++) { v[u] = nx[u]; nx[u] = cand[off + min(k0 + (SEG_U + u) * SEG_BT, hi - 1u)]; }
 #pragma unroll
         for (uint32_t u = 0; u < SEG_U; u++) {
             const uint32_t k = k0 + u * SEG_BT;
@@ -179,10 +186,16 @@ __global__ __launch_bounds__(SEG_BT) void k_center_seg_count(GenParams P, LevelA
     r *= P.gs;
     r *= r;
     uint32_t count = 0;
+    Cand nx[SEG_U];
+    if (lo < hi) {
+#pragma unroll
+        for (uint32_t u = 0; u < SEG_U; u++) nx[u] = cand[off + min(lo + tid + u * SEG_BT, hi - 1u)];
+    }
+#pragma unroll 1
     for (uint32_t k0 = lo + tid; k0 < hi; k0 += SEG_U * SEG_BT) {
         Cand v[SEG_U];
 #pragma unroll
-        for (uint32_t u = 0; u < SEG_U; u++) v[u] = cand[off + min(k0 + u * SEG_BT, hi - 1u)];
+        for (uint32_t u = 0; u < SEG_U; u++) { v[u] = nx[u]; nx[u] = cand[off + min(k0 + (SEG_U + u) * SEG_BT, hi - 1u)]; }
 #pragma unroll
         for (uint32_t u = 0; u < SEG_U; u++)
             if (k0 + u * SEG_BT < hi && lensq(v[u].x - cx, v[u].y - cy, v[u].z - cz) < r) count++;
@@ -239,13 +252,16 @@ __global__ __launch_bounds__(SEG_BT) void k_corners_seg(GenParams P, LevelArrays
     for (uint32_t w = 0; w < SEG_W; w++) before_seg += ahead[w];
     const uint32_t out = poff[node] + before_seg;
     uint32_t base = 0, flip = 0;
+    Cand nx[SEG_U];                                      // the next trip's entries, on their way while this trip's are worked on
+#pragma unroll
+    for (uint32_t u = 0; u < SEG_U; u++) nx[u] = cand[off + min(lo + u * SEG_BT + tid, hi - 1u)];
     for (uint32_t k0 = lo; k0 < hi; k0 += SEG_U * SEG_BT, flip ^= 1u) {
         // SEG_U entries per thread and trip: their loads are in flight together, and one barrier serves them all
         Cand vi[SEG_U];
         bool keep[SEG_U];
         unsigned long long m[SEG_U];
 #pragma unroll
-        for (uint32_t u = 0; u < SEG_U; u++) vi[u] = cand[off + min(k0 + u * SEG_BT + tid, hi - 1u)];
+        for (uint32_t u = 0; u < SEG_U; u++) { vi[u] = nx[u]; nx[u] = cand[off + min(k0 + (SEG_U + u) * SEG_BT + tid, hi - 1u)]; }
 #pragma unroll
         for (uint32_t u = 0; u < SEG_U; u++) {
             keep[u] = k0 + u * SEG_BT + tid < hi && lensq(vi[u].x - cx, vi[u].y - cy, vi[u].z - cz) < r;
@@ -345,7 +361,24 @@ template <int G> __device__ __forceinline__ Best sub_min(Best b)
 // corner j, and the lane computes that corner's value alone (the other form computes all eight on every lane).
 // Same arithmetic per candidate, same tie-breaking (earliest list position), same stable order of the survivors: same bytes.
 constexpr int SIB_CH = 256;                               // list entries per LDS chunk (4 KB per wavefront)
+constexpr int SIB_LD = SIB_CH / 64;                       // loads per lane and chunk
+// a chunk on its way into the lanes' registers (the next one, while the wavefront works on the one in LDS) ...
+struct SibChunk { Cand a, b, c, d; };
+static_assert(SIB_LD == 4, "SibChunk holds four entries per lane");
+__device__ __forceinline__ SibChunk sib_fetch(const Cand *__restrict__ list, uint32_t k0, uint32_t cnt, uint32_t lane)
+{
+    const uint32_t last = cnt - 1u, at = k0 < cnt ? k0 + lane : last;                  // (behind the list's end: its last entry, not used)
+    return SibChunk{ list[min(at, last)], list[min(at + 64u, last)], list[min(at + 128u, last)], list[min(at + 192u, last)] };
+}
+// ... and from there into LDS
+__device__ __forceinline__ void sib_stage(Cand *buf, const SibChunk &pre, uint32_t lane)
+{
+    buf[lane] = pre.a; buf[lane + 64u] = pre.b; buf[lane + 128u] = pre.c; buf[lane + 192u] = pre.d;
+}
 
+// PIPE: the next chunk is fetched while this one is worked on (lists of several chunks; for the short lists of the deepest levels the
+// registers it takes cost more than it brings: 2.7 against 2.2 ms on the last level of the 1 M-point knot)
+template <bool PIPE>
 __global__ __launch_bounds__(64) void k_center_sib(GenParams P, LevelArrays L, const Cand *__restrict__ cand, uint32_t n_nodes, uint32_t *err)
 {
     __shared__ Cand buf[SIB_CH];
@@ -356,10 +389,17 @@ __global__ __launch_bounds__(64) void k_center_sib(GenParams P, LevelArrays L, c
     transform(P, L.px[node] + h, L.py[node] + h, L.pz[node] + h, cx, cy, cz);
     const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.cand_off[node]), cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.cand_cnt[node]);
     Best b{INFINITY, 0xFFFFFFFFu};
+    SibChunk pre{};
+    if (PIPE && cnt) pre = sib_fetch(cand + off, 0, cnt, lane);
     for (uint32_t k0 = 0; k0 < cnt; k0 += SIB_CH) {
         const uint32_t n = min((uint32_t)SIB_CH, cnt - k0);
         if (k0) __syncthreads();                         // the chunk before has been read
-        for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+        if (PIPE) {
+            sib_stage(buf, pre, lane);
+            pre = sib_fetch(cand + off, k0 + SIB_CH, cnt, lane);
+        } else {
+            for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+        }
         __syncthreads();
         for (uint32_t t = j; t < n; t += 8u) {
             const Cand e = buf[t];
@@ -374,11 +414,17 @@ __global__ __launch_bounds__(64) void k_center_sib(GenParams P, LevelArrays L, c
     r *= P.gs;
     r *= r;
     uint32_t count = 0;
+    if (PIPE && cnt > (uint32_t)SIB_CH) pre = sib_fetch(cand + off, 0, cnt, lane);
     for (uint32_t k0 = 0; k0 < cnt; k0 += SIB_CH) {
         const uint32_t n = min((uint32_t)SIB_CH, cnt - k0);
         if (cnt > (uint32_t)SIB_CH) {                    // (a list of one chunk is still there)
             __syncthreads();
-            for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+            if (PIPE) {
+                sib_stage(buf, pre, lane);
+                pre = sib_fetch(cand + off, k0 + SIB_CH, cnt, lane);
+            } else {
+                for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+            }
             __syncthreads();
         }
         if (!bad)
@@ -409,6 +455,7 @@ __device__ __forceinline__ void halve(const Best (&in)[2 * N], Best (&out)[N], b
     }
 }
 
+template <bool PIPE>
 __global__ __launch_bounds__(64) void k_corners_sib(GenParams P, LevelArrays L, const Cand *__restrict__ cand,
                                                     const uint32_t *__restrict__ poff, Cand *__restrict__ possible,
                                                     uint32_t n_nodes, uint32_t *err)
@@ -435,10 +482,17 @@ __global__ __launch_bounds__(64) void k_corners_sib(GenParams P, LevelArrays L, 
 #pragma unroll
     for (int i = 0; i < 8; i++) best[i] = Best{INFINITY, 0xFFFFFFFFu};
     uint32_t base = 0;
+    SibChunk pre{};
+    if (PIPE && cnt) pre = sib_fetch(cand + off, 0, cnt, lane);
     for (uint32_t k0 = 0; k0 < cnt; k0 += SIB_CH) {
         const uint32_t n = min((uint32_t)SIB_CH, cnt - k0);
         if (k0) __syncthreads();
-        for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+        if (PIPE) {
+            sib_stage(buf, pre, lane);
+            pre = sib_fetch(cand + off, k0 + SIB_CH, cnt, lane);
+        } else {
+            for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+        }
         __syncthreads();
         for (uint32_t t0 = 0; t0 < n; t0 += 8u) {        // eight entries per child and round, in list order
             const uint32_t t = t0 + j;
@@ -513,6 +567,32 @@ __global__ void k_root(LevelArrays L, uint32_t n_points)
     L.px[0] = L.py[0] = L.pz[0] = L.inherit[0] = 0.0f;
     L.slot[0] = L.parent[0] = -1;
     L.cand_off[0] = 0; L.cand_cnt[0] = n_points;
+}
+
+// FindDimensions (dllmain.cpp:67-80) over the points as they lie in device memory: per workgroup the minima and maxima of x, y, z
+// (fminf / fmaxf as on the host: a NaN coordinate is passed over), the host folds the BOUNDS_WG partial results
+constexpr uint32_t BOUNDS_WG = 256;
+__global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ verts, uint32_t n, float *__restrict__ partial)
+{
+    __shared__ float sh[4][6];
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += BOUNDS_WG * 256u)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float v = verts[6 * (size_t)i + k];
+            lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v);
+        }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (int o = 32; o > 0; o >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], o)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o)); }
+    if ((threadIdx.x & 63u) == 0)
+        for (int k = 0; k < 3; k++) { sh[threadIdx.x >> 6][k] = lo[k]; sh[threadIdx.x >> 6][3 + k] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6u) {
+        float v = sh[0][threadIdx.x];
+        for (int w = 1; w < 4; w++) v = threadIdx.x < 3u ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
+        partial[6 * blockIdx.x + threadIdx.x] = v;
+    }
 }
 
 // the root's list: every point, in input order
@@ -745,19 +825,7 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
     if (scene_out) *scene_out = nullptr;
     auto t0 = std::chrono::steady_clock::now();
 
-    // FindDimensions, dllmain.cpp:67-80 (host: one pass over the points)
-    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-    for (uint32_t i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) {
-            lo[k] = fminf(lo[k], verts6[6 * (size_t)i + k]);
-            hi[k] = fmaxf(hi[k], verts6[6 * (size_t)i + k]);
-        }
     GenParams P;
-    P.gox = (lo[0] + hi[0]) * 0.5f + 0.003f;
-    P.goy = (lo[1] + hi[1]) * 0.5f + 0.003f;
-    P.goz = (lo[2] + hi[2]) * 0.5f + 0.003f;
-    const float lowest = fminf(lo[0], fminf(lo[1], lo[2])), highest = fmaxf(hi[0], fmaxf(hi[1], hi[2]));
-    P.gs = (highest - lowest) * 1.1f;
     P.max_depth = depth;
 
     int ndev = 0;
@@ -775,13 +843,29 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
         uint32_t *d_err = keep.alloc<uint32_t>(1);
         // (page-locked and mapped; one per host thread, kept for the life of the process: allocating one costs as much as a level)
         static thread_local Report *report = nullptr;
-        if (!report) GEN_TRY(hipHostMalloc((void **)&report, sizeof(Report), hipHostMallocPortable | hipHostMallocMapped));
+        if (!report) GEN_TRY(hipHostMalloc((void **)&report, sizeof(Report) + BOUNDS_WG * 6 * sizeof(float), hipHostMallocPortable | hipHostMallocMapped));
+        float *bounds = reinterpret_cast<float *>(report + 1);
         Cand *cand = lists[0].alloc<Cand>(n);
         if (!d_verts || !d_err || !cand) return GEN_NOMEM();
         GEN_TRY(hipMemcpy(d_verts, verts6, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-        GEN_TRY(hipMemset(d_err, 0, sizeof(uint32_t)));
-        hipLaunchKernelGGL(k_cand_init, dim3(1024), dim3(256), 0, 0, cand, (const float *)d_verts, n);
+        GEN_TRY(hipMemsetAsync(d_err, 0, sizeof(uint32_t), 0));
+        hipLaunchKernelGGL(k_bounds, dim3(BOUNDS_WG), dim3(256), 0, 0, (const float *)d_verts, n, bounds);
+        GEN_TRY(hipStreamSynchronize(0));
+        {   // FindDimensions, dllmain.cpp:67-80 (the pass over the points ran on the device: 2 ms of a 15 ms build on the host)
+            float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+            for (uint32_t w = 0; w < BOUNDS_WG; w++)
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = fminf(lo[k], ((volatile float *)bounds)[6 * w + k]);
+                    hi[k] = fmaxf(hi[k], ((volatile float *)bounds)[6 * w + 3 + k]);
+                }
+            P.gox = (lo[0] + hi[0]) * 0.5f + 0.003f;
+            P.goy = (lo[1] + hi[1]) * 0.5f + 0.003f;
+            P.goz = (lo[2] + hi[2]) * 0.5f + 0.003f;
+            const float lowest = fminf(lo[0], fminf(lo[1], lo[2])), highest = fmaxf(hi[0], fmaxf(hi[1], hi[2]));
+            P.gs = (highest - lowest) * 1.1f;
+        }
         P.verts = d_verts;
+        hipLaunchKernelGGL(k_cand_init, dim3(1024), dim3(256), 0, 0, cand, (const float *)d_verts, n);
 
         LevelArrays L;
         if (!alloc_level(scratch[0], keep, L, 1)) return GEN_NOMEM();
@@ -789,7 +873,7 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
         std::vector<KeptLevel> levels;
         uint32_t n_nodes = 1;
         size_t total_nodes = 0;
-        unsigned long long cand_entries = n;
+        unsigned long long cand_entries = n, list_entries = n;      // all lists so far; the lists of the level at hand
         // (SDFHIP_GEN_WIDE=n: the sibling-block form from n nodes on -- tests set 8 to run small trees through it)
         const uint32_t wide_level = getenv("SDFHIP_GEN_WIDE") ? (uint32_t)atoi(getenv("SDFHIP_GEN_WIDE")) : WIDE_LEVEL;
         const uint32_t seg_target = getenv("SDFHIP_GEN_SEGS") ? (uint32_t)max(1, atoi(getenv("SDFHIP_GEN_SEGS"))) : 4096u;
@@ -807,7 +891,10 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             // in segments, 3.9 by sibling blocks; level 6, 37 896 nodes: 4.7 against 1.9)
             const bool wide = n_nodes >= wide_level && lvl >= 1 && (n_nodes & 7u) == 0;
             SegArrays A{ nullptr, nullptr, nullptr, wide ? 0u : (seg_target + n_nodes - 1) / n_nodes };      // segments per node: ~4 096 workgroups per level
-            if (wide) hipLaunchKernelGGL(k_center_sib, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
+            // (the lists of a level are `list_entries` long together, one per block of eight siblings)
+            const bool pipe = wide && list_entries / (n_nodes / 8) > 2u * (unsigned long long)SIB_CH;
+            if (wide && pipe) hipLaunchKernelGGL(k_center_sib<true>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
+            else if (wide) hipLaunchKernelGGL(k_center_sib<false>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
             else {
                 A.best = mine.alloc<unsigned long long>(n_nodes); A.corner = mine.alloc<unsigned long long>(8 * (size_t)n_nodes);
                 A.count = mine.alloc<uint32_t>((size_t)n_nodes * A.S);
@@ -826,7 +913,9 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             Cand *possible = lists[(lvl + 1) & 1].alloc<Cand>((size_t)total);
             if (!possible) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory for %llu candidate entries", total);
             cand_entries += total;
-            if (wide) hipLaunchKernelGGL(k_corners_sib, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            list_entries = total;
+            if (wide && pipe) hipLaunchKernelGGL(k_corners_sib<true>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            else if (wide) hipLaunchKernelGGL(k_corners_sib<false>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
             else {
                 hipLaunchKernelGGL(k_corners_seg, dim3(n_nodes * A.S), dim3(SEG_BT), 0, 0, P, L, A, cand, poff, possible, n_nodes);
                 hipLaunchKernelGGL(k_corners_fin, dim3((8 * n_nodes + 255) / 256), dim3(256), 0, 0, P, L, A, cand, n_nodes, d_err);
