@@ -127,11 +127,30 @@ __device__ __forceinline__ void segment_of(uint32_t cnt, uint32_t S, uint32_t s,
     lo = min(cnt, s * len); hi = min(cnt, lo + len);
 }
 
+// Which (node, segment) a workgroup of the segment kernels takes.  Workgroups go to the eight XCDs in turn (blockIdx mod 8), each
+// with an L2 of its own, and the eight siblings of a block read the SAME list: numbered node-major, neighbouring nodes land on eight
+// different XCDs and every list comes out of HBM up to eight times (measured: three times its bytes).  So: XCD x takes the x-th
+// eighth of the work, and within the work the eight siblings' segment s are neighbours -- the same L2, at about the same time.
+__device__ __forceinline__ bool seg_work(const SegArrays &A, uint32_t n_nodes, uint32_t &node, uint32_t &s)
+{
+    const uint32_t per = gridDim.x >> 3;                 // the grid is padded to a multiple of 8
+    const uint32_t v = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (v >= n_nodes * A.S) return false;
+    if (n_nodes >= 8u) {                                 // below the root: blocks of eight siblings
+        const uint32_t w = v >> 3;
+        node = (w / A.S) * 8u + (v & 7u); s = w % A.S;
+    } else {
+        node = v / A.S; s = v % A.S;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(SEG_BT) void k_center_seg_min(GenParams P, LevelArrays L, SegArrays A, const Cand *__restrict__ cand, uint32_t n_nodes)
 {
     __shared__ Best sh[SEG_W];
-    const uint32_t node = blockIdx.x / A.S, s = blockIdx.x % A.S, tid = threadIdx.x;
-    if (node >= n_nodes) return;
+    const uint32_t tid = threadIdx.x;
+    uint32_t node, s;
+    if (!seg_work(A, n_nodes, node, s)) return;
     const float h = 0.5f * P.scale;
     float cx, cy, cz;
     transform(P, L.px[node] + h, L.py[node] + h, L.pz[node] + h, cx, cy, cz);
@@ -165,12 +184,13 @@ __global__ __launch_bounds__(SEG_BT) void k_center_seg_count(GenParams P, LevelA
                                                            uint32_t n_nodes, uint32_t *err)
 {
     __shared__ uint32_t shc[SEG_W];
-    const uint32_t node = blockIdx.x / A.S, s = blockIdx.x % A.S, tid = threadIdx.x;
-    if (node >= n_nodes) return;
+    const uint32_t tid = threadIdx.x;
+    uint32_t node, s;
+    if (!seg_work(A, n_nodes, node, s)) return;
     const Best b = unpack_best(A.best[node]);
     if (b.k == 0xFFFFFFFFu || isinf(b.d) || isnan(b.d)) {    // "Did not find" / "NaN distance"
         if (tid == 0) {
-            A.count[blockIdx.x] = 0;
+            A.count[node * A.S + s] = 0;
             if (s == 0) { atomicExch(err, 2u); L.center_value[node] = 0.0f; }
         }
         return;
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(SEG_BT) void k_center_seg_count(GenParams P, LevelA
     if (tid == 0) {
         count = 0;
         for (uint32_t w = 0; w < SEG_W; w++) count += shc[w];
-        A.count[blockIdx.x] = count;
+        A.count[node * A.S + s] = count;
         if (count) atomicAdd(&L.pcount[node], count);
         if (s == 0) L.center_value[node] = center_value;
     }
@@ -218,8 +238,9 @@ __global__ __launch_bounds__(SEG_BT) void k_corners_seg(GenParams P, LevelArrays
     __shared__ Best sh[SEG_W * 8];
     __shared__ uint32_t kept[2][SEG_U][SEG_W];              // survivors per wavefront and chunk, double-buffered over trips
     __shared__ uint32_t ahead[SEG_W];
-    const uint32_t node = blockIdx.x / A.S, s = blockIdx.x % A.S, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (node >= n_nodes) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t node, s;
+    if (!seg_work(A, n_nodes, node, s)) return;
     const Best c = unpack_best(A.best[node]);
     if (c.k == 0xFFFFFFFFu || isinf(c.d) || isnan(c.d)) return;          // no centre value: the build fails (k_center_seg_count said so)
     const float px = L.px[node], py = L.py[node], pz = L.pz[node];
@@ -802,6 +823,7 @@ bool scan_u32(Arena &scratch, const uint32_t *in, uint32_t *out, uint32_t n, con
 }
 
 constexpr uint32_t WIDE_LEVEL = 16384;
+constexpr unsigned long long WIDE_MAX_LIST = 8192;
 struct KeptLevel { LevelArrays L; uint32_t n; uint32_t *cnt, *rank; int32_t *index; };
 
 }  // namespace
@@ -875,7 +897,8 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
         size_t total_nodes = 0;
         unsigned long long cand_entries = n, list_entries = n;      // all lists so far; the lists of the level at hand
         // (SDFHIP_GEN_WIDE=n: the sibling-block form from n nodes on -- tests set 8 to run small trees through it)
-        const uint32_t wide_level = getenv("SDFHIP_GEN_WIDE") ? (uint32_t)atoi(getenv("SDFHIP_GEN_WIDE")) : WIDE_LEVEL;
+        const bool wide_forced = getenv("SDFHIP_GEN_WIDE") != nullptr;
+        const uint32_t wide_level = wide_forced ? (uint32_t)atoi(getenv("SDFHIP_GEN_WIDE")) : WIDE_LEVEL;
         const uint32_t seg_target = getenv("SDFHIP_GEN_SEGS") ? (uint32_t)max(1, atoi(getenv("SDFHIP_GEN_SEGS"))) : 4096u;
         const bool level_timing = getenv("SDFHIP_GEN_LEVELS") != nullptr;      // debug aid: nodes, entries and time of every level on stderr
         for (int lvl = 0;; lvl++) {
@@ -889,7 +912,10 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             // wavefronts and more; below the root a level's nodes come in blocks of eight -- else a node's list over S workgroups of
             // 1 024 threads (k_center_seg_min, ...).  (1 M-point knot, depth 10: level 5, 10 776 nodes with lists of 50 000: 2.9 ms
             // in segments, 3.9 by sibling blocks; level 6, 37 896 nodes: 4.7 against 1.9)
-            const bool wide = n_nodes >= wide_level && lvl >= 1 && (n_nodes & 7u) == 0;
+            // ... and lists short enough that one wavefront per block is not the level's critical path (level 6 of the same knot:
+            // 4 737 blocks with lists of 17 000 -- 1.6 ms by sibling blocks, 1.2 in segments; level 7, lists of 5 000: 1.1 against 2.2)
+            const bool wide = n_nodes >= wide_level && lvl >= 1 && (n_nodes & 7u) == 0 &&
+                              (wide_forced || list_entries / (n_nodes / 8) <= WIDE_MAX_LIST);
             SegArrays A{ nullptr, nullptr, nullptr, wide ? 0u : (seg_target + n_nodes - 1) / n_nodes };      // segments per node: ~4 096 workgroups per level
             // (the lists of a level are `list_entries` long together, one per block of eight siblings)
             const bool pipe = wide && list_entries / (n_nodes / 8) > 2u * (unsigned long long)SIB_CH;
@@ -902,8 +928,8 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
                 GEN_TRY(hipMemsetAsync(A.best, 0xFF, (size_t)n_nodes * 8, 0));
                 GEN_TRY(hipMemsetAsync(A.corner, 0xFF, (size_t)n_nodes * 64, 0));
                 GEN_TRY(hipMemsetAsync(L.pcount, 0, (size_t)n_nodes * 4, 0));
-                hipLaunchKernelGGL(k_center_seg_min, dim3(n_nodes * A.S), dim3(SEG_BT), 0, 0, P, L, A, cand, n_nodes);
-                hipLaunchKernelGGL(k_center_seg_count, dim3(n_nodes * A.S), dim3(SEG_BT), 0, 0, P, L, A, cand, n_nodes, d_err);
+                hipLaunchKernelGGL(k_center_seg_min, dim3((n_nodes * A.S + 7u) & ~7u), dim3(SEG_BT), 0, 0, P, L, A, cand, n_nodes);
+                hipLaunchKernelGGL(k_center_seg_count, dim3((n_nodes * A.S + 7u) & ~7u), dim3(SEG_BT), 0, 0, P, L, A, cand, n_nodes, d_err);
             }
             if (!scan_u32(mine, L.pcount, poff, n_nodes, d_err, report)) return GEN_NOMEM();
             GEN_TRY(hipStreamSynchronize(0));
@@ -917,7 +943,7 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             if (wide && pipe) hipLaunchKernelGGL(k_corners_sib<true>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
             else if (wide) hipLaunchKernelGGL(k_corners_sib<false>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
             else {
-                hipLaunchKernelGGL(k_corners_seg, dim3(n_nodes * A.S), dim3(SEG_BT), 0, 0, P, L, A, cand, poff, possible, n_nodes);
+                hipLaunchKernelGGL(k_corners_seg, dim3((n_nodes * A.S + 7u) & ~7u), dim3(SEG_BT), 0, 0, P, L, A, cand, poff, possible, n_nodes);
                 hipLaunchKernelGGL(k_corners_fin, dim3((8 * n_nodes + 255) / 256), dim3(256), 0, 0, P, L, A, cand, n_nodes, d_err);
             }
             if (!scan_u32(mine, L.split, L.block_of, n_nodes, d_err, report)) return GEN_NOMEM();
