@@ -641,9 +641,16 @@ def main():
             # (the headline's buffers are not needed any more: the path-traced configuration wants 30 GB of queues)
             local = send = frame = gathered = None
             torch.cuda.empty_cache()
-            out["configs"] = run_configs(sb, torch, scene, scene_name, copy_gbs, args.configs_scale, args.depth)
+            # (a configuration that fails says so in its own entry: the headline above has been measured and is printed regardless)
+            try:
+                out["configs"] = run_configs(sb, torch, scene, scene_name, copy_gbs, args.configs_scale, args.depth)
+            except Exception as e:
+                out["configs"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(od, cam, W, H, args.cpu_seconds)
+            try:
+                out["cpu_baseline"] = cpu_baseline(od, cam, W, H, args.cpu_seconds)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     scene.close()
@@ -1135,26 +1142,38 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9):
         torch.cuda.empty_cache()
 
     W4, H4, W2, H2 = 3840 // scale, 2160 // scale, 1920 // scale, 1080 // scale
-    measure("cfg3_4k", scene, scene_name, W4, H4, "default", suffix9,
-            note="BASELINE cfg-3's frame with compaction OFF (the default kernel: faster than either form of compaction)")
-    measure("cfg3_4k_compact", scene, scene_name, W4, H4, "compact", suffix9, flags=sb.FLAG_COMPACT, steps=20, warmup=4, nbuf=2,
-            note="BASELINE cfg-3 as named: wavefront ray compaction ON (persistent waves, ballot / prefix lane refill: k_compact)")
-    pt = sb.PathTrace(spp=16)
-    sb._lib.check(sb._lib.lib.sdfhip_scene_prepare_path(scene._h))       # the bounce levels' grid, at load time
-    measure("cfg5_4k_spp16", scene, scene_name, W4, H4, "spp16", grid_suffix(scene, pt), pt=pt, steps=6, warmup=2, nbuf=2,
-            note="BASELINE cfg-5 on one GPU")
-    # cfg-2 at the reference application's default depth (Model.MaxDepth = 10, SdfBox/Model.cs:18)
-    t0 = time.time()
-    od10 = sb.dragon_standin(depth + 1, nthreads=max(1, min(32, os.cpu_count() or 1)))
-    t_gen = time.time() - t0
-    with sb.Scene(od10, device=scene.device) as sc10:
-        measure("cfg2_depth10", sc10, f"dragon_standin_d{depth + 1}", W2, H2, "default", grid_suffix(sc10),
-                note=f"N={od10.Length} nodes, {od10.nbytes / 1e6:.0f} MB, built in {t_gen:.1f} s")
-    del od10
+
+    def guarded(name, fn):                 # a configuration that fails is reported as such; the others are still measured
+        try:
+            fn()
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+
+    guarded("cfg3_4k", lambda: measure("cfg3_4k", scene, scene_name, W4, H4, "default", suffix9,
+            note="BASELINE cfg-3's frame with compaction OFF (the default kernel: faster than either form of compaction)"))
+    guarded("cfg3_4k_compact", lambda: measure("cfg3_4k_compact", scene, scene_name, W4, H4, "compact", suffix9, flags=sb.FLAG_COMPACT, steps=20, warmup=4, nbuf=2,
+            note="BASELINE cfg-3 as named: wavefront ray compaction ON (persistent waves, ballot / prefix lane refill: k_compact)"))
+
+    def cfg5():
+        pt = sb.PathTrace(spp=16)
+        sb._lib.check(sb._lib.lib.sdfhip_scene_prepare_path(scene._h))       # the bounce levels' grid, at load time
+        measure("cfg5_4k_spp16", scene, scene_name, W4, H4, "spp16", grid_suffix(scene, pt), pt=pt, steps=6, warmup=2, nbuf=2,
+                note="BASELINE cfg-5 on one GPU")
+    guarded("cfg5_4k_spp16", cfg5)
+
+    def depth10():                         # cfg-2 at the reference application's default depth (Model.MaxDepth = 10, SdfBox/Model.cs:18)
+        t0 = time.time()
+        od10 = sb.dragon_standin(depth + 1, nthreads=max(1, min(32, os.cpu_count() or 1)))
+        t_gen = time.time() - t0
+        with sb.Scene(od10, device=scene.device) as sc10:
+            measure("cfg2_depth10", sc10, f"dragon_standin_d{depth + 1}", W2, H2, "default", grid_suffix(sc10),
+                    note=f"N={od10.Length} nodes, {od10.nbytes / 1e6:.0f} MB, built in {t_gen:.1f} s")
+    guarded("cfg2_depth10", depth10)
     # ... and on a MESH-derived scene at that depth: the reference's import flow (Program.cs:613-650: .ply -> SdfGen(depth 10) -> upload)
     # on a 1 M-point cloud (a torus-knot tube: no mesh ships with the reference), the tree built by the GPU builder and never
     # leaving HBM (sdfhip_sdfgen_scene)
-    if scale == 1:
+    def mesh():
         pts = sb.knot_point_cloud(1_000_000)
         sb.Scene.FromPoints(pts[:2000], 3).close()                       # (module load)
         t0 = time.time()
@@ -1163,6 +1182,8 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9):
         with scm:
             measure("cfg2_mesh_knot_d10", scm, f"knot_d{depth + 1}.asdf", W2, H2, "default", grid_suffix(scm),
                     note=f"1 M-point cloud -> sdfhip_sdfgen_scene: N={scm.Length} nodes in {t_build * 1e3:.0f} ms wall ({stg.total_ms:.0f} ms in the library)")
+    if scale == 1:
+        guarded("cfg2_mesh_knot_d10", mesh)
     return out
 
 
