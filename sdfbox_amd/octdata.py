@@ -14,6 +14,20 @@ from . import _lib
 from ._lib import lib, check
 
 
+class _NativeArrays:
+    """The malloc'ed arrays of a tree the library returned; freed (NativeOctData.Free, Logic.cs:99) with the last reference."""
+
+    def __init__(self, raw):
+        self.raw = _lib.COctData()
+        self.raw.length, self.raw.structs, self.raw.values = raw.length, raw.structs, raw.values
+
+    def __del__(self):
+        try:
+            lib.sdfhip_octdata_free(ctypes.byref(self.raw))
+        except Exception:
+            pass
+
+
 class OctData:
     """`Structs` (N x {parent, children} int32) and `Values` (N x 8 uint8, corner
     k = x + 2y + 4z, not texture-swizzled).  Program.cs:503-511."""
@@ -37,13 +51,18 @@ class OctData:
     # -- native hand-off ---------------------------------------------------
     @classmethod
     def _from_native(cls, raw):
+        # The reference copies the native arrays out element by element and then frees them (NativeOctData.ManagedStructs /
+        # ManagedValues + Free, Program.cs:590-611, Logic.cs:97-99).  Here the numpy arrays ARE the native arrays -- 30 ms of
+        # copying for a 12 M-node tree -- and sdfhip_octdata_free runs when the last array (or view of one) has gone.
         n = raw.length
-        try:
-            s = np.ctypeslib.as_array(raw.structs, shape=(n, 2)).copy()
-            v = np.ctypeslib.as_array(raw.values, shape=(n, 8)).copy()
-        finally:
-            lib.sdfhip_octdata_free(ctypes.byref(raw))   # NativeOctData.Free, Logic.cs:99
-        return cls(s, v)
+        if n == 0:
+            lib.sdfhip_octdata_free(ctypes.byref(raw))
+            raise ValueError("OctData: the library returned an empty tree")
+        owner = _NativeArrays(raw)
+        sbuf = (ctypes.c_int32 * (2 * n)).from_address(ctypes.addressof(raw.structs.contents))
+        vbuf = (ctypes.c_uint8 * (8 * n)).from_address(ctypes.addressof(raw.values.contents))
+        sbuf._owner = vbuf._owner = owner                # the arrays' .base keeps the ctypes buffer alive, and that the owner
+        return cls(np.ctypeslib.as_array(sbuf).reshape(n, 2), np.ctypeslib.as_array(vbuf).reshape(n, 8))
 
     def _as_native(self):
         raw = _lib.COctData()
