@@ -271,7 +271,8 @@ __global__ __launch_bounds__(SEG_BT) void k_corners_seg(GenParams P, LevelArrays
     __syncthreads();
     before_seg = 0;
     for (uint32_t w = 0; w < SEG_W; w++) before_seg += ahead[w];
-    const uint32_t out = poff[node] + before_seg;
+    const bool last = P.depth >= P.max_depth;
+    const uint32_t out = last ? 0u : poff[node] + before_seg;
     uint32_t base = 0, flip = 0;
     Cand nx[SEG_U];                                      // the next trip's entries, on their way while this trip's are worked on
 #pragma unroll
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(SEG_BT) void k_corners_seg(GenParams P, LevelArrays
                 const uint32_t k = k0 + u * SEG_BT + tid;
                 const float vx = vi[u].x, vy = vi[u].y, vz = vi[u].z;
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
-                possible[out + base + before + rank] = vi[u];
+                if (!last) possible[out + base + before + rank] = vi[u];
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     float d = lensq(vx - qx[i], vy - qy[i], vz - qz[i]);
@@ -435,8 +436,9 @@ __global__ __launch_bounds__(64) void k_center_sib(GenParams P, LevelArrays L, c
     r *= P.gs;
     r *= r;
     uint32_t count = 0;
-    if (PIPE && cnt > (uint32_t)SIB_CH) pre = sib_fetch(cand + off, 0, cnt, lane);
-    for (uint32_t k0 = 0; k0 < cnt; k0 += SIB_CH) {
+    const bool last = P.depth >= P.max_depth;            // no node of the last level splits: nobody will read its survivors' list,
+    if (PIPE && cnt > (uint32_t)SIB_CH && !last) pre = sib_fetch(cand + off, 0, cnt, lane);      // so nobody needs its length
+    for (uint32_t k0 = 0; k0 < (last ? 0u : cnt); k0 += SIB_CH) {
         const uint32_t n = min((uint32_t)SIB_CH, cnt - k0);
         if (cnt > (uint32_t)SIB_CH) {                    // (a list of one chunk is still there)
             __syncthreads();
@@ -486,7 +488,8 @@ __global__ __launch_bounds__(64) void k_corners_sib(GenParams P, LevelArrays L, 
     if (blockIdx.x * 8u >= n_nodes) return;
     const float px = L.px[node], py = L.py[node], pz = L.pz[node], center_value = L.center_value[node];
     const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.cand_off[node]), cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.cand_cnt[node]);
-    const uint32_t out = poff[node];
+    const bool last = P.depth >= P.max_depth;            // the last level's survivors are looked at (the corner values), not kept
+    const uint32_t out = last ? 0u : poff[node];
     const int slot = L.slot[node];
     const float h = 0.5f * P.scale;
     float cx, cy, cz;
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(64) void k_corners_sib(GenParams P, LevelArrays L, 
             const unsigned long long m = __ballot(keep);
             const uint32_t gm = (uint32_t)(m >> (8u * s)) & 0xFFu;                   // this child's survivors of the round
             if (keep) {
-                possible[out + base + (uint32_t)__popc(gm & ((1u << j) - 1u))] = vi;    // stable: list order
+                if (!last) possible[out + base + (uint32_t)__popc(gm & ((1u << j) - 1u))] = vi;    // stable: list order
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     float d = lensq(vx - qx[i], vy - qy[i], vz - qz[i]);
@@ -931,13 +934,21 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
                 hipLaunchKernelGGL(k_center_seg_min, dim3((n_nodes * A.S + 7u) & ~7u), dim3(SEG_BT), 0, 0, P, L, A, cand, n_nodes);
                 hipLaunchKernelGGL(k_center_seg_count, dim3((n_nodes * A.S + 7u) & ~7u), dim3(SEG_BT), 0, 0, P, L, A, cand, n_nodes, d_err);
             }
-            if (!scan_u32(mine, L.pcount, poff, n_nodes, d_err, report)) return GEN_NOMEM();
-            GEN_TRY(hipStreamSynchronize(0));
-            const unsigned long long total = ((volatile Report *)report)->total;
-            if (total > 0xFFFFFFF0ull) return fail(SDFHIP_ERR_NOMEM, "sdfgen: candidate lists of level %d exceed 2^32 entries", lvl);
-            lists[(lvl + 1) & 1].reset();                 // the lists of level lvl-1: dead since k_children of lvl-1
-            Cand *possible = lists[(lvl + 1) & 1].alloc<Cand>((size_t)total);
-            if (!possible) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory for %llu candidate entries", total);
+            // The survivors' lists of this level are the candidate lists of the next: their lengths are scanned into offsets and the
+            // host allocates them -- except on the last level (lvl == MaxDepth), where no node splits: its survivors are looked at
+            // for the corner values and written nowhere (1.9 GB of stores, a scan and a host round trip on the 1 M-point knot).
+            const bool last_level = lvl >= depth;
+            unsigned long long total = 0;
+            Cand *possible = nullptr;
+            if (!last_level) {
+                if (!scan_u32(mine, L.pcount, poff, n_nodes, d_err, report)) return GEN_NOMEM();
+                GEN_TRY(hipStreamSynchronize(0));
+                total = ((volatile Report *)report)->total;
+                if (total > 0xFFFFFFF0ull) return fail(SDFHIP_ERR_NOMEM, "sdfgen: candidate lists of level %d exceed 2^32 entries", lvl);
+                lists[(lvl + 1) & 1].reset();             // the lists of level lvl-1: dead since k_children of lvl-1
+                possible = lists[(lvl + 1) & 1].alloc<Cand>((size_t)total);
+                if (!possible) return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory for %llu candidate entries", total);
+            }
             cand_entries += total;
             list_entries = total;
             if (wide && pipe) hipLaunchKernelGGL(k_corners_sib<true>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
