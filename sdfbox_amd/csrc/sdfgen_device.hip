@@ -478,16 +478,48 @@ __device__ __forceinline__ void halve(const Best (&in)[2 * N], Best (&out)[N], b
     }
 }
 
-template <bool PIPE>
+// FUSED (the last level, whose survivors' lists nobody needs -- so nothing waits for a scan between the two searches): the centre
+// search of k_center_sib runs first, in this kernel, and a list of one chunk is read once for both.
+template <bool PIPE, bool FUSED = false>
 __global__ __launch_bounds__(64) void k_corners_sib(GenParams P, LevelArrays L, const Cand *__restrict__ cand,
                                                     const uint32_t *__restrict__ poff, Cand *__restrict__ possible,
                                                     uint32_t n_nodes, uint32_t *err)
 {
+    static_assert(!(PIPE && FUSED), "the fused form is for the short lists of the last level");
     __shared__ Cand buf[SIB_CH];
     const uint32_t lane = threadIdx.x, s = lane >> 3, j = lane & 7u, node = blockIdx.x * 8u + s;
     if (blockIdx.x * 8u >= n_nodes) return;
-    const float px = L.px[node], py = L.py[node], pz = L.pz[node], center_value = L.center_value[node];
+    const float px = L.px[node], py = L.py[node], pz = L.pz[node];
     const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.cand_off[node]), cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.cand_cnt[node]);
+    float center_value;
+    bool staged = false;                                 // buf holds the list's only chunk
+    if (FUSED) {
+        const float hh = 0.5f * P.scale;
+        float mx, my, mz;
+        transform(P, px + hh, py + hh, pz + hh, mx, my, mz);
+        Best c{INFINITY, 0xFFFFFFFFu};
+        for (uint32_t k0 = 0; k0 < cnt; k0 += SIB_CH) {
+            const uint32_t n = min((uint32_t)SIB_CH, cnt - k0);
+            if (k0) __syncthreads();
+            for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+            __syncthreads();
+            for (uint32_t t = j; t < n; t += 8u) {
+                const Cand e = buf[t];
+                const float d = lensq(e.x - mx, e.y - my, e.z - mz);
+                if (d < c.d) { c.d = d; c.k = k0 + t; }
+            }
+        }
+        c = sub_min<8>(c);
+        const bool bad = c.k == 0xFFFFFFFFu || isinf(c.d) || isnan(c.d);      // "Did not find" / "NaN distance"
+        center_value = bad ? 0.0f : sqrtf(c.d) / P.gs;
+        if (j == 0) {
+            if (bad) atomicExch(err, 2u);
+            L.center_value[node] = center_value; L.pcount[node] = 0u;
+        }
+        staged = cnt <= (uint32_t)SIB_CH;
+    } else {
+        center_value = L.center_value[node];
+    }
     const bool last = P.depth >= P.max_depth;            // the last level's survivors are looked at (the corner values), not kept
     const uint32_t out = last ? 0u : poff[node];
     const int slot = L.slot[node];
@@ -510,14 +542,16 @@ __global__ __launch_bounds__(64) void k_corners_sib(GenParams P, LevelArrays L, 
     if (PIPE && cnt) pre = sib_fetch(cand + off, 0, cnt, lane);
     for (uint32_t k0 = 0; k0 < cnt; k0 += SIB_CH) {
         const uint32_t n = min((uint32_t)SIB_CH, cnt - k0);
-        if (k0) __syncthreads();
-        if (PIPE) {
-            sib_stage(buf, pre, lane);
-            pre = sib_fetch(cand + off, k0 + SIB_CH, cnt, lane);
-        } else {
-            for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+        if (!(FUSED && staged)) {
+            if (k0 || FUSED) __syncthreads();
+            if (PIPE) {
+                sib_stage(buf, pre, lane);
+                pre = sib_fetch(cand + off, k0 + SIB_CH, cnt, lane);
+            } else {
+                for (uint32_t u = lane; u < n; u += 64u) buf[u] = cand[off + k0 + u];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         for (uint32_t t0 = 0; t0 < n; t0 += 8u) {        // eight entries per child and round, in list order
             const uint32_t t = t0 + j;
             const Cand vi = buf[t < n ? t : 0u];
@@ -922,7 +956,9 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             SegArrays A{ nullptr, nullptr, nullptr, wide ? 0u : (seg_target + n_nodes - 1) / n_nodes };      // segments per node: ~4 096 workgroups per level
             // (the lists of a level are `list_entries` long together, one per block of eight siblings)
             const bool pipe = wide && list_entries / (n_nodes / 8) > 2u * (unsigned long long)SIB_CH;
-            if (wide && pipe) hipLaunchKernelGGL(k_center_sib<true>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
+            const bool fused = wide && !pipe && lvl >= depth;          // the last level: centre and corner searches in one kernel
+            if (fused) ;
+            else if (wide && pipe) hipLaunchKernelGGL(k_center_sib<true>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
             else if (wide) hipLaunchKernelGGL(k_center_sib<false>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, n_nodes, d_err);
             else {
                 A.best = mine.alloc<unsigned long long>(n_nodes); A.corner = mine.alloc<unsigned long long>(8 * (size_t)n_nodes);
@@ -951,7 +987,8 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             }
             cand_entries += total;
             list_entries = total;
-            if (wide && pipe) hipLaunchKernelGGL(k_corners_sib<true>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            if (fused) hipLaunchKernelGGL((k_corners_sib<false, true>), dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
+            else if (wide && pipe) hipLaunchKernelGGL(k_corners_sib<true>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
             else if (wide) hipLaunchKernelGGL(k_corners_sib<false>, dim3(n_nodes / 8), dim3(64), 0, 0, P, L, cand, poff, possible, n_nodes, d_err);
             else {
                 hipLaunchKernelGGL(k_corners_seg, dim3((n_nodes * A.S + 7u) & ~7u), dim3(SEG_BT), 0, 0, P, L, A, cand, poff, possible, n_nodes);
