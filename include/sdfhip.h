@@ -181,6 +181,12 @@ SDFHIP_API int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_
 SDFHIP_API int sdfhip_sdfgen_scene(int device, const float *verts6, uint32_t n, int32_t depth, sdfhip_scene **scene,
                                    sdfhip_octdata *out, sdfhip_sdfgen_stats *stats);
 
+/* The builder keeps the device memory of its work arrays (up to 24 GB per device: what a depth-10 tree of a million points takes) for
+ * the next build of the process -- on this stack the first allocation after gigabytes have been freed takes a third of a second.
+ * This gives it back (Replaces: nothing -- the reference builds on the host; cf. Free, SdfGen/dllmain.cpp:349-358).  A build that
+ * runs out of device memory trims the pool itself and tries again.  SDFHIP_GEN_POOL=0 in the environment turns the pool off. */
+SDFHIP_API int sdfhip_sdfgen_trim(void);
+
 /* Structural check used by upload: 0 = ok; SDFHIP_ERR_BAD_TREE for an index out of
  * range, a cycle in the parent links or a parent chain of more than 64 links (either
  * would keep the shader's ascend loop from terminating).  depth_out = deepest level,

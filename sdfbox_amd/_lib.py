@@ -151,6 +151,7 @@ _SIG = {
                                  _c.POINTER(SdfGenStats)]),
     "sdfhip_sdfgen_scene": (_c.c_int, [_c.c_int, _vp, _c.c_uint32, _c.c_int32, _c.POINTER(_vp), _c.POINTER(COctData),
                                        _c.POINTER(SdfGenStats)]),
+    "sdfhip_sdfgen_trim": (_c.c_int, []),
     "sdfhip_octdata_validate": (_c.c_int, [_vp, _c.c_uint32, _c.POINTER(_c.c_uint32),
                                            _c.POINTER(_c.c_int)]),
     "sdfhip_info_default": (None, [_c.POINTER(Info), _c.c_float, _c.c_float]),

@@ -802,6 +802,19 @@ struct ChunkPool {
         }
         (void)hipFree(base);
     }
+    size_t trim(int device)                              // device < 0: every device's chunks
+    {
+        std::vector<Item> out;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < items.size();)
+                if (device < 0 || items[i].device == device) { out.push_back(items[i]); held -= items[i].size; items.erase(items.begin() + (long)i); }
+                else i++;
+        }
+        size_t freed = 0;
+        for (auto &it : out) { (void)hipFree(it.base); freed += it.size; }
+        return freed;
+    }
 };
 ChunkPool g_pool;
 
@@ -823,7 +836,10 @@ struct Arena {
         void *p = ChunkPool::enabled() ? g_pool.take(device, size, &size) : nullptr;
         if (!p) {
             const auto t0 = std::chrono::steady_clock::now();
-            if (hipMalloc(&p, size) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            if (hipMalloc(&p, size) != hipSuccess) {     // the pool may be holding what this allocation needs, in chunks of other sizes
+                (void)hipGetLastError();
+                if (g_pool.trim(device) == 0 || hipMalloc(&p, size) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            }
             const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (ms > 5.0f && getenv("SDFHIP_GEN_LEVELS")) fprintf(stderr, "sdfgen: hipMalloc(%zu MB) took %.1f ms\n", size >> 20, ms);
         }
@@ -1095,6 +1111,12 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
     } catch (const std::bad_alloc &) {
         return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of host memory");
     }
+}
+
+extern "C" int sdfhip_sdfgen_trim(void)
+{
+    (void)g_pool.trim(-1);
+    return SDFHIP_OK;
 }
 
 extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_t depth, sdfhip_octdata *out,

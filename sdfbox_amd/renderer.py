@@ -316,6 +316,11 @@ def device_pci_bus_id(device=0):
     return out.value.decode()
 
 
+def sdfgen_trim():
+    """Give back the device memory the point-cloud builder keeps between builds (sdfhip_sdfgen_trim)."""
+    check(lib.sdfhip_sdfgen_trim())
+
+
 def device_count():
     n = ctypes.c_int()
     check(lib.sdfhip_device_count(ctypes.byref(n)))

@@ -117,9 +117,9 @@ def test_oracle_structure_and_inheritance(oracle_mod):
 @pytest.mark.parametrize("form", ["default", "sibling blocks everywhere"])
 @pytest.mark.parametrize("cloud,depth", [("sphere20k", 4), ("sphere20k", 6), ("torus", 5), ("torus", 7), ("two", 5)])
 def test_gpu_builder_equals_oracle(sb, oracle_mod, cloud, depth, form, monkeypatch):
-    # two kernel forms per level: several 1 024-thread workgroups per node (levels of fewer than 16 384 nodes) and a wavefront per
-    # block of eight siblings, their shared list staged through LDS (the others); SDFHIP_GEN_WIDE=8 takes even the smallest
-    # levels below the root through the second
+    # two kernel forms per level: several 256-thread workgroups per node (levels of fewer than 16 384 nodes, or with long lists) and a
+    # wavefront per block of eight siblings, their shared list staged through LDS (the others; the last level's centre and corner
+    # searches fused); SDFHIP_GEN_WIDE=8 takes even the smallest levels below the root through the second
     if form != "default":
         monkeypatch.setenv("SDFHIP_GEN_WIDE", "8")
     v = {"sphere20k": fib_sphere(20000), "torus": torus_cloud(30000),
@@ -131,6 +131,20 @@ def test_gpu_builder_equals_oracle(sb, oracle_mod, cloud, depth, form, monkeypat
     assert (od.Values == o["values"]).all()
     assert st.global_scale == np.float32(o["scale"]) and tuple(st.global_offset) == tuple(np.float32(c) for c in o["offset"])
     assert od.validate() == (int(levels_of(od.Structs).max()), True)
+
+
+@pytest.mark.gpu
+def test_builder_gives_its_pool_back(sb):
+    # the builder keeps its work arrays' device memory for the next build; sdfhip_sdfgen_trim returns it, and the next build is the same
+    import torch
+    v = fib_sphere(20000)
+    a = sb.OctData.SdfGen(v, 6)
+    held = torch.cuda.mem_get_info()[0]
+    sb.sdfgen_trim()
+    assert torch.cuda.mem_get_info()[0] >= held + (64 << 20)
+    sb.sdfgen_trim()                                     # (nothing left: still fine)
+    b = sb.OctData.SdfGen(v, 6)
+    assert (a.Structs == b.Structs).all() and (a.Values == b.Values).all()
 
 
 @pytest.mark.gpu
