@@ -516,6 +516,7 @@ def main():
         step(k, last=(k == args.warmup - 1))
     drain()
     barrier()
+    resent_before = resent                    # (the moving-camera passes above resend tails by design; the timed region should not)
     t_start = time.perf_counter()
     for k in range(args.steps):
         step(k, timed=True, last=(k == args.steps - 1))
@@ -621,6 +622,7 @@ def main():
                 "gather_pixel_bytes": (round(s2["prefix"] / (rows_local * W * G), 3) if sparse2 else px_bytes) if sharded else None,
                 "gather_format": ("sparse shares written by the march kernel" if sparse2 else "frame pixels") if sharded else None,
                 "float_tails_sent_again": resent if sparse2 else None,
+                "float_tails_sent_again_in_the_timed_region": (resent - resent_before) if sparse2 else None,
                 "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
                 "gstep_per_s": round(float(counters[2]) / sec_per_step / 1e9, 3),
                 "shadow_rays_per_frame": int(counters[3]),
