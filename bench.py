@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--compact", type=int, default=-1, help="wavefront ray compaction: 1 on, 0 off, -1 default")
     ap.add_argument("--band-rows", type=int, default=16)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="HIP streams / buffers used round-robin (0 = default: 6; 2 for --spp / --compact).  Unsharded: frames in flight.  "
+                    help="HIP streams / buffers used round-robin (0 = default: 4; 2 for --spp / --compact).  Unsharded: frames in flight.  "
                          "Sharded: groups of --gather-every frames in flight")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="sharded runs: frames per gather (fewer, larger messages; one collective launch per "
@@ -123,6 +123,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver supports dmabuf IPC only (RCCL needs it)
+    # HIP deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); streams that share a queue run their
+    # kernels one behind the other.  A renderer that keeps frames in flight wants them on queues of their own: with 8 queues, four
+    # frames in flight give 0.0871 ms per 1080p frame where six streams on four queues gave 0.0881 (and three streams 0.1136: two of
+    # them on one queue) -- scripts/sweep_driver_style.sh, DESIGN.md section 6.  Read by the runtime when it starts: set before torch loads it.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 
@@ -204,12 +209,13 @@ def main():
     G = (args.gather_every if args.gather_every > 0 else (8 if world >= 8 else 4)) if sharded else 1
     if pt is not None or compact:
         G = 1 if not sharded else G            # those kernels render one frame per launch
-    # in flight: 6 frames on one GPU (the long tail of a frame's last waves under the body of the next ones: 1080p 0.163 ms with one
-    # frame in flight, 0.0903 with two or four, 0.0889 / 0.0885 / 0.0893 / 0.0892 with five / six / eight / twelve -- and 0.115 with
-    # three, reproducibly: two of three streams then share a hardware queue); 2 for the path-traced mode (its buffers are gigabytes
-    # per stream and its levels fill the chip); 4 groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4 frames per
-    # launch needs 4 launches in flight to fill the chip -- 0.039 -> 0.024 ms per frame at 8 ranks)
-    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (4 if sharded else 2 if (pt is not None or compact) else 6)
+    # in flight: 4 frames on one GPU, on hardware queues of their own (GPU_MAX_HW_QUEUES above): the long tail of a frame's last waves
+    # runs under the body of the next ones -- 1080p 0.163 ms with one frame in flight, 0.0896 / 0.0872 / 0.0871 with two / three / four,
+    # 0.0998 with five (8 queues; profiles/r04_hw_queues.txt.  On the runtime's default of 4 queues: 0.0898 with four, 0.0881 with
+    # six, 0.1136 with three); 2 for the path-traced mode (its buffers are gigabytes per stream and its levels fill the chip); 4
+    # groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4 frames per launch needs 4 launches in flight to fill the
+    # chip -- 0.039 -> 0.024 ms per frame at 8 ranks)
+    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (4 if sharded else 2 if (pt is not None or compact) else 4)
 
     # rank 0 also assembles the frame (de-interleave + wire expansion of every rank's rows), so it
     # renders a smaller share: --rank0-weight, or measured here before anything is timed
@@ -645,7 +651,7 @@ def main():
             torch.cuda.empty_cache()
             # (a configuration that fails says so in its own entry: the headline above has been measured and is printed regardless)
             try:
-                out["configs"] = run_configs(sb, torch, scene, scene_name, copy_gbs, args.configs_scale, args.depth)
+                out["configs"] = run_configs(sb, torch, scene, scene_name, copy_gbs, args.configs_scale, args.depth, streams)
             except Exception as e:
                 out["configs"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
@@ -672,12 +678,14 @@ def load_package(args):
     return sdfbox_amd
 
 
+
 def main_single_process(args, json_fd):
     """`--single-process`: the N-device frame behind the library's one call (sdfhip_multi_submit / _wait): one process, one
     host thread and one stream per device inside libsdfhip.so, sparse shares written by the march kernel, pushed into
     device 0 over the peers' own links, assembled there.  Same workload, same JSON line; `config.parallelism` says which
     of the two things it measures."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")           # (see main())
     import torch
 
     sb = load_package(args)
@@ -1084,7 +1092,7 @@ def grid_suffix(scene, pt=None):
     return f":grid{lvl}" + ("+blocks" if lvl and gbytes > (16 << (3 * lvl)) and pt is None else "")
 
 
-def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9):
+def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared_streams=None):
     """BASELINE.json's other single-GPU configurations, timed in this process behind the headline: the same
     clock (host time around `steps` frames, synchronised on both sides, frames in flight on their own streams), the HIP-event
     time of a launch beside it, and the counter fractions from the committed PMC pass of the SAME command line
@@ -1093,10 +1101,12 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9):
     out = {}
     suffix9 = grid_suffix(scene)                      # (before the path-traced mode adds its second grid to the byte count)
 
-    def measure(name, sc, sname, W, H, mode, suffix, flags=0, pt=None, steps=60, warmup=12, nbuf=6, note=None):
+    def measure(name, sc, sname, W, H, mode, suffix, flags=0, pt=None, steps=60, warmup=12, nbuf=4, note=None):
         cam = bench_camera(sb, W, H)
         bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-        streams = [torch.cuda.Stream() for _ in range(nbuf)]
+        # the headline's streams again: which hardware queue a stream gets is the runtime's business, and these are known to have
+        # queues of their own (fresh streams for every configuration: the 4K frame took 0.328 ms where the same run alone takes 0.313)
+        streams = (list(shared_streams[:nbuf]) if shared_streams and len(shared_streams) >= nbuf else []) or [torch.cuda.Stream() for _ in range(nbuf)]
 
         def launch(k):
             s = streams[k % nbuf].cuda_stream
