@@ -212,10 +212,11 @@ def main():
     # in flight: 4 frames on one GPU, on hardware queues of their own (GPU_MAX_HW_QUEUES above): the long tail of a frame's last waves
     # runs under the body of the next ones -- 1080p 0.163 ms with one frame in flight, 0.0896 / 0.0872 / 0.0871 with two / three / four,
     # 0.0998 with five (8 queues; profiles/r04_hw_queues.txt.  On the runtime's default of 4 queues: 0.0898 with four, 0.0881 with
-    # six, 0.1136 with three); 2 for the path-traced mode (its buffers are gigabytes per stream and its levels fill the chip); 4
+    # six, 0.1136 with three); 3 for the path-traced mode (its buffers are gigabytes per stream; 21.6 / 20.9 / 20.9 / 20.8 ms per cfg-5 frame
+    # with 2 / 3 / 4 / 5 -- on four hardware queues the third brought nothing); 2 with compaction (its persistent waves fill the chip); 4
     # groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4 frames per launch needs 4 launches in flight to fill the
     # chip -- 0.039 -> 0.024 ms per frame at 8 ranks)
-    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (4 if sharded else 2 if (pt is not None or compact) else 4)
+    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (4 if sharded else 3 if pt is not None else 2 if compact else 4)
 
     # rank 0 also assembles the frame (de-interleave + wire expansion of every rank's rows), so it
     # renders a smaller share: --rank0-weight, or measured here before anything is timed
@@ -1170,7 +1171,7 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
     def cfg5():
         pt = sb.PathTrace(spp=16)
         sb._lib.check(sb._lib.lib.sdfhip_scene_prepare_path(scene._h))       # the bounce levels' grid, at load time
-        measure("cfg5_4k_spp16", scene, scene_name, W4, H4, "spp16", grid_suffix(scene, pt), pt=pt, steps=6, warmup=2, nbuf=2,
+        measure("cfg5_4k_spp16", scene, scene_name, W4, H4, "spp16", grid_suffix(scene, pt), pt=pt, steps=9, warmup=3, nbuf=3,
                 note="BASELINE cfg-5 on one GPU")
     guarded("cfg5_4k_spp16", cfg5)
 
