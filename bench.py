@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--one-kernel", action="store_true",
                     help="A/B: round 1's one-kernel form (lane state machine, shading in place) instead of the default "
                          "k_march (wave-converged march / shading / shadow march)")
-    ap.add_argument("--check", action="store_true", help="verify the assembled frame against a whole-frame render")
+    ap.add_argument("--check", action="store_true", help="verify the assembled frame against a whole-frame render (always done when several ranks take part)")
     ap.add_argument("--rank0-weight", type=float, default=0.0,
                     help="sharded runs: rank 0's share of the frame as a fraction of a peer's share "
                          "(0 = measure at start-up so that render + assembly on rank 0 takes as long as a peer's render)")
@@ -543,7 +543,8 @@ def main():
     frames_per_launch = float(np.mean([n for _, _, n in ev]))
 
     check_ok = None
-    if args.check and sharded and rank == 0:
+    # (always when several ranks took part: a scaling curve is worth what its frames are -- one whole-frame render and a few compares)
+    if (args.check or world > 1) and sharded and rank == 0:
         refs = {}
 
         def ref_of(k):                     # the whole-frame render of frame k's camera
