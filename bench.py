@@ -5,7 +5,7 @@ A "step" is one frame of the workload: every rank ray-marches its row bands of
 the frame (scene and camera already resident in HBM), the band buffers are
 gathered to rank 0 over RCCL and put back in row order.  At N=1 a step is the
 ray-march kernel alone.  Consecutive frames go to separate HIP streams round
-robin (six frames in flight by default), as a renderer would keep them: the
+robin (four frames in flight by default, on hardware queues of their own), as a renderer would keep them: the
 long tail of one frame (a few 100-140-step pixels) overlaps the body of the
 next ones.  Prints ONE JSON line on rank 0.
 
