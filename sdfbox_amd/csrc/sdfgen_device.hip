@@ -238,6 +238,7 @@ __global__ __launch_bounds__(SEG_BT) void k_corners_seg(GenParams P, LevelArrays
     __shared__ Best sh[SEG_W * 8];
     __shared__ uint32_t kept[2][SEG_U][SEG_W];              // survivors per wavefront and chunk, double-buffered over trips
     __shared__ uint32_t ahead[SEG_W];
+    __shared__ Cand surv[SEG_U * SEG_BT];                // the survivors of a trip ({position, place in the list})
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t node, s;
     if (!seg_work(A, n_nodes, node, s)) return;
@@ -290,24 +291,33 @@ __global__ __launch_bounds__(SEG_BT) void k_corners_seg(GenParams P, LevelArrays
             m[u] = __ballot(keep[u]);
             if (lane == 0) kept[flip][u][wave] = (uint32_t)__popcll(m[u]);
         }
-        __syncthreads();
+        __syncthreads();                                 // (also: the corner search of the trip before has read surv)
+        // The survivors go out in list order -- chunk by chunk, wavefront by wavefront -- and into LDS, from where they are dealt to the
+        // threads again, one each, for the eight corner distances: every lane busy, where the distances inside `if (keep)` ran with
+        // the fifth of the lanes whose entry had survived (most of the kernel's instructions, once its lists came from one L2).
+        uint32_t all = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < SEG_U; u++) {           // the survivors stay in list order: chunk by chunk, wavefront by wavefront
-            uint32_t before = 0, all = 0;
-            for (uint32_t w = 0; w < SEG_W; w++) { const uint32_t n = kept[flip][u][w]; before += w < wave ? n : 0u; all += n; }
+        for (uint32_t u = 0; u < SEG_U; u++) {
+            uint32_t before = 0, chunk = 0;
+            for (uint32_t w = 0; w < SEG_W; w++) { const uint32_t n = kept[flip][u][w]; before += w < wave ? n : 0u; chunk += n; }
             if (keep[u]) {
-                const uint32_t k = k0 + u * SEG_BT + tid;
-                const float vx = vi[u].x, vy = vi[u].y, vz = vi[u].z;
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
-                if (!last) possible[out + base + before + rank] = vi[u];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    float d = lensq(vx - qx[i], vy - qy[i], vz - qz[i]);
-                    if (d < best[i].d) { best[i].d = d; best[i].k = k; }
-                }
+                const uint32_t at = all + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
+                if (!last) possible[out + base + at] = vi[u];
+                surv[at] = make_float4(vi[u].x, vi[u].y, vi[u].z, __uint_as_float(k0 + u * SEG_BT + tid));      // w: its place in the list
             }
-            base += all;
+            all += chunk;
         }
+        __syncthreads();
+        for (uint32_t at = tid; at < all; at += SEG_BT) {    // (in list order per thread, and `better` orders the threads: the earliest of equals)
+            const Cand e = surv[at];
+            const uint32_t k = __float_as_uint(e.w);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float d = lensq(e.x - qx[i], e.y - qy[i], e.z - qz[i]);
+                if (d < best[i].d) { best[i].d = d; best[i].k = k; }
+            }
+        }
+        base += all;
     }
     // the eight minima of the workgroup with ONE barrier: every wavefront leaves its own in LDS, thread i of the first eight
     // takes corner i over the wavefronts (eight reductions one after the other, two barriers each, were most of what a
