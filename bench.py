@@ -240,7 +240,10 @@ def main():
         s2 = {"full": full, "bytes": sparse2_bytes(rows_local, W, G, full), "off": sparse2_floats_offset(rows_local, W, G),
               "share": [torch.zeros(sparse2_bytes(rows_local, W, G, full), dtype=torch.uint8, device="cuda") for _ in range(nbuf)],
               "base": [0] * nbuf, "own": [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(nbuf)],
-              "ev": [torch.cuda.Event() for _ in range(nbuf)]}
+              "ev": [torch.cuda.Event() for _ in range(nbuf)],
+              # a partial last group (steps not a multiple of G) renders and expands its own frames only: the share's layout is
+              # that of n frames then (its floats start earlier in the buffer), the bytes that travel stay the same
+              "n": [G] * nbuf, "off_of": {n: sparse2_floats_offset(rows_local, W, n) for n in range(1, G + 1)}}
         render_sparse2(scene, [cam] * G, W, layout, rank, s2["share"][0].data_ptr(), full, 0, flags=flags, stream=main)
         torch.cuda.synchronize()
         used = int(s2["share"][0][:4].view(torch.int32).item())
@@ -290,6 +293,7 @@ def main():
 
     pending = [None] * nbuf
     ev = []                               # (start, end) HIP events around each timed launch
+    rendered = 0                          # frames the timed launches rendered (= steps: a partial last group renders its own frames only)
 
     batched = sharded and pt is None and not compact     # one launch per group (else one per frame)
 
@@ -314,18 +318,20 @@ def main():
     def finish_sparse2(slot, w, st):
         """the gather of sparse2 shares: rank 0 expands them; a share whose floats did not all travel sends the tail again"""
         nonlocal resent
-        off, nsend = s2["off"], s2["send"]
+        n = s2["n"][slot]                                   # frames of this slot's group
+        off = s2["off_of"][n]
+        nsend = (s2["prefix"] - off) // 4                   # floats that travelled: the same bytes, behind a shorter fixed part
         if nccl:
             with torch.cuda.stream(st):
                 w.wait()
                 if rank == 0:
-                    deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=G,
+                    deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=n,
                                          counts_ptr=s2["counts"][slot].data_ptr(), stream=st.cuda_stream)
                     s2["ev"][slot].record(st)
         elif rank == 0:                                   # gloo rehearsal: through host buffers
             for r in range(1, world):
                 s2["gath"][slot][r][:s2["prefix"]].copy_(w[r].cuda())
-            deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=G,
+            deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=n,
                                  counts_ptr=s2["counts"][slot].data_ptr(), stream=main)
             torch.cuda.synchronize()
         if rank == 0:
@@ -349,7 +355,7 @@ def main():
                         dist.recv(host, src=r)
                         tail.copy_(host)
                     with torch.cuda.stream(st):
-                        deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=G, only_rank=r,
+                        deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=n, only_rank=r,
                                              stream=(st.cuda_stream if nccl else main))
         else:
             s2["ev"][slot].synchronize()
@@ -365,6 +371,7 @@ def main():
                     dist.send(tail.cpu(), dst=0)
 
     def step(k, timed=False, last=False):
+        nonlocal rendered
         group, within = divmod(k, G)
         slot = group % nbuf
         if within == 0:
@@ -379,14 +386,15 @@ def main():
                 e0.record(s)
             group = [cam_of(k - within + i) for i in range(within + 1)]
             if sparse2:
-                # (a partial last group renders its last camera again: the share's layout is that of G frames)
-                render_sparse2(scene, group + [group[-1]] * (G - len(group)), W, layout, rank, s2["share"][slot].data_ptr(), s2["full"],
+                s2["n"][slot] = len(group)
+                render_sparse2(scene, group, W, layout, rank, s2["share"][slot].data_ptr(), s2["full"],
                                s2["base"][slot], flags=flags, stream=s.cuda_stream)
             else:
                 render_bands_batch(scene, group, W, layout, rank, local[slot].data_ptr(), flags=flags, stream=s.cuda_stream)
             if timed:
                 e1.record(s)
                 ev.append((e0, e1, within + 1))
+                rendered += len(group)
         else:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -395,6 +403,7 @@ def main():
             if timed:
                 e1.record(s)
                 ev.append((e0, e1, 1))
+                rendered += 1
         if not sharded or not group_ends:
             return
         if sparse2:
@@ -627,6 +636,7 @@ def main():
                               if sharded else None),
                 "frames_in_flight": nbuf * G,
                 "frames_per_gather": G if sharded else None,
+                "frames_rendered_in_the_timed_region": rendered,
                 "gather_pixel_bytes": (round(s2["prefix"] / (rows_local * W * G), 3) if sparse2 else px_bytes) if sharded else None,
                 "gather_format": ("sparse shares written by the march kernel" if sparse2 else "frame pixels") if sharded else None,
                 "float_tails_sent_again": resent if sparse2 else None,

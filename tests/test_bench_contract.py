@@ -76,6 +76,20 @@ def test_cfg4_frame_two_ranks_moving_camera_and_dense_resend():
 
 
 @pytest.mark.gpu
+def test_partial_last_group_renders_its_own_frames_only():
+    # the driver's scaling run times 20 steps; at 8 ranks a group is 8 frames, so the last group holds 4: it must render (and
+    # expand) those 4 only -- the padded form rendered 24 frames for 20 steps -- and the frames must still be exact, resends included
+    j = run_bench("--exercise-gather", "--check", "--gather-every", 8, "--steps", 20, "--warmup", 5, "--depth", 6, "--size", "640x360",
+                  "--no-cpu-baseline")
+    assert j["config"]["frames_per_gather"] == 8 and j["config"]["frames_rendered_in_the_timed_region"] == 20
+    assert j["config"]["assembled_frame_equals_whole_frame_render"] is True
+    j = run_bench("--gpus", 2, "--backend", "gloo", "--check", "--steps", 10, "--warmup", 3, "--depth", 6, "--size", "640x360",
+                  "--orbit", 16, "--sparse-cap-scale", 0.2, "--no-cpu-baseline")
+    assert j["n_gpus"] == 2 and j["config"]["frames_rendered_in_the_timed_region"] == 10
+    assert j["config"]["assembled_frame_equals_whole_frame_render"] is True and j["config"]["float_tails_sent_again"] > 0
+
+
+@pytest.mark.gpu
 def test_cfg5_frame_through_the_sharded_pipelines():
     # BASELINE cfg-5's frame (3840x2160, 16 spp, 3 bounces) through the gather pipelines: the NCCL code path with one rank, two
     # gloo ranks on the one GPU, and the library's own multi-device entry points over the device list [0, 0, 0, 0]; every
