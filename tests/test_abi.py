@@ -142,3 +142,51 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
                 text = open(os.path.join(root, f), errors="replace").read()
                 assert not pat.search(text), os.path.join(root, f)
+
+
+def _c_prototypes():
+    """name -> (return type, [parameter types]) of every SDFHIP_API declaration of include/sdfhip.h"""
+    text = re.sub(r"/\*.*?\*/", " ", open(os.path.join(REPO, "include", "sdfhip.h")).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"SDFHIP_API\s+([^;(]+?)\b(sdfhip_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        protos[name] = (ret, params)
+    return protos
+
+
+def _c_class(t):
+    """pointer / the scalar's width class of a C parameter (its name stripped)"""
+    if "*" in t:
+        return "ptr"
+    base = re.sub(r"\b(const|unsigned)\b", "", t).split()
+    base = base[0] if base else ""
+    return {"uint32_t": "u32", "int32_t": "i32", "int": "i32", "uint64_t": "u64", "float": "f32"}.get(base, base)
+
+
+def _cs_class(t):
+    t = re.sub(r"^\s*\[[A-Za-z][^\]]*\]\s*", "", t).strip()      # a leading attribute: [Out]
+    words = t.split()
+    if words[0] in ("ref", "out") or words[-2].endswith("[]") or words[0] in ("string", "IntPtr", "System.Text.StringBuilder"):
+        return "ptr"
+    return {"uint": "u32", "int": "i32", "ulong": "u64", "float": "f32"}.get(words[0], words[0])
+
+
+def test_csharp_stub_matches_the_header():
+    """INTEGRATION.md's [DllImport] declarations cannot be compiled here (no .NET in the image): at least they must name
+    entry points the header declares, with the same number of parameters, each a pointer where C has a pointer and a scalar
+    of the same width where C has a scalar, and the same kind of return value."""
+    protos = _c_prototypes()
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    decls = re.findall(r"\[DllImport\(Lib(?:,\s*EntryPoint\s*=\s*\"(\w+)\")?\)\]\s*(?:public\s+)?static\s+extern\s+(\w+)\s+(\w+)\s*\(([^;]*)\)\s*;", text)
+    assert len(decls) >= 25, len(decls)
+    for entry, ret, name, args in decls:
+        cname = entry or name
+        assert cname in protos, f"the C# stub imports {cname}, which include/sdfhip.h does not declare"
+        cret, cparams = protos[cname]
+        params = [a.strip() for a in re.sub(r"\[MarshalAs\([^)]*\)\]", "", args).split(",")] if args.strip() else []
+        assert len(params) == len(cparams), f"{cname}: {len(params)} parameters in C#, {len(cparams)} in C"
+        for a, c in zip(params, cparams):
+            assert _cs_class(a) == _c_class(c), f"{cname}: C# `{a}` against C `{c}`"
+        want = "IntPtr" if "*" in cret else {"int": "int", "void": "void", "float": "float"}[cret.split()[-1]]
+        assert ret == want, f"{cname}: returns {ret} in C#, {cret} in C"
