@@ -343,11 +343,10 @@ int sdfhip::take_ticket(sdfhip_scene *s, sdfhip_scene::StatsTicket **out)
     for (int i = 0; i < sdfhip_scene::MAX_TICKETS; i++) {
         sdfhip_scene::StatsTicket &t = s->tickets[i];
         if (t.in_use.load(std::memory_order_acquire)) continue;
-        if (!t.ev0) {
-            HIP_TRY(hipEventCreate(&t.ev0));
-            HIP_TRY(hipEventCreate(&t.ev1));
-            HIP_TRY(hipHostMalloc((void **)&t.h_counters, 6 * sizeof(unsigned long long), hipHostMallocDefault));
-        }
+        // (each piece by itself: a creation that failed half-way is completed by the next call, not taken for done)
+        if (!t.ev0) HIP_TRY(hipEventCreate(&t.ev0));
+        if (!t.ev1) HIP_TRY(hipEventCreate(&t.ev1));
+        if (!t.h_counters) HIP_TRY(hipHostMalloc((void **)&t.h_counters, 6 * sizeof(unsigned long long), hipHostMallocDefault));
         t.counted = false; t.kernel_used = 0;
         t.in_use.store(true, std::memory_order_release);
         *out = &t;
@@ -414,19 +413,26 @@ int sdfhip::render_impl(sdfhip_scene *s, const RenderCall &c, sdfhip_scene::Stat
 
 // ---- entry points: frames that stay in HBM -----------------------------------------------------------------------------------
 namespace {
+// A statistics ticket taken for a call goes back on EVERY way out that does not reach finish_stats (which frees it itself):
+// a failed copy or synchronisation between the launch and the wait must not use one of the handle's tickets up for good.
+struct TicketGuard {
+    sdfhip_scene::StatsTicket *t = nullptr;
+    ~TicketGuard() { if (t) t->in_use.store(false, std::memory_order_release); }
+    sdfhip_scene::StatsTicket *release() { sdfhip_scene::StatsTicket *r = t; t = nullptr; return r; }
+};
 // One device-resident call: the launch under the handle's lock, the wait for its statistics (if asked) outside it.
 int render_resident(sdfhip_scene *s, const RenderCall &c, sdfhip_stats *stats, const char *what)
 {
-    sdfhip_scene::StatsTicket *ticket = nullptr;
+    TicketGuard tg;
     {
         std::lock_guard<std::mutex> lk(s->lock);
         DeviceGuard g(s->device);
         if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "%s: hipSetDevice(%d) failed", what, s->device);
-        if (stats) { int rt = take_ticket(s, &ticket); if (rt != SDFHIP_OK) return rt; }
-        const int rc = render_impl(s, c, ticket);
-        if (rc != SDFHIP_OK) { if (ticket) ticket->in_use.store(false, std::memory_order_release); return rc; }
+        if (stats) { int rt = take_ticket(s, &tg.t); if (rt != SDFHIP_OK) return rt; }
+        const int rc = render_impl(s, c, tg.t);
+        if (rc != SDFHIP_OK) return rc;
     }
-    return stats ? finish_stats(s, ticket, stats) : SDFHIP_OK;
+    return stats ? finish_stats(s, tg.release(), stats) : SDFHIP_OK;
 }
 }  // namespace
 
@@ -628,14 +634,14 @@ extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t 
     if (!banded) {
         RenderCall c = whole;
         c.d_out = reinterpret_cast<float *>(s->d_frame);
-        sdfhip_scene::StatsTicket *ticket = nullptr;
-        if (stats) { int rt = take_ticket(s, &ticket); if (rt != SDFHIP_OK) return rt; }
-        int rc = render_impl(s, c, ticket);
-        if (rc != SDFHIP_OK) { if (ticket) ticket->in_use.store(false, std::memory_order_release); return rc; }
+        TicketGuard tg;
+        if (stats) { int rt = take_ticket(s, &tg.t); if (rt != SDFHIP_OK) return rt; }
+        int rc = render_impl(s, c, tg.t);
+        if (rc != SDFHIP_OK) return rc;
         const hipError_t e = hipMemcpyAsync(rgba_out, s->d_frame, (size_t)width * height * px_bytes, hipMemcpyDeviceToHost, s->stream);
         const hipError_t e2 = hipStreamSynchronize(s->stream);
         if (stats) {
-            rc = finish_stats(s, ticket, stats);
+            rc = finish_stats(s, tg.release(), stats);
             stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (rc != SDFHIP_OK) return rc;
         }
@@ -686,10 +692,10 @@ extern "C" int sdfhip_render_path(sdfhip_scene *s, const sdfhip_info *info, cons
     RenderCall c;
     c.info = info; c.pt = pt; c.width = width; c.height = height; c.band_rows = height; c.nrows_out = height; c.flags = flags;
     c.d_out = reinterpret_cast<float *>(s->d_frame); c.st = s->stream;
-    sdfhip_scene::StatsTicket *ticket = nullptr;
-    if (stats) { int rt = take_ticket(s, &ticket); if (rt != SDFHIP_OK) return rt; }
-    int rc = render_impl(s, c, ticket);
-    if (rc != SDFHIP_OK) { if (ticket) ticket->in_use.store(false, std::memory_order_release); return rc; }
+    TicketGuard tg;
+    if (stats) { int rt = take_ticket(s, &tg.t); if (rt != SDFHIP_OK) return rt; }
+    int rc = render_impl(s, c, tg.t);
+    if (rc != SDFHIP_OK) return rc;
     HIP_TRY(hipMemcpyAsync(rgba_out, s->d_frame, need * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
     uint32_t overflow = 0;                              // a hit that found no room in its queue (see pt_push): never silently
     for (int i = 0; i < s->n_scratch; i++)
@@ -698,7 +704,7 @@ extern "C" int sdfhip_render_path(sdfhip_scene *s, const sdfhip_info *info, cons
                                    sizeof overflow, hipMemcpyDeviceToHost, s->stream));
     const hipError_t es = hipStreamSynchronize(s->stream);
     if (stats) {
-        rc = finish_stats(s, ticket, stats);
+        rc = finish_stats(s, tg.release(), stats);
         stats->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (rc != SDFHIP_OK) return rc;
     }
