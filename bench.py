@@ -28,8 +28,8 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-# Wavefront ray compaction is measured slower than the plain kernel on this workload
-# (DESIGN.md section 6), so it is off unless asked for.
+# Wavefront ray compaction is measured 2-3 % slower than the plain kernel on this workload
+# (DESIGN.md section 4.4), so it is off unless asked for.
 DEFAULT_COMPACT = False
 
 
@@ -213,10 +213,10 @@ def main():
     # runs under the body of the next ones -- 1080p 0.163 ms with one frame in flight, 0.0896 / 0.0872 / 0.0871 with two / three / four,
     # 0.0998 with five (8 queues; profiles/r04_hw_queues.txt.  On the runtime's default of 4 queues: 0.0898 with four, 0.0881 with
     # six, 0.1136 with three); 3 for the path-traced mode (its buffers are gigabytes per stream; 21.6 / 20.9 / 20.9 / 20.8 ms per cfg-5 frame
-    # with 2 / 3 / 4 / 5 -- on four hardware queues the third brought nothing); 2 with compaction (its persistent waves fill the chip); 4
+    # with 2 / 3 / 4 / 5 -- on four hardware queues the third brought nothing); 4
     # groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4 frames per launch needs 4 launches in flight to fill the
     # chip -- 0.039 -> 0.024 ms per frame at 8 ranks)
-    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (4 if sharded else 3 if pt is not None else 2 if compact else 4)
+    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (4 if sharded else 3 if pt is not None else 4)
 
     # rank 0 also assembles the frame (de-interleave + wire expansion of every rank's rows), so it
     # renders a smaller share: --rank0-weight, or measured here before anything is timed
@@ -617,14 +617,19 @@ def main():
                             (f", moving 1 degree per frame round the scene ({len(cams)} cameras)" if args.orbit > 0 else ""),
                 "kernel": ("path/" if pt is not None else "") +
                           ("stack" if (kernel_used & 0xF) == sb.KERNEL_STACK else "generic") + ("+compact" if compact else "") +
-                          ("" if (pt is not None or compact) else ", one kernel" if args.one_kernel else
-                           ", k_march (primary march, shading) -> queue (wavefront ballot + prefix compaction of the shadow rays) -> k_shadow"
+                          ("" if pt is not None else
+                           ", k_march (primary march, shading; the shadow rays of waves that hold fewer than 32 queued by ballot + prefix) -> k_shadow"
+                           if (compact and (kernel_used & 0xF) == sb.KERNEL_STACK) else ", k_compact: persistent waves, lane refill" if compact else
+                           ", one kernel" if args.one_kernel else
+                           ", k_march (primary march, shading) -> queue (wavefront ballot + prefix compaction of every shadow ray) -> k_shadow"
                            if args.shadow_queue else
                            ", k_march: primary march, shading and shadow march as three wave-converged loops of one kernel"),
                 "top_grid": {"level": scene.top_grid_level, "bytes": scene.top_grid_bytes},
-                # BASELINE cfg-3 says "wavefront ray compaction on": which of its readings this line is (both are built, both measured slower)
-                "compaction": "persistent waves, ballot/prefix lane refill (k_compact)" if compact else
-                              "shadow rays compacted by ballot/prefix into a queue, marched by k_shadow" if args.shadow_queue else "off",
+                # BASELINE cfg-3 says "wavefront ray compaction on": which form this line is (three are built, all measured slower than none)
+                "compaction": ("the shadow rays of waves holding fewer than 32 compacted by ballot/prefix into a queue, marched 64 to a wave by k_shadow "
+                               "(SDFHIP_FLAG_COMPACT)" if (kernel_used & 0xF) == sb.KERNEL_STACK else
+                               "persistent waves, ballot/prefix lane refill (k_compact: SDFHIP_FLAG_COMPACT on a tree without a full-depth grid)") if compact else
+                              "every shadow ray compacted by ballot/prefix into a queue, marched by k_shadow (laboratory)" if args.shadow_queue else "off",
                 "parallelism": "1 GPU" if not sharded else
                                f"{world} GPU(s), {args.band_rows}-row bands " +
                                ("round-robin" if not layout.weighted else
@@ -1175,9 +1180,10 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
             torch.cuda.empty_cache()
 
     guarded("cfg3_4k", lambda: measure("cfg3_4k", scene, scene_name, W4, H4, "default", suffix9,
-            note="BASELINE cfg-3's frame with compaction OFF (the default kernel: faster than either form of compaction)"))
-    guarded("cfg3_4k_compact", lambda: measure("cfg3_4k_compact", scene, scene_name, W4, H4, "compact", suffix9, flags=sb.FLAG_COMPACT, steps=20, warmup=4, nbuf=2,
-            note="BASELINE cfg-3 as named: wavefront ray compaction ON (persistent waves, ballot / prefix lane refill: k_compact)"))
+            note="BASELINE cfg-3's frame with compaction OFF (the default kernel: faster than every form of compaction built)"))
+    guarded("cfg3_4k_compact", lambda: measure("cfg3_4k_compact", scene, scene_name, W4, H4, "compact", suffix9, flags=sb.FLAG_COMPACT,
+            note="BASELINE cfg-3 as named: wavefront ray compaction ON (SDFHIP_FLAG_COMPACT: the shadow rays of waves that hold fewer than 32 "
+                 "compacted by ballot / prefix into a queue and marched 64 to a wave by a second kernel)"))
 
     def cfg5():
         pt = sb.PathTrace(spp=16)

@@ -74,8 +74,11 @@ enum {
     SDFHIP_KERNEL_GENERIC = 1,    /* one thread per pixel, follows parent / children links through memory as Compute.hlsl does */
     SDFHIP_KERNEL_STACK = 2,      /* integer cell coordinates and the lookup grids (needs a consistent tree of depth <= 12)   */
     SDFHIP_KERNEL_MASK = 0xF,
-    SDFHIP_FLAG_COMPACT = 0x10,   /* BASELINE cfg-3's wavefront ray compaction: persistent waves, ballot/prefix refill of finished
-                                     lanes.  Bit-identical, and slower than the default on every frame measured */
+    SDFHIP_FLAG_COMPACT = 0x10,   /* BASELINE cfg-3's wavefront ray compaction: after the shading step a wave that holds fewer than 32
+                                     shadow rays hands them to a queue (slots by ballot + prefix count) that a second kernel marches
+                                     64 to a wave; fuller waves march theirs in place.  On a tree without a full-depth grid:
+                                     persistent waves with ballot/prefix refill of finished lanes.  Bit-identical; 2-3 % slower than
+                                     the default on the frames measured -- coherent primary rays leave little to compact */
     SDFHIP_FLAG_COUNT = 0x20,     /* also count algorithmic node/sample reads (slower)     */
     SDFHIP_FLAG_DISPLAY = 0x40,   /* fused display pass: output is RGBA8, gamma 1/2.2 (DisplayFrag.hlsl:24) */
     SDFHIP_FLAG_DISPLAY_DEBUG = 0x80, /* fused display pass, debug heat map w/140 (DisplayFrag.hlsl:21-22) */

@@ -36,13 +36,17 @@ enum {
     /* the one-kernel form with the top grid (level <= 3: SDFHIP_TOP_GRID_LEVEL=3 at upload) staged in LDS per workgroup:
      * north_star's "LDS caching of the hot inner nodes"  */
     SDFHIP_TUNE_LDS_TOP = 0x40000,
-    /* k_march appends its shadow rays to a queue (wavefront ballot + prefix compaction) that a second kernel, k_shadow, marches
-     * 64 to a wave, where by default every wave marches its own shadow rays after the shading step */
+    /* SDFHIP_FLAG_COMPACT's pair of kernels with EVERY shadow ray queued (round 2's form; SDFHIP_SHADOW_MIN_LANES=T in the
+     * environment sets another threshold): k_march appends them to a queue (wavefront ballot + prefix compaction) that
+     * k_shadow marches 64 to a wave.  The product queues the rays of waves that hold fewer than 32 */
     SDFHIP_TUNE_SHADOW_QUEUE = 0x80000,
     /* only meaningful on a scene uploaded with SDFHIP_SAMPLE_RECORDS=1 in the environment, which builds the grid's second
      * form (dense 4-byte words + 64-byte sample records of the non-flat leaves) and makes the default kernel read it: this
      * flag switches such a scene back to the 16-byte cells every other scene reads */
-    SDFHIP_TUNE_BYTE_CELLS = 0x200000
+    SDFHIP_TUNE_BYTE_CELLS = 0x200000,
+    /* with SDFHIP_FLAG_COMPACT on a scene behind a full-depth grid: the persistent-wave lane-refill kernel (k_compact), which carried
+     * that flag until round 4 and still does on trees without such a grid: 2.9 x slower than the default at 4K */
+    SDFHIP_TUNE_PERSISTENT_WAVES = 0x400000
 };
 
 /* ---- round 1 / round 2 gather formats (superseded by the sparse shares the march kernel writes, sdfhip_render_sparse_device) */

@@ -38,7 +38,8 @@ FLAG_WIRE = 0x10000
 TUNE_ORDER_SHIFT, TUNE_BLOCK_SHIFT = 8, 12
 TUNE_ONE_KERNEL = 0x20000     # round 1's one-kernel lane state machine where the default is k_march
 TUNE_LDS_TOP = 0x40000        # the one-kernel form with the top grid (level <= 3) staged in LDS per workgroup
-TUNE_SHADOW_QUEUE = 0x80000   # k_march queues its shadow rays for a second kernel (k_shadow), 64 to a wave
+TUNE_SHADOW_QUEUE = 0x80000   # FLAG_COMPACT's kernels with EVERY shadow ray queued for k_shadow (round 2's form; SDFHIP_SHADOW_MIN_LANES=T sets the threshold)
+TUNE_PERSISTENT_WAVES = 0x400000   # with FLAG_COMPACT on a grid scene: the persistent-wave lane-refill kernel (k_compact), the flag's form until round 4
 TUNE_BYTE_CELLS = 0x200000    # on a scene uploaded under SDFHIP_SAMPLE_RECORDS=1: back to the 16-byte cells every other scene reads
 SHAPE_SPHERE, SHAPE_TORUS, SHAPE_GYROID = 0, 1, 2
 

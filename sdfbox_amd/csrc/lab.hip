@@ -132,22 +132,13 @@ int sdfhip::launch_experiment(sdfhip_scene *s, const RenderCall &c, RenderParams
     const bool two = grid_lookup && !compact && !c.pt && bt == 64 && P.tile_order == 0 && !(flags & SDFHIP_TUNE_ONE_KERNEL);
     if (two) {
         if (flags & SDFHIP_TUNE_SHADOW_QUEUE) {
-            // a queue takes the hits of every 64th workgroup: room for all their pixels
-            P.hit_cap = ((grid.x + HIT_QUEUES - 1u) / HIT_QUEUES) * 64u;
-            const size_t records = (size_t)c.n_frames * HIT_QUEUES * P.hit_cap;
-            sdfhip_scene::Scratch *sc = nullptr;
-            int rcs = get_scratch(s, st, records, &sc);
+            // SDFHIP_SHADOW_MIN_LANES=T: waves with at least T shadow rays march them in place (default here 65: every ray is queued, round 2's form;
+            // the product's SDFHIP_FLAG_COMPACT is this pair of kernels with T = COMPACT_MIN_LANES)
+            uint32_t hit_min = 65u;
+            if (const char *env = getenv("SDFHIP_SHADOW_MIN_LANES")) { const int v = atoi(env); if (v >= 1 && v <= 65) hit_min = (uint32_t)v; }
+            dim3 shade_grid;
+            int rcs = prepare_shadow_queue(s, c, P, grid, hit_min, scp, &shade_grid);
             if (rcs != SDFHIP_OK) return rcs;
-            *scp = sc;
-            P.hit_a = reinterpret_cast<float4 *>(sc->hit_buf);
-            P.hit_b = reinterpret_cast<int4 *>(sc->hit_buf + sc->records * 16);
-            P.hit_c = reinterpret_cast<uint4 *>(sc->hit_buf + sc->records * 32);
-            P.hit_d = reinterpret_cast<float4 *>(sc->hit_buf + sc->records * 48);
-            P.hit_ctl = sc->ctl;
-            P.hit_set = sc->launches++ & 1u;
-            // every queued hit is shaded by a resident wave: at most one chunk of 64 per k_march workgroup
-            const uint32_t resident = (uint32_t)s->cu_count * 32u;
-            const dim3 shade_grid(grid.x < resident ? grid.x : resident, c.n_frames);
             if (cur == CUR_STACK_SPLIT) { if (count) launch_queued<CUR_STACK_SPLIT, true>(mode, grid, shade_grid, st, P); else launch_queued<CUR_STACK_SPLIT, false>(mode, grid, shade_grid, st, P); }
             else                        { if (count) launch_queued<CUR_STACK_FULL, true>(mode, grid, shade_grid, st, P); else launch_queued<CUR_STACK_FULL, false>(mode, grid, shade_grid, st, P); }
             *launched = true;
@@ -171,7 +162,7 @@ int sdfhip::launch_experiment(sdfhip_scene *s, const RenderCall &c, RenderParams
         }
         return SDFHIP_OK;
     }
-    if (compact) return SDFHIP_OK;                    // k_compact is the product's (launch_fallback)
+    if (compact) return SDFHIP_OK;                    // the product's: k_march -> k_shadow, or k_compact (launch_fallback; SDFHIP_TUNE_PERSISTENT_WAVES)
     // the one-kernel form: other workgroup sizes cover 16-pixel-wide tiles
     const uint32_t tile_w = bt >= 128 ? 16u : 8u, tile_h = (uint32_t)bt / 8u / (tile_w / 8u);
     P.tiles_x = (c.width + tile_w - 1) / tile_w;

@@ -236,53 +236,4 @@ __global__ void k_unorm_table(float *out)
     out[threadIdx.x] = unorm8((float)threadIdx.x);
 }
 
-// ---- the second kernel of the queued-shadow A/B form (SDFHIP_TUNE_SHADOW_QUEUE; k_march<..., QUEUE = true> fills the queue) ----
-// One lane per queued shadow ray; a wave takes 64 consecutive records of one queue at a time (chunks are
-// numbered over the frame's queues: a wave-wide scan of the 64 fill counts, once per wave).
-template <int CUR, bool COUNT, int MODE>
-__global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shadow(RenderParams P)
-{
-    typedef typename CursorOf<CUR, COUNT>::type CursorT;
-    const uint32_t f = blockIdx.y, lane = threadIdx.x;
-    FrameInfo I = P.frames[f];
-    asm volatile("" : "+s"(I.margin));
-    const PixelSink<MODE> dst(P, f);
-    // chunks of queue `lane`, and their running sum over the queues (inclusive scan across the wave)
-    const uint32_t fill = min(*hit_count(P, P.hit_set, f, lane), P.hit_cap);
-    if (blockIdx.x == 0 && f == 0)                       // empty the other set -- every frame of it -- for the next launch pair
-        for (uint32_t ff = 0; ff < (uint32_t)MAX_BATCH; ff++) *hit_count(P, P.hit_set ^ 1u, ff, lane) = 0u;
-    const uint32_t chunks = (fill + 63u) >> 6;
-    uint32_t incl = chunks;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    unsigned long long cn = 0, cs = 0, ct = 0, cl = 0;
-    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
-        // queue of chunk t = the number of queues whose inclusive sum is <= t
-        const uint32_t q = (uint32_t)__popcll(__ballot(incl <= t));
-        const uint32_t q_incl = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)q), q_chunks = (uint32_t)__builtin_amdgcn_readlane((int)chunks, (int)q);
-        const uint32_t q_fill = (uint32_t)__builtin_amdgcn_readlane((int)fill, (int)q);
-        const uint32_t i = (t - (q_incl - q_chunks)) * 64u + lane;
-        if (i < q_fill) {
-            const size_t slot = ((size_t)f * HIT_QUEUES + q) * P.hit_cap + i;
-            const float4 a = P.hit_a[slot], d = P.hit_d[slot];
-            const int4 b = P.hit_b[slot];
-            const uint4 e = P.hit_c[slot];
-            RayState r;
-            CursorT c;
-            r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w; r.dx = d.x; r.dy = d.y; r.dz = d.z; r.angle = d.w;
-            r.base = (int)e.y; r.n = 0; r.phase = PH_SHADOW;          // i stays, j starts
-            c.unpack(b, CursorT::units_shift(P.top_level + (CUR == CUR_STACK_SPLIT ? P.fine_bits : 0)));
-            c.v0 = e.z; c.v1 = e.w; c.loads = 0;
-            const size_t lidx = e.x;
-            const float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;      // Compute.hlsl:212
-            r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
-            const bool lit = shadow_march<COUNT>(P, I, r, c, cn, cs);
-            if (lit) dst.grey(lidx, r.angle / (r.dist * r.dist) * I.k_strength, (float)(r.base + r.n));
-            else dst.black(lidx, (float)(r.base + r.n));
-            if (COUNT) { ct += (unsigned long long)(r.base + r.n); cl += c.loads; }
-        }
-    }
-    if (COUNT) flush_counters(P, cn, cs, ct, 0, cl);
-}
-
 }  // namespace sdfhip

@@ -110,19 +110,17 @@ struct RenderParams {
     // path-traced mode (k_path): samples per pixel, diffuse bounces, RNG seed, albedo
     uint32_t pt_spp, pt_bounces, pt_seed;
     float pt_albedo;
-#ifdef SDFHIP_EXPERIMENTS
-    // two-kernel A/B form (k_march -> k_shadow, lab_kernels.h): the pixels whose primary march ended on
-    // the surface facing the light, as records {position, prox | cursor | pixel, steps, values | direction to the
-    // light, Lambert term} in HIT_QUEUES queues per frame
-    // of the launch: arrays [n_frames][HIT_QUEUES][hit_cap]; hit_ctl = two sets of [MAX_BATCH][HIT_QUEUES] fill
-    // counts (a 128-byte line each); this launch pair uses set hit_set and leaves the other one zeroed
+    // SDFHIP_FLAG_COMPACT on a scene with a full-depth grid (k_march<..., QUEUE> -> k_shadow): the shadow rays of the waves that hold
+    // fewer than hit_min of them, as records {position, prox | cursor | pixel, steps, values | direction to the light, Lambert term}
+    // in HIT_QUEUES queues per frame of the launch: arrays [n_frames][HIT_QUEUES][hit_cap]; hit_ctl = two sets of
+    // [MAX_BATCH][HIT_QUEUES] fill counts (a 128-byte line each); this launch pair uses set hit_set and leaves the other one zeroed
     float4 *hit_a;
     int4 *hit_b;
     uint4 *hit_c;
     float4 *hit_d;                 // direction to the light, Lambert term
     uint32_t *hit_ctl;
     uint32_t hit_cap, hit_set;
-#endif
+    uint32_t hit_min;              // a wave with at least this many shadow rays marches them itself (65: every ray is queued)
     // path-traced mode as a pipeline of kernels (k_pt_primary -> k_pt_bounce x (bounces + 1) -> k_pt_resolve):
     // two hit queues used alternately (a level's kernel reads one and fills the other), HIT_QUEUES sub-queues of
     // pt_cap entries each, an entry = four 16-byte records; per-path results [sample][pixel] that k_pt_resolve sums

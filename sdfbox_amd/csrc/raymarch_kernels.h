@@ -1,6 +1,6 @@
 // The ray-march kernels of libsdfhip.so (gfx950): k_march (the default), k_plain, k_compact, the path-traced pipeline
 // and the pieces of Compute.hlsl's main() they are built from.  Device building blocks (cursors, find,
-// sampling): raymarch_device.h.  Host side (launches, C ABI): sdfhip_device.hip.
+// sampling): raymarch_device.h.  Host side (launches, C ABI): render.hip.
 //
 // Replaces: SdfBox/Shaders/Compute.hlsl:180-231 main() and, fused into the epilogue,
 // SdfBox/Shaders/DisplayFrag.hlsl:16-24.
@@ -13,9 +13,10 @@
 //     Compute.hlsl:194-230 as three wave-converged phases -- two tight loops with one exit each and the shading between
 //     them, once per wave;
 //   * k_plain (other trees; A/B knob): the three phases as ONE per-lane state machine around a single find + sample body;
-//   * k_compact: persistent waves pull 8x8 tiles from per-XCD queues and refill finished
-//     lanes by ballot + prefix count (wavefront ray compaction), with refill and shading
-//     batched;
+//   * k_march<..., QUEUE> + k_shadow (SDFHIP_FLAG_COMPACT): the shadow rays of sparse waves compacted into a queue by ballot +
+//     prefix count and marched 64 to a wave;
+//   * k_compact (SDFHIP_FLAG_COMPACT on trees without a full-depth grid): persistent waves pull 8x8 tiles from per-XCD queues
+//     and refill finished lanes by ballot + prefix count, with refill and shading batched;
 //   * k_pt_primary / k_pt_bounce / k_pt_resolve (and the one-kernel k_path): the path-traced mode of BASELINE config 5
 //     (defined by the oracle).
 #pragma once
@@ -429,11 +430,15 @@ __global__ __launch_bounds__(BT, PLAIN_WAVES_PER_SIMD) void k_plain(RenderParams
 // Per-pixel arithmetic, its order and the cursor a pixel carries from the primary into the shadow march are unchanged:
 // images and counters stay bit-identical.
 //
-// A/B form (QUEUE = true, SDFHIP_TUNE_SHADOW_QUEUE): phase 3 appends the shadow rays -- position, prox, step count,
-// cursor, light direction -- to a queue (ballot + mbcnt give the slots, one atomic per wave) and a second kernel, k_shadow,
-// marches them 64 consecutive records to a wave.  Denser waves in the shadow loop (but a wave marches until its longest
-// ray ends: lanes on 52 % there), 64 bytes per shadow ray written and read once, a second launch: 0.107 ms per 1080p frame
-// against 0.090, 0.346 against 0.311 at 4K.  Measured, kept as a knob.
+// QUEUE = true (SDFHIP_FLAG_COMPACT, BASELINE cfg-3's "wavefront ray compaction"): after the shading step a wave counts its shadow
+// rays (one ballot).  A wave that holds at least P.hit_min of them marches them in place, as above.  A sparser wave -- a silhouette,
+// a shadow edge: a handful of live lanes that would keep 64 marching -- appends its rays (position, prox, step count, cursor, light
+// direction: 64 bytes) to a queue, slots by ballot + mbcnt prefix and one atomic per wave, and ends; a second kernel, k_shadow,
+// marches the queued rays 64 consecutive records to a wave.  Measured (scripts/shadow_hybrid_ab.sh): with every ray queued
+// (hit_min = 65, round 2's A/B form) 0.095 ms per 1080p frame against 0.087 and 0.341 against 0.311 at 4K -- the coherent primary
+// rays of these frames leave most waves either full of shadow rays or empty, and the queue's 128 bytes per ray and the second
+// launch cost more than the denser waves return; with hit_min = 32 0.0894 and 0.3168: within 2-3 % of no compaction at all,
+// against 0.285 / 0.917 for the persistent-wave lane refill (k_compact) that carried the flag until round 4.
 // =====================================================================================
 enum { OUT_RGBA32F = 0, OUT_GAMMA8 = 1, OUT_HEAT8 = 2, OUT_WIRE = 3, OUT_SPARSE = 4 };
 
@@ -543,7 +548,6 @@ __device__ __forceinline__ uint32_t tile_of_block(const RenderParams &P, uint32_
     const uint32_t row = r * 8 + xcd;
     return row < P.tiles_y ? row * P.tiles_x + cx : 0xFFFFFFFFu;
 }
-#ifdef SDFHIP_EXPERIMENTS
 // Fill count of queue q of frame f, one 128-byte line each, in two sets: a launch pair uses set
 // P.hit_set, and its k_shadow zeroes the other set for the next pair on this scratch -- nothing else
 // touches that set meanwhile (launches that share a scratch run in stream order), so the queues are
@@ -553,7 +557,6 @@ __device__ __forceinline__ uint32_t *hit_count(const RenderParams &P, uint32_t s
 {
     return P.hit_ctl + (((size_t)set * MAX_BATCH + f) * HIT_QUEUES + q) * 32u;
 }
-#endif
 
 // The shadow march of Compute.hlsl:214-230 for a lane whose RayState holds the shading step's results (pos, dir, prox,
 // dist; n = 0).  Every exit is black (:223, :229) except the one that reaches the light (:215-219): returns that.
@@ -587,7 +590,7 @@ __device__ __forceinline__ bool shadow_march(const RenderParams &P, const FrameI
 }
 
 // QUEUE = false (the default): the wave marches its own shadow rays after the shading step.  QUEUE = true
-// (SDFHIP_TUNE_SHADOW_QUEUE, an A/B knob): it appends them to the queue that k_shadow marches 64 to a wave.
+// (SDFHIP_FLAG_COMPACT): a wave with fewer than P.hit_min of them appends them to the queue that k_shadow marches 64 to a wave.
 template <int CUR, bool COUNT, int MODE, bool QUEUE = false>
 __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams P)
 {
@@ -670,7 +673,11 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
             }
         }
     }
-    if (!QUEUE) {
+    // QUEUE: a wave that holds at least P.hit_min shadow rays marches them in place -- the queue (and the second kernel) take the
+    // rays of the sparse waves only, the silhouettes and shadow edges, where a wave of 64 lanes would march a handful
+    bool in_place = !QUEUE;
+    if constexpr (QUEUE) in_place = (uint32_t)__popcll(__ballot(shadow)) >= P.hit_min;
+    if (in_place) {
         if (shadow) {
             const PixelSink<MODE> dst(P, f, &wire_px);
             const float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;      // Compute.hlsl:212
@@ -690,7 +697,6 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
         if (COUNT) { flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, 0u); flush_classes(P, classes); }
         return;
     }
-#ifdef SDFHIP_EXPERIMENTS
     if constexpr (QUEUE) {
     const unsigned long long hits = __ballot(shadow);
     if (hits) {
@@ -709,7 +715,55 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     }
     if (COUNT) flush_counters(P, cn, cs, ct, shadow ? 1u : 0u, c.loads, shadow ? 1u : 0u);
     }
-#endif
+}
+
+// ---- the second kernel of SDFHIP_FLAG_COMPACT (k_march<..., QUEUE = true> fills the queue) ----
+// One lane per queued shadow ray; a wave takes 64 consecutive records of one queue at a time (chunks are
+// numbered over the frame's queues: a wave-wide scan of the 64 fill counts, once per wave).
+template <int CUR, bool COUNT, int MODE>
+__global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_shadow(RenderParams P)
+{
+    typedef typename CursorOf<CUR, COUNT>::type CursorT;
+    const uint32_t f = blockIdx.y, lane = threadIdx.x;
+    FrameInfo I = P.frames[f];
+    asm volatile("" : "+s"(I.margin));
+    const PixelSink<MODE> dst(P, f);
+    // chunks of queue `lane`, and their running sum over the queues (inclusive scan across the wave)
+    const uint32_t fill = min(*hit_count(P, P.hit_set, f, lane), P.hit_cap);
+    if (blockIdx.x == 0 && f == 0)                       // empty the other set -- every frame of it -- for the next launch pair
+        for (uint32_t ff = 0; ff < (uint32_t)MAX_BATCH; ff++) *hit_count(P, P.hit_set ^ 1u, ff, lane) = 0u;
+    const uint32_t chunks = (fill + 63u) >> 6;
+    uint32_t incl = chunks;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    unsigned long long cn = 0, cs = 0, ct = 0, cl = 0;
+    for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+        // queue of chunk t = the number of queues whose inclusive sum is <= t
+        const uint32_t q = (uint32_t)__popcll(__ballot(incl <= t));
+        const uint32_t q_incl = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)q), q_chunks = (uint32_t)__builtin_amdgcn_readlane((int)chunks, (int)q);
+        const uint32_t q_fill = (uint32_t)__builtin_amdgcn_readlane((int)fill, (int)q);
+        const uint32_t i = (t - (q_incl - q_chunks)) * 64u + lane;
+        if (i < q_fill) {
+            const size_t slot = ((size_t)f * HIT_QUEUES + q) * P.hit_cap + i;
+            const float4 a = P.hit_a[slot], d = P.hit_d[slot];
+            const int4 b = P.hit_b[slot];
+            const uint4 e = P.hit_c[slot];
+            RayState r;
+            CursorT c;
+            r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w; r.dx = d.x; r.dy = d.y; r.dz = d.z; r.angle = d.w;
+            r.base = (int)e.y; r.n = 0; r.phase = PH_SHADOW;          // i stays, j starts
+            c.unpack(b, CursorT::units_shift(P.top_level + (CUR == CUR_STACK_SPLIT ? P.fine_bits : 0)));
+            c.v0 = e.z; c.v1 = e.w; c.loads = 0;
+            const size_t lidx = e.x;
+            const float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;      // Compute.hlsl:212
+            r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+            const bool lit = shadow_march<COUNT>(P, I, r, c, cn, cs);
+            if (lit) dst.grey(lidx, r.angle / (r.dist * r.dist) * I.k_strength, (float)(r.base + r.n));
+            else dst.black(lidx, (float)(r.base + r.n));
+            if (COUNT) { ct += (unsigned long long)(r.base + r.n); cl += c.loads; }
+        }
+    }
+    if (COUNT) flush_counters(P, cn, cs, ct, 0, cl);
 }
 
 // ---- persistent waves with lane refill and state batching (wavefront ray compaction) --

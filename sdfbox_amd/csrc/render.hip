@@ -32,6 +32,7 @@ namespace {
 // ---- kernel parameters of a call ------------------------------------------------------------------------------------------
 struct Plan {
     bool use_stack = false, compact = false, count = false, grid_lookup = false;
+    bool persistent = false;          // (experiments build) SDFHIP_FLAG_COMPACT as the persistent-wave kernel on a grid cursor too
     int cur = CUR_GENERIC;
     uint32_t out_mode = 0;
     dim3 grid;
@@ -80,6 +81,9 @@ int fill_params(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &pla
 #endif
     plan.use_stack = kind == SDFHIP_KERNEL_STACK || (kind == SDFHIP_KERNEL_AUTO && s->stack_ok);
     plan.compact = (flags & SDFHIP_FLAG_COMPACT) != 0;
+#ifdef SDFHIP_EXPERIMENTS
+    plan.persistent = plan.compact && (flags & SDFHIP_TUNE_PERSISTENT_WAVES) != 0;
+#endif
     plan.count = (flags & SDFHIP_FLAG_COUNT) != 0;
     plan.out_mode = c.sparse ? (uint32_t)OUT_SPARSE : (flags & SDFHIP_FLAG_DISPLAY_DEBUG) ? (uint32_t)OUT_HEAT8 : (flags & SDFHIP_FLAG_DISPLAY) ? (uint32_t)OUT_GAMMA8 : (uint32_t)OUT_RGBA32F;
     if (c.sparse && (plan.compact || c.pt || (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG))))
@@ -92,8 +96,6 @@ int fill_params(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &pla
     }
     if (c.n_frames > 1 && (plan.compact || c.pt || plan.count))
         return fail(SDFHIP_ERR_ARG, "render_batch: only the default kernels, without counting, render several frames per launch");
-    if (plan.compact && (c.width > 65535u || c.nrows_out > 65535u))
-        return fail(SDFHIP_ERR_ARG, "render: the compact kernel packs a pixel's x and row into 16 bits each (frame %u x %u)", c.width, c.nrows_out);
 
     memset(&P, 0, sizeof P);
     P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level; P.fine = s->d_fine; P.fine_bits = s->fine_bits; P.fine_order = 0;
@@ -146,6 +148,8 @@ int fill_params(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &pla
     plan.grid_lookup = plan.cur == CUR_STACK_FULL || plan.cur == CUR_STACK_SPLIT;
     // one 8x8 tile per 64-lane workgroup, XCD k renders tile rows k, k + 8, ... (tile_of_block): the grid is padded to 8 * ceil(tiles_y / 8) rows
     plan.grid = dim3(8u * ((P.tiles_y + 7u) / 8u) * P.tiles_x, c.n_frames);
+    if (plan.compact && (!plan.grid_lookup || plan.persistent) && (c.width > 65535u || c.nrows_out > 65535u))
+        return fail(SDFHIP_ERR_ARG, "render: the persistent-wave compact kernel packs a pixel's x and row into 16 bits each (frame %u x %u)", c.width, c.nrows_out);
     if (c.sparse && !plan.grid_lookup)
         return fail(SDFHIP_ERR_ARG, "render_sparse: this scene has no full-depth grid (trees deeper than 12 levels or with inconsistent links render dense shares)");
     return SDFHIP_OK;
@@ -306,7 +310,31 @@ int launch_path(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &pla
     return plan.count ? launch_pt_pipeline<CUR_STACK_FULL, true>(s, grid, st, P) : launch_pt_pipeline<CUR_STACK_FULL, false>(s, grid, st, P);
 }
 
-// ---- trees without a full-depth grid, and wavefront ray compaction ---------------------------------------------------------
+// ---- wavefront ray compaction (SDFHIP_FLAG_COMPACT) on the default kernel: k_march<..., QUEUE> -> k_shadow -----------------------
+template <int CUR, bool COUNT>
+void launch_queued(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, const RenderParams &P)
+{
+    auto go = [&](auto march, auto shade) {
+        hipLaunchKernelGGL(march, grid, dim3(64), 0, st, P);
+        hipLaunchKernelGGL(shade, shade_grid, dim3(64), 0, st, P);
+    };
+    if (mode == OUT_RGBA32F)     go(k_march<CUR, COUNT, OUT_RGBA32F, true>, k_shadow<CUR, COUNT, OUT_RGBA32F>);
+    else if (mode == OUT_GAMMA8) go(k_march<CUR, COUNT, OUT_GAMMA8, true>, k_shadow<CUR, COUNT, OUT_GAMMA8>);
+    else                         go(k_march<CUR, COUNT, OUT_HEAT8, true>, k_shadow<CUR, COUNT, OUT_HEAT8>);
+}
+
+int launch_compact(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &plan)
+{
+    dim3 shade_grid;
+    int rc = prepare_shadow_queue(s, c, P, plan.grid, COMPACT_MIN_LANES, &plan.sc, &shade_grid);
+    if (rc != SDFHIP_OK) return rc;
+    const uint32_t mode = plan.out_mode;
+    if (plan.cur == CUR_STACK_SPLIT) { if (plan.count) launch_queued<CUR_STACK_SPLIT, true>(mode, plan.grid, shade_grid, c.st, P); else launch_queued<CUR_STACK_SPLIT, false>(mode, plan.grid, shade_grid, c.st, P); }
+    else                             { if (plan.count) launch_queued<CUR_STACK_FULL, true>(mode, plan.grid, shade_grid, c.st, P); else launch_queued<CUR_STACK_FULL, false>(mode, plan.grid, shade_grid, c.st, P); }
+    return SDFHIP_OK;
+}
+
+// ---- trees without a full-depth grid (and their form of the compaction: persistent waves with lane refill) ---------------------
 template <int CUR, bool COUNT>
 void launch_plain_or_compact(bool compact, dim3 grid, hipStream_t st, const RenderParams &P)
 {
@@ -328,14 +356,45 @@ int launch_fallback(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan 
         HIP_TRY(hipMemsetAsync(P.queue, 0, sdfhip_scene::CTL_QUEUE_WORDS * sizeof(uint32_t), st));
     }
     const bool k = plan.count, cp = plan.compact;
+#ifdef SDFHIP_EXPERIMENTS
+    // (A/B, SDFHIP_TUNE_PERSISTENT_WAVES: the persistent-wave form on a grid cursor, which carried SDFHIP_FLAG_COMPACT until round 4)
     if (plan.cur == CUR_STACK_SPLIT)     { if (k) launch_plain_or_compact<CUR_STACK_SPLIT, true>(cp, grid, st, P); else launch_plain_or_compact<CUR_STACK_SPLIT, false>(cp, grid, st, P); }
     else if (plan.cur == CUR_STACK_FULL) { if (k) launch_plain_or_compact<CUR_STACK_FULL, true>(cp, grid, st, P); else launch_plain_or_compact<CUR_STACK_FULL, false>(cp, grid, st, P); }
-    else if (plan.cur == CUR_STACK)      { if (k) launch_plain_or_compact<CUR_STACK, true>(cp, grid, st, P); else launch_plain_or_compact<CUR_STACK, false>(cp, grid, st, P); }
+    else
+#else
+    if (plan.grid_lookup) return fail(SDFHIP_ERR_ARG, "render: no fallback kernel for a scene behind a full-depth grid");
+#endif
+    if (plan.cur == CUR_STACK)           { if (k) launch_plain_or_compact<CUR_STACK, true>(cp, grid, st, P); else launch_plain_or_compact<CUR_STACK, false>(cp, grid, st, P); }
     else                                 { if (k) launch_plain_or_compact<CUR_GENERIC, true>(cp, grid, st, P); else launch_plain_or_compact<CUR_GENERIC, false>(cp, grid, st, P); }
     return SDFHIP_OK;
 }
 
 }  // namespace
+
+// the shadow-ray queue of a k_march<..., QUEUE> / k_shadow launch pair on the stream's scratch
+int sdfhip::prepare_shadow_queue(sdfhip_scene *s, const RenderCall &c, RenderParams &P, dim3 grid, uint32_t hit_min, sdfhip_scene::Scratch **scp,
+                                 dim3 *shade_grid)
+{
+    // a queue takes the rays of every HIT_QUEUES-th workgroup, and a workgroup queues fewer than hit_min of its 64 pixels
+    const uint32_t per_wave = hit_min > 64u ? 64u : hit_min - 1u;
+    P.hit_min = hit_min;
+    P.hit_cap = ((grid.x + HIT_QUEUES - 1u) / HIT_QUEUES) * (per_wave ? per_wave : 1u);
+    const size_t records = (size_t)c.n_frames * HIT_QUEUES * P.hit_cap;
+    sdfhip_scene::Scratch *sc = nullptr;
+    int rcs = get_scratch(s, c.st, records, &sc);
+    if (rcs != SDFHIP_OK) return rcs;
+    *scp = sc;
+    P.hit_a = reinterpret_cast<float4 *>(sc->hit_buf);
+    P.hit_b = reinterpret_cast<int4 *>(sc->hit_buf + sc->records * 16);
+    P.hit_c = reinterpret_cast<uint4 *>(sc->hit_buf + sc->records * 32);
+    P.hit_d = reinterpret_cast<float4 *>(sc->hit_buf + sc->records * 48);
+    P.hit_ctl = sc->ctl;
+    P.hit_set = sc->launches++ & 1u;
+    // every queued ray is marched by a resident wave: at most one chunk of 64 per k_march workgroup
+    const uint32_t resident = (uint32_t)s->cu_count * 32u;
+    *shade_grid = dim3(grid.x < resident ? grid.x : resident, c.n_frames);
+    return SDFHIP_OK;
+}
 
 // ---- statistics of a call, collected outside the handle's lock --------------------------------------------------------------
 int sdfhip::take_ticket(sdfhip_scene *s, sdfhip_scene::StatsTicket **out)
@@ -395,6 +454,7 @@ int sdfhip::render_impl(sdfhip_scene *s, const RenderCall &c, sdfhip_scene::Stat
     if (!launched) {
         if (c.pt) rc = launch_path(s, c, P, plan);
         else if (plan.grid_lookup && !plan.compact) rc = launch_default(s, c, P, plan);
+        else if (plan.grid_lookup && !plan.persistent) rc = launch_compact(s, c, P, plan);
         else rc = launch_fallback(s, c, P, plan);
         if (rc != SDFHIP_OK) return rc;
     }

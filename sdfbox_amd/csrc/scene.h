@@ -34,10 +34,10 @@ struct sdfhip_scene {
     // and must not, so every stream that renders on this handle gets its own.
     struct Scratch {
         hipStream_t stream = nullptr;
-        char *hit_buf = nullptr;      // (experiments build: the shadow-ray queue of the two-kernel A/B form, `records` x 64 bytes)
+        char *hit_buf = nullptr;      // SDFHIP_FLAG_COMPACT: the shadow-ray queue between k_march and k_shadow, `records` x 64 bytes
         size_t records = 0;
         uint32_t *ctl = nullptr;      // control words, see CTL_* below
-        uint32_t launches = 0;        // (experiments build) two-kernel launch pairs so far: its parity selects the set of fill counts
+        uint32_t launches = 0;        // k_march / k_shadow launch pairs so far: its parity selects the set of fill counts
         uint64_t last_use = 0;        // the handle's render count when this scratch was last handed out (the oldest idle one is recycled)
         hipEvent_t idle = nullptr;    // the library's own event behind the last launch that used this scratch: "is it idle?" never asks
                                       // the caller's stream handle, which may have been destroyed since
@@ -57,7 +57,7 @@ struct sdfhip_scene {
         sdfhip_info ord_info;                        // the camera block of the frame the order was made from
     };
     static constexpr int MAX_SCRATCH = 16;
-    // ctl: [hit fill counts, two sets (experiments build)] [the compact kernel's 8 tile queues] [the path-traced pipeline's fill counts
+    // ctl: [the shadow-ray queues' fill counts, two sets] [the compact kernel's 8 tile queues] [the path-traced pipeline's fill counts
     // + its overflow word's line] [the counters of SDFHIP_FLAG_COUNT renders on this stream, 16 x u64: nodes, samples, steps,
     // shadow rays, loads, hits, and from [6] the step classes of sdfhip_debug_step_classes]
     static constexpr size_t CTL_HIT_WORDS = (size_t)2 * sdfhip::MAX_BATCH * sdfhip::HIT_QUEUES * 32, CTL_QUEUE_WORDS = 8 * 32,
@@ -148,6 +148,11 @@ struct RenderCall {
     uint32_t sparse_cap = 0, sparse_base = 0;
 };
 int render_impl(sdfhip_scene *s, const RenderCall &call, sdfhip_scene::StatsTicket *ticket);
+// SDFHIP_FLAG_COMPACT on a scene with a full-depth grid: the shadow-ray queue of k_march<..., QUEUE> / k_shadow on the stream's scratch
+// (waves holding fewer than hit_min shadow rays queue them); fills P.hit_* and the second kernel's grid
+constexpr uint32_t COMPACT_MIN_LANES = 32;
+int prepare_shadow_queue(sdfhip_scene *s, const RenderCall &call, RenderParams &P, dim3 grid, uint32_t hit_min, sdfhip_scene::Scratch **sc,
+                         dim3 *shade_grid);
 int take_ticket(sdfhip_scene *s, sdfhip_scene::StatsTicket **out);           // under the handle's lock
 int finish_stats(sdfhip_scene *s, sdfhip_scene::StatsTicket *t, sdfhip_stats *stats);   // outside it
 

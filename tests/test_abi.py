@@ -52,7 +52,7 @@ def test_flag_constants_match_the_headers(sb):
         return {m.group(1): int(m.group(2), 0) for m in re.finditer(r"\bSDFHIP_((?:FLAG|TUNE|KERNEL)_\w+)\s*=\s*(0x[0-9A-Fa-f]+|\d+)", text)}
     product, lab = enums("sdfhip.h"), enums("sdfhip_experimental.h")
     assert {"FLAG_COMPACT", "FLAG_COUNT", "FLAG_DISPLAY", "FLAG_DISPLAY_DEBUG", "FLAG_TILE_ORDER", "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_STACK", "KERNEL_MASK"} == set(product)
-    assert {"FLAG_WIRE", "TUNE_ONE_KERNEL", "TUNE_SHADOW_QUEUE", "TUNE_LDS_TOP", "TUNE_BYTE_CELLS", "TUNE_ORDER_SHIFT", "TUNE_BLOCK_SHIFT"} == set(lab)
+    assert {"FLAG_WIRE", "TUNE_ONE_KERNEL", "TUNE_SHADOW_QUEUE", "TUNE_LDS_TOP", "TUNE_BYTE_CELLS", "TUNE_PERSISTENT_WAVES", "TUNE_ORDER_SHIFT", "TUNE_BLOCK_SHIFT"} == set(lab)
     header = dict(product, **lab)
     L = sb._lib
     seen = 0

@@ -16,12 +16,13 @@ pytestmark = pytest.mark.gpu
 # Every test of this file runs on BOTH flavours of the library: the product (libsdfhip.so, include/sdfhip.h) and the experiments
 # build (libsdfhip_lab.so, include/sdfhip_experimental.h: the same sources + the A/B kernel forms and superseded gather formats).
 # "stack" = the default: k_march (primary march, shading, shadow march as wave-converged loops) wherever the scene has a full-depth or split
-# grid (every test scene of depth <= 12 does); "generic" = the shader's own traversal; "+compact" = BASELINE cfg-3's wavefront ray compaction.
-# Experiments build only: "stack+one" = round 1's one-kernel form of the same traversal; "stack+queue" = k_march queues its shadow
-# rays for k_shadow (SDFHIP_TUNE_SHADOW_QUEUE); "stack+bytes" = SDFHIP_TUNE_BYTE_CELLS (a no-op unless SDFHIP_SAMPLE_RECORDS=1 built the
-# grid's second form)
+# grid (every test scene of depth <= 12 does); "generic" = the shader's own traversal; "+compact" = BASELINE cfg-3's wavefront ray compaction
+# (SDFHIP_FLAG_COMPACT: on "stack" the shadow rays of sparse waves queued for k_shadow, on "generic" persistent waves with lane refill).
+# Experiments build only: "stack+one" = round 1's one-kernel form of the same traversal; "stack+queue" = EVERY shadow ray queued for
+# k_shadow (SDFHIP_TUNE_SHADOW_QUEUE); "stack+persistent" = the persistent-wave kernel on a grid scene too (SDFHIP_TUNE_PERSISTENT_WAVES,
+# the flag's form until round 4); "stack+bytes" = SDFHIP_TUNE_BYTE_CELLS (a no-op unless SDFHIP_SAMPLE_RECORDS=1 built the grid's second form)
 PRODUCT_VARIANTS = ["generic", "stack", "generic+compact", "stack+compact"]
-LAB_VARIANTS = ["stack+one", "stack+queue", "stack+bytes"]
+LAB_VARIANTS = ["stack+one", "stack+queue", "stack+persistent", "stack+bytes"]
 ALL_VARIANTS = PRODUCT_VARIANTS + LAB_VARIANTS
 
 
@@ -56,7 +57,8 @@ def lab_only(sb):
 def flags_of(sb, name):
     f = {"generic": sb.KERNEL_GENERIC, "stack": sb.KERNEL_STACK}[name.split("+")[0]]
     return f | (sb.FLAG_COMPACT if name.endswith("compact") else 0) | (sb.TUNE_ONE_KERNEL if name.endswith("+one") else 0) | \
-        (sb._lib.TUNE_SHADOW_QUEUE if name.endswith("+queue") else 0) | (sb._lib.TUNE_BYTE_CELLS if name.endswith("+bytes") else 0)
+        (sb._lib.TUNE_SHADOW_QUEUE if name.endswith("+queue") else 0) | (sb._lib.TUNE_BYTE_CELLS if name.endswith("+bytes") else 0) | \
+        ((sb.FLAG_COMPACT | sb._lib.TUNE_PERSISTENT_WAVES) if name.endswith("+persistent") else 0)
 
 
 @pytest.fixture(scope="module")
