@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--depth", type=int, default=9, help="octree depth of the dragon stand-in")
     ap.add_argument("--asdf", default=None, help="render this .asdf instead of the synthetic scene")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "stack"])
+    ap.add_argument("--top-grid-level", type=int, default=None,
+                    help="A/B: upload the scene with a plain lookup grid of this level (sdfhip_upload_options; the tree's depth = the dense full-depth grid)")
+    ap.add_argument("--top-grid-split", type=int, default=None, help="A/B: upload the scene with a split grid of this coarse level")
     ap.add_argument("--compact", type=int, default=-1, help="wavefront ray compaction: 1 on, 0 off, -1 default")
     ap.add_argument("--band-rows", type=int, default=16)
     ap.add_argument("--frames-in-flight", type=int, default=0,
@@ -168,7 +171,7 @@ def main():
         od = sb.dragon_standin(args.depth, nthreads=max(1, min(32, ncpu // max(1, min(world, ndev * 8)))))
         scene_name = f"dragon_standin_d{args.depth}"
     t_gen = time.time() - t0
-    scene = sb.Scene(od, device=device)
+    scene = sb.Scene(od, device=device, top_grid_level=args.top_grid_level, top_grid_split=args.top_grid_split)
 
     # ---- camera: SURVEY.md 8d cfg-2 ---------------------------------------------------
     cam = sb.Logic(W, H)

@@ -245,6 +245,19 @@ SDFHIP_API int sdfhip_device_pci_bus_id(int device, char *out, uint32_t len);
  * device `device` once.  Host arrays may be freed after return. */
 SDFHIP_API int sdfhip_scene_upload(int device, const int32_t *structs, const uint8_t *values,
                                    uint32_t n, sdfhip_scene **out);
+/* The same with the choices the upload otherwise makes by itself (sdfhip_scene_top_grid below describes them).  Every field:
+ * -1 = choose.  A host uses this to bound the accelerators' memory or to take a particular grid; the pixels never depend on it. */
+typedef struct sdfhip_upload_options {
+    uint32_t size;            /* sizeof(sdfhip_upload_options), set by sdfhip_upload_options_default: lets the struct grow */
+    int32_t top_grid_level;   /* 0 = no grid; 1..10 = a plain grid of that level, as deep as the tree at most -- the tree's depth asks
+                                 for the dense full-depth grid, taken if it fits 1/64 of the device's memory (2.1 GB at depth 9) */
+    int32_t top_grid_split;   /* 0 = never a split grid; 1..8 = a split grid with that coarse level (needs depth - level <= 6) */
+    int32_t scatter_grid;     /* the path-traced mode's second grid: 0 = none, 1..4 = the levels of its blocks (8^n cells each) */
+    int32_t scatter_order;    /* ... 0 = its blocks in x-y-z order (default: 2x2x2 sub-cubes, one cache line each) */
+} sdfhip_upload_options;
+SDFHIP_API void sdfhip_upload_options_default(sdfhip_upload_options *opt);
+SDFHIP_API int sdfhip_scene_upload_ex(int device, const int32_t *structs, const uint8_t *values, uint32_t n,
+                                      const sdfhip_upload_options *opt, sdfhip_scene **out);
 SDFHIP_API int sdfhip_scene_free(sdfhip_scene *scene);
 SDFHIP_API int sdfhip_scene_info(const sdfhip_scene *scene, uint32_t *n, uint32_t *depth,
                                  int *stack_kernel_ok, int *device);
@@ -259,10 +272,9 @@ SDFHIP_API int sdfhip_scene_info(const sdfhip_scene *scene, uint32_t *n, uint32_
  * no larger than the tree's own records) whose internal cells point at dense blocks of the remaining <= 4
  * levels, built only where the tree is deep (`bytes` counts both; a find is one or two loads), if the blocks
  * fit 1/16 of the memory; else a plain grid of at most level 8, no larger than the tree's own records.
- * Environment, read at upload: SDFHIP_TOP_GRID_LEVEL (0..10) asks for a plain grid of that level (0 = none;
- * the tree's depth = the dense full-depth grid, if it fits 1/64 of the memory: 2.1 GB at depth 9),
- * SDFHIP_TOP_GRID_SPLIT for a split grid with that coarse level.  The grid shrinks by itself when memory is
- * short. */
+ * sdfhip_scene_upload_ex takes other choices (sdfhip_upload_options: a plain grid of a given level, none at all,
+ * a split grid with a given coarse level).  The grid shrinks by itself when memory is short.  (The laboratory
+ * library also reads them from the environment: SDFHIP_TOP_GRID_LEVEL, SDFHIP_TOP_GRID_SPLIT.) */
 SDFHIP_API int sdfhip_scene_top_grid(const sdfhip_scene *scene, int32_t *level, uint64_t *bytes);
 
 /* Replaces: Program.Draw's UpdateBuffer(info) + DispatchSized(W, H, 1),
@@ -307,8 +319,8 @@ typedef struct sdfhip_pathtrace {
 /* The bounce levels of the path-traced pipeline read a second split grid of the scene's cells, with larger blocks (+0.83 GB for
  * the depth-9 bench scene).  sdfhip_scene_prepare_path builds it at load time (allocations, kernels and two
  * stream synchronisations on the scene's own stream); without the call the first path-traced render builds it before its clock
- * starts.  Environment, read then: SDFHIP_SCATTER_GRID=0 no second grid, 1..4 the levels of its blocks (default 4: 16^3 cells; 3 for trees of depth < 6);
- * SDFHIP_SCATTER_ORDER=0 blocks in x-y-z order (default: 2x2x2 sub-cubes, one cache line each).  sdfhip_scene_top_grid counts its
+ * starts.  Its blocks hold 16^3 cells by default (8^3 for trees of depth < 6) in the order of 2x2x2 sub-cubes, one cache line each;
+ * sdfhip_upload_options.scatter_grid / scatter_order choose otherwise (0 = no second grid).  sdfhip_scene_top_grid counts its
  * bytes once it exists.  sdfhip_render_path returns SDFHIP_ERR_NOMEM, not a wrong image, if a hit ever found no room in its queue
  * (their capacity is the worst case of every sub-queue, so this is a check, not a limit). */
 SDFHIP_API int sdfhip_scene_prepare_path(sdfhip_scene *scene);
@@ -427,6 +439,10 @@ SDFHIP_API int sdfhip_deinterleave_sparse2_device(int device, const void *const 
  * ncclGroupStart/End instead, RCCL loaded with dlopen); devices[0] expands them into the frame in row order.  Inside the
  * library: one host thread per device, the band layout, the gather, the float tail of a share that needed more than was
  * sent, no Python.  The same device may appear several times (a rehearsal of the pipeline on one GPU; not with RCCL).
+ * Environment, read at create: SDFHIP_MULTI_TRANSPORT (above), SDFHIP_RCCL_LIB (the RCCL library to dlopen, if not the system's),
+ * SDFHIP_MULTI_RCCL_SELF=1 (with ONE device and the RCCL transport: its share travels through ncclSend / ncclRecv to itself -- all
+ * of that transport a single GPU can run).  With SDFHIP_GEN_POOL these are the only variables the product library reads; every
+ * other choice is an argument (sdfhip_upload_options, sdfhip_multi_configure).
  *   sdfhip_multi_render        one frame to a host array: the viewer's call (latency: every device works on this frame)
  *   sdfhip_multi_submit/_wait  groups of n_frames <= 8 frames (one camera block each, one launch per device), up to 4 groups
  *                              in flight (slot 0..3): throughput.  d_frames_out: device memory on devices[0] for
@@ -461,8 +477,8 @@ typedef struct sdfhip_multi_link {
 } sdfhip_multi_link;
 SDFHIP_API int sdfhip_multi_selftest(sdfhip_multi *m, sdfhip_multi_link *links);
 SDFHIP_API int sdfhip_multi_free(sdfhip_multi *m);
-/* band height (a multiple of 8; default 16, or SDFHIP_MULTI_BAND_ROWS) and the share of devices[0], which also assembles
- * the frame, as a fraction of a peer's (default 1, or SDFHIP_MULTI_RANK0_WEIGHT); no slot may be in flight */
+/* band height (a multiple of 8; default 16) and the share of devices[0], which also assembles the frame, as a fraction of a
+ * peer's (default 1); no slot may be in flight */
 SDFHIP_API int sdfhip_multi_configure(sdfhip_multi *m, uint32_t band_rows, float rank0_weight);
 SDFHIP_API int sdfhip_multi_info(const sdfhip_multi *m, uint32_t *n_devices, int *devices, uint32_t *band_rows,
                                  float *rank0_weight, int *transport /* 0 peer copies, 1 RCCL */);

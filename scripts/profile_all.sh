@@ -11,7 +11,7 @@ bash scripts/profile.sh ${R}_4k_compact --size 3840x2160 --compact 1 && \
 bash scripts/profile.sh ${R}_1080p_display --display                && \
 bash scripts/profile.sh ${R}_1080p_d10 --depth 10                   && \
 bash scripts/profile.sh ${R}_cfg5 --size 3840x2160 --spp 16           && \
-SDFHIP_TOP_GRID_LEVEL=9 bash scripts/profile.sh ${R}_1080p_dense      && \
-SDFHIP_TOP_GRID_LEVEL=9 bash scripts/profile.sh ${R}_4k_dense --size 3840x2160 && \
-SDFHIP_TOP_GRID_SPLIT=7 bash scripts/profile.sh ${R}_1080p_split7     && \
-SDFHIP_TOP_GRID_SPLIT=6 bash scripts/profile.sh ${R}_1080p_split6
+bash scripts/profile.sh ${R}_1080p_dense --top-grid-level 9             && \
+bash scripts/profile.sh ${R}_4k_dense --size 3840x2160 --top-grid-level 9 && \
+bash scripts/profile.sh ${R}_1080p_split7 --top-grid-split 7            && \
+bash scripts/profile.sh ${R}_1080p_split6 --top-grid-split 6

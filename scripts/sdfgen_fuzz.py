@@ -3,7 +3,8 @@ structs and values expected).  python scripts/sdfgen_fuzz.py [cases]"""
 import sys
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import sdfbox_amd as sb
+import sdfbox_amd.lab
+sb = sdfbox_amd.lab.load()          # SDFHIP_GEN_WIDE is a knob of the laboratory library
 import oracle
 import os
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100

@@ -47,7 +47,7 @@ SHAPE_SPHERE, SHAPE_TORUS, SHAPE_GYROID = 0, 1, 2
 if __name__ != "sdfbox_amd._lib":
     # the package imported a second time against another flavour of the library (sdfbox_amd.lab.load()): both flavours share ONE
     # set of ctypes classes, so that a camera, a PathTrace or a Stats object made with either package is accepted by both
-    from sdfbox_amd._lib import COctData, CPoints, Info, MultiLink, MultiStats, PathTrace, SdfGenStats, SdfHipError, Stats   # noqa: F401
+    from sdfbox_amd._lib import COctData, CPoints, Info, MultiLink, MultiStats, PathTrace, SdfGenStats, SdfHipError, Stats, UploadOptions   # noqa: F401
 else:
     class Info(ctypes.Structure):
         """The 112-byte `Info` cbuffer (Logic.cs:407-420)."""
@@ -103,6 +103,16 @@ else:
 
         def __init__(self, spp=16, max_bounces=3, seed=0x5DFB0C5, albedo=0.8):
             super().__init__(int(spp), int(max_bounces), int(seed), float(albedo))
+
+
+    class UploadOptions(ctypes.Structure):
+        """sdfhip_upload_options: the upload's own choices, overridden (None / -1 = choose)."""
+        _fields_ = [("size", ctypes.c_uint32), ("top_grid_level", ctypes.c_int32), ("top_grid_split", ctypes.c_int32),
+                    ("scatter_grid", ctypes.c_int32), ("scatter_order", ctypes.c_int32)]
+
+        def __init__(self, top_grid_level=None, top_grid_split=None, scatter_grid=None, scatter_order=None):
+            f = lambda v: -1 if v is None else int(v)
+            super().__init__(ctypes.sizeof(type(self)), f(top_grid_level), f(top_grid_split), f(scatter_grid), f(scatter_order))
 
 
     class CPoints(ctypes.Structure):
@@ -162,6 +172,8 @@ _SIG = {
     "sdfhip_device_pci_bus_id": (_c.c_int, [_c.c_int, _c.c_char_p, _c.c_uint32]),
     "sdfhip_multi_selftest": (_c.c_int, [_vp, _c.POINTER(MultiLink)]),
     "sdfhip_scene_upload": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.POINTER(_vp)]),
+    "sdfhip_upload_options_default": (None, [_c.POINTER(UploadOptions)]),
+    "sdfhip_scene_upload_ex": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.POINTER(UploadOptions), _c.POINTER(_vp)]),
     "sdfhip_scene_free": (_c.c_int, [_vp]),
     "sdfhip_scene_info": (_c.c_int, [_vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint32),
                                      _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),

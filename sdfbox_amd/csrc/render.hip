@@ -653,7 +653,7 @@ extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t 
     // 1080p march is a fifth of its copy: measured 0.735 / 0.744 / 0.757 ms with 1 / 2 / 4 bands against 0.770 in the plain form;
     // 4K: 2.77 / 2.62 / 2.51 against 2.75; 4K RGBA8: 0.96 / 0.84 / 0.76 against 0.96 -- scripts/host_frame.py);
     // SDFHIP_HOST_BANDS=n sets the number, 0 = the plain form (no tile order either)
-    const char *hb = getenv("SDFHIP_HOST_BANDS");
+    const char *hb = lab_env("SDFHIP_HOST_BANDS");
     // (any flag beyond the output mode -- counting, compaction, the experiments build's A/B knobs -- takes the plain form)
     const bool viewer = !stats && !(flags & ~(uint32_t)(SDFHIP_KERNEL_MASK | SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG | SDFHIP_FLAG_TILE_ORDER)) &&
                         !(hb && atoi(hb) == 0);

@@ -25,6 +25,7 @@ struct sdfhip_scene {
     // Same cells, same cursor; built by sdfhip_scene_prepare_path or on the first path-traced render.
     sdfhip::TopCell *d_top2 = nullptr, *d_fine2 = nullptr;
     int top2_level = 0, fine2_bits = 0, fine2_order = 0, scatter_tried = 0;
+    int opt_scatter_grid = -1, opt_scatter_order = -1;   // sdfhip_upload_options (-1: choose)
     uint64_t top2_bytes = 0;
     size_t total_mem = 0;
     uint32_t *d_verdict = nullptr;    // k_validate's two words (upload)

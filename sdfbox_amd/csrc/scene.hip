@@ -128,13 +128,40 @@ bool sdfhip::build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_
 extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uint8_t *values,
                                    uint32_t n, sdfhip_scene **out)
 {
-    return sdfhip::scene_from_arrays(device, structs, values, n, false, out);
+    return sdfhip::scene_from_arrays(device, structs, values, n, false, nullptr, out);
+}
+
+extern "C" void sdfhip_upload_options_default(sdfhip_upload_options *opt)
+{
+    if (!opt) return;
+    opt->size = (uint32_t)sizeof *opt;
+    opt->top_grid_level = opt->top_grid_split = opt->scatter_grid = opt->scatter_order = -1;
+}
+
+extern "C" int sdfhip_scene_upload_ex(int device, const int32_t *structs, const uint8_t *values, uint32_t n,
+                                      const sdfhip_upload_options *opt, sdfhip_scene **out)
+{
+    if (opt && opt->size != sizeof *opt)
+        return fail(SDFHIP_ERR_ARG, "scene_upload_ex: options of %u bytes (this library's are %zu: start from sdfhip_upload_options_default)", opt->size, sizeof *opt);
+    if (opt && (opt->top_grid_level < -1 || opt->top_grid_level > 10 || opt->top_grid_split < -1 || opt->top_grid_split > 8 ||
+                opt->scatter_grid < -1 || opt->scatter_grid > 4 || opt->scatter_order < -1 || opt->scatter_order > 1))
+        return fail(SDFHIP_ERR_ARG, "scene_upload_ex: an option out of range (top_grid_level -1..10, top_grid_split -1..8, scatter_grid -1..4, scatter_order -1..1)");
+    return sdfhip::scene_from_arrays(device, structs, values, n, false, opt, out);
 }
 
 // structs / values on the host (sdfhip_scene_upload), or already in `device`'s memory (sdfhip_sdfgen_scene: the tree the GPU
 // builder has just made never leaves HBM)
-int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t *values, uint32_t n, bool resident, sdfhip_scene **out)
+int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t *values, uint32_t n, bool resident, const sdfhip_upload_options *opt,
+                              sdfhip_scene **out)
 {
+    // the grid choices: the caller's (sdfhip_scene_upload_ex), else -- laboratory library only -- the environment's, else ours
+    auto choice = [](int32_t given, const char *env_name, int lo, int hi) {
+        if (given >= 0) return (int)given;
+        if (const char *e = lab_env(env_name)) { const int v = atoi(e); if (v >= lo && v <= hi) return v; }
+        return -1;
+    };
+    const int opt_level = choice(opt ? opt->top_grid_level : -1, "SDFHIP_TOP_GRID_LEVEL", 0, 10);
+    const int opt_split = choice(opt ? opt->top_grid_split : -1, "SDFHIP_TOP_GRID_SPLIT", 0, 8);
     if (!structs || !values || !out || n == 0)
         return fail(SDFHIP_ERR_ARG, "scene_upload: null argument or empty scene");
     *out = nullptr;
@@ -157,6 +184,8 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
     s->device = device; s->n = n;                                       // (depth and stack_ok are set once the tree has been validated, below)
     s->total_mem = prop.totalGlobalMem;
     s->cu_count = prop.multiProcessorCount;
+    s->opt_scatter_grid = opt ? opt->scatter_grid : -1;
+    s->opt_scatter_order = opt ? opt->scatter_order : -1;
 
     void *d_s = nullptr, *d_v = nullptr;
     auto bail = [&](hipError_t e, const char *what) {
@@ -231,8 +260,7 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
     // default no larger than the tree's own records (16 bytes per cell and per node; at least 64 KB); 0 = none.
     int top_level = 0;
     const uint64_t dense_bytes = depth <= 10 ? ((uint64_t)sizeof(TopCell) << (3 * depth)) : ~0ull;
-    const char *env_level = getenv("SDFHIP_TOP_GRID_LEVEL");
-    const bool dense_asked = env_level && atoi(env_level) >= (int)depth && dense_bytes <= prop.totalGlobalMem / FULL_GRID_SHARE;
+    const bool dense_asked = opt_level >= (int)depth && dense_bytes <= prop.totalGlobalMem / FULL_GRID_SHARE;
     if (depth >= 1 && depth <= 10 && (dense_bytes <= DENSE_GRID_MAX_BYTES || dense_asked)) {
         top_level = (int)depth;
     } else {
@@ -241,15 +269,12 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
                (sizeof(TopCell) << (3 * (top_level + 1))) <= budget)
             top_level++;
     }
-    if (const char *env = getenv("SDFHIP_TOP_GRID_LEVEL")) {
-        const int v = atoi(env);
-        if (v >= 0 && v <= 10) top_level = v < (int)depth ? v : (int)depth;
-    }
+    if (opt_level >= 0) top_level = opt_level < (int)depth ? opt_level : (int)depth;
     // Split grid for trees too deep for a dense grid of their depth (10-12 levels): a dense coarse level C whose
     // internal cells point at dense blocks of the remaining FB = depth - C levels.  Every leaf is one or two
     // loads away (CursorF kernels), the coarse level stays cache-resident, and the blocks exist only where the
-    // tree is deep.  Taken when the blocks fit 1/16 of the device's memory; SDFHIP_TOP_GRID_SPLIT=C forces a
-    // coarse level (0 = never).
+    // tree is deep.  Taken when the blocks fit 1/16 of the device's memory; sdfhip_upload_options.top_grid_split
+    // forces a coarse level (0 = never).
     int split = 0;
     if ((uint32_t)top_level < depth && depth <= (uint32_t)LM) {
         // coarse level: as deep as 8, no larger than the tree's own records, leaving at most 4 levels to the blocks
@@ -258,11 +283,8 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
         while (C < MAX_TOP_LEVEL && C + 1 < (int)depth && (sizeof(TopCell) << (3 * (C + 1))) <= budget) C++;
         if (C >= 1 && (int)depth - C <= 4) split = C;
     }
-    if (const char *env = getenv("SDFHIP_TOP_GRID_SPLIT")) {
-        const int v = atoi(env);
-        split = (v >= 1 && v < (int)depth && (int)depth - v <= 6 && v <= 8) ? v : 0;
-    }
-    if (getenv("SDFHIP_TOP_GRID_LEVEL")) split = getenv("SDFHIP_TOP_GRID_SPLIT") ? split : 0;   // an explicit level means a plain grid
+    if (opt_split >= 0) split = (opt_split >= 1 && opt_split < (int)depth && (int)depth - opt_split <= 6 && opt_split <= 8) ? opt_split : 0;
+    if (opt_level >= 0) split = opt_split >= 0 ? split : 0;       // an explicit level means a plain grid
     bool split_built = false;
     if (s->stack_ok && split > 0) {
         TopCell *coarse = nullptr, *fine = nullptr;
@@ -338,15 +360,17 @@ void sdfhip::ensure_scatter_grid(sdfhip_scene *s)
     if (s->scatter_tried) return;
     s->scatter_tried = 1;
     if (!s->stack_ok || !s->d_top || !((s->fine_bits && s->d_fine) || (uint32_t)s->top_level >= s->depth)) return;   // the pipeline needs a full-depth grid
-    const char *env = getenv("SDFHIP_SCATTER_GRID");
     // blocks of 8^FB fine cells; 0 = off.  Default 16^3-cell blocks (64 KB each) for trees of depth 6 and more: cfg-5 21.9 ms
     // against 22.3 with 8^3 (and 24.6 with 4^3) for 1.00 instead of 0.83 GB at depth 9, on a 288 GB device
-    // (without the variable, blocks that do not fit the memory share fall back to the next smaller size)
-    for (int FB = env ? atoi(env) : ((int)s->depth >= 6 ? 4 : 3); FB >= 1; FB = env ? 0 : FB - 1) {
+    // (unless a size was asked for, blocks that do not fit the memory share fall back to the next smaller size)
+    int asked = s->opt_scatter_grid, order = s->opt_scatter_order;
+    if (asked < 0) if (const char *e = lab_env("SDFHIP_SCATTER_GRID")) asked = atoi(e);
+    if (order < 0) if (const char *e = lab_env("SDFHIP_SCATTER_ORDER")) order = atoi(e);
+    for (int FB = asked >= 0 ? asked : ((int)s->depth >= 6 ? 4 : 3); FB >= 1; FB = asked >= 0 ? 0 : FB - 1) {
         if (!(FB <= 4 && (int)s->depth - FB >= 1 && (int)s->depth - FB <= MAX_TOP_LEVEL)) continue;
         if (s->fine_bits && s->top_level == (int)s->depth - FB) return;            // the scene's own grid is that grid
         uint64_t fbytes = 0;
-        s->fine2_order = (FB >= 2 && !(getenv("SDFHIP_SCATTER_ORDER") && atoi(getenv("SDFHIP_SCATTER_ORDER")) == 0)) ? 1 : 0;
+        s->fine2_order = (FB >= 2 && order != 0) ? 1 : 0;
         if (build_split_grid(s, (int)s->depth - FB, FB, s->fine2_order, s->total_mem / 32, &s->d_top2, &s->d_fine2, &fbytes)) {
             s->top2_level = (int)s->depth - FB; s->fine2_bits = FB;
             s->top2_bytes = ((uint64_t)sizeof(TopCell) << (3 * s->top2_level)) + fbytes;

@@ -851,7 +851,7 @@ struct Arena {
                 if (g_pool.trim(device) == 0 || hipMalloc(&p, size) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
             }
             const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (ms > 5.0f && getenv("SDFHIP_GEN_LEVELS")) fprintf(stderr, "sdfgen: hipMalloc(%zu MB) took %.1f ms\n", size >> 20, ms);
+            if (ms > 5.0f && lab_env("SDFHIP_GEN_LEVELS")) fprintf(stderr, "sdfgen: hipMalloc(%zu MB) took %.1f ms\n", size >> 20, ms);
         }
         chunks.push_back(Chunk{ (char *)p, size, bytes });
         grow = grow < ((size_t)1 << 30) ? grow * 2 : grow;
@@ -960,10 +960,10 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
         size_t total_nodes = 0;
         unsigned long long cand_entries = n, list_entries = n;      // all lists so far; the lists of the level at hand
         // (SDFHIP_GEN_WIDE=n: the sibling-block form from n nodes on -- tests set 8 to run small trees through it)
-        const bool wide_forced = getenv("SDFHIP_GEN_WIDE") != nullptr;
-        const uint32_t wide_level = wide_forced ? (uint32_t)atoi(getenv("SDFHIP_GEN_WIDE")) : WIDE_LEVEL;
-        const uint32_t seg_target = getenv("SDFHIP_GEN_SEGS") ? (uint32_t)max(1, atoi(getenv("SDFHIP_GEN_SEGS"))) : 4096u;
-        const bool level_timing = getenv("SDFHIP_GEN_LEVELS") != nullptr;      // debug aid: nodes, entries and time of every level on stderr
+        const bool wide_forced = lab_env("SDFHIP_GEN_WIDE") != nullptr;
+        const uint32_t wide_level = wide_forced ? (uint32_t)atoi(lab_env("SDFHIP_GEN_WIDE")) : WIDE_LEVEL;
+        const uint32_t seg_target = lab_env("SDFHIP_GEN_SEGS") ? (uint32_t)max(1, atoi(lab_env("SDFHIP_GEN_SEGS"))) : 4096u;
+        const bool level_timing = lab_env("SDFHIP_GEN_LEVELS") != nullptr;      // debug aid: nodes, entries and time of every level on stderr
         for (int lvl = 0;; lvl++) {
             auto tl = std::chrono::steady_clock::now();
             Arena &mine = scratch[lvl & 1], &other = scratch[(lvl + 1) & 1];
@@ -1046,7 +1046,7 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             n_nodes = (uint32_t)(8 * n_split);
         }
 
-        const bool timing = getenv("SDFHIP_GEN_TIMING") != nullptr;       // debug aid: phase times on stderr
+        const bool timing = lab_env("SDFHIP_GEN_TIMING") != nullptr;       // debug aid: phase times on stderr
         auto lap = [&](const char *what) {
             if (!timing) return;
             (void)hipDeviceSynchronize();
@@ -1088,7 +1088,7 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             // the viewer's generate -> upload flow (Program.cs:613-650 -> :147-152) without the round trip: the scene's records
             // and grids are made from the arrays the builder has just written (12 ms of copy to the host and 8 ms back, at depth 10)
             GEN_TRY(hipDeviceSynchronize());
-            const int rc = sdfhip::scene_from_arrays(device, d_S, d_V, (uint32_t)total_nodes, true, scene_out);
+            const int rc = sdfhip::scene_from_arrays(device, d_S, d_V, (uint32_t)total_nodes, true, nullptr, scene_out);
             if (rc != SDFHIP_OK) return rc;
             lap("scene made on the device");
         }

@@ -3,6 +3,7 @@
 #include "../../include/sdfhip.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 namespace sdfhip {
 
@@ -11,8 +12,18 @@ namespace sdfhip {
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void clear_error();
 
-// sdfhip_scene_upload, or the same from arrays that are already in `device`'s memory (sdfhip_device.hip)
-int scene_from_arrays(int device, const int32_t *structs, const uint8_t *values, uint32_t n, bool resident, sdfhip_scene **out);
+// A measurement or test knob of the environment: read by the laboratory library only.  The product takes its choices through
+// its ABI (sdfhip_upload_options, sdfhip_multi_configure) and reads four variables in all, each named in include/sdfhip.h:
+// SDFHIP_MULTI_TRANSPORT, SDFHIP_RCCL_LIB, SDFHIP_MULTI_RCCL_SELF (the RCCL transport's self-test on one device), SDFHIP_GEN_POOL.
+#ifdef SDFHIP_EXPERIMENTS
+inline const char *lab_env(const char *name) { return getenv(name); }
+#else
+inline const char *lab_env(const char *) { return nullptr; }
+#endif
+
+// sdfhip_scene_upload[_ex], or the same from arrays that are already in `device`'s memory (sdfhip_sdfgen_scene); opt may be null
+int scene_from_arrays(int device, const int32_t *structs, const uint8_t *values, uint32_t n, bool resident, const sdfhip_upload_options *opt,
+                      sdfhip_scene **out);
 // true when find() on this scene is a grid lookup (a dense grid as deep as the tree, or a split one): the default kernel
 // k_march renders it and can write sparse wire shares (sdfhip_render_sparse_device)
 bool scene_has_full_depth_grid(const sdfhip_scene *scene);

@@ -648,8 +648,8 @@ extern "C" int sdfhip_multi_create(const int *devices, uint32_t n_devices, const
     if (!m) return fail(SDFHIP_ERR_NOMEM, "multi_create: out of host memory");
     m->n = n_devices;
     for (uint32_t r = 0; r < MAX_RANKS; r++) { m->devices[r] = r < n_devices ? devices[r] : 0; m->scenes[r] = nullptr; m->workers[r] = nullptr; m->est[r] = 0; m->comms[r] = nullptr; }
-    if (const char *e = getenv("SDFHIP_MULTI_BAND_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096 && v % 8 == 0) m->band_rows = (uint32_t)v; }
-    if (const char *e = getenv("SDFHIP_MULTI_RANK0_WEIGHT")) { const float v = (float)atof(e); if (v > 0.0f && v <= 1.0f) m->rank0_weight = v; }
+    if (const char *e = lab_env("SDFHIP_MULTI_BAND_ROWS")) { const int v = atoi(e); if (v >= 8 && v <= 4096 && v % 8 == 0) m->band_rows = (uint32_t)v; }
+    if (const char *e = lab_env("SDFHIP_MULTI_RANK0_WEIGHT")) { const float v = (float)atof(e); if (v > 0.0f && v <= 1.0f) m->rank0_weight = v; }
     auto bail = [&](int rc) { char msg[256]; strncpy(msg, sdfhip_last_error(), sizeof msg - 1); msg[sizeof msg - 1] = 0; sdfhip_multi_free(m); return fail(rc, "%s", msg); };
     for (uint32_t r = 1; r < n_devices; r++) {
         Worker *w = new (std::nothrow) Worker();

@@ -56,12 +56,20 @@ class Scene:
     """A scene resident in one GPU's HBM (replaces the `data` / `values`
     bindings of Program.cs:147-152)."""
 
-    def __init__(self, octdata, device=0):
+    def __init__(self, octdata, device=0, top_grid_level=None, top_grid_split=None, scatter_grid=None, scatter_order=None):
+        """top_grid_level / top_grid_split / scatter_grid / scatter_order: sdfhip_upload_options (None = the upload chooses):
+        a plain lookup grid of that level (0 = none), a split grid with that coarse level (0 = never), the levels of the
+        path-traced mode's second grid's blocks (0 = none) and 0 for its blocks in x-y-z order.  Pixels never depend on them."""
         self._h = ctypes.c_void_p()
         self.device = int(device)
-        check(lib.sdfhip_scene_upload(self.device, octdata.Structs.ctypes.data,
-                                      octdata.Values.ctypes.data, octdata.Length,
-                                      ctypes.byref(self._h)))
+        if (top_grid_level, top_grid_split, scatter_grid, scatter_order) == (None, None, None, None):
+            check(lib.sdfhip_scene_upload(self.device, octdata.Structs.ctypes.data,
+                                          octdata.Values.ctypes.data, octdata.Length,
+                                          ctypes.byref(self._h)))
+        else:
+            opt = _lib.UploadOptions(top_grid_level, top_grid_split, scatter_grid, scatter_order)
+            check(lib.sdfhip_scene_upload_ex(self.device, octdata.Structs.ctypes.data, octdata.Values.ctypes.data, octdata.Length,
+                                             ctypes.byref(opt), ctypes.byref(self._h)))
         self._describe()
 
     def _describe(self):

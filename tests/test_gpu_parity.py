@@ -350,29 +350,20 @@ def test_path_traced_mode(sb, oracle_mod, scenes, gpu_scenes, kernel):
 
 @pytest.mark.parametrize("blocks,order", [("0", "1"), ("1", "1"), ("2", "1"), ("2", "0"), ("3", "1"), ("4", "1"), ("4", "0")])
 def test_path_traced_mode_through_every_scatter_grid(sb, oracle_mod, scenes, blocks, order):
-    # The bounce levels of the path-traced pipeline read a split grid of their own (SDFHIP_SCATTER_GRID: the levels inside a block,
-    # 0 = the scene's grid; SDFHIP_SCATTER_ORDER: blocks stored sub-cube by sub-cube or in x-y-z order).  Whatever the grid, the frame
-    # is the oracle's.  (The knobs are read when the scatter grid is built: a handle of its own per setting.)
+    # The bounce levels of the path-traced pipeline read a split grid of their own (sdfhip_upload_options.scatter_grid: the levels inside
+    # a block, 0 = the scene's grid; scatter_order: blocks stored sub-cube by sub-cube or in x-y-z order).  Whatever the grid, the frame
+    # is the oracle's.
     od = scenes["torus_d6"]
     W, H = 61, 37
     cam = make_camera("rotated", W, H)
     pt = sb.PathTrace(spp=8, max_bounces=3)
     ref, cnt = oracle_mod.render_pt(od.Structs, od.Values, cam.State, W, H, spp=pt.spp, max_bounces=pt.max_bounces, seed=pt.seed,
                                     albedo=pt.albedo, nthreads=8)
-    prev = {k: os.environ.get(k) for k in ("SDFHIP_SCATTER_GRID", "SDFHIP_SCATTER_ORDER")}
-    os.environ["SDFHIP_SCATTER_GRID"] = blocks; os.environ["SDFHIP_SCATTER_ORDER"] = order
-    try:
-        with sb.Scene(od) as sc:
-            img, st = sc.DrawPath(cam, W, H, pt, flags=sb.FLAG_COUNT, want_stats=True)
-            assert_frames_identical(img, ref, f"scatter grid {blocks} order {order}, counting")
-            assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
-            assert_frames_identical(sc.DrawPath(cam, W, H, pt), ref, f"scatter grid {blocks} order {order}")
-    finally:
-        for k, v in prev.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    with sb.Scene(od, scatter_grid=int(blocks), scatter_order=int(order)) as sc:
+        img, st = sc.DrawPath(cam, W, H, pt, flags=sb.FLAG_COUNT, want_stats=True)
+        assert_frames_identical(img, ref, f"scatter grid {blocks} order {order}, counting")
+        assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
+        assert_frames_identical(sc.DrawPath(cam, W, H, pt), ref, f"scatter grid {blocks} order {order}")
 
 
 def test_path_traced_bounce_levels_ordered_by_key(sb, oracle_mod, scenes):
@@ -649,19 +640,14 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
     od6 = scenes["torus_d6"]
     cases = [(scenes["sphere_d4"], "default"), (od6, "rotated"), (od6, "closeup")]
     W, H = 96, 80
-    prev = os.environ.get("SDFHIP_TOP_GRID_LEVEL")
-    try:
+    if True:
         for od, camname in cases:
             cam = make_camera(camname, W, H)
             ongrid = sb.Logic(W, H); ongrid.Position = (0.25, 0.5, -0.125); ongrid.Heading = (0.0, 0.0)   # rays along cell faces
             refs = [oracle_mod.render(od.Structs, od.Values, c.State, W, H) for c in (cam, ongrid)]
             levels_seen = set()
-            for lv in ("0", "1", "2", "3", "4", "5", "6", None):
-                if lv is None:
-                    os.environ.pop("SDFHIP_TOP_GRID_LEVEL", None)
-                else:
-                    os.environ["SDFHIP_TOP_GRID_LEVEL"] = lv
-                with sb.Scene(od) as scene:
+            for lv in (0, 1, 2, 3, 4, 5, 6, None):
+                with sb.Scene(od, top_grid_level=lv) as scene:
                     levels_seen.add(scene.top_grid_level)
                     assert scene.top_grid_level <= scene.depth
                     assert scene.top_grid_bytes == (16 << (3 * scene.top_grid_level) if scene.top_grid_level else 0)
@@ -682,13 +668,11 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
                         assert_frames_identical(pimg, pref, f"top grid {lv}, path-traced")
             assert len(levels_seen) >= 4
             # split grids: a coarse dense level whose internal cells point at blocks of finer cells
-            os.environ.pop("SDFHIP_TOP_GRID_LEVEL", None)
-            for sp in ("1", "2", "3", "5"):
-                if int(sp) >= od_depth(sb, od):
+            for sp in (1, 2, 3, 5):
+                if sp >= od_depth(sb, od):
                     continue
-                os.environ["SDFHIP_TOP_GRID_SPLIT"] = sp
-                try:
-                    with sb.Scene(od) as scene:
+                if True:
+                    with sb.Scene(od, top_grid_split=sp) as scene:
                         assert scene.top_grid_level == int(sp) and scene.top_grid_bytes >= 16 << (3 * int(sp))
                         for c, (ref, cnt) in zip((cam, ongrid), refs):
                             for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT) + ((sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL,) if sb._lib.EXPERIMENTS else ()):
@@ -701,13 +685,6 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
                             pimg = scene.DrawPath(c, W, H, pt=sb.PathTrace(spp=2))
                             pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
                             assert_frames_identical(pimg, pref, f"split grid {sp}, path-traced")
-                finally:
-                    os.environ.pop("SDFHIP_TOP_GRID_SPLIT", None)
-    finally:
-        if prev is None:
-            os.environ.pop("SDFHIP_TOP_GRID_LEVEL", None)
-        else:
-            os.environ["SDFHIP_TOP_GRID_LEVEL"] = prev
 
 
 def od_depth(sb, od):
@@ -883,11 +860,8 @@ def test_tile_order_flag_changes_no_pixel(sb, oracle_mod, scenes, split):
     # took would show
     import torch
     od = scenes["torus_d6"]
-    prev = os.environ.get("SDFHIP_TOP_GRID_SPLIT")
-    if split is not None:
-        os.environ["SDFHIP_TOP_GRID_SPLIT"] = split
-    try:
-        with sb.Scene(od) as sc:
+    if True:
+        with sb.Scene(od, top_grid_split=None if split is None else int(split)) as sc:
             F = sb.KERNEL_STACK | sb.FLAG_TILE_ORDER
             streams = [torch.cuda.Stream(), torch.cuda.Stream()]
             refs = {}
@@ -926,11 +900,6 @@ def test_tile_order_flag_changes_no_pixel(sb, oracle_mod, scenes, split):
                 sc.DrawDevice(make_camera("closeup", W, H), W, H, buf.data_ptr(), nrows_out=len(rows), band_rows=16, band_first=first, band_stride=2, flags=F)
                 torch.cuda.synchronize()
                 assert_frames_identical(buf.cpu().numpy(), whole[rows], f"tile order, bands from {first}")
-    finally:
-        if prev is None:
-            os.environ.pop("SDFHIP_TOP_GRID_SPLIT", None)
-        else:
-            os.environ["SDFHIP_TOP_GRID_SPLIT"] = prev
 
 
 def test_frames_in_flight_on_one_handle_do_not_share_scratch(sb, oracle_mod, scenes, gpu_scenes):
@@ -1238,17 +1207,13 @@ def test_pre_decoded_cells_of_split_grids(sb, oracle_mod, seed):
         if kind != 5:
             cam.Heading = (float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-3, 3)))
         cams.append(cam)
-    prev = os.environ.get("SDFHIP_TOP_GRID_SPLIT")
     os.environ["SDFHIP_SAMPLE_RECORDS"] = "1"
     try:
         for fb in (0, 1, 2, 3, 4):
             if depth - fb < 1:
                 continue
-            if fb:
-                os.environ["SDFHIP_TOP_GRID_SPLIT"] = str(depth - fb)
-            else:
-                os.environ.pop("SDFHIP_TOP_GRID_SPLIT", None)        # fb 0: the tree's default grid (dense up to depth 8)
-            with sb.Scene(od) as sc:
+            # (fb 0: the tree's default grid, dense up to depth 8)
+            with sb.Scene(od, top_grid_split=(depth - fb) if fb else None) as sc:
                 if fb and sc.depth <= depth - fb:
                     continue
                 if fb:
@@ -1263,10 +1228,6 @@ def test_pre_decoded_cells_of_split_grids(sb, oracle_mod, seed):
                     assert (sc.DrawDisplay(cam, W, H) == sc.DrawDisplay(cam, W, H, flags=sb._lib.TUNE_BYTE_CELLS)).all()
     finally:
         os.environ.pop("SDFHIP_SAMPLE_RECORDS", None)
-        if prev is None:
-            os.environ.pop("SDFHIP_TOP_GRID_SPLIT", None)
-        else:
-            os.environ["SDFHIP_TOP_GRID_SPLIT"] = prev
 
 
 # SDFHIP_FUZZ_SEEDS=n runs n seeds instead of 6 (a one-off campaign; the committed default stays small)
@@ -1317,19 +1278,43 @@ def test_fuzz_random_trees_and_on_grid_cameras(sb, oracle_mod, seed):
                     assert (pst.n_nodes, pst.n_samples, pst.n_steps, pst.n_shadow_rays) == tuple(int(c) for c in pcnt), (seed, kern)
                     assert_frames_identical(sc.DrawPath(cam, W, H, pt=sb.PathTrace(spp=2), flags=kern), pref, f"seed {seed} path-traced, not counting")
     if depth >= 7:           # the same tree behind a split grid (what trees of depth 10-12 get when they are large)
-        prev = os.environ.get("SDFHIP_TOP_GRID_SPLIT")
-        os.environ["SDFHIP_TOP_GRID_SPLIT"] = str(min(8, depth - int(rng.integers(1, 5))))
-        try:
-            with sb.Scene(od) as sc:
-                if sc.depth > int(os.environ["SDFHIP_TOP_GRID_SPLIT"]):     # a random tree may be shallower than asked
+        coarse = min(8, depth - int(rng.integers(1, 5)))
+        if True:
+            with sb.Scene(od, top_grid_split=coarse) as sc:
+                if sc.depth > coarse:     # a random tree may be shallower than asked
                     for ci, cam in enumerate(cams[:3]):
                         ref, cnt = oracle_mod.render(s, v, cam.State, W, H, nthreads=8)
                         img, st = sc.Draw(cam, W, H, sb.FLAG_COUNT, want_stats=True)
                         assert_frames_identical(img, ref, f"seed {seed} cam {ci} split grid")
                         assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), (seed, ci)
                         assert_frames_identical(sc.Draw(cam, W, H), ref, f"seed {seed} cam {ci} split grid, not counting")
-        finally:
-            if prev is None:
-                os.environ.pop("SDFHIP_TOP_GRID_SPLIT", None)
-            else:
-                os.environ["SDFHIP_TOP_GRID_SPLIT"] = prev
+
+
+def test_upload_options_are_arguments_and_the_environment_is_the_laboratorys(sb, scenes, monkeypatch):
+    # sdfhip_scene_upload_ex: the grid choices as arguments (checked: size, ranges); the measurement knobs of the environment
+    # (SDFHIP_TOP_GRID_LEVEL ...) are defaults of those options in the laboratory library only -- the product does not read them
+    import ctypes
+    od = scenes["torus_d6"]
+    with sb.Scene(od) as sc:
+        assert sc.top_grid_level == sc.depth == 6                       # the default for a shallow tree: a dense grid as deep as the tree
+    with sb.Scene(od, top_grid_level=3) as sc:
+        assert sc.top_grid_level == 3 and sc.top_grid_bytes == 16 << 9
+    with sb.Scene(od, top_grid_level=0) as sc:
+        assert sc.top_grid_level == 0 and sc.top_grid_bytes == 0
+    with sb.Scene(od, top_grid_split=4) as sc:
+        assert sc.top_grid_level == 4 and sc.top_grid_bytes > 16 << 12
+    monkeypatch.setenv("SDFHIP_TOP_GRID_LEVEL", "2")
+    with sb.Scene(od) as sc:
+        assert sc.top_grid_level == (2 if sb._lib.EXPERIMENTS else 6)
+    with sb.Scene(od, top_grid_level=4) as sc:                          # an argument goes before the environment
+        assert sc.top_grid_level == 4
+    monkeypatch.delenv("SDFHIP_TOP_GRID_LEVEL")
+    L = sb._lib
+    h = ctypes.c_void_p()
+    opt = L.UploadOptions(top_grid_level=11)
+    assert L.lib.sdfhip_scene_upload_ex(0, od.Structs.ctypes.data, od.Values.ctypes.data, od.Length, ctypes.byref(opt), ctypes.byref(h)) == L.ERR_ARG
+    opt = L.UploadOptions(); opt.size = 8
+    assert L.lib.sdfhip_scene_upload_ex(0, od.Structs.ctypes.data, od.Values.ctypes.data, od.Length, ctypes.byref(opt), ctypes.byref(h)) == L.ERR_ARG
+    d = L.UploadOptions(1, 2, 3, 0)
+    L.lib.sdfhip_upload_options_default(ctypes.byref(d))
+    assert (d.size, d.top_grid_level, d.top_grid_split, d.scatter_grid, d.scatter_order) == (ctypes.sizeof(L.UploadOptions), -1, -1, -1, -1)
