@@ -169,6 +169,15 @@ public:
         if (scene) sdfhip_scene_free(scene);
         scene = fresh;
     }
+    // ... with the upload's choices taken by the host (sdfhip_upload_options: start from sdfhip_upload_options_default, -1 = choose):
+    // e.g. top_grid_level = 0 for no lookup grid at all on a device short of memory
+    void Load(const OctData &model, const sdfhip_upload_options &options)
+    {
+        sdfhip_scene *fresh = nullptr;
+        Check(sdfhip_scene_upload_ex(device, &model.Structs[0].Parent, model.Values.data(), (uint32_t)model.Length(), &options, &fresh));
+        if (scene) sdfhip_scene_free(scene);
+        scene = fresh;
+    }
     // Draw's UpdateBuffer(info) + DispatchSized(W, H, 1), Program.cs:81,94 -> RGBA32F frame
     void Draw(const Info &state, int width, int height, std::vector<float> &frame, uint32_t flags = 0)
     {

@@ -59,6 +59,16 @@ int main(int argc, char **argv)
         }
         program.Load(model);                       // reload swaps the scene (Program.cs:59-65)
         program.Draw(logic.State, W, H, frame);
+        {   // the upload's choices as arguments: no lookup grid at all (the cursor-stack kernel walks the tree) gives the same frame
+            sdfhip_upload_options opt;
+            sdfhip_upload_options_default(&opt);
+            opt.top_grid_level = 0;
+            program.Load(model, opt);
+            std::vector<float> plain;
+            program.Draw(logic.State, W, H, plain);
+            if (plain.size() != frame.size() || memcmp(plain.data(), frame.data(), frame.size() * 4) != 0) return 20;
+            program.Load(model);
+        }
         {   // the same frame over three ranks (the one GPU named three times): ProgramMulti.Draw is still one call
             ProgramMulti multi({0, 0, 0});
             multi.Load(model);
