@@ -5,7 +5,7 @@ grouped mode (throughput; groups of G frames per launch and gather, four groups 
     T(N) = (s * t1 + E) / N + c_group / (G * 4)
     t1       one GPU, frames in flight, ms per frame                          (bench line)
     s        a rank's march writing a sparse share instead of the frame       ((sharded one-rank line - E) / t1)
-    E        rank 0's expansion of all shares into the frame                  (133 MB at ~4 TB/s per 4K frame, by pixels)
+    E        rank 0's expansion of all shares into the frame                  (133 MB at 5.8 TB/s per 4K frame in groups of four, by pixels)
     the rank-0 weight balances its share against E, so E divides by N as well; c_group = 60 us of host work per group and rank
     (launch, copy, events), G = 4 (8 at N = 8), hidden behind the other groups unless a share takes less.  Links: a rank's share
     is 1.1-1.5 bytes per pixel / N over its own xGMI link (~100 GB/s assumed of 153 peak): 14 us per 4K frame at N = 8 -- beside the march.
@@ -29,7 +29,7 @@ def line(name):
 t1 = {"1080p": line("1080p_default")["ms_per_step"], "4K": line("4k_default")["ms_per_step"], "cfg-5 (4K, 16 spp)": line("cfg5_4k_spp16")["ms_per_step"]}
 lat1 = {"1080p": line("1080p_default")["latency_ms"], "4K": line("4k_default")["latency_ms"], "cfg-5 (4K, 16 spp)": line("cfg5_4k_spp16")["latency_ms"]}
 px = {"1080p": 1920 * 1080, "4K": 3840 * 2160}
-E4k = 0.033
+E4k = 0.0228
 s = (line("sharded_1rank_nccl_4k")["ms_per_step"] - E4k) / t1["4K"]
 f = {1: 0.048 + 0.011, 2: 0.048 + 0.028, 4: 0.048 + 0.042, 8: 0.048 + 0.048}
 chain, link_gbs = 0.10, 100.0

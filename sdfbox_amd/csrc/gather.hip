@@ -47,6 +47,23 @@ int sdfhip::deinterleave_impl(int device, const void *d_gathered, void *d_frame,
         return fail(SDFHIP_ERR_ARG, "deinterleave: rows_per_rank %u < %u needed for %u bands over %u ranks", rows_per_rank, need_rows, nbands, world);
     DeviceGuard g(device);
     if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "deinterleave: hipSetDevice(%d) failed", device);
+    if (nbands <= (uint32_t)MAX_BAND_LIST && world <= 64 && (pixel_bytes == 16 || pixel_bytes == 4)) {
+        // the frame's geometry in the launch grid (k_deinterleave_rows): a round-robin deal gets its band map here
+        if (!M.n) {
+            for (uint32_t b = 0; b < nbands; b++) M.src[b] = (uint16_t)((b % world) << 10 | (b / world));
+            M.n = nbands;
+        }
+        const uint32_t rows_per_block = band_rows % 8u == 0 ? 8u : band_rows, parts = band_rows / rows_per_block;
+        const dim3 grid((width + 255u) / 256u, nbands * parts, frames);
+        if (pixel_bytes == 16)
+            hipLaunchKernelGGL((k_deinterleave_rows<float4>), grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)d_gathered, (float4 *)d_frame,
+                               width, height, band_rows, rows_per_block, parts, rows_per_rank, frames, M, only_rank);
+        else
+            hipLaunchKernelGGL((k_deinterleave_rows<uint32_t>), grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t *)d_gathered, (uint32_t *)d_frame,
+                               width, height, band_rows, rows_per_block, parts, rows_per_rank, frames, M, only_rank);
+        HIP_TRY(hipGetLastError());
+        return SDFHIP_OK;
+    }
     size_t total = (size_t)width * height * frames;
     uint32_t blocks = (uint32_t)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (pixel_bytes == 16)
@@ -139,6 +156,23 @@ extern "C" int sdfhip_deinterleave_sparse2_device(int device, const void *const 
     const uint32_t only = only_rank < 0 ? 0xFFFFFFFFu : (uint32_t)only_rank;
     auto q = [](float c) { float v = powf(c, 1.0f / 2.2f); v = v > 1.0f ? 1.0f : (v > 0.0f ? v : 0.0f); return (uint32_t)(v * 255.0f + 0.5f); };
     const uint32_t sky8 = q(0.005f) | (q(0.01f) << 8) | (q(0.2f) << 16);
+    if (nbands <= (uint32_t)MAX_BAND_LIST) {           // (512 bands x at most band_rows / 8 parts: far inside the grid's 65 535)
+        // the frame's geometry in the launch grid (k_expand_sparse2): a round-robin deal gets its band map here
+        if (!M.n) {
+            for (uint32_t b = 0; b < nbands; b++) M.src[b] = (uint16_t)((b % world) << 10 | (b / world));
+            M.n = nbands;
+        }
+        const uint32_t rows_per_block = band_rows % 8u == 0 ? 8u : band_rows, parts = band_rows / rows_per_block;
+        const dim3 grid((width + 255u) / 256u, nbands * parts, frames);
+        if (flags & SDFHIP_FLAG_DISPLAY_DEBUG)
+            hipLaunchKernelGGL((k_expand_sparse2<OUT_HEAT8>), grid, dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, rows_per_block, parts, world, L, M, only, sky8, counts_out);
+        else if (flags & SDFHIP_FLAG_DISPLAY)
+            hipLaunchKernelGGL((k_expand_sparse2<OUT_GAMMA8>), grid, dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, rows_per_block, parts, world, L, M, only, sky8, counts_out);
+        else
+            hipLaunchKernelGGL((k_expand_sparse2<OUT_RGBA32F>), grid, dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, rows_per_block, parts, world, L, M, only, sky8, counts_out);
+        HIP_TRY(hipGetLastError());
+        return SDFHIP_OK;
+    }
     if (flags & SDFHIP_FLAG_DISPLAY_DEBUG)
         hipLaunchKernelGGL((k_deinterleave_sparse2<OUT_HEAT8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, d_frame, width, height, band_rows, world, L, M, only, sky8, counts_out);
     else if (flags & SDFHIP_FLAG_DISPLAY)

@@ -43,6 +43,26 @@ __global__ void k_deinterleave(const In *__restrict__ gathered, Out *__restrict_
     }
 }
 
+// The same with the frame's geometry in the launch grid (see k_expand_sparse2 below: no division per pixel): workgroup
+// (blockIdx.x, band * parts + part, frame) copies up to rows_per_block rows of 256 neighbouring columns.  Needs the band map.
+template <class T>
+__global__ __launch_bounds__(256) void k_deinterleave_rows(const T *__restrict__ gathered, T *__restrict__ frame, uint32_t width, uint32_t height,
+                                                           uint32_t band_rows, uint32_t rows_per_block, uint32_t parts, uint32_t rows_per_rank,
+                                                           uint32_t frames, const BandMap M, uint32_t only_rank)
+{
+    const uint32_t band = blockIdx.y / parts, part = blockIdx.y - band * parts, f = blockIdx.z, x = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t e = M.src[band];
+    uint32_t rank = e >> 10;
+    const uint32_t lband = e & 1023u;
+    if (only_rank != 0xFFFFFFFFu) { if (rank != only_rank) return; rank = 0; }
+    const uint32_t first = part * rows_per_block, y0 = band * band_rows + first;
+    if (x >= width || y0 >= height) return;
+    const uint32_t rows = min(rows_per_block, height - y0);
+    const T *__restrict__ src = gathered + (((size_t)rank * frames + f) * rows_per_rank + (size_t)lband * band_rows + first) * width + x;
+    T *__restrict__ dst = frame + ((size_t)f * height + y0) * width + x;
+    for (uint32_t j = 0; j < rows; j++) dst[(size_t)j * width] = src[(size_t)j * width];
+}
+
 // rank 0: the sparse shares the ranks' march kernels wrote themselves (OUT_SPARSE, raymarch_kernels.h) -> frames in row
 // order.  One pointer per rank (a rank's share holds all frames of the group; rank 0's own is read where it was rendered).
 // MODE: RGBA32F as Compute.hlsl writes it, or through the display pass (DisplayFrag.hlsl) as RGBA8.
@@ -83,6 +103,59 @@ __global__ __launch_bounds__(256) void k_deinterleave_sparse2(const ShareTable S
         }
         else {
             const float4 v = wire_expand(a, code);
+            uint32_t q;
+            if (MODE == OUT_HEAT8) q = heat8(v.w);
+            else if (code > 140u) q = sky8 | alpha8(v.w);
+            else { const uint32_t g = gamma8(a); q = g | (g << 8) | (g << 16) | alpha8(v.w); }
+            __builtin_nontemporal_store(q, reinterpret_cast<uint32_t *>(frame) + i);
+        }
+    }
+}
+// The same expansion with the frame's geometry in the launch grid instead of in divisions: workgroup (blockIdx.x, band, frame) takes
+// 256 neighbouring columns of one band of one frame and walks the band's rows, so which rank rendered the band, where its rows lie in
+// that rank's share and the tile row are per-workgroup scalars (the per-pixel form above spends five integer divisions, two of them
+// 64-bit, on every pixel -- about as long as the frame's bytes take to write); a tile's mask and slot base are loaded once per eight
+// rows.  Needs the band map (frames of at most MAX_BAND_LIST bands: the host fills it for round-robin deals too).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_expand_sparse2(const ShareTable S, void *__restrict__ frame, uint32_t width, uint32_t height,
+                                                        uint32_t band_rows, uint32_t rows_per_block, uint32_t parts, uint32_t world,
+                                                        Sparse2Layout L, const BandMap M, uint32_t only_rank, uint32_t sky8,
+                                                        uint32_t *__restrict__ counts)
+{
+    if (counts && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < world && S.p[threadIdx.x])
+        counts[threadIdx.x] = *reinterpret_cast<const uint32_t *>(S.p[threadIdx.x]);
+    // blockIdx.y = band * parts + part: a band of 16 rows goes to two workgroups of one tile row each (rows_per_block = 8 when the
+    // bands are whole tile rows, else the band)
+    const uint32_t band = blockIdx.y / parts, part = blockIdx.y - band * parts, f = blockIdx.z, x = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t e = M.src[band], rank = e >> 10, lband = e & 1023u;
+    if (only_rank != 0xFFFFFFFFu && rank != only_rank) return;
+    const uint32_t first = part * rows_per_block, y0 = band * band_rows + first;
+    if (x >= width || y0 >= height) return;
+    const uint8_t *__restrict__ src = S.p[rank];
+    const uint32_t rows = min(rows_per_block, height - y0), yl0 = lband * band_rows + first;
+    const unsigned long long *__restrict__ masks = reinterpret_cast<const unsigned long long *>(src + L.off_masks);
+    const uint32_t *__restrict__ bases = reinterpret_cast<const uint32_t *>(src + L.off_bases);
+    const float *__restrict__ floats = reinterpret_cast<const float *>(src + L.off_floats);
+    const size_t ft0 = (size_t)f * L.tiles + (x >> 3);
+    size_t i = ((size_t)f * height + y0) * width + x;
+    unsigned long long m = 0;
+    uint32_t base = 0;
+    for (uint32_t j = 0; j < rows; j++, i += width) {
+        const uint32_t yl = yl0 + j;
+        const size_t ft = ft0 + (size_t)(yl >> 3) * L.tiles_x;
+        if (j == 0 || (yl & 7u) == 0) { m = masks[ft]; base = bases[ft]; }
+        const uint32_t bit = (yl & 7u) * 8u + (x & 7u);
+        const uint32_t code = src[L.off_codes + ft * 64 + bit];
+        float a = 0.0f;
+        if ((m >> bit) & 1ull) {
+            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << bit) - 1ull));
+            if (slot < L.capacity) a = floats[slot];
+        }
+        const float4 v = wire_expand(a, code);
+        if (MODE == OUT_RGBA32F) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(frame) + i);
+        } else {
             uint32_t q;
             if (MODE == OUT_HEAT8) q = heat8(v.w);
             else if (code > 140u) q = sky8 | alpha8(v.w);
