@@ -66,7 +66,7 @@ template <int CUR, bool COUNT>
 void launch_queued(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, const RenderParams &P)
 {
     auto go = [&](auto march, auto shade) {
-        hipLaunchKernelGGL(march, grid, dim3(64), 0, st, P);
+        hipLaunchKernelGGL(march, march_grid(P, grid), dim3(64), 0, st, P);
         hipLaunchKernelGGL(shade, shade_grid, dim3(64), 0, st, P);
     };
     if (mode == OUT_RGBA32F)     go(k_march<CUR, COUNT, OUT_RGBA32F, true>, k_shadow<CUR, COUNT, OUT_RGBA32F>);
@@ -79,17 +79,17 @@ void launch_queued(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, co
 template <int CUR, bool COUNT>
 void launch_march_wire(dim3 grid, hipStream_t st, const RenderParams &P)
 {
-    hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_WIRE, false>), grid, dim3(64), 0, st, P);
+    hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_WIRE, false>), march_grid(P, grid), dim3(64), 0, st, P);
 }
 
 // the default kernel through the grid's second form, 4-byte words + sample records (CursorFF): not counting, shadow rays marched in the wave
 void launch_fast(uint32_t mode, dim3 grid, hipStream_t st, const RenderParams &P)
 {
-    if (mode == OUT_RGBA32F)     hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_RGBA32F, false>), grid, dim3(64), 0, st, P);
-    else if (mode == OUT_GAMMA8) hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_GAMMA8, false>), grid, dim3(64), 0, st, P);
-    else if (mode == OUT_HEAT8)  hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_HEAT8, false>), grid, dim3(64), 0, st, P);
-    else if (mode == OUT_SPARSE) hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_SPARSE, false>), grid, dim3(64), 0, st, P);
-    else                         hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_WIRE, false>), grid, dim3(64), 0, st, P);
+    if (mode == OUT_RGBA32F)     hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_RGBA32F, false>), march_grid(P, grid), dim3(64), 0, st, P);
+    else if (mode == OUT_GAMMA8) hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_GAMMA8, false>), march_grid(P, grid), dim3(64), 0, st, P);
+    else if (mode == OUT_HEAT8)  hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_HEAT8, false>), march_grid(P, grid), dim3(64), 0, st, P);
+    else if (mode == OUT_SPARSE) hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_SPARSE, false>), march_grid(P, grid), dim3(64), 0, st, P);
+    else                         hipLaunchKernelGGL((k_march<CUR_DENSE4, false, OUT_WIRE, false>), march_grid(P, grid), dim3(64), 0, st, P);
 }
 
 // round 1's one-kernel form for any cursor and workgroup size

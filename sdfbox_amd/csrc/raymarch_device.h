@@ -39,6 +39,7 @@ struct FrameInfo {
     float lightx, lighty, lightz;
     float fov, k_strength;     // k_strength = exp2f(strength) - 1, evaluated on the host
     float margin2;             // margin * 2 (exact), Compute.hlsl:194
+    float half_aspect;         // screen_w / screen_h * 0.5f (Compute.hlsl:165), the same two IEEE operations, once per frame on the host
 };
 constexpr int MAX_BATCH = 8;   // frames one k_plain launch can render (grid.y)
 constexpr int MAX_BAND_LIST = 512;   // bands one launch can be handed as an explicit list
@@ -870,7 +871,7 @@ __device__ __forceinline__ void gradient(const Cell &c, float px, float py, floa
 __device__ __forceinline__ void ray(const FrameInfo &I, uint32_t cx, uint32_t cy, float &dx,
                                     float &dy, float &dz)
 {
-    float sx = (float)cx / I.screen_h - I.screen_w / I.screen_h * 0.5f;
+    float sx = (float)cx / I.screen_h - I.half_aspect;
     float sy = (float)cy / I.screen_h - 0.5f;
     float vx = sx * I.fov, vy = sy * I.fov, vz = 0.5f;
     float d0 = dot3(vx, vy, vz, I.h0x, I.h0y, I.h0z);
@@ -898,7 +899,7 @@ __device__ __forceinline__ float rnd(uint32_t seed, uint32_t p, uint32_t s, uint
 // ray() through a fractional pixel coordinate
 __device__ __forceinline__ void ray_f(const FrameInfo &I, float fx, float fy, float &dx, float &dy, float &dz)
 {
-    float sx = fx / I.screen_h - I.screen_w / I.screen_h * 0.5f;
+    float sx = fx / I.screen_h - I.half_aspect;
     float sy = fy / I.screen_h - 0.5f;
     float vx = sx * I.fov, vy = sy * I.fov, vz = 0.5f;
     float d0 = dot3(vx, vy, vz, I.h0x, I.h0y, I.h0z);

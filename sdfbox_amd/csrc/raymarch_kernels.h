@@ -74,6 +74,8 @@ struct RayState {
 
 __device__ __forceinline__ uint32_t global_row(const RenderParams &P, uint32_t yl)
 {
+    // (every band of the frame, in order -- a whole frame, whatever its band height: local rows are frame rows, and no division)
+    if (!P.n_band_list && P.band_first == 0u && P.band_stride == 1u) return yl;
     const uint32_t band = yl / P.band_rows, within = yl - band * P.band_rows;
     if (P.n_band_list) {
         if (band >= P.n_band_list) return 0xFFFFFFFFu;
@@ -595,14 +597,25 @@ template <int CUR, bool COUNT, int MODE, bool QUEUE = false>
 __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams P)
 {
     typedef typename CursorOf<CUR, COUNT>::type CursorT;
-    const uint32_t f = blockIdx.y;
+    // grid: x = 8 tiles_x (XCD label in the low three bits, tile column above), y = groups of eight tile rows, z = frame of the batch:
+    // tile_of_block's mapping (XCD k renders tile rows k, k + 8, ...) read off the block's coordinates, without its division
+    const uint32_t f = blockIdx.z;
     FrameInfo I = P.frames[f];
     // the scalars every march step reads stay in SGPRs: left alone, the compiler reloads them
     // from the kernel arguments (s_load + s_waitcnt) in every iteration
     asm volatile("" : "+s"(I.margin2), "+s"(I.limit));
-    const uint32_t tile = P.tile_perm ? P.tile_perm[blockIdx.x] : tile_of_block(P, blockIdx.x, f);
-    if (tile >= P.n_tiles) return;
-    const uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x, lane = threadIdx.x;
+    uint32_t tile, tx, ty;
+    if (P.tile_perm) {
+        tile = P.tile_perm[blockIdx.y * gridDim.x + blockIdx.x];
+        if (tile >= P.n_tiles) return;
+        tx = tile % P.tiles_x; ty = tile / P.tiles_x;
+    } else {
+        tx = blockIdx.x >> 3;
+        ty = blockIdx.y * 8u + ((blockIdx.x + f * (P.tiles_y & 7u)) & 7u);
+        if (ty >= P.tiles_y) return;
+        tile = ty * P.tiles_x + tx;
+    }
+    const uint32_t lane = threadIdx.x;
     const uint32_t x = tx * 8 + (lane & 7u), yl = ty * 8 + (lane >> 3);
     unsigned long long cn = 0, cs = 0, ct = 0;   // nodes, samples, steps (of the pixels that end here)
     StepClasses classes;                         // (counting builds only)
@@ -700,7 +713,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     if constexpr (QUEUE) {
     const unsigned long long hits = __ballot(shadow);
     if (hits) {
-        const uint32_t q = blockIdx.x & (HIT_QUEUES - 1u);
+        const uint32_t q = (blockIdx.y * gridDim.x + blockIdx.x) & (HIT_QUEUES - 1u);     // (the workgroup's number in the frame: what the queues' capacity counts)
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(hit_count(P, P.hit_set, f, q), (uint32_t)__popcll(hits));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);

@@ -52,6 +52,7 @@ void unpack_info(const sdfhip_info *in, FrameInfo &I)
     I.lightx = in->light[0]; I.lighty = in->light[1]; I.lightz = in->light[2];
     I.fov = in->fov;
     I.k_strength = exp2f(in->strength) - 1.0f;   // Compute.hlsl:216, once per frame
+    I.half_aspect = in->screen_size[0] / in->screen_size[1] * 0.5f;   // Compute.hlsl:165, the shader's own two operations
 }
 
 // the sky constant of Compute.hlsl:196 through DisplayFrag.hlsl:24, alpha excluded
@@ -163,8 +164,9 @@ int need_scratch(sdfhip_scene *s, const RenderCall &c, Plan &plan)
 
 // ---- the product's path: k_march --------------------------------------------------------------------------------------------
 template <int CUR, bool COUNT>
-void launch_march(uint32_t mode, dim3 grid, hipStream_t st, const RenderParams &P)
+void launch_march(uint32_t mode, dim3 flat, hipStream_t st, const RenderParams &P)
 {
+    const dim3 grid = march_grid(P, flat);
     if (mode == OUT_RGBA32F)     hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_RGBA32F, false>), grid, dim3(64), 0, st, P);
     else if (mode == OUT_GAMMA8) hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_GAMMA8, false>), grid, dim3(64), 0, st, P);
     else if (mode == OUT_HEAT8)  hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_HEAT8, false>), grid, dim3(64), 0, st, P);
@@ -315,7 +317,7 @@ template <int CUR, bool COUNT>
 void launch_queued(uint32_t mode, dim3 grid, dim3 shade_grid, hipStream_t st, const RenderParams &P)
 {
     auto go = [&](auto march, auto shade) {
-        hipLaunchKernelGGL(march, grid, dim3(64), 0, st, P);
+        hipLaunchKernelGGL(march, march_grid(P, grid), dim3(64), 0, st, P);
         hipLaunchKernelGGL(shade, shade_grid, dim3(64), 0, st, P);
     };
     if (mode == OUT_RGBA32F)     go(k_march<CUR, COUNT, OUT_RGBA32F, true>, k_shadow<CUR, COUNT, OUT_RGBA32F>);
