@@ -604,6 +604,16 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     // the scalars every march step reads stay in SGPRs: left alone, the compiler reloads them
     // from the kernel arguments (s_load + s_waitcnt) in every iteration
     asm volatile("" : "+s"(I.margin2), "+s"(I.limit));
+    // the kernel arguments this wave's set-up reads, asked for together: left to itself the compiler fetches each where it is first
+    // used -- a dozen scalar loads, each waited for by itself, in a row at the start of every wave
+    {
+        const uint32_t a0 = P.width, a1 = P.height, a2 = P.nrows_out, a3 = P.tiles_x, a4 = P.tiles_y, a5 = P.n_band_list, a6 = P.band_first,
+                       a7 = P.band_stride, a8 = P.n_tiles;
+        const int32_t b0 = P.top_level, b1 = P.fine_bits;
+        const void *p0 = P.nodes, *p1 = P.top, *p2 = P.fine, *p3 = P.out, *p4 = P.tile_perm, *p5 = P.tile_cost;
+        asm volatile("" :: "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7), "s"(a8), "s"(b0), "s"(b1),
+                     "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5));
+    }
     uint32_t tile, tx, ty;
     if (P.tile_perm) {
         tile = P.tile_perm[blockIdx.y * gridDim.x + blockIdx.x];
