@@ -82,6 +82,7 @@ struct RenderParams {
     float4 *out;               // compact rows: nrows_out x width
     uint32_t width, height;    // full frame
     uint32_t band_rows, band_first, band_stride, nrows_out;
+    uint32_t band_shift;       // log2(band_rows) when that is a power of two (a rank's 16-row bands: a shift, not a division, per pixel), else 32
     // n_band_list != 0: local band i is band band_list[i] of the frame (an explicit list instead of
     // every band_stride-th band: layouts that give the ranks unequal shares).  Up to INLINE_BAND_LIST bands travel
     // in the kernel arguments (read-only: the kernels index them there); a longer list is in device memory at band_ptr.

@@ -76,7 +76,7 @@ __device__ __forceinline__ uint32_t global_row(const RenderParams &P, uint32_t y
 {
     // (every band of the frame, in order -- a whole frame, whatever its band height: local rows are frame rows, and no division)
     if (!P.n_band_list && P.band_first == 0u && P.band_stride == 1u) return yl;
-    const uint32_t band = yl / P.band_rows, within = yl - band * P.band_rows;
+    const uint32_t band = P.band_shift < 32u ? yl >> P.band_shift : yl / P.band_rows, within = yl - band * P.band_rows;
     if (P.n_band_list) {
         if (band >= P.n_band_list) return 0xFFFFFFFFu;
         const uint32_t b = P.n_band_list <= (uint32_t)INLINE_BAND_LIST ? P.band_list[band] : P.band_ptr[band];

@@ -103,6 +103,8 @@ int fill_params(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &pla
     P.out = reinterpret_cast<float4 *>(c.d_out);
     P.width = c.width; P.height = c.height;
     P.band_rows = c.band_rows; P.band_first = c.band_first; P.band_stride = c.band_stride;
+    P.band_shift = 32u;
+    if ((c.band_rows & (c.band_rows - 1u)) == 0u) { P.band_shift = 0u; while ((1u << P.band_shift) < c.band_rows) P.band_shift++; }
     P.nrows_out = c.nrows_out;
     if (c.bands) {                                      // an explicit band list replaces first/stride
         if (c.n_bands == 0 || c.n_bands > (uint32_t)MAX_BAND_LIST)
