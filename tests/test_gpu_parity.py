@@ -640,51 +640,49 @@ def test_top_grid_levels_never_change_results(sb, oracle_mod, scenes):
     od6 = scenes["torus_d6"]
     cases = [(scenes["sphere_d4"], "default"), (od6, "rotated"), (od6, "closeup")]
     W, H = 96, 80
-    if True:
-        for od, camname in cases:
-            cam = make_camera(camname, W, H)
-            ongrid = sb.Logic(W, H); ongrid.Position = (0.25, 0.5, -0.125); ongrid.Heading = (0.0, 0.0)   # rays along cell faces
-            refs = [oracle_mod.render(od.Structs, od.Values, c.State, W, H) for c in (cam, ongrid)]
-            levels_seen = set()
-            for lv in (0, 1, 2, 3, 4, 5, 6, None):
-                with sb.Scene(od, top_grid_level=lv) as scene:
-                    levels_seen.add(scene.top_grid_level)
-                    assert scene.top_grid_level <= scene.depth
-                    assert scene.top_grid_bytes == (16 << (3 * scene.top_grid_level) if scene.top_grid_level else 0)
-                    if lv is None:       # the default for shallow trees: as deep as the tree (every leaf in the grid)
-                        assert scene.top_grid_level == scene.depth
-                    for c, (ref, cnt) in zip((cam, ongrid), refs):
-                        for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT) + ((sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL,) if sb._lib.EXPERIMENTS else ()):
-                            img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
-                            assert_frames_identical(img, ref, f"top grid {lv}")
-                            assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), lv
-                        if sb._lib.EXPERIMENTS and 0 < scene.top_grid_level <= 3 and scene.top_grid_level < scene.depth:
-                            # the measurement variant that stages the top grid in LDS (64- and 256-thread workgroups)
-                            for block in (0, 3):
-                                img = scene.Draw(c, W, H, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL | sb._lib.TUNE_LDS_TOP | (block << 12))
-                                assert_frames_identical(img, ref, f"top grid {lv} staged in LDS, block knob {block}")
-                        pimg = scene.DrawPath(c, W, H, pt=sb.PathTrace(spp=2))
-                        pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
-                        assert_frames_identical(pimg, pref, f"top grid {lv}, path-traced")
-            assert len(levels_seen) >= 4
-            # split grids: a coarse dense level whose internal cells point at blocks of finer cells
-            for sp in (1, 2, 3, 5):
-                if sp >= od_depth(sb, od):
-                    continue
-                if True:
-                    with sb.Scene(od, top_grid_split=sp) as scene:
-                        assert scene.top_grid_level == int(sp) and scene.top_grid_bytes >= 16 << (3 * int(sp))
-                        for c, (ref, cnt) in zip((cam, ongrid), refs):
-                            for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT) + ((sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL,) if sb._lib.EXPERIMENTS else ()):
-                                img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
-                                assert_frames_identical(img, ref, f"split grid {sp}")
-                                assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), sp
-                                assert_frames_identical(scene.Draw(c, W, H, flags), ref, f"split grid {sp}, not counting")
-                                if sb._lib.EXPERIMENTS:
-                                    assert_frames_identical(scene.Draw(c, W, H, flags | sb._lib.TUNE_BYTE_CELLS), ref, f"split grid {sp}, byte cells")
-                            pimg = scene.DrawPath(c, W, H, pt=sb.PathTrace(spp=2))
-                            pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
-                            assert_frames_identical(pimg, pref, f"split grid {sp}, path-traced")
+    for od, camname in cases:
+        cam = make_camera(camname, W, H)
+        ongrid = sb.Logic(W, H); ongrid.Position = (0.25, 0.5, -0.125); ongrid.Heading = (0.0, 0.0)   # rays along cell faces
+        refs = [oracle_mod.render(od.Structs, od.Values, c.State, W, H) for c in (cam, ongrid)]
+        levels_seen = set()
+        for lv in (0, 1, 2, 3, 4, 5, 6, None):
+            with sb.Scene(od, top_grid_level=lv) as scene:
+                levels_seen.add(scene.top_grid_level)
+                assert scene.top_grid_level <= scene.depth
+                assert scene.top_grid_bytes == (16 << (3 * scene.top_grid_level) if scene.top_grid_level else 0)
+                if lv is None:       # the default for shallow trees: as deep as the tree (every leaf in the grid)
+                    assert scene.top_grid_level == scene.depth
+                for c, (ref, cnt) in zip((cam, ongrid), refs):
+                    for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT) + ((sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL,) if sb._lib.EXPERIMENTS else ()):
+                        img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
+                        assert_frames_identical(img, ref, f"top grid {lv}")
+                        assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), lv
+                    if sb._lib.EXPERIMENTS and 0 < scene.top_grid_level <= 3 and scene.top_grid_level < scene.depth:
+                        # the measurement variant that stages the top grid in LDS (64- and 256-thread workgroups)
+                        for block in (0, 3):
+                            img = scene.Draw(c, W, H, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL | sb._lib.TUNE_LDS_TOP | (block << 12))
+                            assert_frames_identical(img, ref, f"top grid {lv} staged in LDS, block knob {block}")
+                    pimg = scene.DrawPath(c, W, H, pt=sb.PathTrace(spp=2))
+                    pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
+                    assert_frames_identical(pimg, pref, f"top grid {lv}, path-traced")
+        assert len(levels_seen) >= 4
+        # split grids: a coarse dense level whose internal cells point at blocks of finer cells
+        for sp in (1, 2, 3, 5):
+            if sp >= od_depth(sb, od):
+                continue
+            with sb.Scene(od, top_grid_split=sp) as scene:
+                assert scene.top_grid_level == int(sp) and scene.top_grid_bytes >= 16 << (3 * int(sp))
+                for c, (ref, cnt) in zip((cam, ongrid), refs):
+                    for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT) + ((sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL,) if sb._lib.EXPERIMENTS else ()):
+                        img, st = scene.Draw(c, W, H, flags | sb.FLAG_COUNT, want_stats=True)
+                        assert_frames_identical(img, ref, f"split grid {sp}")
+                        assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in cnt), sp
+                        assert_frames_identical(scene.Draw(c, W, H, flags), ref, f"split grid {sp}, not counting")
+                        if sb._lib.EXPERIMENTS:
+                            assert_frames_identical(scene.Draw(c, W, H, flags | sb._lib.TUNE_BYTE_CELLS), ref, f"split grid {sp}, byte cells")
+                    pimg = scene.DrawPath(c, W, H, pt=sb.PathTrace(spp=2))
+                    pref, _ = oracle_mod.render_pt(od.Structs, od.Values, c.State, W, H, spp=2)
+                    assert_frames_identical(pimg, pref, f"split grid {sp}, path-traced")
 
 
 def od_depth(sb, od):
@@ -860,46 +858,45 @@ def test_tile_order_flag_changes_no_pixel(sb, oracle_mod, scenes, split):
     # took would show
     import torch
     od = scenes["torus_d6"]
-    if True:
-        with sb.Scene(od, top_grid_split=None if split is None else int(split)) as sc:
-            F = sb.KERNEL_STACK | sb.FLAG_TILE_ORDER
-            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-            refs = {}
+    with sb.Scene(od, top_grid_split=None if split is None else int(split)) as sc:
+        F = sb.KERNEL_STACK | sb.FLAG_TILE_ORDER
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        refs = {}
 
-            def ref(name, W, H):
-                if (name, W, H) not in refs:
-                    refs[(name, W, H)] = oracle_mod.render(od.Structs, od.Values, make_camera(name, W, H).State, W, H, nthreads=8)
-                return refs[(name, W, H)]
+        def ref(name, W, H):
+            if (name, W, H) not in refs:
+                refs[(name, W, H)] = oracle_mod.render(od.Structs, od.Values, make_camera(name, W, H).State, W, H, nthreads=8)
+            return refs[(name, W, H)]
 
-            def draw(name, W, H, flags=F, stream=None):
-                buf = torch.full((H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
-                st = sb.Stats()
-                sc.DrawDevice(make_camera(name, W, H), W, H, buf.data_ptr(), flags=flags,
-                              stream=stream.cuda_stream if stream is not None else None, stats=st if flags & sb.FLAG_COUNT else None)
-                torch.cuda.synchronize()
-                assert_frames_identical(buf.cpu().numpy(), ref(name, W, H)[0], f"tile order, {name} {W}x{H} flags {flags:#x}")
-                if flags & sb.FLAG_COUNT:
-                    assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in ref(name, W, H)[1])
+        def draw(name, W, H, flags=F, stream=None):
+            buf = torch.full((H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+            st = sb.Stats()
+            sc.DrawDevice(make_camera(name, W, H), W, H, buf.data_ptr(), flags=flags,
+                          stream=stream.cuda_stream if stream is not None else None, stats=st if flags & sb.FLAG_COUNT else None)
+            torch.cuda.synchronize()
+            assert_frames_identical(buf.cpu().numpy(), ref(name, W, H)[0], f"tile order, {name} {W}x{H} flags {flags:#x}")
+            if flags & sb.FLAG_COUNT:
+                assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(v) for v in ref(name, W, H)[1])
 
-            for name, W, H in (("closeup", 200, 120), ("closeup", 200, 120), ("rotated", 200, 120), ("default", 200, 120),
-                               ("closeup", 97, 61), ("closeup", 200, 120), ("rotated", 200, 120), ("rotated", 200, 120)):
-                draw(name, W, H)
-            for k in range(6):                                   # two streams, each with its own last frame
-                draw(("closeup", "rotated", "default")[k % 3], 200, 120, stream=streams[k & 1])
-            draw("closeup", 200, 120, flags=F | sb.FLAG_COUNT)
-            draw("rotated", 200, 120, flags=F | sb.FLAG_COUNT)
-            if sb._lib.EXPERIMENTS:
-                draw("closeup", 200, 120, flags=F | sb.TUNE_SHADOW_QUEUE)
-                draw("rotated", 200, 120, flags=F | sb.TUNE_SHADOW_QUEUE)
-            # bands of a frame (what a rank of the sharded pipeline renders): rows 16..31, 48..63, ... twice, then the other ranks' bands
-            W, H = 200, 128
-            whole = ref("closeup", W, H)[0]
-            for first in (1, 1, 0, 1):
-                rows = [y for y in range(H) if (y // 16) % 2 == first]
-                buf = torch.full((len(rows), W, 4), float("nan"), dtype=torch.float32, device="cuda")
-                sc.DrawDevice(make_camera("closeup", W, H), W, H, buf.data_ptr(), nrows_out=len(rows), band_rows=16, band_first=first, band_stride=2, flags=F)
-                torch.cuda.synchronize()
-                assert_frames_identical(buf.cpu().numpy(), whole[rows], f"tile order, bands from {first}")
+        for name, W, H in (("closeup", 200, 120), ("closeup", 200, 120), ("rotated", 200, 120), ("default", 200, 120),
+                           ("closeup", 97, 61), ("closeup", 200, 120), ("rotated", 200, 120), ("rotated", 200, 120)):
+            draw(name, W, H)
+        for k in range(6):                                   # two streams, each with its own last frame
+            draw(("closeup", "rotated", "default")[k % 3], 200, 120, stream=streams[k & 1])
+        draw("closeup", 200, 120, flags=F | sb.FLAG_COUNT)
+        draw("rotated", 200, 120, flags=F | sb.FLAG_COUNT)
+        if sb._lib.EXPERIMENTS:
+            draw("closeup", 200, 120, flags=F | sb.TUNE_SHADOW_QUEUE)
+            draw("rotated", 200, 120, flags=F | sb.TUNE_SHADOW_QUEUE)
+        # bands of a frame (what a rank of the sharded pipeline renders): rows 16..31, 48..63, ... twice, then the other ranks' bands
+        W, H = 200, 128
+        whole = ref("closeup", W, H)[0]
+        for first in (1, 1, 0, 1):
+            rows = [y for y in range(H) if (y // 16) % 2 == first]
+            buf = torch.full((len(rows), W, 4), float("nan"), dtype=torch.float32, device="cuda")
+            sc.DrawDevice(make_camera("closeup", W, H), W, H, buf.data_ptr(), nrows_out=len(rows), band_rows=16, band_first=first, band_stride=2, flags=F)
+            torch.cuda.synchronize()
+            assert_frames_identical(buf.cpu().numpy(), whole[rows], f"tile order, bands from {first}")
 
 
 def test_frames_in_flight_on_one_handle_do_not_share_scratch(sb, oracle_mod, scenes, gpu_scenes):
@@ -1279,15 +1276,14 @@ def test_fuzz_random_trees_and_on_grid_cameras(sb, oracle_mod, seed):
                     assert_frames_identical(sc.DrawPath(cam, W, H, pt=sb.PathTrace(spp=2), flags=kern), pref, f"seed {seed} path-traced, not counting")
     if depth >= 7:           # the same tree behind a split grid (what trees of depth 10-12 get when they are large)
         coarse = min(8, depth - int(rng.integers(1, 5)))
-        if True:
-            with sb.Scene(od, top_grid_split=coarse) as sc:
-                if sc.depth > coarse:     # a random tree may be shallower than asked
-                    for ci, cam in enumerate(cams[:3]):
-                        ref, cnt = oracle_mod.render(s, v, cam.State, W, H, nthreads=8)
-                        img, st = sc.Draw(cam, W, H, sb.FLAG_COUNT, want_stats=True)
-                        assert_frames_identical(img, ref, f"seed {seed} cam {ci} split grid")
-                        assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), (seed, ci)
-                        assert_frames_identical(sc.Draw(cam, W, H), ref, f"seed {seed} cam {ci} split grid, not counting")
+        with sb.Scene(od, top_grid_split=coarse) as sc:
+            if sc.depth > coarse:     # a random tree may be shallower than asked
+                for ci, cam in enumerate(cams[:3]):
+                    ref, cnt = oracle_mod.render(s, v, cam.State, W, H, nthreads=8)
+                    img, st = sc.Draw(cam, W, H, sb.FLAG_COUNT, want_stats=True)
+                    assert_frames_identical(img, ref, f"seed {seed} cam {ci} split grid")
+                    assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), (seed, ci)
+                    assert_frames_identical(sc.Draw(cam, W, H), ref, f"seed {seed} cam {ci} split grid, not counting")
 
 
 def test_upload_options_are_arguments_and_the_environment_is_the_laboratorys(sb, scenes, monkeypatch):
