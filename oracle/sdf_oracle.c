@@ -56,11 +56,17 @@
  *                     down by the lowest bit of x -- ray directions, light directions and normals all move.
  * The default build (none of them) is the oracle; the variants are never compared with the kernels.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE            /* sched_getaffinity / pthread_setaffinity_np: oracle_bench_rows only */
+#endif
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ---- Info, 112 bytes, Logic.cs:407-420 / Compute.hlsl:70-81 ------------- */
 typedef struct {
@@ -595,6 +601,183 @@ int oracle_render_rows_pt(const int32_t *structs, const uint8_t *values, uint32_
     if (spp == 0) return -1;
     return o_render_rows(structs, values, n, info112, W, row0, nrows, row_step, rgba, counters, NULL,
                          nthreads, spp, max_bounces, seed, albedo);
+}
+
+/* ---- the timed CPU baseline (bench.py's cpu_baseline leg) ------------------------------------------------
+ * The same o_pixel over the same rows as oracle_render_rows, arranged so that what is timed is the march and nothing
+ * else: the worker threads exist, are pinned and have their data in place BEFORE the clock starts, the clock is read
+ * inside this function between two barriers, and the work is dealt dynamically.
+ *   - threads are pinned one per CPU of the caller's affinity mask, dealt round robin over the NUMA nodes those CPUs
+ *     belong to (/sys/devices/system/node/node<k>/cpulist; one node when that cannot be read), within a node in the
+ *     order of the list -- on the usual enumeration a core's first hardware thread comes before any second one;
+ *   - flags & 1: every node's first thread makes that node's own copy of the two scene arrays (first touch by a thread
+ *     that runs there), and the node's threads read that copy: no thread walks the tree through the socket interconnect;
+ *   - pixels are dealt in chunks of 64 consecutive pixels of a row from one atomic counter (rows differ tenfold in
+ *     cost: sky against grazing rays), so no thread waits for a neighbour's expensive rows;
+ *   - `rgba` (nrows x W x 4, may be NULL: then nothing is stored) is written by the workers themselves -- fresh pages
+ *     are first touched by the thread that fills them.
+ * -> 0, *seconds = wall time between the barriers, counters[4] as oracle_render_rows, topo[4] = {threads started,
+ * NUMA nodes used, CPUs in the affinity mask, scene copies made}. */
+typedef struct {
+    o_scene sc;
+    o_info inf;
+    float k;
+    uint32_t W, row0, nrows, row_step;
+    float *rgba;
+    uint64_t cnt[4];
+    int cpu, node, leader;
+    struct o_bench_shared *sh;
+    char pad[64];
+} o_bench_job;
+
+struct o_bench_shared {
+    pthread_barrier_t bar;                            /* initialised for the threads that really started, before `go` is set */
+    pthread_mutex_t mu; pthread_cond_t cv; int go;
+    uint64_t next __attribute__((aligned(128)));      /* next chunk */
+    uint64_t nchunks, chunks_per_row;
+    const int32_t *node_structs[64];
+    const uint8_t *node_values[64];
+    int copy, failed;
+    const int32_t *structs; const uint8_t *values; uint32_t n;
+    struct timespec t0, t1;
+};
+
+static int o_parse_cpulist(const char *path, cpu_set_t *set)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    char buf[4096];
+    size_t len = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[len] = 0;
+    CPU_ZERO(set);
+    for (char *p = buf; *p && *p != '\n';) {
+        char *e;
+        long a = strtol(p, &e, 10), b = a;
+        if (e == p) break;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET((int)c, set);
+        p = (*e == ',') ? e + 1 : e;
+    }
+    return 0;
+}
+
+O_CLONES static void *o_bench_worker_impl(void *arg)
+{
+    o_bench_job *jb = (o_bench_job *)arg;
+    struct o_bench_shared *sh = jb->sh;
+    pthread_mutex_lock(&sh->mu);
+    while (!sh->go) pthread_cond_wait(&sh->cv, &sh->mu);
+    pthread_mutex_unlock(&sh->mu);
+    if (jb->cpu >= 0) {
+        cpu_set_t one;
+        CPU_ZERO(&one); CPU_SET(jb->cpu, &one);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+    }
+    if (sh->copy && jb->leader) {                       /* this node's copy of the scene, first touched here */
+        size_t bs = (size_t)sh->n * 8;
+        int32_t *s = (int32_t *)malloc(bs);
+        uint8_t *v = (uint8_t *)malloc(bs);
+        if (s && v) { memcpy(s, sh->structs, bs); memcpy(v, sh->values, bs); sh->node_structs[jb->node] = s; sh->node_values[jb->node] = v; }
+        else { free(s); free(v); sh->failed = 1; }
+    }
+    pthread_barrier_wait(&sh->bar);                     /* every copy is in place */
+    if (sh->copy && sh->node_structs[jb->node]) { jb->sc.structs = sh->node_structs[jb->node]; jb->sc.values = sh->node_values[jb->node]; }
+    if (pthread_barrier_wait(&sh->bar) == PTHREAD_BARRIER_SERIAL_THREAD) clock_gettime(CLOCK_MONOTONIC, &sh->t0);
+    pthread_barrier_wait(&sh->bar);                     /* ---- the clock runs from here ---- */
+    float scratch[4];
+    for (;;) {
+        uint64_t c = __atomic_fetch_add(&sh->next, 1, __ATOMIC_RELAXED);
+        if (c >= sh->nchunks) break;
+        uint32_t r = (uint32_t)(c / sh->chunks_per_row), x0 = (uint32_t)(c % sh->chunks_per_row) * 64u;
+        uint32_t x1 = x0 + 64u < jb->W ? x0 + 64u : jb->W;
+        for (uint32_t x = x0; x < x1; x++)
+            o_pixel(&jb->sc, &jb->inf, jb->k, x, jb->row0 + r * jb->row_step,
+                    jb->rgba ? jb->rgba + 4 * ((size_t)r * jb->W + x) : scratch, jb->cnt);
+    }
+    if (pthread_barrier_wait(&sh->bar) == PTHREAD_BARRIER_SERIAL_THREAD) clock_gettime(CLOCK_MONOTONIC, &sh->t1);
+    pthread_barrier_wait(&sh->bar);
+    return NULL;
+}
+static void *o_bench_worker(void *arg) { return o_bench_worker_impl(arg); }
+
+int oracle_bench_rows(const int32_t *structs, const uint8_t *values, uint32_t n, const void *info112, uint32_t W,
+                      uint32_t row0, uint32_t nrows, uint32_t row_step, float *rgba, uint64_t *counters, int nthreads,
+                      int flags, double *seconds, int *topo)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return -2;
+    /* the allowed CPUs node by node */
+    static int cpus[64][CPU_SETSIZE];
+    int ncpu[64], nnodes = 0, nallowed = CPU_COUNT(&allowed);
+    cpu_set_t seen;
+    CPU_ZERO(&seen);
+    for (int k = 0; k < 64; k++) {
+        char path[96];
+        cpu_set_t ns;
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", k);
+        if (o_parse_cpulist(path, &ns) != 0) break;
+        int m = 0;
+        for (int c = 0; c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &ns) && CPU_ISSET(c, &allowed) && !CPU_ISSET(c, &seen)) { cpus[nnodes][m++] = c; CPU_SET(c, &seen); }
+        if (m) ncpu[nnodes++] = m;
+    }
+    if (CPU_COUNT(&seen) != nallowed) {                 /* no (or an incomplete) node map: one node, every allowed CPU */
+        nnodes = 1; ncpu[0] = 0;
+        for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus[0][ncpu[0]++] = c;
+    }
+    o_bench_job *jobs = NULL;
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    struct o_bench_shared *sh = NULL;
+    if (posix_memalign((void **)&jobs, 128, (size_t)nthreads * sizeof(o_bench_job)) != 0) jobs = NULL;
+    if (posix_memalign((void **)&sh, 128, sizeof *sh) != 0) sh = NULL;
+    if (!jobs || !th || !sh) { free(jobs); free(th); free(sh); return -1; }
+    memset(jobs, 0, (size_t)nthreads * sizeof(o_bench_job));
+    memset(sh, 0, sizeof *sh);
+    o_info inf;
+    memcpy(&inf, info112, sizeof inf);
+    const float k = exp2f(inf.strength) - 1.0f;
+    sh->copy = (flags & 1) && nnodes > 1;
+    sh->structs = structs; sh->values = values; sh->n = n;
+    sh->chunks_per_row = (W + 63u) / 64u;
+    sh->nchunks = (uint64_t)nrows * sh->chunks_per_row;
+    pthread_mutex_init(&sh->mu, NULL); pthread_cond_init(&sh->cv, NULL);
+    int used_nodes = 0, node_has_leader[64] = {0};
+    for (int t = 0; t < nthreads; t++) {
+        const int node = t % nnodes, slot = t / nnodes;
+        jobs[t].sc.structs = structs; jobs[t].sc.values = values; jobs[t].sc.n = n;
+        jobs[t].inf = inf; jobs[t].k = k;
+        jobs[t].W = W; jobs[t].row0 = row0; jobs[t].nrows = nrows; jobs[t].row_step = row_step ? row_step : 1;
+        jobs[t].rgba = rgba; jobs[t].sh = sh;
+        jobs[t].node = node; jobs[t].cpu = cpus[node][slot % ncpu[node]];
+        jobs[t].leader = !node_has_leader[node];
+        if (jobs[t].leader) { node_has_leader[node] = 1; used_nodes++; }
+    }
+    int started = 0;
+    for (; started < nthreads; started++)
+        if (pthread_create(&th[started], NULL, o_bench_worker, &jobs[started]) != 0) break;
+    if (started == 0) { free(jobs); free(th); free(sh); return -3; }
+    nthreads = started;                                 /* (a thread limit: the run goes on with the threads there are) */
+    pthread_barrier_init(&sh->bar, NULL, (unsigned)nthreads);
+    pthread_mutex_lock(&sh->mu); sh->go = 1; pthread_cond_broadcast(&sh->cv); pthread_mutex_unlock(&sh->mu);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    if (seconds) *seconds = (double)(sh->t1.tv_sec - sh->t0.tv_sec) + 1e-9 * (double)(sh->t1.tv_nsec - sh->t0.tv_nsec);
+    if (counters) {
+        counters[0] = counters[1] = counters[2] = counters[3] = 0;
+        for (int t = 0; t < nthreads; t++)
+            for (int c = 0; c < 4; c++) counters[c] += jobs[t].cnt[c];
+    }
+    int copies = 0;
+    for (int k2 = 0; k2 < 64; k2++)
+        if (sh->node_structs[k2]) { free((void *)sh->node_structs[k2]); free((void *)sh->node_values[k2]); copies++; }
+    if (topo) { topo[0] = nthreads; topo[1] = used_nodes; topo[2] = nallowed; topo[3] = copies; }
+    const int failed = sh->failed;
+    pthread_barrier_destroy(&sh->bar); pthread_mutex_destroy(&sh->mu); pthread_cond_destroy(&sh->cv);
+    free(jobs); free(th); free(sh);
+    return failed ? -1 : 0;
 }
 
 /* One pixel, for unit tests.  out[4] = rgba, cnt[4] = nodes, samples, steps, shadow rays. */

@@ -111,6 +111,16 @@ def test_threads_and_row_windows_do_not_change_pixels(oracle_mod, scenes):
     assert cnt.tolist() == cnt_mt.tolist()
     part, _ = oracle_mod.render(od.Structs, od.Values, cam.State, 96, 40, row0=13, nrows=9)
     assert_frames_identical(part, full[13:22], "row window")
+    # the timed baseline's entry point (pinned pool, chunks of 64 pixels from one counter, clock inside): the same pixels and counts,
+    # with more threads than this machine has CPUs, with and without storing the frame
+    for nt in (1, 3, 40):
+        img, c, sec, topo = oracle_mod.bench_rows(od.Structs, od.Values, cam.State, 96, 40, nthreads=nt)
+        assert_frames_identical(img, full, f"bench_rows, {nt} threads")
+        assert c.tolist() == cnt.tolist() and sec > 0 and topo["threads"] == nt and topo["numa_nodes"] >= 1
+    img, c, _, _ = oracle_mod.bench_rows(od.Structs, od.Values, cam.State, 96, 40, row0=1, row_step=3, nthreads=2)
+    assert_frames_identical(img, full[1::3], "bench_rows, every third row")
+    none, c2, _, _ = oracle_mod.bench_rows(od.Structs, od.Values, cam.State, 96, 40, row0=1, row_step=3, nthreads=2, store=False)
+    assert none is None and c2.tolist() == c.tolist()
 
 
 def _leaf_corners(od, count, seed):
