@@ -577,7 +577,7 @@ def main():
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
-        copy_gbs = measured_copy_bandwidth()           # the box's own figure beside the nameplate
+        copy_gbs = measured_hbm_bandwidth(sb, device)   # the box's own figure beside the nameplate
         mode = "spp%d" % args.spp if pt is not None else "display" if args.display else "compact" if compact else "default"
         if args.shadow_queue and not compact and pt is None and not args.one_kernel:
             mode += ":shadow-queue"
@@ -643,6 +643,9 @@ def main():
                 "transport": (("RCCL through torch.distributed (backend nccl)" if nccl else "gloo through host buffers (a rehearsal, not a performance mode)")
                               if sharded else None),
                 "frames_in_flight": nbuf * G,
+                # the hardware queues the runtime deals this process's streams onto: read when the runtime starts, so what the
+                # ENVIRONMENT held then (a PMC pass must be collected with the same value: scripts/profile.sh exports it)
+                "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "frames_per_gather": G if sharded else None,
                 "frames_rendered_in_the_timed_region": rendered,
                 "gather_pixel_bytes": (round(s2["prefix"] / (rows_local * W * G), 3) if sparse2 else px_bytes) if sharded else None,
@@ -679,6 +682,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(od, cam, W, H, args.cpu_seconds)
             except Exception as e:
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        # LAST key (the driver's record keeps the line's last 2 000 characters): every configuration in <= 600 characters
+        out["configs_summary"] = configs_summary(out, out.get("configs"))
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     scene.close()
@@ -824,7 +829,7 @@ def main_single_process(args, json_fd):
     px_bytes = 4 if args.display else 16
     ref_bytes = 8 * st.n_nodes + 8 * st.n_samples + px_bytes * W * H
     own_bytes = 16 * st.n_loads + px_bytes * W * H
-    roof = roofline(sec_per_step, own_bytes, ref_bytes, None, measured_copy_bandwidth())
+    roof = roofline(sec_per_step, own_bytes, ref_bytes, None, measured_hbm_bandwidth(sb, devices[0]))
     roof.update({"time_ms": round(sec_per_step * 1e3, 4), "note": "no PMC pass exists for a multi-device run: no fraction, only the demand figures"})
     n_st = max(1, len(stats_seen))
     out = {
@@ -975,7 +980,10 @@ def orbit_cameras(sb, W, H, n, step_deg=1.0):
 
 
 # the kernel sources of the frame's pipeline (device code only: host-side edits do not change what the counters measured)
-KERNEL_SOURCES = ("raymarch_device.h", "raymarch_kernels.h", "upload_kernels.h", "tile_order_kernels.h")
+KERNEL_SOURCES = ("raymarch_device.h", "raymarch_kernels.h", "upload_kernels.h", "tile_order_kernels.h",
+                  #  what else decides the counters: COMPACT_MIN_LANES and march_grid (scene.h), the launch shapes, hit_cap
+                  # and shade_grid (render.hip), the sparse-share kernels (gather_kernels.h)
+                  "scene.h", "render.hip", "gather_kernels.h")
 
 
 def kernel_source_hash():
@@ -1020,72 +1028,67 @@ HBM_PEAK_GBS = 8000.0                    # HBM3E spec (MI355X_MICROARCH.md)
 N_SIMD, CLOCK_GHZ = 256 * 4, 2.4
 
 
-def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
-    """Which roof does the frame sit under?  Over the steady-state time per frame (the driver-verifiable ms_per_step; with
-    frames in flight the per-launch durations overlap), from the rocprofv3 counters of THIS build and workload
-    (profiles/hbm_traffic.json; the PMC passes serialise launches: one frame in flight while they count, which changes times,
-    not counts):
-      valu         issued VALU wave instructions per frame (SQ_INSTS_VALU) / time against the chip's SPEC issue rate, 1 228.8 G
-                   wave64 instructions per second (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles); `frac_of_measured_ceiling` beside it:
-                   against the rate of the cheapest instruction as measured on this chip (2.35 cycles, scripts/micro/valu_mix.hip)
-      hbm_frac     HBM bytes per frame (2 x FETCH_SIZE + WRITE_SIZE, separate passes, the guide's gfx950 correction) / time
-                   / 8 TB/s -- what BASELINE's "% of HBM roofline" asks; hbm_frac_of_measured_copy: the same over the
-                   box's own device-to-device copy rate
-      valu_busy    SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x 2.4 GHz x time).  NOT a utilisation: the counter charges every VALU
-                   instruction one quad-cycle whatever it costs, so this is the instruction count again, priced at 4 cycles
-    `frac` is the larger of valu (of spec) and hbm_frac -- both measured quantities against hard ceilings, <= 1 -- and `bound`
-    names it.  `pmc_stale` = true: the committed PMC pass was measured on other kernel sources (or there is none); then no
-    fraction is reported, only `demand`.
-    `demand`: the bytes this kernel's own algorithm asks of the MEMORY SYSTEM per frame (16 B per grid cell a LANE loads, the
-    pixel store; counted by the counting build) and the bytes the REFERENCE algorithm would read for the same pixels (SURVEY.md
-    8d: 8 B per node visit of find(), Compute.hlsl:88-108, 8 B per sample, the store), each over 8 TB/s x time.  Both ratios
-    exceed 1 on the bench frames: they are not fractions of any roof.  The kernel does not perform the reference's loads (one
-    lookup in a grid built at upload replaces the descent: 1.1 loads per step instead of 8.2), and of its own loads the lanes of
-    a wave mostly ask for the same few cells, which L1 and L2 serve (77 % / 72 % hits at 1080p): SURVEY 8d's algorithmic-bytes
-    roofline does not describe this design, the counters above do."""
-    cands = {}
-    traffic = None
+def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, measured):
+    """The frame against its two roofs, both from the rocprofv3 counters of THIS build and workload (profiles/hbm_traffic.json;
+    the PMC passes serialise launches -- one frame in flight while they count -- which changes times, not counts), over the
+    steady-state time per frame (the driver-verifiable ms_per_step; with frames in flight the launch durations overlap):
+      frac = hbm_frac   HBM bytes per frame (2 x FETCH_SIZE + WRITE_SIZE, separate passes, the guide's gfx950 correction) / time
+                        / 8 TB/s.  THIS is the fraction SURVEY.md 8d and BASELINE's "% of HBM roofline" ask for, so it is the
+                        object's `frac`, with bound = "hbm", achieved / peak in GB/s and `traffic` the counter bytes.
+                        hbm_frac_of_measured: the same over `measured` -- the box's own streaming rate (the library's float4
+                        copy / triad, sdfhip_device_bandwidth), SURVEY 8d's "measured device bandwidth" denominator.
+      valu_frac_of_spec issued VALU wave instructions per frame (SQ_INSTS_VALU) / time against the chip's SPEC issue rate, 1 228.8 G
+                        wave64 instructions per second (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles); valu_frac_of_measured_ceiling:
+                        against the cheapest instruction as measured here (2.35 cycles, scripts/micro/valu_mix.hip).  The PEER of
+                        hbm_frac, not a substitute: `limiting` names the larger of the two -- "valu" on the primary-ray frames
+                        (the march is instruction-issue bound: its lookups mostly hit L1 / L2), "hbm" on cfg-5 and the depth-10 scene.
+      valu_busy         SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles: the instruction count priced at 4 cycles each, NOT a utilisation.
+    pmc_stale = true: the committed PMC pass was measured on other kernel sources (or there is none): no fraction, only `demand`.
+    `demand`: the bytes this kernel's own algorithm asks of the MEMORY SYSTEM per frame (16 B per cell a LANE loads + the pixel
+    store, by the counting build) and the bytes the REFERENCE algorithm would read for the same pixels (8 B per node
+    visit of find(), Compute.hlsl:88-108, 8 B per sample, the store), each over 8 TB/s x time.  Both exceed 1 on the bench
+    frames: they are ratios, not fractions of a roof -- a lookup grid built at upload replaces the descent (1.1 loads per step
+    instead of 8.2), and L1 / L2 serve most of the kernel's own loads."""
     dropped = pmc.get("dropped") if isinstance(pmc, dict) else None
     if dropped:
         pmc = None
-    hbm_frac = hbm_frac_copy = valu_busy = None
+    best_gbs = measured.get("best_gbs") if isinstance(measured, dict) else measured
+    traffic = hbm = valu = valu_busy = None
     if pmc:
         traffic = int(pmc["hbm_bytes_per_frame"])
-        cands["hbm-traffic"] = {"achieved": traffic / sec_per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": traffic}
-        hbm_frac = round(traffic / sec_per_frame / 1e9 / HBM_PEAK_GBS, 4)
-        if copy_gbs:
-            hbm_frac_copy = round(traffic / sec_per_frame / 1e9 / copy_gbs, 4)
+        ach = traffic / sec_per_frame / 1e9
+        hbm = {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": traffic, "frac": round(ach / HBM_PEAK_GBS, 4),
+               "frac_of_measured": round(ach / best_gbs, 4) if best_gbs else None}
         if pmc.get("valu_insts_per_frame"):
             ach = pmc["valu_insts_per_frame"] / sec_per_frame / 1e9
-            cands["valu"] = {"achieved": ach, "peak": round(VALU_PEAK_SPEC_GINSTR, 1),
-                             "peak_is": "spec: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
-                             "measured_ceiling": round(VALU_PEAK_GINSTR, 1),
-                             "measured_ceiling_is": "the cheapest VALU instruction on this chip, 2.35 cycles (scripts/micro/valu_mix.hip)",
-                             "frac_of_measured_ceiling": round(ach / VALU_PEAK_GINSTR, 4),
-                             "unit": "G wave-instr/s", "per_frame": int(pmc["valu_insts_per_frame"])}
+            valu = {"achieved": round(ach, 1), "peak": round(VALU_PEAK_SPEC_GINSTR, 1),
+                    "peak_is": "spec: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
+                    "measured_ceiling": round(VALU_PEAK_GINSTR, 1),
+                    "measured_ceiling_is": "the cheapest VALU instruction on this chip, 2.35 cycles (scripts/micro/valu_mix.hip)",
+                    "frac": round(ach / VALU_PEAK_SPEC_GINSTR, 4), "frac_of_measured_ceiling": round(ach / VALU_PEAK_GINSTR, 4),
+                    "unit": "G wave-instr/s", "per_frame": int(pmc["valu_insts_per_frame"])}
         if pmc.get("valu_active_quad_cycles_per_frame"):
             valu_busy = round(pmc["valu_active_quad_cycles_per_frame"] * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9 * sec_per_frame), 4)
-    for c in cands.values():
-        c["frac"] = round(c["achieved"] / c["peak"], 4)
-        c["achieved"] = round(c["achieved"], 1)
-    if cands:
-        name = max(cands, key=lambda k: cands[k]["frac"])
-        b = cands[name]
-    else:
-        name, b = None, {"achieved": None, "peak": None, "unit": None, "frac": None}
+    cands = {k: v for k, v in (("hbm-traffic", hbm), ("valu", valu)) if v}
+    limiting = max(cands, key=lambda k: cands[k]["frac"]) if cands else None
     own_over, ref_over = own_bytes / sec_per_frame / 1e9 / HBM_PEAK_GBS, ref_bytes / sec_per_frame / 1e9 / HBM_PEAK_GBS
     return {
-        "bound": None if name is None else ("hbm" if name.startswith("hbm") else "valu"),
-        "binding": name,
-        "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"],
+        # the contract's object: the HBM roof, which is what SURVEY 8d / BASELINE ask the fraction of
+        "bound": "hbm" if hbm else None,
+        "achieved": hbm["achieved"] if hbm else None, "peak": hbm["peak"] if hbm else None, "unit": hbm["unit"] if hbm else None,
+        "frac": hbm["frac"] if hbm else None,
+        "frac_is": "hbm_frac: counter HBM bytes / time / 8 TB/s -- the fraction SURVEY.md 8d asks for; valu_frac_of_spec is its peer, "
+                   "`limiting` the larger of the two",
+        "traffic": traffic,
         "pmc_stale": not cands,
-        "hbm_frac": hbm_frac, "hbm_frac_of_measured_copy": hbm_frac_copy,
-        "valu_frac_of_spec": cands["valu"]["frac"] if "valu" in cands else None,
-        "valu_frac_of_measured_ceiling": cands["valu"]["frac_of_measured_ceiling"] if "valu" in cands else None,
+        "hbm_frac": hbm["frac"] if hbm else None,
+        "hbm_frac_of_measured": hbm["frac_of_measured"] if hbm else None,
+        "valu_frac_of_spec": valu["frac"] if valu else None,
+        "valu_frac_of_measured_ceiling": valu["frac_of_measured_ceiling"] if valu else None,
+        "limiting": None if limiting is None else ("hbm" if limiting.startswith("hbm") else "valu"),
         "valu_busy": valu_busy,
         "valu_busy_is": "SQ_ACTIVE_INST_VALU x 4 cycles over the SIMD-cycles of the frame: every instruction is charged one quad-cycle, "
                         "so this is the instruction count at 4 cycles each, not a measured utilisation",
-        "traffic": traffic,
         "traffic_source": ({"profile": pmc.get("profile"), "kernel_source_sha": pmc.get("kernel_source_sha"),
                             "frames_in_flight_while_counting": 1} if pmc else
                            (dropped or "no PMC pass of this build and workload under profiles/ (scripts/profile.sh)")),
@@ -1094,8 +1097,31 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, copy_gbs):
                    "reference_bytes_per_frame": int(ref_bytes), "reference_demand_over_hbm_peak": round(ref_over, 3),
                    "note": "requests to the memory system over 8 TB/s x time, NOT roofline fractions: the lookup grid built at upload replaces "
                            "the reference's descent and L1 / L2 serve most of the kernel's own loads (see roofline() in bench.py)"},
-        "measured_copy_gbs": copy_gbs,
+        "measured_hbm_gbs": measured,
     }
+
+
+def configs_summary(out, cfgs):
+    """<= 600 characters that carry every configuration's time, rays and fractions: the LAST key of the line, so that the last
+    2 000 characters of it (what the driver's record keeps) hold all of them.  ms per frame / Mray/s / hbm_frac (of 8 TB/s) /
+    hbm_frac_of_measured / valu_frac_of_spec; '-' where there is no PMC pass of this build."""
+    names = {"cfg3_4k": "cfg3", "cfg3_4k_compact": "cfg3c", "cfg5_4k_spp16": "cfg5", "cfg2_depth10": "d10", "cfg2_mesh_knot_d10": "mesh"}
+
+    def f(v, nd):
+        return "-" if v is None else f"{v:.{nd}f}"
+
+    def one(tag, e, r):
+        if "error" in e:
+            return f"{tag} ERR {str(e['error'])[:40]}"
+        return f"{tag} {f(e.get('ms_per_step'), 4)}/{f(e.get('value'), 0)}/{f(r.get('hbm_frac'), 2)}/{f(r.get('hbm_frac_of_measured'), 2)}/{f(r.get('valu_frac_of_spec'), 2)}"
+    parts = [one("cfg2", out, out.get("roofline") or {})]
+    if isinstance(cfgs, dict):
+        if "error" in cfgs and not any(k in cfgs for k in names):
+            parts.append("configs ERR " + str(cfgs["error"])[:60])
+        for k, e in cfgs.items():
+            if isinstance(e, dict) and k != "error":
+                parts.append(one(names.get(k, k[:10]), e, e))
+    return ("ms/Mray/hbm/hbm_meas/valu: " + "; ".join(parts))[:600]
 
 
 def bench_camera(sb, W, H):
@@ -1164,11 +1190,12 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
         else:
             e["traffic"] = int(pmc["hbm_bytes_per_frame"])
             e["hbm_frac"] = round(e["traffic"] / sec / 1e9 / HBM_PEAK_GBS, 4)
-            e["hbm_frac_of_measured_copy"] = round(e["traffic"] / sec / 1e9 / copy_gbs, 4) if copy_gbs else None
+            best_gbs = copy_gbs.get("best_gbs") if isinstance(copy_gbs, dict) else copy_gbs
+            e["hbm_frac_of_measured"] = round(e["traffic"] / sec / 1e9 / best_gbs, 4) if best_gbs else None
             if pmc.get("valu_insts_per_frame"):
                 e["valu_insts_per_frame"] = int(pmc["valu_insts_per_frame"])
                 e["valu_frac_of_spec"] = round(pmc["valu_insts_per_frame"] / sec / 1e9 / VALU_PEAK_SPEC_GINSTR, 4)
-            e["bound"] = "hbm" if (e["hbm_frac"] or 0) >= (e["valu_frac_of_spec"] or 0) else "valu"
+            e["limiting"] = "hbm" if (e["hbm_frac"] or 0) >= (e["valu_frac_of_spec"] or 0) else "valu"
         out[name] = e
         del bufs, streams
         torch.cuda.empty_cache()
@@ -1220,23 +1247,20 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
     return out
 
 
-def measured_copy_bandwidth(nbytes=1 << 30, reps=10):
-    """Device-to-device copy of 1 GiB, read + written bytes per second in GB/s: what this
-    box's HBM delivers to a streaming kernel, reported next to the 8 TB/s nameplate."""
-    import torch
+def measured_hbm_bandwidth(sb, device=0, nbytes=2 << 30, reps=10):
+    """SURVEY.md 8d's denominator: what this box's HBM delivers to a streaming kernel -- the library's own float4 grid-stride
+    copy and STREAM triad over 2 GiB arrays (sdfhip_device_bandwidth, csrc/bandwidth.hip: best of four grid sizes, plain and
+    non-temporal accesses), bytes read + written per second in GB/s.  -> {"copy_gbs", "triad_gbs", "best_gbs", ...} or None.
+    (Until round 5 this was a torch `copy_` of 1 GiB, which reached 4.8-5.3 TB/s -- below what the frame's own kernels
+    sustain on cfg-5, so fractions of it exceeded 1.)"""
     try:
-        src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            dst.copy_(src)
-        b.record()
-        torch.cuda.synchronize()
-        return round(2 * nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9, 1)
-    except RuntimeError:
+        c, t = sb.device_bandwidth(device, nbytes, reps)
+    except Exception as e:                       # (out of memory beside a large scene: the line goes on without the figure)
+        print(f"[bench] measured_hbm_bandwidth: {type(e).__name__}: {e}", file=sys.stderr)
         return None
+    return {"copy_gbs": round(c, 1), "triad_gbs": round(t, 1), "best_gbs": round(max(c, t), 1), "array_bytes": nbytes, "reps": reps,
+            "is": "sdfhip_device_bandwidth: float4 grid-stride copy (2 x array bytes moved) and triad a = b + s c (3 x) over arrays far "
+                  "larger than the 256 MiB Infinity Cache, HIP-event time, best of 4 grid sizes x {plain, non-temporal}"}
 
 
 def cpu_limits():

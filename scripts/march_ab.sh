@@ -3,6 +3,8 @@
 #   for v in 0 1 2 3; do make -C sdfbox_amd/csrc product EXTRA_HIPFLAGS=-DMARCH_AB=$v OUT=../libsdfhip_ab$v.so; rm -rf sdfbox_amd/csrc/obj; done
 #   bash scripts/march_ab.sh        (on the GPU box)  -> gpurun_out/march_ab/
 set -u
+# the hardware queues bench.py asks for: under rocprofv3 --pmc the profiler has initialised the GPU before bench.py can set it
+export GPU_MAX_HW_QUEUES=8
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 OUT=$ROOT/gpurun_out/march_ab

@@ -3,6 +3,8 @@
 #   for v in 1 4 5; do (cd sdfbox_amd/csrc && rm -rf obj && make -j8 product EXTRA_HIPFLAGS=-DMARCH_AB=$v OUT=../libsdfhip_ab$v.so); done
 #   bash scripts/march_ab2.sh "1 4 5"       (on the GPU box)  -> gpurun_out/march_ab2/
 set -u
+# the hardware queues bench.py asks for: under rocprofv3 --pmc the profiler has initialised the GPU before bench.py can set it
+export GPU_MAX_HW_QUEUES=8
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 VARS=${1:-"1 4 5"}

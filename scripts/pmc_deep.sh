@@ -1,6 +1,6 @@
 #!/bin/bash
 # deeper SQ counters of the default kernel (one frame in flight: PMC serialises launches anyway)
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/pmc_deep; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp; cd $ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/pmc_deep; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp; export GPU_MAX_HW_QUEUES=8; cd $ROOT
 A="--steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1 $*"
 rocprofv3 --pmc SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_LEVEL_WAVES SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/p1 -- python3 bench.py $A > $OUT/p1.json 2> $OUT/p1.err
 rocprofv3 --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_SALU --output-format csv -d $OUT/p2 -- python3 bench.py $A > $OUT/p2.json 2> $OUT/p2.err

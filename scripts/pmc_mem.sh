@@ -2,7 +2,7 @@
 # memory-path counters of the default kernel (one frame in flight: PMC serialises launches anyway)
 # usage: bash scripts/pmc_mem.sh <tag> [bench args]     (few counters per pass: the TA / TCP blocks have few slots)
 TAG=${1:-mem}; shift || true
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/pmc_mem_$TAG; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp; cd $ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/pmc_mem_$TAG; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp; export GPU_MAX_HW_QUEUES=8; cd $ROOT
 A="--steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1 $*"
 i=0
 for pass in "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes of the path-traced kernel (1080p, 4 spp): HBM traffic, cache hit rates, waits, lane utilisation
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/pmc_path; mkdir -p $OUT; export TMPDIR=/tmp; cd $ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/pmc_path; mkdir -p $OUT; export TMPDIR=/tmp; export GPU_MAX_HW_QUEUES=8; cd $ROOT
 A="--spp 4 --steps 3 --warmup 1 --no-cpu-baseline --frames-in-flight 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/p1 -- python3 bench.py $A > $OUT/p1.json 2> $OUT/p1.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/p2 -- python3 bench.py $A > $OUT/p2.json 2> $OUT/p2.err

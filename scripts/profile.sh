@@ -4,6 +4,8 @@
 # Output: gpurun_out/prof_<tag>/...  (scripts/summarise_profile.py turns it into
 # profiles/<tag>_*.{csv,json}, which are committed)
 set -u
+# the hardware queues bench.py asks for: under rocprofv3 --pmc the profiler has initialised the GPU before bench.py can set it
+export GPU_MAX_HW_QUEUES=8
 TAG=${1:-r02}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for the GPU SdfGen builder on the 1 M-point knot, depth 9 and 10: kernel trace + stats, then
 # separate FETCH_SIZE / WRITE_SIZE passes.  usage (GPU box): bash scripts/profile_sdfgen.sh <tag>
-TAG=${1:-r03}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/prof_${TAG}_sdfgen; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp; cd $ROOT
+TAG=${1:-r03}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/prof_${TAG}_sdfgen; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp; export GPU_MAX_HW_QUEUES=8; cd $ROOT
 for d in 9 10; do
   echo "depth $d: stats" >> $OUT/progress.txt
   timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_d$d -- python3 scripts/sdfgen_profile.py $d > $OUT/stats_d$d.log 2>&1

@@ -3,6 +3,8 @@
 # (separate --pmc FETCH_SIZE / WRITE_SIZE / TCC hit passes) of cfg-5, R = 0 (off) and the values given.  Runs on the GPU box:
 #   bash scripts/pt_sort_ab.sh 0 3     -> gpurun_out/pt_sort/<R>/...
 set -u
+# the hardware queues bench.py asks for: under rocprofv3 --pmc the profiler has initialised the GPU before bench.py can set it
+export GPU_MAX_HW_QUEUES=8
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 export TMPDIR=/tmp

@@ -3,6 +3,8 @@
 # waves hand theirs to the queue (ballot + prefix) for k_shadow -- against the default kernel.  T = 65 queues every ray (the
 # form measured in rounds 2-3), T = 1 queues none.  usage: bash scripts/shadow_hybrid_ab.sh   -> gpurun_out/shadow_hybrid/
 set -u
+# the hardware queues bench.py asks for: under rocprofv3 --pmc the profiler has initialised the GPU before bench.py can set it
+export GPU_MAX_HW_QUEUES=8
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"
 OUT=$ROOT/gpurun_out/shadow_hybrid; mkdir -p "$OUT"
 # parity first: the queued form's tests with a threshold in the middle

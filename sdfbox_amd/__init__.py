@@ -9,10 +9,10 @@ from ._lib import (FLAG_COMPACT, FLAG_COUNT, FLAG_DISPLAY, FLAG_DISPLAY_DEBUG, F
                    MultiStats, PathTrace, SdfHipError, Stats)
 from .logic import Logic
 from .octdata import OctData, dragon_standin, knot_point_cloud, sphere_d4, torus_d6, write_ply
-from .renderer import HostFrame, MultiScene, Scene, device_count, device_pci_bus_id, sdfgen_trim, unorm_table
+from .renderer import HostFrame, MultiScene, Scene, device_bandwidth, device_count, device_pci_bus_id, sdfgen_trim, unorm_table
 
 __all__ = [
     "FLAG_COMPACT", "FLAG_COUNT", "FLAG_DISPLAY", "FLAG_DISPLAY_DEBUG", "FLAG_TILE_ORDER", "FLAG_WIRE", "KERNEL_AUTO", "KERNEL_GENERIC", "KERNEL_STACK", "TUNE_ONE_KERNEL", "TUNE_SHADOW_QUEUE", "Info",
     "PathTrace", "SdfHipError", "Stats", "Logic", "OctData", "dragon_standin", "knot_point_cloud", "write_ply", "sphere_d4", "torus_d6",
-    "Scene", "HostFrame", "MultiScene", "MultiStats", "device_count", "device_pci_bus_id", "sdfgen_trim", "unorm_table",
+    "Scene", "HostFrame", "MultiScene", "MultiStats", "device_bandwidth", "device_count", "device_pci_bus_id", "sdfgen_trim", "unorm_table",
 ]

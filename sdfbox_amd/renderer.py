@@ -324,6 +324,13 @@ def device_pci_bus_id(device=0):
     return out.value.decode()
 
 
+def device_bandwidth(device=0, nbytes=2 << 30, reps=10, triad=True):
+    """(copy GB/s, triad GB/s) of the device's memory for a streaming kernel (sdfhip_device_bandwidth): arrays of nbytes each."""
+    c, t = ctypes.c_double(), ctypes.c_double()
+    check(lib.sdfhip_device_bandwidth(int(device), int(nbytes), int(reps), ctypes.byref(c), ctypes.byref(t) if triad else None))
+    return c.value, (t.value if triad else None)
+
+
 def sdfgen_trim():
     """Give back the device memory the point-cloud builder keeps between builds (sdfhip_sdfgen_trim)."""
     check(lib.sdfhip_sdfgen_trim())

@@ -159,33 +159,38 @@ def test_bench_ab_forms_need_the_experiments_flavour():
 
 
 def test_roofline_reports_only_measured_fractions():
-    # bench.py's roofline(): with a PMC entry of this build the fraction is the larger of two measured quantities against
-    # hard ceilings (HBM counter bytes against 8 TB/s, issued VALU instructions against the chip's spec issue rate);
-    # without one no fraction is reported at all, only the demand figures, which are labelled as not being fractions
+    # bench.py's roofline(): `frac` is the fraction SURVEY.md 8d asks for -- HBM counter bytes / time / 8 TB/s (bound "hbm") --
+    # with the issued-VALU fraction of the chip's spec rate as its PEER and `limiting` naming the larger; fractions of the
+    # MEASURED streaming rate beside the nameplate ones; without a PMC entry of this build no fraction at all, only the demand
+    # figures, which are labelled as not being fractions
     sys.path.insert(0, REPO)
     import bench
     assert bench.VALU_PEAK_SPEC_GINSTR == 1228.8
     pmc = {"hbm_bytes_per_frame": 580_000_000, "valu_insts_per_frame": 68_000_000, "profile": "profiles/x.json", "kernel_source_sha": "abc"}
-    r = bench.roofline(0.1232e-3, 904e6, 3.92e9, pmc, 5500.0)
-    assert r["binding"] == "hbm-traffic" and r["bound"] == "hbm" and r["traffic"] == 580_000_000 and r["pmc_stale"] is False
-    assert abs(r["frac"] - 580e6 / 0.1232e-3 / 1e9 / 8000.0) < 1e-3 and r["frac"] <= 1.0
+    measured = {"copy_gbs": 6100.0, "triad_gbs": 6300.0, "best_gbs": 6300.0}
+    r = bench.roofline(0.1232e-3, 904e6, 3.92e9, pmc, measured)
+    assert r["bound"] == "hbm" and r["limiting"] == "hbm" and r["traffic"] == 580_000_000 and r["pmc_stale"] is False and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - 580e6 / 0.1232e-3 / 1e9 / 8000.0) < 1e-3 and r["frac"] == r["hbm_frac"] <= 1.0
+    assert abs(r["hbm_frac_of_measured"] - 580e6 / 0.1232e-3 / 1e9 / 6300.0) < 1e-3 and r["measured_hbm_gbs"] == measured
     assert abs(r["candidates"]["valu"]["frac"] - 68e6 / 0.1232e-3 / 1e9 / 1228.8) < 1e-3 and r["valu_frac_of_spec"] == r["candidates"]["valu"]["frac"]
     assert abs(r["valu_frac_of_measured_ceiling"] - 68e6 / 0.1232e-3 / 1e9 / bench.VALU_PEAK_GINSTR) < 1e-3
     assert r["demand"]["own_bytes_per_frame"] == 904_000_000 and "algorithmic" not in r
+    # an issue-bound frame: `frac` stays the HBM fraction (what 8d asks), `limiting` says valu and the peer carries its fraction
     r4k = bench.roofline(0.388e-3, 3.62e9, 15.7e9, {"hbm_bytes_per_frame": 1_178_000_000, "valu_insts_per_frame": 259_000_000}, None)
-    assert r4k["binding"] == "valu" and r4k["bound"] == "valu" and r4k["frac"] <= 1.0 and r4k["peak"] == 1228.8
+    assert r4k["bound"] == "hbm" and r4k["limiting"] == "valu" and r4k["frac"] == r4k["hbm_frac"] < r4k["valu_frac_of_spec"] <= 1.0
+    assert r4k["hbm_frac_of_measured"] is None and r4k["candidates"]["valu"]["peak"] == 1228.8
     none = bench.roofline(0.388e-3, 3.62e9, 15.7e9, None, None)      # the demand of 64 lanes asking for the same cells is not an HBM figure
-    assert none["binding"] is None and none["traffic"] is None and none["pmc_stale"] is True and none["frac"] is None
+    assert none["bound"] is None and none["limiting"] is None and none["traffic"] is None and none["pmc_stale"] is True and none["frac"] is None
     assert none["demand"]["own_demand_over_hbm_peak"] > 1.0 and none["demand"]["reference_demand_over_hbm_peak"] > 5.0     # 9.3 TB/s of demand is no HBM fraction
     # PMC figures are reported only for the build they were measured on
     assert "dropped" in bench.load_pmc("no such workload")            # ... and the line says why there are none
     gone = bench.roofline(0.1e-3, 1.0e9, 4.0e9, bench.load_pmc("no such workload"), 5000.0)
     assert gone["traffic"] is None and "no PMC pass" in gone["traffic_source"] and gone["hbm_frac"] is None and gone["valu_busy"] is None and gone["pmc_stale"]
     full = bench.roofline(0.098e-3, 968e6, 3.92e9, {"hbm_bytes_per_frame": 236_142_336, "valu_insts_per_frame": 59_606_143,
-                                                    "valu_active_quad_cycles_per_frame": 59_900_000, "profile": "p", "kernel_source_sha": "s"}, 5100.0)
-    assert abs(full["hbm_frac"] - 236_142_336 / 0.098e-3 / 8e12) < 1e-3 and abs(full["hbm_frac_of_measured_copy"] - 236_142_336 / 0.098e-3 / 5.1e12) < 1e-3
+                                                    "valu_active_quad_cycles_per_frame": 59_900_000, "profile": "p", "kernel_source_sha": "s"}, 6100.0)
+    assert abs(full["hbm_frac"] - 236_142_336 / 0.098e-3 / 8e12) < 1e-3 and abs(full["hbm_frac_of_measured"] - 236_142_336 / 0.098e-3 / 6.1e12) < 1e-3
     assert abs(full["valu_busy"] - 59.9e6 * 4 / (1024 * 2.4e9 * 0.098e-3)) < 1e-3 and "not a measured utilisation" in full["valu_busy_is"]
-    assert full["bound"] == "valu" and abs(full["frac"] - 59_606_143 / 0.098e-3 / 1228.8e9) < 1e-3
+    assert full["limiting"] == "valu" and abs(full["valu_frac_of_spec"] - 59_606_143 / 0.098e-3 / 1228.8e9) < 1e-3 and full["frac"] == full["hbm_frac"]
     assert full["candidates"]["valu"]["measured_ceiling"] == round(bench.VALU_PEAK_GINSTR, 1) and full["traffic_source"]["frames_in_flight_while_counting"] == 1
     import json as _json
     with open(os.path.join(REPO, "profiles", "hbm_traffic.json")) as f:
@@ -193,6 +198,22 @@ def test_roofline_reports_only_measured_fractions():
     for key, e in t.items():
         assert set(e) >= {"hbm_bytes_per_frame", "valu_insts_per_frame", "profile", "kernel_source_sha"}, key
         assert os.path.exists(os.path.join(REPO, e["profile"])), key
+
+
+def test_configs_summary_is_short_and_names_every_config():
+    # the driver keeps the last 2 000 characters of the line: `configs_summary`, its LAST key, carries every configuration's time
+    # and both fractions in <= 600 characters
+    sys.path.insert(0, REPO)
+    import bench
+    cfgs = {n: {"ms_per_step": 0.3066 + i, "value": 27012.3, "hbm_frac": 0.1712, "hbm_frac_of_measured": 0.2175, "valu_frac_of_spec": 0.5431,
+                "pmc_stale": False} for i, n in enumerate(("cfg3_4k", "cfg3_4k_compact", "cfg5_4k_spp16", "cfg2_depth10", "cfg2_mesh_knot_d10"))}
+    cfgs["cfg5_4k_spp16"] = {"error": "RuntimeError: out of memory " + "x" * 300}
+    cfgs["cfg2_depth10"].update(pmc_stale=True, hbm_frac=None, valu_frac_of_spec=None, hbm_frac_of_measured=None)
+    text = bench.configs_summary({"ms_per_step": 0.0901, "value": 23014.0, "roofline": {"hbm_frac": 0.33, "hbm_frac_of_measured": 0.42, "valu_frac_of_spec": 0.52}}, cfgs)
+    assert len(text) <= 600 and text.startswith("ms/Mray/hbm/hbm_meas/valu: cfg2 0.0901/23014/0.33/0.42/0.52")
+    for n in ("cfg3 ", "cfg3c ", "cfg5 ", "d10 ", "mesh "):
+        assert n in text, n
+    assert "cfg5 ERR" in text and "d10 3.3066/27012/-/-/-" in text
 
 
 def test_orbit_cameras_walk_round_the_scene():
