@@ -99,10 +99,57 @@ def parse():
     ap.add_argument("--multi-mode", default="groups", choices=["groups", "frame"],
                     help="--single-process: 'groups' = groups of --gather-every frames, four groups in flight (throughput); "
                          "'frame' = one frame at a time across all devices, launch to completion (what a viewer waits for)")
+    ap.add_argument("--init-timeout", type=float, default=90.0,
+                    help="N > 1: seconds the rendezvous (init_process_group) and every later collective may take before it raises")
+    ap.add_argument("--watchdog-seconds", type=float, default=-1.0,
+                    help="a daemon thread writes the run's phase to stderr every few seconds and ends the process with exit code 3 once "
+                         "the whole run has taken this long (-1 = default: 420 for N > 1, off for N = 1; 0 = off)")
     ap.add_argument("--lab", action="store_true",
                     help="load the experiments flavour of the library (libsdfhip_lab.so, include/sdfhip_experimental.h): needed by the A/B "
                          "forms --one-kernel and --shadow-queue")
     return ap.parse_args()
+
+
+class Watchdog:
+    """First contact with N GPUs must end in bounded time and say where it stopped: a daemon thread that
+    writes `[bench rank r] phase ..., s in it` to stderr every `every` seconds while the run is in a phase that can block on
+    another rank, and ends THIS process with os._exit(3) -- a fresh exit, no re-exec, no clean-up that could block in turn --
+    once the run has taken `budget` seconds (or a phase its own limit).  The launcher then ends the other ranks."""
+
+    def __init__(self, rank, budget, every=5.0):
+        import threading
+        self.rank, self.budget, self.every = rank, budget, every
+        self.t0 = self.t_phase = time.monotonic()
+        self.name, self.limit, self.quiet = "start", None, True
+        self.lock = threading.Lock()
+        self.thread = None
+        if budget > 0:
+            self.thread = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
+            self.thread.start()
+
+    def phase(self, name, limit=None, quiet=False):
+        """enter a phase; `limit` = seconds this phase alone may take; quiet phases are not logged while they run"""
+        with self.lock:
+            self.name, self.limit, self.quiet, self.t_phase = name, limit, quiet, time.monotonic()
+        if self.budget > 0 and not quiet:
+            print(f"[bench rank {self.rank}] phase: {name}", file=sys.stderr, flush=True)
+
+    def _run(self):
+        while True:
+            time.sleep(min(self.every, 1.0))
+            now = time.monotonic()
+            with self.lock:
+                name, limit, quiet, in_phase = self.name, self.limit, self.quiet, now - self.t_phase
+            total = now - self.t0
+            over = total > self.budget or (limit is not None and in_phase > limit)
+            if over:
+                why = (f"phase '{name}' has taken {in_phase:.0f} s (limit {limit:.0f})" if (limit is not None and in_phase > limit)
+                       else f"the run has taken {total:.0f} s (budget {self.budget:.0f}), in phase '{name}' for {in_phase:.0f} s")
+                print(f"[bench rank {self.rank}] WATCHDOG: {why}: giving up with exit code 3", file=sys.stderr, flush=True)
+                os._exit(3)
+            if not quiet and in_phase >= self.every and int(in_phase / self.every) != int((in_phase - min(self.every, 1.0)) / self.every):
+                print(f"[bench rank {self.rank}] still in phase '{name}' after {in_phase:.0f} s ({total:.0f} s of {self.budget:.0f})",
+                      file=sys.stderr, flush=True)
 
 
 def main():
@@ -125,6 +172,8 @@ def main():
             raise SystemExit(spawn_ranks(args.gpus))   # nothing has touched the GPU yet in this process
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    budget = args.watchdog_seconds if args.watchdog_seconds >= 0 else (420.0 if world > 1 else 0.0)
+    wd = Watchdog(rank, budget)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver supports dmabuf IPC only (RCCL needs it)
     # HIP deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); streams that share a queue run their
     # kernels one behind the other.  A renderer that keeps frames in flight wants them on queues of their own: with 8 queues, four
@@ -139,28 +188,44 @@ def main():
         sb.tiles.BandLayout, sb.tiles.deinterleave, sb.tiles.deinterleave_sparse2, sb.tiles.render_bands, sb.tiles.render_bands_batch,
         sb.tiles.render_sparse2, sb.tiles.sparse2_bytes, sb.tiles.sparse2_floats_offset)
 
+    import datetime
+    sharded = world > 1 or args.exercise_gather
+    nccl = args.backend == "nccl"
+
+    def rendezvous(**kw):
+        """first contact: every rank must arrive within --init-timeout, or this rank says so and ends non-zero"""
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        wd.phase(f"rendezvous ({args.backend} init_process_group, world {world}, {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')})",
+                 limit=args.init_timeout + 30.0)
+        try:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=args.init_timeout), **kw)
+        except Exception as e:
+            print(f"[bench rank {rank}] rendezvous failed after at most {args.init_timeout:.0f} s: not every one of the {world} ranks "
+                  f"arrived ({type(e).__name__}: {str(e)[:300]})", file=sys.stderr, flush=True)
+            raise SystemExit(4)
+    if sharded and not nccl:
+        rendezvous()                      # gloo needs no GPU: before anything touches one
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     ndev = torch.cuda.device_count()
     device = local_rank % ndev            # the gloo rehearsal may put several ranks on one GPU
     torch.cuda.set_device(device)
-    sharded = world > 1 or args.exercise_gather
-    if sharded:
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-        kw = {"device_id": torch.device("cuda", device)} if args.backend == "nccl" else {}
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
-    nccl = args.backend == "nccl"
+    if sharded and nccl:
+        rendezvous(device_id=torch.device("cuda", device))
 
     W, H = (int(v) for v in args.size.lower().split("x"))
     # who really takes part (the line says so: a scaling curve is only one if the ranks sit on different GPUs)
+    wd.phase("who takes part (all_gather of the PCI bus ids: the first collective)", limit=args.init_timeout + 30.0)
     bus_ids = [sb.device_pci_bus_id(device)]
     if sharded and world > 1:
         got = [None] * world
         dist.all_gather_object(got, bus_ids[0])
         bus_ids = got
 
+    wd.phase("scene build + upload", quiet=True)
     # ---- scene: built on the host, resident in HBM before anything is timed ----------
     t0 = time.time()
     ncpu = os.cpu_count() or 1
@@ -223,12 +288,14 @@ def main():
 
     # rank 0 also assembles the frame (de-interleave + wire expansion of every rank's rows), so it
     # renders a smaller share: --rank0-weight, or measured here before anything is timed
+    wd.phase("rank-0 weight search (rank 0 times shares; the others wait in a broadcast)")
     w0 = args.rank0_weight if world > 1 else 1.0
     if sharded and world > 1 and w0 <= 0:
         w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, share_shape, px_dtype, px_bytes,
                                   rank, nccl, pt, compact, G, nbuf, sparse2)
     if (H + args.band_rows - 1) // args.band_rows > 512 or w0 > 0.98:
         w0 = 1.0
+    wd.phase("buffers, first share, channel set-up (the first send / recv between two ranks)")
     layout = BandLayout(H, world, args.band_rows, w0)
     streams = [torch.cuda.Stream() for _ in range(nbuf)]                       # one per group in flight
     main = torch.cuda.current_stream().cuda_stream
@@ -451,6 +518,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    wd.phase("counting render", quiet=True)
     # ---- algorithmic work of one frame: counting build of the same kernel, untimed ------
     st = sb.Stats()
     count_buf = local[0] if not sparse2 else torch.zeros((rows_local, W, 4), dtype=torch.float32, device="cuda")
@@ -515,6 +583,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()) / n * 1e3
 
+    wd.phase("latency passes (one group at a time)")
     n_lat = 5 if pt is not None else 40
     latency = {"frames": G, "ms": round(latency_pass(cams, n_lat), 4)}
     if pt is None and not args.check:
@@ -530,11 +599,13 @@ def main():
                                      "orbit_quarter_degree_ms": round(latency_pass(slow, n_lat, sb.FLAG_TILE_ORDER), 4),
                                      "orbit_quarter_degree_ms_default_order": round(latency_pass(slow, n_lat), 4)}
 
+    wd.phase("warm-up")
     # ---- warm-up, then the timed region ---------------------------------------------------
     for k in range(args.warmup):
         step(k, last=(k == args.warmup - 1))
     drain()
     barrier()
+    wd.phase("timed region", quiet=True)              # (no print between the barrier and the clock)
     resent_before = resent                    # (the moving-camera passes above resend tails by design; the timed region should not)
     t_start = time.perf_counter()
     for k in range(args.steps):
@@ -554,6 +625,7 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
     frames_per_launch = float(np.mean([n for _, _, n in ev]))
 
+    wd.phase("check (assembled frames against a whole-frame render)")
     check_ok = None
     # (always when several ranks took part: a scaling curve is worth what its frames are -- one whole-frame render and a few compares)
     if (args.check or world > 1) and sharded and rank == 0:
@@ -575,6 +647,7 @@ def main():
                   for w in range(G) if g * G + w < args.steps]
         check_ok = all(bool(torch.equal(frame[sl][w].view(torch.int32), ref_of(k).view(torch.int32))) for sl, w, k in filled)
 
+    wd.phase("report (bandwidth, configs, cpu baseline on rank 0; the others wait at the last barrier)", quiet=world == 1)
     if rank == 0:
         sec_per_step = elapsed / args.steps
         copy_gbs = measured_hbm_bandwidth(sb, device)   # the box's own figure beside the nameplate

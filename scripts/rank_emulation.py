@@ -1,91 +1,95 @@
-"""Dev script (GPU): what ONE rank of an N-rank sharded run does on its GPU, timed alone on this one -- its bands of G frames per
-launch into a sparse share (sdfhip_render_sparse_device), four launches in flight as bench.py keeps them -- in the steady state
-and as the short burst the driver's scaling run times (20 steps after a synchronisation).  No gather, no expansion: an upper
-bound of the scaling the march itself allows, t(1 rank, whole frame) / t(rank's share).
-usage: python scripts/rank_emulation.py [WxH]"""
-import os, sys, time
+"""Dev script (GPU): what the ranks of an N-rank sharded run do on their GPUs, timed alone on this one.
+
+A peer renders its bands of G frames per launch into a sparse share (sdfhip_render_sparse_device), `nbuf` launches in flight as
+bench.py keeps them; rank 0 renders a smaller share (the weight bench.py searches at start-up) AND expands all N shares into the
+frames (its own share stands in for the peers': the expansion reads as many bytes).  The larger of the two is what a frame costs the
+pipeline before any byte travels.  Timed in the steady state (400 steps) and as the short burst the driver's scaling run times
+(`--steps`, default 20, after a synchronisation), against the whole frame on one GPU under the same clock: t(1 GPU) / t(N ranks).
+No gather: the links are what this cannot emulate.
+
+usage: python scripts/rank_emulation.py [WxH] [--steps 20] [--sweep] [--order]
+  --sweep   every (G, nbuf) of a small table instead of bench.py's own choice (tiles.group_plan)
+  --order   the shares' tiles launched in the order of their cost in the last launch (SDFHIP_FLAG_TILE_ORDER on a batch)"""
+import argparse, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, ".")
 import torch
 import sdfbox_amd as sb
-from sdfbox_amd.tiles import BandLayout, deinterleave_sparse2, render_sparse2, sparse2_bytes
+from sdfbox_amd.tiles import BandLayout, deinterleave_sparse2, group_plan, render_sparse2, sparse2_bytes
 
-W, H = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1920x1080").split("x"))
+ap = argparse.ArgumentParser()
+ap.add_argument("size", nargs="?", default="1920x1080")
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--sweep", action="store_true")
+ap.add_argument("--order", action="store_true")
+ap.add_argument("--worlds", default="2,4,8")
+args = ap.parse_args()
+W, H = (int(v) for v in args.size.split("x"))
+STEPS = args.steps
+FLAGS = sb.FLAG_TILE_ORDER if args.order else 0
 od = sb.dragon_standin(9); sc = sb.Scene(od)
 cam = sb.Logic(W, H); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
-NBUF = 4
-streams = [torch.cuda.Stream() for _ in range(NBUF)]
+MAXBUF = 8
+streams = [torch.cuda.Stream() for _ in range(MAXBUF)]
 
-# the whole frame on one GPU, four frames in flight (the N = 1 line's steady state and its 20-step burst)
-bufs = [torch.zeros((H, W, 4), device="cuda") for _ in range(NBUF)]
+
+def best(fn, n, reps):
+    return min(fn(n) for _ in range(reps))
+
+
+# the whole frame on one GPU, four frames in flight (the N = 1 line's steady state and its burst)
+bufs = [torch.zeros((H, W, 4), device="cuda") for _ in range(4)]
 def whole(n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(n):
-        sc.DrawDevice(cam, W, H, bufs[k % NBUF].data_ptr(), stream=streams[k % NBUF].cuda_stream)
+        sc.DrawDevice(cam, W, H, bufs[k % 4].data_ptr(), stream=streams[k % 4].cuda_stream)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 whole(40)
-t1 = min(whole(400) for _ in range(3)); t1_20 = min(whole(20) for _ in range(5))
-print(f"{W}x{H} whole frame, 4 in flight: {t1:.4f} ms steady, {t1_20:.4f} ms per frame in a 20-step burst", flush=True)
+t1 = best(whole, 400, 3); t1_b = best(whole, STEPS, 7)
+print(f"{W}x{H} whole frame, 4 in flight: {t1:.4f} ms steady, {t1_b:.4f} ms per frame in a {STEPS}-step burst", flush=True)
 del bufs
 
-for world in (2, 4, 8):
-    for G in ((4, 8) if world == 8 else (4,)):
-        lay = BandLayout(H, world, 16)
-        full = lay.rows_per_rank * W * G
-        shares = [torch.zeros(sparse2_bytes(lay.rows_per_rank, W, G, full), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
-        base = [0] * NBUF
-        for rank in (0, world - 1):
-            def run(nframes):
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                k = 0
-                while k < nframes:
-                    g = min(G, nframes - k); slot = (k // G) % NBUF
-                    render_sparse2(sc, [cam] * g, W, lay, rank, shares[slot].data_ptr(), full, base[slot], stream=streams[slot].cuda_stream)
-                    k += g
-                torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / nframes * 1e3
-                for s in range(NBUF):
-                    base[s] = int(shares[s][:4].view(torch.int32).item()) & 0xFFFFFFFF
-                return dt
-            run(40)
-            steady = min(run(400) for _ in range(3)); burst = min(run(20) for _ in range(5))
-            print(f"world {world} G={G} rank {rank}: share {steady:.4f} ms steady ({t1 / steady:.2f}x of {world}), "
-                  f"{burst:.4f} ms per frame in a 20-step burst ({t1_20 / burst:.2f}x)", flush=True)
-        del shares
 
-# ... and rank 0's whole job: its (smaller, weighted) share AND the expansion of all N shares into the frames (its own share stands in
-# for the peers': the expansion reads as many bytes) -- against a peer's share, by the weight of rank 0's share.  The larger of the
-# two is what a frame costs the pipeline before any byte travels.
-for world in (2, 4, 8):
-    G = 8 if world == 8 else 4
+def measure(world, G, nbuf, weight):
+    """(rank 0 steady, peer steady, rank 0 burst, peer burst) in ms per frame for this layout"""
+    lay = BandLayout(H, world, 16, weight)
+    full = lay.rows_per_rank * W * G
+    shares = [torch.zeros(sparse2_bytes(lay.rows_per_rank, W, G, full), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     frames = torch.zeros((G, H, W, 4), device="cuda")
-    rows = []
-    for weight in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5):
-        lay = BandLayout(H, world, 16, weight)
-        full = lay.rows_per_rank * W * G
-        shares = [torch.zeros(sparse2_bytes(lay.rows_per_rank, W, G, full), dtype=torch.uint8, device="cuda") for _ in range(NBUF)]
-        base = [0] * NBUF
+    base = [0] * nbuf
 
-        def job(rank, nframes, expand):
-            for s_ in range(NBUF):
-                shares[s_][:4].zero_(); base[s_] = 0
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            k = 0
-            while k < nframes:
-                g = min(G, nframes - k); slot = (k // G) % NBUF
-                if k >= G * NBUF:            # the slot's counter runs on: read it back as bench.py does (its previous group is complete by now)
-                    streams[slot].synchronize(); base[slot] = int(shares[slot][:4].view(torch.int32).item()) & 0xFFFFFFFF
-                render_sparse2(sc, [cam] * g, W, lay, rank, shares[slot].data_ptr(), full, base[slot], stream=streams[slot].cuda_stream)
-                if expand:
-                    deinterleave_sparse2(0, [shares[slot].data_ptr()] * world, frames.data_ptr(), W, lay, full, frames=g, stream=streams[slot].cuda_stream)
-                k += g
-            torch.cuda.synchronize(); return (time.perf_counter() - t0) / nframes * 1e3
-        job(0, 40, True)
-        r0 = min(job(0, 400, True) for _ in range(3)); r0b = min(job(0, 20, True) for _ in range(5))
-        p1 = min(job(1, 400, False) for _ in range(3)); p1b = min(job(1, 20, False) for _ in range(5))
-        rows.append((max(r0, p1), weight, r0, p1, r0b, p1b))
-        del shares
-        if r0 <= p1:
-            break
-    best, weight, r0, p1, r0b, p1b = min(rows)
-    print(f"world {world} G={G}: rank 0 renders {weight:.1f} of a peer's share and expands: {r0:.4f} ms per frame, a peer {p1:.4f} -> {t1 / best:.2f}x of {world} steady; "
-          f"20-step burst {r0b:.4f} / {p1b:.4f} -> {t1_20 / max(r0b, p1b):.2f}x", flush=True)
+    def job(rank, nframes, expand):
+        for s_ in range(nbuf):
+            shares[s_][:4].zero_(); base[s_] = 0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        k = 0
+        while k < nframes:
+            g = min(G, nframes - k); slot = (k // G) % nbuf
+            if k >= G * nbuf:            # the slot's counter runs on: read it back as bench.py does (its previous group is complete by now)
+                streams[slot].synchronize(); base[slot] = int(shares[slot][:4].view(torch.int32).item()) & 0xFFFFFFFF
+            render_sparse2(sc, [cam] * g, W, lay, rank, shares[slot].data_ptr(), full, base[slot], flags=FLAGS, stream=streams[slot].cuda_stream)
+            if expand:
+                deinterleave_sparse2(0, [shares[slot].data_ptr()] * world, frames.data_ptr(), W, lay, full, frames=g, stream=streams[slot].cuda_stream)
+            k += g
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / nframes * 1e3
+    job(0, 40, True); job(1, 40, False)
+    r = (best(lambda n: job(0, n, True), 400, 2), best(lambda n: job(1, n, False), 400, 2),
+         best(lambda n: job(0, n, True), STEPS, 7), best(lambda n: job(1, n, False), STEPS, 7))
+    del shares, frames
+    return r
+
+
+for world in (int(w) for w in args.worlds.split(",")):
+    plans = [(1, 4), (2, 4), (4, 4), (8, 4), (2, 8), (4, 2), (8, 2), (5, 4), (7, 3), (10, 2), (20, 1)] if args.sweep else [group_plan(world, STEPS)]
+    for G, nbuf in plans:
+        if G > 8 or nbuf > MAXBUF:       # (MAX_BATCH frames per launch)
+            continue
+        rows = []
+        for weight in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4):
+            r0, p1, r0b, p1b = measure(world, G, nbuf, weight)
+            rows.append((max(r0b, p1b), weight, r0, p1, r0b, p1b))
+            if r0b <= p1b and r0 <= p1:
+                break
+        _, weight, r0, p1, r0b, p1b = min(rows)
+        print(f"world {world} G={G} nbuf={nbuf}{' ordered' if args.order else ''}: rank 0 renders {weight:.1f} of a peer's share and expands: steady {r0:.4f} / peer {p1:.4f} ms per frame "
+              f"-> {t1 / max(r0, p1):.2f}x of {world}; {STEPS}-step burst {r0b:.4f} / {p1b:.4f} -> {t1_b / max(r0b, p1b):.2f}x", flush=True)

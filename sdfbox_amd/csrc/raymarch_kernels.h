@@ -599,7 +599,9 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     typedef typename CursorOf<CUR, COUNT>::type CursorT;
     // grid: x = 8 tiles_x (XCD label in the low three bits, tile column above), y = groups of eight tile rows, z = frame of the batch:
     // tile_of_block's mapping (XCD k renders tile rows k, k + 8, ...) read off the block's coordinates, without its division
-    const uint32_t f = blockIdx.z;
+    // ... or, for a launch in tile order (P.tile_perm): x = XCD label, y = frame of the batch, z = order slot -- the batch's frames
+    // are neighbours in the dispatch order, so the expensive tiles of ALL its frames start first
+    const uint32_t f = P.tile_perm ? blockIdx.y : blockIdx.z;
     FrameInfo I = P.frames[f];
     // the scalars every march step reads stay in SGPRs: left alone, the compiler reloads them
     // from the kernel arguments (s_load + s_waitcnt) in every iteration
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     }
     uint32_t tile, tx, ty;
     if (P.tile_perm) {
-        tile = P.tile_perm[blockIdx.y * gridDim.x + blockIdx.x];
+        tile = P.tile_perm[blockIdx.z * 8u + blockIdx.x];
         if (tile >= P.n_tiles) return;
         tx = tile % P.tiles_x; ty = tile / P.tiles_x;
     } else {

@@ -180,7 +180,8 @@ int launch_default(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &
     hipStream_t st = c.st;
     // SDFHIP_FLAG_TILE_ORDER: this frame's tiles in the order made from the last frame of the same geometry on this stream
     // (frames of more than 65 536 tiles -- 4K -- run 16 rounds of workgroups: their tail is short and the order costs locality)
-    const bool ordered = (c.flags & SDFHIP_FLAG_TILE_ORDER) != 0 && c.n_frames == 1 && P.n_tiles <= 65536u &&
+    // A batch (n_frames > 1: the frames of a gather group) is ordered by the costs of its LAST frame in the previous launch.
+    const bool ordered = (c.flags & SDFHIP_FLAG_TILE_ORDER) != 0 && P.n_tiles <= 65536u && plan.grid.x / 8u <= 65535u &&
                          plan.grid.x <= 8u * 1024u * (uint32_t)ORDER_SPAN && !P.tile_perm && !P.tile_cost;
     sdfhip_scene::Scratch *sc = nullptr;
     if (ordered) {
@@ -195,7 +196,7 @@ int launch_default(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &
             if (sc->ord_class) (void)hipFree(sc->ord_class);
             if (sc->ord_perm) (void)hipFree(sc->ord_perm);
             sc->ord_cost = nullptr; sc->ord_class = nullptr; sc->ord_perm = nullptr; sc->ord_tiles = sc->ord_blocks = 0; sc->ord_valid = false;
-            HIP_TRY(hipMalloc((void **)&sc->ord_cost, (size_t)P.n_tiles * sizeof(uint16_t)));
+            HIP_TRY(hipMalloc((void **)&sc->ord_cost, (size_t)MAX_BATCH * P.n_tiles * sizeof(uint16_t)));     // (every frame of a batch writes its costs)
             HIP_TRY(hipMalloc((void **)&sc->ord_class, (size_t)P.n_tiles));
             HIP_TRY(hipMalloc((void **)&sc->ord_perm, (size_t)plan.grid.x * sizeof(uint32_t)));
             sc->ord_tiles = P.n_tiles; sc->ord_blocks = plan.grid.x;
@@ -208,9 +209,11 @@ int launch_default(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &
     else                             { if (plan.count) launch_march<CUR_STACK_FULL, true>(plan.out_mode, plan.grid, st, P); else launch_march<CUR_STACK_FULL, false>(plan.out_mode, plan.grid, st, P); }
     // the next frame's launch order, behind this frame in its stream -- unless the order in use was made from a frame with this
     // very camera block: the same camera gives the same costs and the same order (a viewer at rest pays for the order once)
-    if (ordered && !(sc->ord_valid && memcmp(c.info, &sc->ord_info, sizeof(sdfhip_info)) == 0)) {
-        sc->ord_info = *c.info;
-        hipLaunchKernelGGL(k_tile_class, dim3((P.n_tiles + 255u) / 256u), dim3(256), 0, st, sc->ord_cost, sc->ord_class, P.tiles_x, P.tiles_y);
+    const sdfhip_info *last = c.info + (c.n_frames - 1u);
+    if (ordered && !(sc->ord_valid && memcmp(last, &sc->ord_info, sizeof(sdfhip_info)) == 0)) {
+        sc->ord_info = *last;
+        hipLaunchKernelGGL(k_tile_class, dim3((P.n_tiles + 255u) / 256u), dim3(256), 0, st, sc->ord_cost + (size_t)(c.n_frames - 1u) * P.n_tiles,
+                           sc->ord_class, P.tiles_x, P.tiles_y);
         hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(1024), 0, st, sc->ord_class, sc->ord_perm, P.tiles_x, P.tiles_y);
         sc->ord_valid = true;
     }

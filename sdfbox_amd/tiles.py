@@ -95,6 +95,16 @@ class BandLayout:
         return self.owner[b], self._local[b] * self.band_rows + y % self.band_rows
 
 
+def group_plan(world, steps=0):
+    """(frames per launch and gather, groups in flight) of a sharded run of `steps` frames over `world` ranks (0 = a long run).
+    A rank's share of one frame is small (1 / world of it) behind a fixed cost per launch, collective and wait, so G frames share
+    a launch; and a launch alone ends with its longest waves' chain of dependent steps, so several are kept in flight.  A short
+    run (the driver's scaling run times 20 steps) is one fill and one drain with little between them: fewer, fuller groups
+    (scripts/rank_emulation.py --sweep, profiles/r05_rank_emulation.txt)."""
+    G = 8 if world >= 8 else 4
+    return G, 4
+
+
 def wire_shape(rows, width):
     """Shape of the uint8 tensor that holds one frame-share of `rows` x `width` wire pixels: the
     first 4 * rows * width bytes are the float plane, the last rows * width the byte plane."""

@@ -120,6 +120,44 @@ def test_sparse_share_written_by_the_march_kernel_expands_to_the_frame(sb, torch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,weight", [(2, 1.0), (4, 0.6)])
+def test_sparse_shares_of_a_batch_launched_in_tile_order(sb, torch_mod, scenes, world, weight):
+    # SDFHIP_FLAG_TILE_ORDER on the batched launch of a gather group (round 5: a rank's short burst ends with its longest waves, so
+    # the group's expensive tiles -- of ALL its frames -- go first): launch after launch on one stream, the order made from the last
+    # frame of the launch before -- same cameras again, other cameras (a stale order), a partial last group (fewer frames: another
+    # share layout), a second stream with its own order.  Every expanded frame must equal the whole-frame render; the shares start
+    # as garbage, so a tile no workgroup took would show.
+    torch = torch_mod
+    BandLayout = sb.tiles.BandLayout
+    T = sb.tiles
+    W, H, G = 333, 211, 4
+    od = scenes["torus_d6"]
+    names = ("rotated", "closeup", "default", "rotated")
+    lay = BandLayout(H, world, 16, weight)
+    cap = lay.rows_per_rank * W * G
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    with sb.Scene(od) as scene:
+        refs = {n: whole_frame(sb, torch, scene, make_camera(n, W, H), W, H) for n in set(names)}
+        groups = (names, names, names[::-1], names[:3], names[1:2], names, names[:2], names)
+        stream_of = lambda k: streams[k % 3 == 2]              # (launches 2 and 5 on the second stream)
+        shares = {}
+        for r in range(world):                                 # a rank's launches one after the other, as on its own GPU: the order
+            for k, group in enumerate(groups):                 # a launch uses is the one made behind the same rank's launch before it
+                cams = [make_camera(n, W, H) for n in group]
+                shares[k, r] = torch.full((T.sparse2_bytes(lay.rows_per_rank, W, len(cams), cap),), 0xA5, dtype=torch.uint8, device="cuda")
+                T.render_sparse2(scene, cams, W, lay, r, shares[k, r].data_ptr(), cap, 0xA5A5A5A5, flags=sb.FLAG_TILE_ORDER,
+                                 stream=stream_of(k).cuda_stream)
+        torch.cuda.synchronize()
+        for k, group in enumerate(groups):
+            n = len(group)
+            out = torch.full((n, H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+            T.deinterleave_sparse2(0, [shares[k, r].data_ptr() for r in range(world)], out.data_ptr(), W, lay, cap, frames=n)
+            torch.cuda.synchronize()
+            for f in range(n):
+                assert torch.equal(out[f].view(torch.int32), refs[group[f]].view(torch.int32)), f"world {world} launch {k} frame {f}"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0], [0] * 7])
 def test_multi_frame_equals_the_oracle_and_one_device(sb, oracle_mod, scenes, devices):
     for sname, cname, (W, H) in (("sphere_d4", "default", (256, 256)), ("torus_d6", "rotated", (200, 120)), ("torus_d6", "closeup", (129, 65))):
