@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--tile-order", action="store_true",
                     help="render every frame with SDFHIP_FLAG_TILE_ORDER (tiles in descending order of their cost in the stream's "
                          "last frame); without it only the latency.tile_order figures use the flag")
+    ap.add_argument("--no-tile-order", action="store_true",
+                    help="A/B: sharded runs (N > 1) launch their shares' tiles in the default order instead of by last launch's cost")
     ap.add_argument("--shadow-queue", action="store_true",
                     help="A/B knob: k_march queues its shadow rays for a second kernel (k_shadow), 64 to a wave")
     ap.add_argument("--one-kernel", action="store_true",
@@ -87,6 +89,10 @@ def parse():
     ap.add_argument("--rank0-weight", type=float, default=0.0,
                     help="sharded runs: rank 0's share of the frame as a fraction of a peer's share "
                          "(0 = measure at start-up so that render + assembly on rank 0 takes as long as a peer's render)")
+    ap.add_argument("--deal", default="cost", choices=["cost", "weight"],
+                    help="sharded runs: how the frame's bands are dealt -- 'cost': by their measured cost, longest first, rank 0 charged for "
+                         "the assembly (tiles.balanced_owner); 'weight': round robin by credit with rank 0's share a searched fraction of a "
+                         "peer's (rounds 2-4; also what the other output modes use)")
     ap.add_argument("--sparse-cap-scale", type=float, default=1.25,
                     help="sparse shares: the floats that travel with a share = this x the lit pixels measured before the timed region (a value "
                          "below 1 forces tails to be sent again)")
@@ -274,7 +280,8 @@ def main():
     # flight (so G*nbuf frames).  A rank's share is mostly the serial tail of its longest
     # pixels: G frames in one grid share that tail
     # (8 at 8 ranks: the shares are small there, and a group costs ~60 us of host time: launch, collective, wait)
-    G = (args.gather_every if args.gather_every > 0 else (8 if world >= 8 else 4)) if sharded else 1
+    plan_G, plan_nbuf = sb.tiles.group_plan(world, args.steps)
+    G = (args.gather_every if args.gather_every > 0 else plan_G) if sharded else 1
     if pt is not None or compact:
         G = 1 if not sharded else G            # those kernels render one frame per launch
     # in flight: 4 frames on one GPU, on hardware queues of their own (GPU_MAX_HW_QUEUES above): the long tail of a frame's last waves
@@ -284,19 +291,29 @@ def main():
     # with 2 / 3 / 4 / 5 -- on four hardware queues the third brought nothing); 4
     # groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4 frames per launch needs 4 launches in flight to fill the
     # chip -- 0.039 -> 0.024 ms per frame at 8 ranks)
-    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (4 if sharded else 3 if pt is not None else 4)
+    nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (plan_nbuf if sharded else 3 if pt is not None else 4)
+    # the shares of a sharded run launch their tiles in the order of their cost in the stream's last launch (SDFHIP_FLAG_TILE_ORDER on
+    # the batched launch): a rank's share is small, and a short run ends with its longest waves -- they start first
+    if sparse2 and world > 1 and not args.no_tile_order:
+        flags |= sb.FLAG_TILE_ORDER
 
     # rank 0 also assembles the frame (de-interleave + wire expansion of every rank's rows), so it
     # renders a smaller share: --rank0-weight, or measured here before anything is timed
     wd.phase("rank-0 weight search (rank 0 times shares; the others wait in a broadcast)")
     w0 = args.rank0_weight if world > 1 else 1.0
+    deal = None
+    n_bands_frame = (H + args.band_rows - 1) // args.band_rows
     if sharded and world > 1 and w0 <= 0:
-        w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, share_shape, px_dtype, px_bytes,
-                                  rank, nccl, pt, compact, G, nbuf, sparse2)
-    if (H + args.band_rows - 1) // args.band_rows > 512 or w0 > 0.98:
+        if sparse2 and args.deal == "cost" and world <= n_bands_frame <= 512:
+            # the bands dealt by their measured cost, rank 0 charged for the assembly (tiles.balanced_owner)
+            deal = measure_band_deal(sb, scene, cam, W, H, world, args.band_rows, flags, rank, nccl, G, nbuf, args.steps)
+        else:
+            w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, share_shape, px_dtype, px_bytes,
+                                      rank, nccl, pt, compact, G, nbuf, sparse2)
+    if n_bands_frame > 512 or w0 > 0.98 or w0 <= 0:
         w0 = 1.0
     wd.phase("buffers, first share, channel set-up (the first send / recv between two ranks)")
-    layout = BandLayout(H, world, args.band_rows, w0)
+    layout = BandLayout(H, world, args.band_rows, w0, owner=deal)
     streams = [torch.cuda.Stream() for _ in range(nbuf)]                       # one per group in flight
     main = torch.cuda.current_stream().cuda_stream
     rows_local = layout.rows_per_rank if sharded else H
@@ -709,6 +726,8 @@ def main():
                 "parallelism": "1 GPU" if not sharded else
                                f"{world} GPU(s), {args.band_rows}-row bands " +
                                ("round-robin" if not layout.weighted else
+                                f"dealt by measured cost, rank 0 charged for the assembly (rank 0: {len(layout.bands_of(0))} of {layout.n_bands} bands)"
+                                if layout.dealt_by_cost else
                                 f"dealt by weight (rank 0: {layout.rank0_weight:.3f} of a peer's share)") +
                                f" + gather to rank 0 ({args.backend})",
                 "ranks_seen": dist.get_world_size() if sharded else 1,
@@ -723,6 +742,7 @@ def main():
                 "frames_rendered_in_the_timed_region": rendered,
                 "gather_pixel_bytes": (round(s2["prefix"] / (rows_local * W * G), 3) if sparse2 else px_bytes) if sharded else None,
                 "gather_format": ("sparse shares written by the march kernel" if sparse2 else "frame pixels") if sharded else None,
+                "shares_in_tile_order": bool(flags & sb.FLAG_TILE_ORDER) if sharded else None,
                 "float_tails_sent_again": resent if sparse2 else None,
                 "float_tails_sent_again_in_the_timed_region": (resent - resent_before) if sparse2 else None,
                 "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
@@ -1017,6 +1037,77 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
         w = w.cuda()
     dist.broadcast(w, src=0)
     return float(w.item())
+
+
+def measure_band_deal(sb, scene, cam, W, H, world, band_rows, flags, rank, nccl, G, nbuf, steps):
+    """The frame's bands dealt by their measured COST (tiles.balanced_owner), with rank 0 -- which also expands all shares into
+    the frame -- charged for that work.  Before anything is timed, rank 0 renders the frame once, prices every band from the
+    step counts (tiles.band_costs), and tries deals that charge it 0 .. 20 % of the frame's cost for the assembly: for each it
+    times its own job (its share + the expansion of `world` shares, its own standing in for the peers') and two peers' shares
+    (the scene is replicated: it can render them itself), in the shape the run will have (a short run -- the driver's scaling run
+    times 20 steps -- is timed as that burst).  Every rank then receives the deal with the smallest maximum.  -> owner[band]."""
+    import torch
+    import torch.distributed as dist
+    T = sb.tiles
+    n_bands = (H + band_rows - 1) // band_rows
+    owner = torch.zeros(n_bands, dtype=torch.uint8)
+    if rank == 0:
+        streams = [torch.cuda.Stream() for _ in range(nbuf)]
+        whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        scene.DrawDevice(cam, W, H, whole.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        costs = T.band_costs(whole[..., 3], band_rows)
+        del whole
+        total = sum(costs)
+        frames = torch.zeros((G, H, W, 4), dtype=torch.float32, device="cuda")
+        burst = 0 < steps <= 64
+        n_frames = steps if burst else 16 * G
+
+        def job(lay, r, shares, expand):
+            full = lay.rows_per_rank * W * G
+
+            def run():
+                for sh in shares:
+                    sh[:4].zero_()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                k = 0
+                while k < n_frames:
+                    g = min(G, n_frames - k)
+                    slot = (k // G) % nbuf
+                    T.render_sparse2(scene, [cam] * g, W, lay, r, shares[slot].data_ptr(), full, 0, flags=flags, stream=streams[slot].cuda_stream)
+                    if expand:
+                        T.deinterleave_sparse2(torch.cuda.current_device(), [shares[slot].data_ptr()] * world, frames.data_ptr(), W, lay, full,
+                                               frames=g, stream=streams[slot].cuda_stream)
+                    k += g
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n_frames
+            run()                                             # (and, with SDFHIP_FLAG_TILE_ORDER, the order every stream's launches will use)
+            return min(run() for _ in range(5 if burst else 2))
+
+        tried = []
+        for frac in (0.0, 0.04, 0.07, 0.10, 0.13, 0.16, 0.20):
+            own = T.balanced_owner(costs, world, extra0=frac * total)
+            lay = T.BandLayout(H, world, band_rows, owner=own)
+            full = lay.rows_per_rank * W * G
+            shares = [torch.zeros(T.sparse2_bytes(lay.rows_per_rank, W, G, full), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+            t0 = job(lay, 0, shares, True)
+            t1 = max(job(lay, r, shares, False) for r in sorted({1, world - 1}))
+            tried.append((max(t0, t1), frac, t0, t1, own))
+            del shares
+            if t0 <= t1 and frac > 0:                     # rank 0 is no longer the slowest: charging it more only loads the peers
+                break
+        _, frac, t0, t1, own = min(tried, key=lambda e: e[0])
+        owner = torch.tensor(own, dtype=torch.uint8)
+        print("[bench] band deal by cost (" + ("%d-step burst" % steps if burst else "steady state") + "): " +
+              ", ".join(f"assembly charged {f:.2f}: rank0 {a * 1e3:.4f} / peers {b * 1e3:.4f} ms" for _, f, a, b, _ in tried) + f" -> {frac:.2f}",
+              file=sys.stderr)
+        del frames
+        torch.cuda.empty_cache()
+    if nccl:
+        owner = owner.cuda()
+    dist.broadcast(owner, src=0)
+    return [int(v) for v in owner.cpu().tolist()]
 
 
 def spawn_ranks(n):
@@ -1388,13 +1479,18 @@ def cpu_baseline(od, cam, W, H, target_seconds):
     budget = target_seconds / len(cands)
     sweep, best, best_img, best_step = [], None, None, 1
     for nt in cands:
-        # rows for ~budget seconds if the threads scaled perfectly up to what the host lets this process use
-        rows = int(min(H, max(8, budget * min(nt, usable) / max(per_row1, 1e-9))))
+        # rows for ~budget seconds if the threads scaled perfectly up to what the host lets this process use; when the whole frame
+        # is not enough (a cgroup grants CPU time in 100 ms periods: a quota shows in a timed region of seconds, not in a burst of
+        # 0.2 s) the frame is rendered several times over
+        want = budget * min(nt, usable) / max(per_row1, 1e-9)
+        rows = int(min(H, max(8, want)))
         step = max(1, H // rows)
         nrows = (H + step - 1) // step
-        img, _, sec, topo = oracle.bench_rows(od.Structs, od.Values, cam.State, W, H, row_step=step, nthreads=nt, **kw)
-        e = {"threads": topo["threads"], "value": round(nrows * W / sec / 1e6, 3), "numa_nodes": topo["numa_nodes"],
-             "scene_copies": topo["scene_copies"], "sample": f"every {step}th row = {nrows * W} pixels in {sec:.2f} s"}
+        repeat = max(1, int(round(want / nrows)))
+        img, _, sec, topo = oracle.bench_rows(od.Structs, od.Values, cam.State, W, H, row_step=step, nthreads=nt, repeat=repeat, **kw)
+        e = {"threads": topo["threads"], "value": round(repeat * nrows * W / sec / 1e6, 3), "numa_nodes": topo["numa_nodes"],
+             "scene_copies": topo["scene_copies"],
+             "sample": f"every {step}th row = {nrows * W} pixels" + (f", {repeat} times over," if repeat > 1 else "") + f" in {sec:.2f} s"}
         sweep.append(e)
         if best is None or e["value"] > best["value"]:
             best, best_img, best_step = e, img, step

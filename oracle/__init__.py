@@ -80,7 +80,7 @@ def _bind(L):
     L.oracle_render_rows_pt.restype = c.c_int
     L.oracle_render_rows_pt.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, u32, u32, u32, c.c_float, vp, vp, c.c_int]
     L.oracle_bench_rows.restype = c.c_int
-    L.oracle_bench_rows.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, vp, vp, c.c_int, c.c_int, c.POINTER(c.c_double), c.POINTER(c.c_int * 4)]
+    L.oracle_bench_rows.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, vp, vp, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double), c.POINTER(c.c_int * 4)]
     L.oracle_pixel.restype = None
     L.oracle_pixel.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp]
     L.oracle_distance_at.restype = c.c_float
@@ -126,9 +126,10 @@ def render(structs, values, info, width, height, row0=0, nrows=None, nthreads=1,
 
 
 def bench_rows(structs, values, info, width, height, row0=0, nrows=None, row_step=1, nthreads=1, numa_copies=True,
-               native=False, store=True):
+               native=False, store=True, repeat=1):
     """The timed CPU baseline (oracle_bench_rows): the same pixels as render(), by a pool of threads that are pinned, have
     their node's copy of the scene and wait at a barrier before the clock starts; pixels dealt in chunks of 64 from one counter.
+    repeat: the sample rendered that many times over (counters count every pass).
     -> (rgba or None, counters[4], seconds between the barriers, {"threads", "numa_nodes", "affinity_cpus", "scene_copies"})."""
     structs = np.ascontiguousarray(structs, dtype=np.int32)
     values = np.ascontiguousarray(values, dtype=np.uint8)
@@ -141,7 +142,7 @@ def bench_rows(structs, values, info, width, height, row0=0, nrows=None, row_ste
     ib = _info_buf(info)
     rc = lib(native).oracle_bench_rows(structs.ctypes.data, values.ctypes.data, structs.size // 2, ctypes.addressof(ib), width, row0, nrows,
                                        row_step, out.ctypes.data if store else None, cnt.ctypes.data, int(nthreads),
-                                       1 if numa_copies else 0, ctypes.byref(sec), ctypes.byref(topo))
+                                       1 if numa_copies else 0, int(repeat), ctypes.byref(sec), ctypes.byref(topo))
     if rc != 0:
         raise RuntimeError(f"oracle_bench_rows failed with code {rc}")
     return out, cnt, sec.value, {"threads": topo[0], "numa_nodes": topo[1], "affinity_cpus": topo[2], "scene_copies": topo[3]}

@@ -615,7 +615,9 @@ int oracle_render_rows_pt(const int32_t *structs, const uint8_t *values, uint32_
  *   - pixels are dealt in chunks of 64 consecutive pixels of a row from one atomic counter (rows differ tenfold in
  *     cost: sky against grazing rays), so no thread waits for a neighbour's expensive rows;
  *   - `rgba` (nrows x W x 4, may be NULL: then nothing is stored) is written by the workers themselves -- fresh pages
- *     are first touched by the thread that fills them.
+ *     are first touched by the thread that fills them;
+ *   - `repeat` > 1 renders the sample that many times over (the counters count every pass): a host whose cgroup grants CPU time
+ *     in 100 ms periods needs a timed region of seconds to show its steady rate, and a frame has only so many rows.
  * -> 0, *seconds = wall time between the barriers, counters[4] as oracle_render_rows, topo[4] = {threads started,
  * NUMA nodes used, CPUs in the affinity mask, scene copies made}. */
 typedef struct {
@@ -634,7 +636,7 @@ struct o_bench_shared {
     pthread_barrier_t bar;                            /* initialised for the threads that really started, before `go` is set */
     pthread_mutex_t mu; pthread_cond_t cv; int go;
     uint64_t next __attribute__((aligned(128)));      /* next chunk */
-    uint64_t nchunks, chunks_per_row;
+    uint64_t nchunks, chunks_per_row, chunks_per_pass;     /* nchunks = repeat x chunks_per_pass */
     const int32_t *node_structs[64];
     const uint8_t *node_values[64];
     int copy, failed;
@@ -689,6 +691,7 @@ O_CLONES static void *o_bench_worker_impl(void *arg)
     for (;;) {
         uint64_t c = __atomic_fetch_add(&sh->next, 1, __ATOMIC_RELAXED);
         if (c >= sh->nchunks) break;
+        c %= sh->chunks_per_pass;                       /* (a repeated pass renders the same pixels again) */
         uint32_t r = (uint32_t)(c / sh->chunks_per_row), x0 = (uint32_t)(c % sh->chunks_per_row) * 64u;
         uint32_t x1 = x0 + 64u < jb->W ? x0 + 64u : jb->W;
         for (uint32_t x = x0; x < x1; x++)
@@ -703,7 +706,7 @@ static void *o_bench_worker(void *arg) { return o_bench_worker_impl(arg); }
 
 int oracle_bench_rows(const int32_t *structs, const uint8_t *values, uint32_t n, const void *info112, uint32_t W,
                       uint32_t row0, uint32_t nrows, uint32_t row_step, float *rgba, uint64_t *counters, int nthreads,
-                      int flags, double *seconds, int *topo)
+                      int flags, int repeat, double *seconds, int *topo)
 {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 1024) nthreads = 1024;
@@ -743,7 +746,8 @@ int oracle_bench_rows(const int32_t *structs, const uint8_t *values, uint32_t n,
     sh->copy = (flags & 1) && nnodes > 1;
     sh->structs = structs; sh->values = values; sh->n = n;
     sh->chunks_per_row = (W + 63u) / 64u;
-    sh->nchunks = (uint64_t)nrows * sh->chunks_per_row;
+    sh->chunks_per_pass = (uint64_t)nrows * sh->chunks_per_row;
+    sh->nchunks = sh->chunks_per_pass * (uint64_t)(repeat < 1 ? 1 : repeat);
     pthread_mutex_init(&sh->mu, NULL); pthread_cond_init(&sh->cv, NULL);
     int used_nodes = 0, node_has_leader[64] = {0};
     for (int t = 0; t < nthreads; t++) {

@@ -41,7 +41,7 @@ class BandLayout:
     the whole frame (sky and object rows in every share).  A rank's bands sit in its compact
     buffer in increasing band order either way."""
 
-    def __init__(self, height, world, band_rows=16, rank0_weight=1.0):
+    def __init__(self, height, world, band_rows=16, rank0_weight=1.0, owner=None):
         if band_rows < 1 or world < 1 or height < 1:
             raise ValueError("BandLayout: height, world and band_rows must be positive")
         if not 0.0 < rank0_weight <= 1.0:
@@ -51,7 +51,16 @@ class BandLayout:
         self.n_bands = (self.height + self.band_rows - 1) // self.band_rows
         self.rank0_weight = float(rank0_weight) if world > 1 else 1.0
         self.weighted = self.rank0_weight < 1.0
-        if self.weighted:
+        self.dealt_by_cost = owner is not None
+        if owner is not None:
+            # an explicit deal (balanced_owner: bands dealt by their measured cost): owner[b] = the rank that renders band b
+            owner = [int(o) for o in owner]
+            if len(owner) != self.n_bands or self.n_bands > 512 or self.world > 64 or any(not 0 <= o < self.world for o in owner):
+                raise ValueError("BandLayout: owner must name a rank for each of the frame's bands (at most 512 bands, 64 ranks)")
+            if any(r not in owner for r in range(self.world)):
+                raise ValueError("BandLayout: every rank must own a band (its share may not be empty)")
+            self.owner, self.weighted = owner, True
+        elif self.weighted:
             if self.n_bands > 512 or self.world > 64:
                 raise ValueError("BandLayout: a weighted layout holds at most 512 bands and 64 ranks")
             # integer credits (no float accumulation: every rank must compute the same deal)
@@ -93,6 +102,57 @@ class BandLayout:
         """global row -> (rank, local_row): the inverse used by the de-interleave."""
         b = y // self.band_rows
         return self.owner[b], self._local[b] * self.band_rows + y % self.band_rows
+
+
+def balanced_owner(costs, world, extra0=0.0, max_bands=None):
+    """Deal the frame's bands to the ranks by COST (longest processing time first: the most expensive band still undealt goes to
+    the rank with the least work so far) instead of by count.  costs[b] = the measured cost of band b (band_costs), extra0 = the
+    work rank 0 has besides its bands, in the same unit (it assembles the frame).  No rank receives more than max_bands bands (the
+    shares travel in messages of equal size, as large as the largest share: default the even count + a quarter, at least + 2),
+    every rank at least one.  Deterministic: every rank that computes it gets the same deal.  -> owner[b]."""
+    n = len(costs)
+    if world < 1 or n < world:
+        raise ValueError("balanced_owner: fewer bands than ranks")
+    even = (n + world - 1) // world
+    if max_bands is None:
+        max_bands = even + max(2, even // 4)
+    max_bands = max(max_bands, even)
+    load = [float(extra0)] + [0.0] * (world - 1)
+    count = [0] * world
+    owner = [-1] * n
+    order = sorted(range(n), key=lambda b: (-float(costs[b]), b))
+    for i, b in enumerate(order):
+        left = n - i                                        # bands still to deal, this one included
+        empty = [r for r in range(world) if count[r] == 0]
+        if len(empty) >= left:                              # the last bands go to the ranks that have none
+            r = min(empty, key=lambda r: (load[r], r))
+        else:
+            r = min((r for r in range(world) if count[r] < max_bands), key=lambda r: (load[r], r))
+        owner[b] = r
+        load[r] += float(costs[b])
+        count[r] += 1
+    return owner
+
+
+def band_costs(frame_alpha, band_rows, fixed=4.0):
+    """The cost of every band of a frame from its rendered step counts (the alpha channel of the RGBA32F frame, a torch tensor
+    H x W): a wave renders an 8x8 tile and runs as many iterations as its longest pixel takes, so a tile costs max(alpha) + `fixed`
+    (the wave's start and its stores, in iterations) and a band the sum over its tiles.  -> list of floats, one per band."""
+    import torch
+    H, W = frame_alpha.shape
+    a = torch.nan_to_num(frame_alpha.float(), nan=0.0, posinf=140.0, neginf=0.0)
+    ph, pw = (-H) % 8, (-W) % 8
+    if ph or pw:
+        a = torch.nn.functional.pad(a, (0, pw, 0, ph))
+    t = a.reshape(a.shape[0] // 8, 8, a.shape[1] // 8, 8).amax(dim=(1, 3)) + float(fixed)      # per tile
+    rows = t.sum(dim=1)                                                                         # per tile row
+    per_band = max(1, band_rows // 8)
+    n_bands = (H + band_rows - 1) // band_rows
+    out = []
+    for b in range(n_bands):
+        out.append(float(rows[b * per_band:(b + 1) * per_band].sum().item()) if band_rows % 8 == 0 else
+                   float(rows[(b * band_rows) // 8:((b + 1) * band_rows + 7) // 8].sum().item()))
+    return out
 
 
 def group_plan(world, steps=0):

@@ -140,11 +140,12 @@ def test_sparse_shares_of_a_batch_launched_in_tile_order(sb, torch_mod, scenes, 
         refs = {n: whole_frame(sb, torch, scene, make_camera(n, W, H), W, H) for n in set(names)}
         groups = (names, names, names[::-1], names[:3], names[1:2], names, names[:2], names)
         stream_of = lambda k: streams[k % 3 == 2]              # (launches 2 and 5 on the second stream)
-        shares = {}
+        shares = {(k, r): torch.full((T.sparse2_bytes(lay.rows_per_rank, W, len(group), cap),), 0xA5, dtype=torch.uint8, device="cuda")
+                  for k, group in enumerate(groups) for r in range(world)}
+        torch.cuda.synchronize()                               # (the fills run on torch's stream, the renders on their own)
         for r in range(world):                                 # a rank's launches one after the other, as on its own GPU: the order
             for k, group in enumerate(groups):                 # a launch uses is the one made behind the same rank's launch before it
                 cams = [make_camera(n, W, H) for n in group]
-                shares[k, r] = torch.full((T.sparse2_bytes(lay.rows_per_rank, W, len(cams), cap),), 0xA5, dtype=torch.uint8, device="cuda")
                 T.render_sparse2(scene, cams, W, lay, r, shares[k, r].data_ptr(), cap, 0xA5A5A5A5, flags=sb.FLAG_TILE_ORDER,
                                  stream=stream_of(k).cuda_stream)
         torch.cuda.synchronize()

@@ -50,6 +50,43 @@ def test_weighted_layout_gives_rank0_less_and_spreads_every_share():
         BandLayout(8192, 8, 8, 0.5)                            # 1024 bands > 512 in a weighted layout
 
 
+def test_bands_dealt_by_cost():
+    # tiles.balanced_owner: longest processing time first, rank 0 charged for the assembly, every rank at least one band and none
+    # more than the cap; tiles.band_costs: a tile costs its longest pixel's steps + a fixed part, a band the sum of its tiles
+    import torch
+    from sdfbox_amd.tiles import BandLayout, balanced_owner, band_costs
+    rng = np.random.default_rng(5)
+    costs = [float(c) for c in rng.choice([12, 14, 40, 90, 300, 700], size=68)]
+    total = sum(costs)
+    own = balanced_owner(costs, 8, extra0=0.08 * total)
+    lay = BandLayout(1080, 8, 16, owner=own)
+    assert lay.weighted and lay.dealt_by_cost and lay.owner == own and sum(len(lay.bands_of(r)) for r in range(8)) == 68
+    load = [sum(costs[b] for b in lay.bands_of(r)) for r in range(8)]
+    assert max(load[1:]) - min(load[1:]) <= 0.03 * max(load[1:])          # the peers within 3 % of each other
+    assert abs(load[0] + 0.08 * total - np.mean(load[1:])) <= 0.05 * np.mean(load[1:])     # rank 0's bands + its assembly = a peer's
+    assert balanced_owner(costs, 8, extra0=0.08 * total) == own            # deterministic
+    assert max(len(lay.bands_of(r)) for r in range(8)) <= 9 + 2 and lay.rows_per_rank == 16 * max(len(lay.bands_of(r)) for r in range(8))
+    for y in range(1080):                                                  # the inverse the de-interleave uses
+        r, l = lay.source_of(y)
+        assert (l, y) in set(lay.rows_of(r)) if y % 97 == 0 else True
+    # a rank 0 charged more than a share is worth still gets one band (its share may not be empty), and the cap binds
+    own = balanced_owner([1.0] * 16 + [100.0] * 4, 4, extra0=1e6)
+    assert own.count(0) == 1 and max(own.count(r) for r in range(4)) <= 5 + 2
+    assert balanced_owner([5, 1, 1, 1], 4, extra0=100) == [1, 2, 3, 0]
+    with pytest.raises(ValueError):
+        balanced_owner([1.0] * 3, 4)
+    with pytest.raises(ValueError):
+        BandLayout(64, 2, 16, owner=[0, 0, 0, 0])                          # rank 1 would have no band
+    with pytest.raises(ValueError):
+        BandLayout(64, 2, 16, owner=[0, 1, 2, 0])
+    # band_costs: alpha = steps; 16 x 24 frame = 2 x 3 tiles, band_rows 8 -> two bands
+    a = torch.zeros(16, 24)
+    a[0, 0] = 100.0; a[3, 9] = 7.0; a[9, 20] = 30.0; a[15, 23] = float("nan")
+    assert band_costs(a, 8, fixed=4.0) == [100 + 7 + 0 + 12.0, 0 + 0 + 30 + 12.0]
+    assert band_costs(a, 16, fixed=0.0) == [137.0]
+    assert len(band_costs(torch.zeros(1080, 1920), 16)) == 68 and len(band_costs(torch.zeros(37, 50), 16)) == 3
+
+
 def wire_pack(img):
     """numpy model of the kernel's wire buffer (FrameSink mode 3, raymarch_kernels.h): every pixel is
     (a, a, a, n), n <= 140, or the sky constant (0.005, 0.01, 0.2, n), n <= 100 -> a plane of floats
@@ -122,7 +159,19 @@ def _rank_main(rank, world, port, W, H, band_rows, q, rank0_weight=1.0, wire=Fal
     dist.init_process_group("gloo", rank=rank, world_size=world)
     od = sb.torus_d6()
     cam = make_camera("default", W, H)
-    lay = BandLayout(H, world, band_rows, rank0_weight)
+    if rank0_weight == "cost":
+        # the deal bench.py makes (measure_band_deal): rank 0 prices the bands from a rendered frame's step counts, charges itself
+        # for the assembly, and every rank receives the owner list in a broadcast
+        from sdfbox_amd.tiles import balanced_owner, band_costs
+        owner = torch.zeros((H + band_rows - 1) // band_rows, dtype=torch.uint8)
+        if rank == 0:
+            full0, _ = oracle.render(od.Structs, od.Values, cam.State, W, H)
+            costs = band_costs(torch.from_numpy(full0[..., 3].copy()), band_rows)
+            owner = torch.tensor(balanced_owner(costs, world, extra0=0.2 * sum(costs)), dtype=torch.uint8)
+        dist.broadcast(owner, src=0)
+        lay = BandLayout(H, world, band_rows, owner=owner.tolist())
+    else:
+        lay = BandLayout(H, world, band_rows, rank0_weight)
     local = np.zeros((lay.rows_per_rank, W, 4), dtype=np.float32)
     # the oracle renders this rank's bands (the GPU kernel's stand-in on CPU)
     for lb, b in enumerate(lay.bands_of(rank)):
@@ -143,7 +192,8 @@ def _rank_main(rank, world, port, W, H, band_rows, q, rank0_weight=1.0, wire=Fal
 
 
 @pytest.mark.parametrize("world,H,band_rows,rank0_weight,wire", [(2, 40, 8, 1.0, False), (2, 37, 16, 1.0, False),
-                                                                 (2, 56, 8, 0.6, True)])
+                                                                 (2, 56, 8, 0.6, True), (2, 56, 8, "cost", False),
+                                                                 (3, 61, 8, "cost", True)])
 def test_two_rank_gather_reassembles_the_frame(world, H, band_rows, rank0_weight, wire):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
