@@ -1075,6 +1075,9 @@ def measure_band_deal(sb, scene, cam, W, H, world, band_rows, flags, rank, nccl,
                 while k < n_frames:
                     g = min(G, n_frames - k)
                     slot = (k // G) % nbuf
+                    if k >= G * nbuf:                         # (the share's counter starts at 0 again: its floats are stored as in the run)
+                        with torch.cuda.stream(streams[slot]):
+                            shares[slot][:4].zero_()
                     T.render_sparse2(scene, [cam] * g, W, lay, r, shares[slot].data_ptr(), full, 0, flags=flags, stream=streams[slot].cuda_stream)
                     if expand:
                         T.deinterleave_sparse2(torch.cuda.current_device(), [shares[slot].data_ptr()] * world, frames.data_ptr(), W, lay, full,
@@ -1412,19 +1415,20 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
 
 
 def measured_hbm_bandwidth(sb, device=0, nbytes=2 << 30, reps=10):
-    """SURVEY.md 8d's denominator: what this box's HBM delivers to a streaming kernel -- the library's own float4 grid-stride
-    copy and STREAM triad over 2 GiB arrays (sdfhip_device_bandwidth, csrc/bandwidth.hip: best of four grid sizes, plain and
-    non-temporal accesses), bytes read + written per second in GB/s.  -> {"copy_gbs", "triad_gbs", "best_gbs", ...} or None.
-    (Until round 5 this was a torch `copy_` of 1 GiB, which reached 4.8-5.3 TB/s -- below what the frame's own kernels
-    sustain on cfg-5, so fractions of it exceeded 1.)"""
+    """SURVEY.md 8d's denominator: what this box's HBM delivers to a streaming kernel -- the library's own float4 copy, STREAM
+    triad and read-only sum over 2 GiB arrays (sdfhip_device_bandwidth, csrc/bandwidth.hip; the kernel shapes chosen by
+    scripts/micro/bw_variants.hip), bytes read + written per second in GB/s; `best_gbs` = the largest of the three, the roof no
+    kernel of this repository beats.  -> dict or None.  (Until round 5 this was a torch `copy_` of 1 GiB, which reaches
+    4.8-5.3 TB/s -- below what the frame's own kernels sustain on cfg-5, so fractions of it exceeded 1.)"""
     try:
-        c, t = sb.device_bandwidth(device, nbytes, reps)
+        c, t, r = sb.device_bandwidth(device, nbytes, reps)
     except Exception as e:                       # (out of memory beside a large scene: the line goes on without the figure)
         print(f"[bench] measured_hbm_bandwidth: {type(e).__name__}: {e}", file=sys.stderr)
         return None
-    return {"copy_gbs": round(c, 1), "triad_gbs": round(t, 1), "best_gbs": round(max(c, t), 1), "array_bytes": nbytes, "reps": reps,
-            "is": "sdfhip_device_bandwidth: float4 grid-stride copy (2 x array bytes moved) and triad a = b + s c (3 x) over arrays far "
-                  "larger than the 256 MiB Infinity Cache, HIP-event time, best of 4 grid sizes x {plain, non-temporal}"}
+    return {"copy_gbs": round(c, 1), "triad_gbs": round(t, 1), "read_gbs": round(r, 1), "best_gbs": round(max(c, t, r), 1), "array_bytes": nbytes,
+            "reps": reps,
+            "is": "sdfhip_device_bandwidth: float4 copy (2 x array bytes moved), triad a = b + s c (3 x) and a read-only sum (1 x) over arrays far "
+                  "larger than the 256 MiB Infinity Cache, HIP-event time; best_gbs = the largest of the three"}
 
 
 def cpu_limits():

@@ -240,13 +240,13 @@ SDFHIP_API float sdfhip_camera_mouse_wheel(float m_speed, float wheel_delta);
 SDFHIP_API int sdfhip_device_count(int *count);
 /* The PCI bus id of a device ("0000:c1:00.0"; out holds at least 16 bytes): what tells two ranks of a multi-GPU run apart. */
 SDFHIP_API int sdfhip_device_pci_bus_id(int device, char *out, uint32_t len);
-/* What this device's memory delivers to a streaming kernel, in GB/s (1e9 bytes): a float4 grid-stride copy (reads + writes
- * 2 x bytes) and STREAM's triad a = b + s c (3 x bytes) over arrays of `bytes` each (>= 1 MiB; use >= 1 GiB: the Infinity
- * Cache holds 256 MiB), `reps` launches timed with HIP events, best of a few grid sizes.  Either result pointer may be null
- * (no triad: one array less).  SURVEY.md 8d's "measured device bandwidth on the box": the denominator bench.py quotes HBM
+/* What this device's memory delivers to a streaming kernel, in GB/s (1e9 bytes): a float4 copy (reads + writes 2 x bytes),
+ * STREAM's triad a = b + s c (3 x bytes) and a read-only sum (1 x bytes) over arrays of `bytes` each (>= 1 MiB; use >= 1 GiB:
+ * the Infinity Cache holds 256 MiB), `reps` launches timed with HIP events.  Any result pointer may be null (no triad: one
+ * array less; read only: one array).  SURVEY.md 8d's "measured device bandwidth on the box": the denominator bench.py quotes HBM
  * fractions against, beside the 8 TB/s nameplate.  Nothing in the reference corresponds to it (it displays FPS only,
  * SdfBox/Logic.cs:298-301). */
-SDFHIP_API int sdfhip_device_bandwidth(int device, uint64_t bytes, uint32_t reps, double *copy_gbs, double *triad_gbs);
+SDFHIP_API int sdfhip_device_bandwidth(int device, uint64_t bytes, uint32_t reps, double *copy_gbs, double *triad_gbs, double *read_gbs);
 
 /* Replaces: OctData.StructBuffer() + OctData.ValueTexture(),
  * SdfBox/Program.cs:543-572, bound at Program.cs:147-152: copies the scene to

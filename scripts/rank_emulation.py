@@ -66,6 +66,8 @@ def measure(world, G, nbuf, lay):
     shares = [torch.zeros(sparse2_bytes(lay.rows_per_rank, W, G, full), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     frames = torch.zeros((G, H, W, 4), device="cuda")
     base = [0] * nbuf
+    own = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(nbuf)]      # the share's counter on its way back, as bench.py
+    evs = [torch.cuda.Event() for _ in range(nbuf)]                                  # keeps it: pinned copy + event on the slot's stream
 
     def job(rank, nframes, expand):
         for s_ in range(nbuf):
@@ -74,11 +76,14 @@ def measure(world, G, nbuf, lay):
         k = 0
         while k < nframes:
             g = min(G, nframes - k); slot = (k // G) % nbuf
-            if k >= G * nbuf:            # the slot's counter runs on: read it back as bench.py does (its previous group is complete by now)
-                streams[slot].synchronize(); base[slot] = int(shares[slot][:4].view(torch.int32).item()) & 0xFFFFFFFF
+            if k >= G * nbuf:            # the slot's previous group is complete by now: its counter has arrived (finish() in bench.py)
+                evs[slot].synchronize(); base[slot] = int(own[slot].item()) & 0xFFFFFFFF
             render_sparse2(sc, [cam] * g, W, lay, rank, shares[slot].data_ptr(), full, base[slot], flags=FLAGS, stream=streams[slot].cuda_stream)
             if expand:
                 deinterleave_sparse2(0, [shares[slot].data_ptr()] * world, frames.data_ptr(), W, lay, full, frames=g, stream=streams[slot].cuda_stream)
+            with torch.cuda.stream(streams[slot]):
+                own[slot].copy_(shares[slot][:4].view(torch.int32), non_blocking=True)
+                evs[slot].record(streams[slot])
             k += g
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / nframes * 1e3
     warm = 2 * G * nbuf

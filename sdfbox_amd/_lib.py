@@ -170,7 +170,7 @@ _SIG = {
     "sdfhip_info_set_position": (None, [_c.POINTER(Info), _c.c_float, _c.c_float, _c.c_float]),
     "sdfhip_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
     "sdfhip_device_pci_bus_id": (_c.c_int, [_c.c_int, _c.c_char_p, _c.c_uint32]),
-    "sdfhip_device_bandwidth": (_c.c_int, [_c.c_int, _c.c_uint64, _c.c_uint32, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
+    "sdfhip_device_bandwidth": (_c.c_int, [_c.c_int, _c.c_uint64, _c.c_uint32, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "sdfhip_multi_selftest": (_c.c_int, [_vp, _c.POINTER(MultiLink)]),
     "sdfhip_scene_upload": (_c.c_int, [_c.c_int, _vp, _vp, _c.c_uint32, _c.POINTER(_vp)]),
     "sdfhip_upload_options_default": (None, [_c.POINTER(UploadOptions)]),

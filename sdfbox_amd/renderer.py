@@ -324,11 +324,11 @@ def device_pci_bus_id(device=0):
     return out.value.decode()
 
 
-def device_bandwidth(device=0, nbytes=2 << 30, reps=10, triad=True):
-    """(copy GB/s, triad GB/s) of the device's memory for a streaming kernel (sdfhip_device_bandwidth): arrays of nbytes each."""
-    c, t = ctypes.c_double(), ctypes.c_double()
-    check(lib.sdfhip_device_bandwidth(int(device), int(nbytes), int(reps), ctypes.byref(c), ctypes.byref(t) if triad else None))
-    return c.value, (t.value if triad else None)
+def device_bandwidth(device=0, nbytes=2 << 30, reps=10):
+    """(copy, triad, read) GB/s of the device's memory for a streaming kernel (sdfhip_device_bandwidth): arrays of nbytes each."""
+    c, t, r = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    check(lib.sdfhip_device_bandwidth(int(device), int(nbytes), int(reps), ctypes.byref(c), ctypes.byref(t), ctypes.byref(r)))
+    return c.value, t.value, r.value
 
 
 def sdfgen_trim():
