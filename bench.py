@@ -193,6 +193,7 @@ def main():
     BandLayout, deinterleave, deinterleave_sparse2, render_bands, render_bands_batch, render_sparse2, sparse2_bytes, sparse2_floats_offset = (
         sb.tiles.BandLayout, sb.tiles.deinterleave, sb.tiles.deinterleave_sparse2, sb.tiles.render_bands, sb.tiles.render_bands_batch,
         sb.tiles.render_sparse2, sb.tiles.sparse2_bytes, sb.tiles.sparse2_floats_offset)
+    SparseShareCall, SparseExpandCall = sb.tiles.SparseShareCall, sb.tiles.SparseExpandCall
 
     import datetime
     sharded = world > 1 or args.exercise_gather
@@ -364,6 +365,28 @@ def main():
 
     def s2_ptrs(slot):                     # rank 0 reads its own share where it rendered it
         return [s2["share"][slot].data_ptr()] + [s2["gath"][slot][r].data_ptr() for r in range(1, world)]
+    if sparse2:
+        # what a group's launch, gather and expansion need, made once: the host's work per group is a handful of calls, none of
+        # which builds an argument array or a tensor view (a rank's share of a 1080p group at 8 ranks is ~90 us of GPU work)
+        s2["call"] = SparseShareCall(scene, W, layout, rank, s2["full"], max_frames=G, flags=flags)
+        s2["mine"] = [s2["share"][sl][:s2["prefix"]] for sl in range(nbuf)]
+        s2["own_src"] = [s2["share"][sl][:4].view(torch.int32) for sl in range(nbuf)]
+        s2["ptr"] = [s2["share"][sl].data_ptr() for sl in range(nbuf)]
+        if rank == 0:
+            s2["expand"] = SparseExpandCall(device, W, layout, s2["full"])
+            s2["ptrs"] = [s2_ptrs(sl) for sl in range(nbuf)]
+            s2["glist"] = [[s2["gath"][sl][r][:s2["prefix"]] for r in range(world)] for sl in range(nbuf)]
+            s2["frame_ptr"] = [frame[sl].data_ptr() for sl in range(nbuf)]
+            s2["counts_ptr"] = [s2["counts"][sl].data_ptr() for sl in range(nbuf)]
+    static_groups = {}
+
+    def group_of(k, n):                    # the cameras of the n frames that end at step k; a camera at rest: one list object per n
+        if len(cams) == 1:
+            key = (id(cams[0]), n)
+            if key not in static_groups:
+                static_groups[key] = [cams[0]] * n
+            return static_groups[key]
+        return [cam_of(k - n + 1 + i) for i in range(n)]
 
     def assemble(slot, st):
         deinterleave(device, gathered[slot].data_ptr(), frame[slot].data_ptr(), W, layout, stream=st, pixel_bytes=px_bytes, frames=G)
@@ -412,8 +435,7 @@ def main():
             with torch.cuda.stream(st):
                 w.wait()
                 if rank == 0:
-                    deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=n,
-                                         counts_ptr=s2["counts"][slot].data_ptr(), stream=st.cuda_stream)
+                    s2["expand"](slot, s2["ptrs"][slot], s2["frame_ptr"][slot], frames=n, counts_ptr=s2["counts_ptr"][slot], stream=st.cuda_stream)
                     s2["ev"][slot].record(st)
         elif rank == 0:                                   # gloo rehearsal: through host buffers
             for r in range(1, world):
@@ -471,11 +493,10 @@ def main():
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(s)
-            group = [cam_of(k - within + i) for i in range(within + 1)]
+            group = group_of(k, within + 1)
             if sparse2:
                 s2["n"][slot] = len(group)
-                render_sparse2(scene, group, W, layout, rank, s2["share"][slot].data_ptr(), s2["full"],
-                               s2["base"][slot], flags=flags, stream=s.cuda_stream)
+                s2["call"](group, s2["ptr"][slot], s2["base"][slot], stream=s.cuda_stream, flags=flags)
             else:
                 render_bands_batch(scene, group, W, layout, rank, local[slot].data_ptr(), flags=flags, stream=s.cuda_stream)
             if timed:
@@ -496,11 +517,11 @@ def main():
         if sparse2:
             if rank != 0:                             # this rank's own counter, for finish()
                 with torch.cuda.stream(s):
-                    s2["own"][slot].copy_(s2["share"][slot][:4].view(torch.int32), non_blocking=True)
+                    s2["own"][slot].copy_(s2["own_src"][slot], non_blocking=True)
                     s2["ev"][slot].record(s)
-            mine = s2["share"][slot][:s2["prefix"]]
+            mine = s2["mine"][slot]
             if nccl:
-                glist = [s2["gath"][slot][r][:s2["prefix"]] for r in range(world)] if rank == 0 else None
+                glist = s2["glist"][slot] if rank == 0 else None
                 with torch.cuda.stream(s):
                     pending[slot] = dist.gather(mine, glist, dst=0, async_op=True)
             else:

@@ -16,7 +16,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, ".")
 import torch
 import sdfbox_amd as sb
-from sdfbox_amd.tiles import BandLayout, balanced_owner, band_costs, deinterleave_sparse2, group_plan, render_sparse2, sparse2_bytes
+from sdfbox_amd.tiles import BandLayout, SparseExpandCall, SparseShareCall, balanced_owner, band_costs, group_plan, sparse2_bytes
 
 ap = argparse.ArgumentParser()
 ap.add_argument("size", nargs="?", default="1920x1080")
@@ -69,7 +69,17 @@ def measure(world, G, nbuf, lay):
     own = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(nbuf)]      # the share's counter on its way back, as bench.py
     evs = [torch.cuda.Event() for _ in range(nbuf)]                                  # keeps it: pinned copy + event on the slot's stream
 
+    expand_call = SparseExpandCall(0, W, lay, full)
+    calls = {r: SparseShareCall(sc, W, lay, r, full, max_frames=G, flags=FLAGS) for r in range(world)}
+    ptr = [sh.data_ptr() for sh in shares]
+    ptrs = [[p] * world for p in ptr]
+    own_src = [sh[:4].view(torch.int32) for sh in shares]
+    groups = {g: [cam] * g for g in range(1, G + 1)}
+    frames_ptr = frames.data_ptr()
+    host = [0.0, 0]
+
     def job(rank, nframes, expand):
+        call = calls[rank]
         for s_ in range(nbuf):
             shares[s_][:4].zero_(); base[s_] = 0
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -78,11 +88,13 @@ def measure(world, G, nbuf, lay):
             g = min(G, nframes - k); slot = (k // G) % nbuf
             if k >= G * nbuf:            # the slot's previous group is complete by now: its counter has arrived (finish() in bench.py)
                 evs[slot].synchronize(); base[slot] = int(own[slot].item()) & 0xFFFFFFFF
-            render_sparse2(sc, [cam] * g, W, lay, rank, shares[slot].data_ptr(), full, base[slot], flags=FLAGS, stream=streams[slot].cuda_stream)
+            h0 = time.perf_counter()
+            call(groups[g], ptr[slot], base[slot], stream=streams[slot].cuda_stream)
             if expand:
-                deinterleave_sparse2(0, [shares[slot].data_ptr()] * world, frames.data_ptr(), W, lay, full, frames=g, stream=streams[slot].cuda_stream)
+                expand_call(slot, ptrs[slot], frames_ptr, frames=g, stream=streams[slot].cuda_stream)
+            host[0] += time.perf_counter() - h0; host[1] += 1
             with torch.cuda.stream(streams[slot]):
-                own[slot].copy_(shares[slot][:4].view(torch.int32), non_blocking=True)
+                own[slot].copy_(own_src[slot], non_blocking=True)
                 evs[slot].record(streams[slot])
             k += g
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / nframes * 1e3
@@ -94,6 +106,7 @@ def measure(world, G, nbuf, lay):
         job(r, warm, False)                       # (and, with --order, this rank's tile order on every stream)
         p = max(p, best(lambda n: job(r, n, False), 400, 2)); pb = max(pb, best(lambda n: job(r, n, False), STEPS, 7))
     del shares, frames
+    measure.host_us = host[0] / max(1, host[1]) * 1e6          # host time of a group's launch call(s)
     return r0, p, r0b, pb
 
 
@@ -119,4 +132,4 @@ for world in (int(w) for w in args.worlds.split(",")):
         _, what, r0, p1, r0b, p1b = min(rows)
         st = min(max(r[2], r[3]) for r in rows)
         print(f"world {world} G={G} nbuf={nbuf}{' ordered' if args.order else ''} deal={args.deal}: rank 0 {what}, expands: steady {r0:.4f} / slowest peer {p1:.4f} ms per frame "
-              f"-> {t1 / max(r0, p1):.2f}x of {world} (best steady over the deals tried {t1 / st:.2f}x); {STEPS}-step burst {r0b:.4f} / {p1b:.4f} -> {t1_b / max(r0b, p1b):.2f}x", flush=True)
+              f"-> {t1 / max(r0, p1):.2f}x of {world} (best steady over the deals tried {t1 / st:.2f}x); {STEPS}-step burst {r0b:.4f} / {p1b:.4f} -> {t1_b / max(r0b, p1b):.2f}x  [{measure.host_us:.1f} us of host time per launch call]", flush=True)

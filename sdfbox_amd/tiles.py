@@ -309,6 +309,56 @@ def render_sparse2(scene, states, width, layout, rank, share_ptr, capacity, coun
                                           ctypes.c_void_p(int(share_ptr)), ctypes.c_void_p(int(stream)) if stream else None))
 
 
+class SparseShareCall:
+    """render_sparse2 for a renderer that launches the same share frame after frame: the band list, the camera array and the
+    argument objects are made ONCE; a call copies the group's camera blocks (112 bytes each) and enters the library.  A group's
+    launch is then a few microseconds of host time instead of several tens (a rank's share of a frame is 10 - 40 us of GPU work:
+    the host must not be what the GPU waits for)."""
+
+    def __init__(self, scene, width, layout, rank, capacity, max_frames=8, flags=0):
+        from ._lib import Info
+        self._h, self._w, self._h_frame = scene._h, int(width), layout.height
+        blist = layout.bands_of(rank)
+        self._bands = (ctypes.c_uint16 * len(blist))(*blist)
+        self._nb, self._band_rows, self._rows = len(blist), layout.band_rows, layout.rows_per_rank
+        self._cap, self._flags = int(capacity), int(flags)
+        self._infos = (Info * max_frames)()
+        self._max = max_frames
+        self._last = None                      # the states of the last call: a camera at rest is not copied again
+        self._size = ctypes.sizeof(Info)
+
+    def __call__(self, states, share_ptr, count_base, stream=None, flags=None):
+        n = len(states)
+        if n > self._max:
+            raise ValueError("SparseShareCall: more frames than it was made for")
+        if states is not self._last:
+            for i, st in enumerate(states):
+                ctypes.memmove(ctypes.addressof(self._infos) + i * self._size, ctypes.addressof(getattr(st, "State", st)), self._size)
+            self._last = states
+        check(lib.sdfhip_render_sparse_device(self._h, self._infos, n, self._w, self._h_frame, self._band_rows, self._bands, self._nb,
+                                              self._rows, self._cap, int(count_base) & 0xFFFFFFFF, self._flags if flags is None else int(flags),
+                                              ctypes.c_void_p(int(share_ptr)), ctypes.c_void_p(int(stream)) if stream else None))
+
+
+class SparseExpandCall:
+    """deinterleave_sparse2 with its argument arrays made once (see SparseShareCall)."""
+
+    def __init__(self, device, width, layout, capacity, flags=0):
+        self._dev, self._w, self._lay, self._cap, self._flags = int(device), int(width), layout, int(capacity), int(flags)
+        self._owner = (ctypes.c_uint8 * layout.n_bands)(*layout.owner) if layout.weighted else None
+        self._ptrs = {}
+
+    def __call__(self, key, share_ptrs, frame_ptr, frames=1, only_rank=-1, counts_ptr=None, stream=None):
+        """key: names the list of share pointers (a slot number): its array is kept"""
+        lay = self._lay
+        if key not in self._ptrs:
+            self._ptrs[key] = (ctypes.c_void_p * lay.world)(*[int(p) if p else None for p in share_ptrs])
+        check(lib.sdfhip_deinterleave_sparse2_device(self._dev, self._ptrs[key], ctypes.c_void_p(int(frame_ptr)), self._w, lay.height,
+                                                     lay.band_rows, lay.world, lay.rows_per_rank, self._owner, self._cap, int(frames),
+                                                     self._flags, int(only_rank), ctypes.c_void_p(int(counts_ptr)) if counts_ptr else None,
+                                                     ctypes.c_void_p(int(stream)) if stream else None))
+
+
 def deinterleave_sparse2(device, share_ptrs, frame_ptr, width, layout, capacity, frames=1, flags=0, only_rank=-1, counts_ptr=None,
                          stream=None):
     """Rank 0: the ranks' shares (one device pointer per rank; rank 0's own may be the buffer it rendered into) ->
