@@ -25,6 +25,7 @@ ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--order", action="store_true")
 ap.add_argument("--worlds", default="2,4,8")
 ap.add_argument("--deal", default="cost", choices=["cost", "weight"])
+ap.add_argument("--band-order", action="store_true", help="experiment: a share's bands in descending order of their cost (the expansion scrambles rows: timing only)")
 args = ap.parse_args()
 W, H = (int(v) for v in args.size.split("x"))
 STEPS = args.steps
@@ -70,7 +71,8 @@ def measure(world, G, nbuf, lay):
     evs = [torch.cuda.Event() for _ in range(nbuf)]                                  # keeps it: pinned copy + event on the slot's stream
 
     expand_call = SparseExpandCall(0, W, lay, full)
-    calls = {r: SparseShareCall(sc, W, lay, r, full, max_frames=G, flags=FLAGS) for r in range(world)}
+    calls = {r: SparseShareCall(sc, W, lay, r, full, max_frames=G, flags=FLAGS,
+                                bands=sorted(lay.bands_of(r), key=lambda b: (-COSTS[b], b)) if args.band_order else None) for r in range(world)}
     ptr = [sh.data_ptr() for sh in shares]
     ptrs = [[p] * world for p in ptr]
     own_src = [sh[:4].view(torch.int32) for sh in shares]
@@ -131,5 +133,5 @@ for world in (int(w) for w in args.worlds.split(",")):
                     break
         _, what, r0, p1, r0b, p1b = min(rows)
         st = min(max(r[2], r[3]) for r in rows)
-        print(f"world {world} G={G} nbuf={nbuf}{' ordered' if args.order else ''} deal={args.deal}: rank 0 {what}, expands: steady {r0:.4f} / slowest peer {p1:.4f} ms per frame "
+        print(f"world {world} G={G} nbuf={nbuf}{' ordered' if args.order else ''} deal={args.deal}{' bands by cost' if args.band_order else ''}: rank 0 {what}, expands: steady {r0:.4f} / slowest peer {p1:.4f} ms per frame "
               f"-> {t1 / max(r0, p1):.2f}x of {world} (best steady over the deals tried {t1 / st:.2f}x); {STEPS}-step burst {r0b:.4f} / {p1b:.4f} -> {t1_b / max(r0b, p1b):.2f}x  [{measure.host_us:.1f} us of host time per launch call]", flush=True)

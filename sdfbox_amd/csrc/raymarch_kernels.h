@@ -597,11 +597,13 @@ template <int CUR, bool COUNT, int MODE, bool QUEUE = false>
 __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams P)
 {
     typedef typename CursorOf<CUR, COUNT>::type CursorT;
-    // grid: x = 8 tiles_x (XCD label in the low three bits, tile column above), y = groups of eight tile rows, z = frame of the batch:
+    // grid: x = 8 tiles_x (XCD label in the low three bits, tile column above), y = frame of the batch, z = groups of eight tile rows:
     // tile_of_block's mapping (XCD k renders tile rows k, k + 8, ...) read off the block's coordinates, without its division
-    // ... or, for a launch in tile order (P.tile_perm): x = XCD label, y = frame of the batch, z = order slot -- the batch's frames
-    // are neighbours in the dispatch order, so the expensive tiles of ALL its frames start first
-    const uint32_t f = P.tile_perm ? blockIdx.y : blockIdx.z;
+    // (round 5: the frame is y and the row group z, not the other way round -- the dispatcher walks x, then y, then z, so the
+    // frames of a batch are neighbours in the dispatch order and a row group of ALL frames starts before the next one: with the
+    // share's expensive bands first in its buffer, the batch's longest waves start first.)  Or, for a launch in tile order
+    // (P.tile_perm): x = XCD label, y = frame, z = order slot.
+    const uint32_t f = blockIdx.y;
     FrameInfo I = P.frames[f];
     // the scalars every march step reads stay in SGPRs: left alone, the compiler reloads them
     // from the kernel arguments (s_load + s_waitcnt) in every iteration
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
         tx = tile % P.tiles_x; ty = tile / P.tiles_x;
     } else {
         tx = blockIdx.x >> 3;
-        ty = blockIdx.y * 8u + ((blockIdx.x + f * (P.tiles_y & 7u)) & 7u);
+        ty = blockIdx.z * 8u + ((blockIdx.x + f * (P.tiles_y & 7u)) & 7u);
         if (ty >= P.tiles_y) return;
         tile = ty * P.tiles_x + tx;
     }
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     if constexpr (QUEUE) {
     const unsigned long long hits = __ballot(shadow);
     if (hits) {
-        const uint32_t q = (blockIdx.y * gridDim.x + blockIdx.x) & (HIT_QUEUES - 1u);     // (the workgroup's number in the frame: what the queues' capacity counts)
+        const uint32_t q = (blockIdx.z * gridDim.x + blockIdx.x) & (HIT_QUEUES - 1u);     // (the workgroup's number in the frame: what the queues' capacity counts)
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(hit_count(P, P.hit_set, f, q), (uint32_t)__popcll(hits));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);

@@ -150,11 +150,11 @@ struct RenderCall {
 };
 int render_impl(sdfhip_scene *s, const RenderCall &call, sdfhip_scene::StatsTicket *ticket);
 // k_march's launch grid: the workgroups of a frame's flat numbering (x: 8 * ceil(tiles_y / 8) * tiles_x, y: frames of the batch) as
-// (8 tiles_x, ceil(tiles_y / 8), frames), so that the kernel reads tile column, tile row and XCD label off its block coordinates
+// (8 tiles_x, frames, ceil(tiles_y / 8)), so that the kernel reads tile column, tile row and XCD label off its block coordinates
 // -- or, in tile order (P.tile_perm: one entry per workgroup of a frame's flat numbering), as (8 XCD labels, frames, order slots)
 inline dim3 march_grid(const RenderParams &P, dim3 flat)
 {
-    return P.tile_perm ? dim3(8u, flat.y, flat.x / 8u) : dim3(8u * P.tiles_x, (P.tiles_y + 7u) / 8u, flat.y);
+    return P.tile_perm ? dim3(8u, flat.y, flat.x / 8u) : dim3(8u * P.tiles_x, flat.y, (P.tiles_y + 7u) / 8u);
 }
 // SDFHIP_FLAG_COMPACT on a scene with a full-depth grid: the shadow-ray queue of k_march<..., QUEUE> / k_shadow on the stream's scratch
 // (waves holding fewer than hit_min shadow rays queue them); fills P.hit_* and the second kernel's grid

@@ -315,10 +315,10 @@ class SparseShareCall:
     launch is then a few microseconds of host time instead of several tens (a rank's share of a frame is 10 - 40 us of GPU work:
     the host must not be what the GPU waits for)."""
 
-    def __init__(self, scene, width, layout, rank, capacity, max_frames=8, flags=0):
+    def __init__(self, scene, width, layout, rank, capacity, max_frames=8, flags=0, bands=None):
         from ._lib import Info
         self._h, self._w, self._h_frame = scene._h, int(width), layout.height
-        blist = layout.bands_of(rank)
+        blist = layout.bands_of(rank) if bands is None else list(bands)
         self._bands = (ctypes.c_uint16 * len(blist))(*blist)
         self._nb, self._band_rows, self._rows = len(blist), layout.band_rows, layout.rows_per_rank
         self._cap, self._flags = int(capacity), int(flags)
