@@ -281,7 +281,7 @@ def main():
     # flight (so G*nbuf frames).  A rank's share is mostly the serial tail of its longest
     # pixels: G frames in one grid share that tail
     # (8 at 8 ranks: the shares are small there, and a group costs ~60 us of host time: launch, collective, wait)
-    plan_G, plan_nbuf = sb.tiles.group_plan(world, args.steps)
+    plan_G, plan_nbuf, plan_ordered = sb.tiles.group_plan(world, args.steps)
     G = (args.gather_every if args.gather_every > 0 else plan_G) if sharded else 1
     if pt is not None or compact:
         G = 1 if not sharded else G            # those kernels render one frame per launch
@@ -293,9 +293,9 @@ def main():
     # groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4 frames per launch needs 4 launches in flight to fill the
     # chip -- 0.039 -> 0.024 ms per frame at 8 ranks)
     nbuf = args.frames_in_flight if args.frames_in_flight > 0 else (plan_nbuf if sharded else 3 if pt is not None else 4)
-    # the shares of a sharded run launch their tiles in the order of their cost in the stream's last launch (SDFHIP_FLAG_TILE_ORDER on
-    # the batched launch): a rank's share is small, and a short run ends with its longest waves -- they start first
-    if sparse2 and world > 1 and not args.no_tile_order:
+    # the shares of a SHORT sharded run launch their tiles in the order of their cost in the stream's last launch (SDFHIP_FLAG_TILE_ORDER
+    # on the batched launch): a short run ends with its longest waves -- they start first (tiles.group_plan says when)
+    if sparse2 and world > 1 and not args.no_tile_order and (plan_ordered or args.tile_order):
         flags |= sb.FLAG_TILE_ORDER
 
     # rank 0 also assembles the frame (de-interleave + wire expansion of every rank's rows), so it

@@ -20,6 +20,9 @@ def default_perm():
     b = np.arange(nblk); xcd = b & 7; j = b >> 3; r = j // tx; cx = j - r * tx; row = r * 8 + xcd
     return np.where(row < ty, row * tx + cx, 0xFFFFFFFF).astype(np.uint32)
 base = default_perm()
+def pack(p):                      # what k_march reads: tile row << 16 | tile column (all ones: an idle workgroup), [XCD label][slot]
+    e = np.where(p != 0xFFFFFFFF, (p // tx) << 16 | (p % tx), 0xFFFFFFFF).astype(np.uint32)
+    return np.ascontiguousarray(e.reshape(-1, 8).T).reshape(-1)
 buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
 cost = torch.zeros(tx * ty, dtype=torch.int16, device="cuda")
 perm = torch.from_numpy(base.astype(np.int64)).to(torch.int32).cuda() if False else torch.from_numpy(base.view(np.int32)).cuda()
@@ -79,7 +82,7 @@ for mode in ("default order", "previous frame's cost, descending per XCD", "prev
                 c = dilate(c, int(mode.split()[-1]))
             p = row_perm(c, "sum") if "summed" in mode else row_perm(c, "max") if "rows" in mode else \
                 long_first_perm(c, int(mode.split()[-1])) if mode.startswith("long") else sorted_perm(c)
-            perm.copy_(torch.from_numpy(p.view(np.int32)))
+            perm.copy_(torch.from_numpy(pack(p).view(np.int32)))
             check(lib.sdfhip_debug_tile_order(sc._h, ctypes.c_void_p(perm.data_ptr()), ctypes.c_void_p(cost.data_ptr())))
         times.append(frame(cam))
     ref_ok = True
@@ -93,7 +96,7 @@ streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in streams]
 for name, p in (("default order", None), ("by cost, descending per XCD", sorted_perm(c)), ("long tiles first, threshold 60", long_first_perm(c, 60))):
     if p is not None:
-        perm.copy_(torch.from_numpy(p.view(np.int32)))
+        perm.copy_(torch.from_numpy(pack(p).view(np.int32)))
     check(lib.sdfhip_debug_tile_order(sc._h, ctypes.c_void_p(perm.data_ptr()) if p is not None else None, None))
     for rep in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()

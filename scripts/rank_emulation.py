@@ -25,6 +25,8 @@ ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--order", action="store_true")
 ap.add_argument("--worlds", default="2,4,8")
 ap.add_argument("--deal", default="cost", choices=["cost", "weight"])
+ap.add_argument("--verbose", action="store_true")
+ap.add_argument("--fixed", type=float, default=4.0, help="band_costs: a tile's fixed part, in iterations")
 ap.add_argument("--band-order", action="store_true", help="experiment: a share's bands in descending order of their cost (the expansion scrambles rows: timing only)")
 args = ap.parse_args()
 W, H = (int(v) for v in args.size.split("x"))
@@ -56,7 +58,7 @@ del bufs
 # the cost of every band, as bench.py prices them before its deal (tiles.band_costs on the frame's step counts)
 _whole = torch.zeros((H, W, 4), device="cuda")
 sc.DrawDevice(cam, W, H, _whole.data_ptr(), stream=torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
-COSTS = band_costs(_whole[..., 3], 16); TOTAL = sum(COSTS)
+COSTS = band_costs(_whole[..., 3], 16, fixed=args.fixed); TOTAL = sum(COSTS)
 del _whole
 
 
@@ -104,16 +106,20 @@ def measure(world, G, nbuf, lay):
     job(0, warm, True)
     r0, r0b = best(lambda n: job(0, n, True), 400, 2), best(lambda n: job(0, n, True), STEPS, 7)
     p, pb = 0.0, 0.0
+    per = []
     for r in range(1, world):
         job(r, warm, False)                       # (and, with --order, this rank's tile order on every stream)
-        p = max(p, best(lambda n: job(r, n, False), 400, 2)); pb = max(pb, best(lambda n: job(r, n, False), STEPS, 7))
+        a, b = best(lambda n: job(r, n, False), 400, 2), best(lambda n: job(r, n, False), STEPS, 7)
+        per.append((r, a, b, sum(COSTS[q] for q in lay.bands_of(r)) / TOTAL, len(lay.bands_of(r))))
+        p = max(p, a); pb = max(pb, b)
+    measure.per = "; ".join(f"rank {r}: {a * 1e3:.1f} / {b * 1e3:.1f} us, {c * 100:.1f} % of the cost in {n} bands" for r, a, b, c, n in per)
     del shares, frames
     measure.host_us = host[0] / max(1, host[1]) * 1e6          # host time of a group's launch call(s)
     return r0, p, r0b, pb
 
 
 for world in (int(w) for w in args.worlds.split(",")):
-    plans = [(2, 4), (4, 4), (8, 4), (4, 2), (8, 2), (5, 4), (7, 3)] if args.sweep else [group_plan(world, STEPS)]
+    plans = [(4, 4), (8, 4), (5, 4), (7, 3), (4, 5), (4, 8), (2, 8), (8, 3), (6, 4), (3, 7)] if args.sweep else [group_plan(world, STEPS)[:2]]
     for G, nbuf in plans:
         if G > 8 or nbuf > MAXBUF:       # (MAX_BATCH frames per launch)
             continue
@@ -135,3 +141,5 @@ for world in (int(w) for w in args.worlds.split(",")):
         st = min(max(r[2], r[3]) for r in rows)
         print(f"world {world} G={G} nbuf={nbuf}{' ordered' if args.order else ''} deal={args.deal}{' bands by cost' if args.band_order else ''}: rank 0 {what}, expands: steady {r0:.4f} / slowest peer {p1:.4f} ms per frame "
               f"-> {t1 / max(r0, p1):.2f}x of {world} (best steady over the deals tried {t1 / st:.2f}x); {STEPS}-step burst {r0b:.4f} / {p1b:.4f} -> {t1_b / max(r0b, p1b):.2f}x  [{measure.host_us:.1f} us of host time per launch call]", flush=True)
+        if args.verbose:
+            print("    peers (steady / burst): " + measure.per, flush=True)

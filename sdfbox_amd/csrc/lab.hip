@@ -126,6 +126,7 @@ int sdfhip::launch_experiment(sdfhip_scene *s, const RenderCall &c, RenderParams
     const uint32_t btsel = (flags >> SDFHIP_TUNE_BLOCK_SHIFT) & 0xF;
     const int bt = btsel == 3 ? 256 : (btsel == 2 ? 128 : 64);
     P.tile_perm = c.n_frames == 1 ? s->dbg_tile_perm : nullptr;      // (the experiment hook is for single frames: its arrays hold one frame's tiles)
+    P.perm_per_label = grid.x / 8u;                                  // (the hook's array: [XCD label][slot], as the library's own)
     P.tile_cost = c.n_frames == 1 ? s->dbg_tile_cost : nullptr;
     const bool grid_lookup = cur == CUR_STACK_FULL || cur == CUR_STACK_SPLIT;
     // where the product launches k_march

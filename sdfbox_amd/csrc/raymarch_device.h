@@ -144,9 +144,10 @@ struct RenderParams {
     uint32_t *pt_hist;
     uint32_t pt_sort_bits;
 #endif
-    // k_march, optional: tile_perm[b] = the tile workgroup b renders (a permutation of the default order: the
-    // previous frame's expensive tiles first); tile_cost[tile] = march iterations the tile's wave ran
-    const uint32_t *tile_perm;
+    // k_march, optional: tile_perm[b] = the tile workgroup b renders, as tile row << 16 | tile column (a permutation of the
+    // default order: the previous frame's expensive tiles first; all ones = idle); tile_cost[tile] = march iterations the tile's wave ran
+    const uint32_t *tile_perm;       // [XCD label][slot]: perm_per_label slots per label
+    uint32_t perm_per_label;
     uint16_t *tile_cost;
 };
 constexpr uint32_t HIT_QUEUES = 64;   // one fill counter (its own 128-byte line) per queue: a wave's append is one atomic, spread over 64 words

@@ -620,9 +620,12 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     }
     uint32_t tile, tx, ty;
     if (P.tile_perm) {
-        tile = P.tile_perm[blockIdx.z * 8u + blockIdx.x];
-        if (tile >= P.n_tiles) return;
-        tx = tile % P.tiles_x; ty = tile / P.tiles_x;
+        // a launch in tile order.  (label-major: the slots of one XCD label are neighbours in memory)
+        const uint32_t wg = blockIdx.z * gridDim.x + blockIdx.x;
+        const uint32_t e = P.tile_perm[(wg & 7u) * P.perm_per_label + (wg >> 3)];  // tile row << 16 | tile column; all ones: an idle workgroup
+        tx = e & 0xFFFFu; ty = e >> 16;
+        if (ty >= P.tiles_y || tx >= P.tiles_x) return;
+        tile = ty * P.tiles_x + tx;
     } else {
         tx = blockIdx.x >> 3;
         ty = blockIdx.z * 8u + ((blockIdx.x + f * (P.tiles_y & 7u)) & 7u);

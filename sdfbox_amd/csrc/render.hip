@@ -203,7 +203,11 @@ int launch_default(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &
         }
         if (memcmp(sig, sc->ord_sig, sizeof sig) != 0) { sc->ord_valid = false; memcpy(sc->ord_sig, sig, sizeof sig); }
         P.tile_perm = sc->ord_valid ? sc->ord_perm : nullptr;
-        P.tile_cost = sc->ord_cost;
+        P.perm_per_label = plan.grid.x / 8u;
+        // (a camera at rest: the order in use was made from this very camera block -- the same costs would come out, and the order
+        // is not made again below: the waves need not report them.  Two wave-wide reductions and two stores per tile less.)
+        const sdfhip_info *last_info = c.info + (c.n_frames - 1u);
+        P.tile_cost = (sc->ord_valid && memcmp(last_info, &sc->ord_info, sizeof(sdfhip_info)) == 0) ? nullptr : sc->ord_cost;
     }
     if (plan.cur == CUR_STACK_SPLIT) { if (plan.count) launch_march<CUR_STACK_SPLIT, true>(plan.out_mode, plan.grid, st, P); else launch_march<CUR_STACK_SPLIT, false>(plan.out_mode, plan.grid, st, P); }
     else                             { if (plan.count) launch_march<CUR_STACK_FULL, true>(plan.out_mode, plan.grid, st, P); else launch_march<CUR_STACK_FULL, false>(plan.out_mode, plan.grid, st, P); }

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint8_t *__restrict__
     const uint32_t per_label = ((tiles_y + 7u) >> 3) * tiles_x;       // workgroups (and order slots) per XCD label
     const uint32_t span = (per_label + 1023u) / 1024u, lo = min(per_label, t * span), hi = min(per_label, lo + span);
     auto tile_of = [&](uint32_t j) { const uint32_t r = j / tiles_x, row = r * 8u + x; return row < tiles_y ? row * tiles_x + (j - r * tiles_x) : 0xFFFFFFFFu; };
+    auto coords = [&](uint32_t tile) { const uint32_t row = tile / tiles_x; return row << 16 | (tile - row * tiles_x); };     // what k_march reads
     // the classes of this thread's tiles, 4 bits each (15 = no tile), kept for the second pass
     unsigned long long packed = ~0ull;
     uint32_t mine[ORDER_CLASSES];
@@ -86,10 +87,10 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint8_t *__restrict__
         if (c == 0xFu) continue;
         uint32_t slot = 0;
         for (int k = 0; k < ORDER_CLASSES; k++) { const bool m = c == (uint32_t)k; slot = m ? at[k] : slot; at[k] += m ? 1u : 0u; }
-        perm[(size_t)slot * 8u + x] = tile_of(lo + (uint32_t)i);
+        perm[(size_t)x * per_label + slot] = coords(tile_of(lo + (uint32_t)i));
     }
     // the label's idle workgroups (rows past the frame's last tile row) behind its tiles
     const uint32_t real = base[ORDER_CLASSES];
-    for (uint32_t j = real + t; j < per_label; j += 1024u) perm[(size_t)j * 8u + x] = 0xFFFFFFFFu;
+    for (uint32_t j = real + t; j < per_label; j += 1024u) perm[(size_t)x * per_label + j] = 0xFFFFFFFFu;
 }
 }  // namespace sdfhip

@@ -156,13 +156,18 @@ def band_costs(frame_alpha, band_rows, fixed=4.0):
 
 
 def group_plan(world, steps=0):
-    """(frames per launch and gather, groups in flight) of a sharded run of `steps` frames over `world` ranks (0 = a long run).
-    A rank's share of one frame is small (1 / world of it) behind a fixed cost per launch, collective and wait, so G frames share
-    a launch; and a launch alone ends with its longest waves' chain of dependent steps, so several are kept in flight.  A short
-    run (the driver's scaling run times 20 steps) is one fill and one drain with little between them: fewer, fuller groups
-    (scripts/rank_emulation.py --sweep, profiles/r05_rank_emulation.txt)."""
+    """(frames per launch and gather, groups in flight, shares launched in tile order) of a sharded run of `steps` frames over
+    `world` ranks (0 = a long run).  A rank's share of one frame is small (1 / world of it) behind a fixed cost per launch,
+    collective and wait, so G frames share a launch; and a launch alone ends with its longest waves' chain of dependent steps,
+    so several are kept in flight.  A short run (the driver's scaling run times 20 steps) is one fill and one drain with little
+    between them: its launches take their tiles in the order of their cost in the last launch (SDFHIP_FLAG_TILE_ORDER: the
+    longest waves start first; 1080p at 8 ranks: 15.4 -> 14.6 us per frame of a 20-step burst).  A long run keeps the default
+    order: the order costs every wave a lookup in front of everything else and launches a group's expensive tiles all at once --
+    12.3 -> 13.7 us per frame in the steady state (scripts/rank_emulation.py, profiles/r05_rank_emulation.txt)."""
     G = 8 if world >= 8 else 4
-    return G, 4
+    nbuf = 4
+    ordered = 0 < steps <= 4 * G * nbuf
+    return G, nbuf, ordered
 
 
 def wire_shape(rows, width):

@@ -829,7 +829,8 @@ def test_tile_order_hook_permutes_work_not_results(sb, oracle_mod, scenes):
             p = None
             if perm is not None:
                 # a permutation of the workgroups' tiles: entries >= the tile count idle, every tile appears once
-                tiles = np.where(perm < tx * ty, perm, 0xFFFFFFFF).astype(np.uint32)
+                # (an entry is tile row << 16 | tile column)
+                tiles = np.where(perm < tx * ty, (perm // tx) << 16 | (perm % tx), 0xFFFFFFFF).astype(np.uint32)
                 p = torch.from_numpy(tiles.view(np.int32)).cuda()
             check(lib.sdfhip_debug_tile_order(sc._h, ctypes.c_void_p(p.data_ptr()) if p is not None else None, ctypes.c_void_p(cost.data_ptr())))
             sc.DrawDevice(cam, W, H, buf.data_ptr())
