@@ -782,6 +782,23 @@ __device__ __forceinline__ float sample_after_find(const CursorFT<EXACT, SPLIT, 
     float loadH = bilerp(t.v[4], t.v[5], t.v[6], t.v[7], dx, dy);
     return (lerp(loadL, loadH, dz) - 0.25f) * scale * 2.0f;
 }
+// The same for a cell that is known not to be flat (the flat-run form of the march loops: k_march, MARCH_FLAT_RUN).
+template <bool EXACT, bool SPLIT, bool ORDERED>
+__device__ __forceinline__ float sample_nonflat(const CursorFT<EXACT, SPLIT, ORDERED> &c, const Scaled &u)
+{
+    const uint32_t s = c.s & 15u;
+    const float scale = __uint_as_float((s + (uint32_t)(127 - LM)) << 23);
+    const uint32_t k = s - c.sh;
+    const float inv = __uint_as_float((127u - k) << 23);
+    const int32_t keep = (int32_t)(0xFFFFFFFFu << (k & 31u));
+    float dx = sat((u.x - (float)(c.ax & keep)) * inv);
+    float dy = sat((u.y - (float)(c.ay & keep)) * inv);
+    float dz = sat((u.z - (float)(c.az & keep)) * inv);
+    Texels t = decode(c.v0, c.v1);
+    float loadL = bilerp(t.v[0], t.v[1], t.v[2], t.v[3], dx, dy);
+    float loadH = bilerp(t.v[4], t.v[5], t.v[6], t.v[7], dx, dy);
+    return (lerp(loadL, loadH, dz) - 0.25f) * scale * 2.0f;
+}
 // what k_top_grid / k_fine_blocks store in a flat cell: the line above on eight equal texels
 __device__ __forceinline__ uint32_t flat_cell_distance_bits(uint32_t byte, uint32_t s)
 {
