@@ -256,7 +256,9 @@ SDFHIP_API int sdfhip_scene_upload(int device, const int32_t *structs, const uin
 /* The same with the choices the upload otherwise makes by itself (sdfhip_scene_top_grid below describes them).  Every field:
  * -1 = choose.  A host uses this to bound the accelerators' memory or to take a particular grid; the pixels never depend on it. */
 typedef struct sdfhip_upload_options {
-    uint32_t size;            /* sizeof(sdfhip_upload_options), set by sdfhip_upload_options_default: lets the struct grow */
+    uint32_t size;            /* sizeof(sdfhip_upload_options), set by sdfhip_upload_options_default: lets the struct grow -- a smaller
+                                 (older) struct is accepted from version 1's 20 bytes on, its missing fields mean "choose"; a larger
+                                 (newer) one is accepted when the fields this library does not know are all -1 */
     int32_t top_grid_level;   /* 0 = no grid; 1..10 = a plain grid of that level, as deep as the tree at most -- the tree's depth asks
                                  for the dense full-depth grid, taken if it fits 1/64 of the device's memory (2.1 GB at depth 9) */
     int32_t top_grid_split;   /* 0 = never a split grid; 1..8 = a split grid with that coarse level (needs depth - level <= 6) */

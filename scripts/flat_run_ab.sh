@@ -1,6 +1,6 @@
 #!/bin/bash
-# the flat-run form of k_march's loops (MARCH_FLAT_RUN, raymarch_kernels.h) against the default kernel.
-# Build first:   cd sdfbox_amd/csrc && for v in 1 2; do rm -rf obj; make -s -j8 product EXTRA_HIPFLAGS=-DMARCH_FLAT_RUN=$v OUT=../libsdfhip_fr$v.so; done; rm -rf obj; make -s -j8
+# the flat-run form of k_march loops (MARCH_FLAT_RUN in raymarch_kernels.h as of commit 972d54c; removed since: it lost) against
+# the default kernel.  Build first (at that commit):   cd sdfbox_amd/csrc && for v in 1 2; do rm -rf obj; make -s -j8 product EXTRA_HIPFLAGS=-DMARCH_FLAT_RUN=$v OUT=../libsdfhip_fr$v.so; done; rm -rf obj; make -s -j8
 # On the GPU box: bash scripts/flat_run_ab.sh "0 1 2"   -> gpurun_out/flat_run_ab/summary.txt
 #   parity of every variant first (the whole parity suite + 300 fuzz seeds through SDFHIP_LIB), then A/B/A/B bench lines at 1080p (400 steps and the
 #   driver's 20), 4K and the depth-10 stand-in, then PMC passes (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU, SQ_WAIT_ANY, ...).

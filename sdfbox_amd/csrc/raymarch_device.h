@@ -655,69 +655,19 @@ __device__ __forceinline__ int32_t cvt_floor(float u)
 //     a = 0, s = LM: the descent restarts at level 0 and "same cell above level 0" holds for 0 <= D < 2^LM) -- what the
 //     plain lookup does, so the first step skips the lattice test.  (The reference's default camera sits at x = y = 0.5:
 //     without this every pixel's first step takes the exact rule.)
-// MARCH_AB (A/B builds of round 4, `make product EXTRA_HIPFLAGS=-DMARCH_AB=n OUT=../libsdfhip_abN.so`; scripts/march_ab.sh,
-// profiles/r04_k_march_ab.txt):
-//   0  round 2's kernel as it was
-//   1  (the product since round 4) the lattice branch told which way it usually goes (__builtin_expect): same instructions,
-//      another block layout; 1080p 0.0883 -> 0.0881, 4K 0.3118 -> 0.3105 (A/B/A/B)
-//   2  the coarse cell's load issued by hand BEFORE the lattice test, its wait behind it (the test's ~10 instructions leave the
-//      critical path of a step; on a lattice hit the speculative load is waited for and the exact path loads again): the waves
-//      wait 5 % less (SQ_WAIT_ANY 239.8 M -> 227.9 M) and issue 13 % more VALU instructions (the asm's register tuple is copied
-//      into the cursor's): 0.0909 ms, slower
-//   (3, since removed: a wave whose lanes are all strictly inside the cube skips the three float clamps in front of the
-//      conversion -- the wave-wide test costs more than the clamps: 63.7 M VALU against 59.1 M, 0.0967 ms)
-#ifndef MARCH_AB
-#define MARCH_AB 1
-#endif
+// (Round 4 A/B'd three forms of this function with PMC -- the lattice branch told which way it usually goes, kept: the
+// __builtin_expect below; the coarse cell's load issued by hand before the lattice test: waits 5 % less, issues 13 % more, slower;
+// waves strictly inside the cube skipping the clamps: slower -- profiles/r04_k_march_ab.txt, docs/history.md section 4.6.)
 template <bool SPLIT, bool FRESH, bool ORDERED>
 __device__ __forceinline__ uint32_t find_units(CursorFT<false, SPLIT, ORDERED> &c, const GridRef &g, float px, float py, float pz, Scaled &u)
 {
     const int F = g.level + (SPLIT ? g.fine_bits : 0), sh = LM - F;
     const float unit = __uint_as_float((uint32_t)(127 + F) << 23), top = unit - 1.0f;      // 2^F, and the last cell
     u.x = px * unit; u.y = py * unit; u.z = pz * unit;
-#if MARCH_AB == 2
-    // the cell of the common case, asked for first ...
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    constexpr bool SPEC = !FRESH && !ORDERED;
-    int32_t Sx = 0, Sy = 0, Sz = 0;
-    u32x4 spec = {0u, 0u, 0u, 0u};
-    if (SPEC) {
-        Sx = cvt_floor(__builtin_amdgcn_fmed3f(u.x, 0.0f, top)); Sy = cvt_floor(__builtin_amdgcn_fmed3f(u.y, 0.0f, top));
-        Sz = cvt_floor(__builtin_amdgcn_fmed3f(u.z, 0.0f, top));
-        const int FB = SPLIT ? g.fine_bits : 0;
-        const u32x4 *addr = reinterpret_cast<const u32x4 *>(g.top) + top_index((uint32_t)Sx >> FB, (uint32_t)Sy >> FB, (uint32_t)Sz >> FB, g.level);
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(spec) : "v"(addr) : "memory");
-    }
-#endif
     const float fx = __builtin_amdgcn_fractf(u.x), fy = __builtin_amdgcn_fractf(u.y), fz = __builtin_amdgcn_fractf(u.z);
     const float fm = __builtin_fminf(__builtin_fminf(fx, fy), fz);                           // NaN: never zero; the three are >= 0
     int32_t Dx, Dy, Dz;
-#if MARCH_AB == 2
-    // ... then the lattice test, while it is on its way (the wait names the test's result: it stays behind it)
-    const unsigned long long lattice = __ballot(fm == 0.0f);
-    if (SPEC) asm volatile("s_waitcnt vmcnt(0)" : "+v"(spec) : "s"(lattice) : "memory");
-    if (SPEC && lattice == 0ull) {
-        const int FB = SPLIT ? g.fine_bits : 0;
-        c.sh = (uint32_t)sh;
-        c.loads++;
-        uint4 e = make_uint4(spec.x, spec.y, spec.z, spec.w);
-        if (SPLIT && e.x == 15u) {
-            c.loads++;
-            const uint32_t m = (1u << FB) - 1u;
-            const uint32_t local = fine_cell_index((uint32_t)Sx & m, (uint32_t)Sy & m, (uint32_t)Sz & m, FB, 0);
-            e = reinterpret_cast<const uint4 *>(g.fine)[e.w + local];
-            asm volatile("" : "+v"(e.y), "+v"(e.z), "+v"(e.w));
-        }
-        c.s = e.x; c.v0 = e.y; c.v1 = e.z;
-        c.ax = Sx; c.ay = Sy; c.az = Sz;
-        return 0;
-    }
-    if (FRESH || lattice == 0ull) {
-#elif MARCH_AB == 1
     if (FRESH || __builtin_expect(__ballot(fm == 0.0f) == 0ull, 1)) {
-#else
-    if (FRESH || __ballot(fm == 0.0f) == 0ull) {
-#endif
         Dx = cvt_floor(__builtin_amdgcn_fmed3f(u.x, 0.0f, top)); Dy = cvt_floor(__builtin_amdgcn_fmed3f(u.y, 0.0f, top));
         Dz = cvt_floor(__builtin_amdgcn_fmed3f(u.z, 0.0f, top));
     } else {
@@ -773,23 +723,6 @@ __device__ __forceinline__ float sample_after_find(const CursorFT<EXACT, SPLIT, 
     const float scale = __uint_as_float((c.s + (uint32_t)(127 - LM)) << 23);     // 2^-level = 2^(s - LM)
     const uint32_t k = c.s - c.sh;                                               // non-flat here: s has no flag bit set
     const float inv = __uint_as_float((127u - k) << 23);                         // 2^-k
-    const int32_t keep = (int32_t)(0xFFFFFFFFu << (k & 31u));
-    float dx = sat((u.x - (float)(c.ax & keep)) * inv);
-    float dy = sat((u.y - (float)(c.ay & keep)) * inv);
-    float dz = sat((u.z - (float)(c.az & keep)) * inv);
-    Texels t = decode(c.v0, c.v1);
-    float loadL = bilerp(t.v[0], t.v[1], t.v[2], t.v[3], dx, dy);
-    float loadH = bilerp(t.v[4], t.v[5], t.v[6], t.v[7], dx, dy);
-    return (lerp(loadL, loadH, dz) - 0.25f) * scale * 2.0f;
-}
-// The same for a cell that is known not to be flat (the flat-run form of the march loops: k_march, MARCH_FLAT_RUN).
-template <bool EXACT, bool SPLIT, bool ORDERED>
-__device__ __forceinline__ float sample_nonflat(const CursorFT<EXACT, SPLIT, ORDERED> &c, const Scaled &u)
-{
-    const uint32_t s = c.s & 15u;
-    const float scale = __uint_as_float((s + (uint32_t)(127 - LM)) << 23);
-    const uint32_t k = s - c.sh;
-    const float inv = __uint_as_float((127u - k) << 23);
     const int32_t keep = (int32_t)(0xFFFFFFFFu << (k & 31u));
     float dx = sat((u.x - (float)(c.ax & keep)) * inv);
     float dy = sat((u.y - (float)(c.ay & keep)) * inv);

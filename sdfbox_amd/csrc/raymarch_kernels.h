@@ -560,9 +560,6 @@ __device__ __forceinline__ uint32_t *hit_count(const RenderParams &P, uint32_t s
     return P.hit_ctl + (((size_t)set * MAX_BATCH + f) * HIT_QUEUES + q) * 32u;
 }
 
-#ifndef MARCH_FLAT_RUN
-#define MARCH_FLAT_RUN 0          // A/B builds: make product EXTRA_HIPFLAGS=-DMARCH_FLAT_RUN=1|2 OUT=../libsdfhip_fr1.so (scripts/flat_run_ab.sh)
-#endif
 // The shadow march of Compute.hlsl:214-230 for a lane whose RayState holds the shading step's results (pos, dir, prox,
 // dist; n = 0).  Every exit is black (:223, :229) except the one that reaches the light (:215-219): returns that.
 // One loop exit, as in the primary march: the three tests are combined without a branch (the gradient of :221-223 only for
@@ -578,45 +575,6 @@ __device__ __forceinline__ bool shadow_march(const RenderParams &P, const FrameI
         const float lo = __builtin_fminf(__builtin_fminf(r.px, r.py), r.pz), hi = __builtin_fmaxf(__builtin_fmaxf(r.px, r.py), r.pz);
         return r.prox > r.dist || lo < 0.0f || hi > 1.0f;
     };
-#if MARCH_FLAT_RUN >= 2
-    // the flat-run form (see k_march's primary march): a wave-iteration is a step of the lanes that hold a flat cell, or -- once no
-    // marching lane does -- a trilinear sample of all of them
-    if (!COUNT) {
-        auto go_on = [&]() {
-            bool go = ((int)header() & (int)!at_light()) != 0;
-            if (go && r.prox < I.margin) {
-                float gx, gy, gz;
-                gradient(cell_of(c, P), r.px, r.py, r.pz, gx, gy, gz);
-                go = !(dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f);
-            }
-            return go;
-        };
-        typename CursorT::Pos u;
-        const GridRef g = grid_of(P, nullptr);
-        bool act = go_on();
-        if (act) find(c, P.nodes, g, P.n_nodes, nullptr, 0, r.px, r.py, r.pz, u);
-        while (__ballot(act)) {
-            const bool flat = (c.s & FLAT_BIT) != 0u;
-            bool stepping;
-            if (__ballot(act && flat)) {
-                stepping = act && flat;
-                if (stepping) r.prox = __uint_as_float(c.v1);
-            } else {
-                stepping = act;
-                if (stepping) r.prox = sample_nonflat(c, u);
-            }
-            if (stepping) {
-                const float step = r.prox + I.margin;
-                r.px = __builtin_fmaf(r.dx, step, r.px);
-                r.py = __builtin_fmaf(r.dy, step, r.py);
-                r.pz = __builtin_fmaf(r.dz, step, r.pz);
-                r.n++;
-                act = go_on();
-                if (act) find(c, P.nodes, g, P.n_nodes, nullptr, 0, r.px, r.py, r.pz, u);
-            }
-        }
-    } else
-#endif
     for (;;) {
         bool go = ((int)header() & (int)!at_light()) != 0;
         if (go && r.prox < I.margin) {
@@ -690,45 +648,8 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     // Compute.hlsl:194-203.  One exit: the loop-header test and the escape test are evaluated together and
     // told apart after the loop (a lane that left keeps its state), header first, as the shader orders them.
     auto marching = [&]() { return (r.prox > I.margin2 || r.prox < 0.0f) && r.n < 100; };
-#if MARCH_FLAT_RUN
-    // VERDICT r4 item 3, the experiment: flat and non-flat steps separated in TIME.  83 % of the lane-steps of the bench frame sample
-    // a flat cell (8 equal bytes: the distance is stored), yet the 44-instruction trilinear block runs in half of all wave-iterations,
-    // because flat and non-flat lanes share an iteration.  Here a wave-iteration is one or the other: while ANY marching lane holds a
-    // flat cell, the lanes that do take their step (move, exit tests, next lookup) and the others wait with their cell; once every
-    // marching lane holds a non-flat cell, all of them sample together.  A lane's own sequence of operations is the loop's below.
-    if (!COUNT && live) {
-        auto go_on = [&]() { return ((int)marching() & (int)!(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit)) != 0; };
-        typename CursorT::Pos u;
-        const GridRef g = grid_of(P, nullptr);
-        bool act = go_on();
-        if (act) find_fresh(c, P.nodes, g, P.n_nodes, nullptr, 0, r.px, r.py, r.pz, u);
-        // MARCH_FLAT_RUN >= 3: the trilinear block does not wait for the last flat lane -- it runs as soon as FLAT_RUN_BATCH lanes
-        // wait for it (the flat lanes sit that iteration out), which bounds how long a lane near the surface is held up by a
-        // neighbour on its way through empty space
-        constexpr int FLAT_RUN_BATCH = MARCH_FLAT_RUN == 3 ? 8 : MARCH_FLAT_RUN == 4 ? 16 : MARCH_FLAT_RUN == 5 ? 32 : 65;
-        unsigned long long m_act;
-        while ((m_act = __ballot(act)) != 0ull) {
-            const bool flat = (c.s & FLAT_BIT) != 0u;
-            const unsigned long long m_flat = __ballot(act && flat);
-            bool stepping;
-            if (m_flat && __popcll(m_act & ~m_flat) < FLAT_RUN_BATCH) {
-                stepping = act && flat;
-                if (stepping) r.prox = __uint_as_float(c.v1);
-            } else {
-                stepping = act && !flat;
-                if (stepping) r.prox = sample_nonflat(c, u);
-            }
-            if (stepping) {
-                r.px = __builtin_fmaf(r.dx, r.prox, r.px);
-                r.py = __builtin_fmaf(r.dy, r.prox, r.py);
-                r.pz = __builtin_fmaf(r.dz, r.prox, r.pz);
-                r.n++;
-                act = go_on();
-                if (act) find(c, P.nodes, g, P.n_nodes, nullptr, 0, r.px, r.py, r.pz, u);
-            }
-        }
-    } else
-#endif
+    // (Flat and non-flat lanes share an iteration.  Separating them in time -- flat lanes step while the others wait, then all sample
+    // together -- was built bit-identical in round 5 and is 1.5-2.8x slower: profiles/r05_flat_run_ab.txt, commit 972d54c.)
     if (live) {
         // (both tests every time, combined without a branch: the escape test is three instructions)
         auto go_on = [&]() { return ((int)marching() & (int)!(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit)) != 0; };

@@ -125,7 +125,7 @@ int fill_params(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &pla
             int rcs = get_scratch(s, c.st, 0, &sc);
             if (rcs != SDFHIP_OK) return rcs;
             plan.sc = sc;
-            if (!sc->band_list) HIP_TRY(hipMalloc((void **)&sc->band_list, (size_t)MAX_BAND_LIST * sizeof(uint16_t)));
+            if (!sc->band_list) HIP_TRY(device_alloc((void **)&sc->band_list, (size_t)MAX_BAND_LIST * sizeof(uint16_t)));
             if (sc->band_n != c.n_bands || memcmp(sc->band_host, c.bands, (size_t)c.n_bands * sizeof(uint16_t)) != 0) {
                 memcpy(sc->band_host, c.bands, (size_t)c.n_bands * sizeof(uint16_t));
                 HIP_TRY(hipMemcpyAsync(sc->band_list, sc->band_host, (size_t)c.n_bands * sizeof(uint16_t), hipMemcpyHostToDevice, c.st));
@@ -196,9 +196,9 @@ int launch_default(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &
             if (sc->ord_class) (void)hipFree(sc->ord_class);
             if (sc->ord_perm) (void)hipFree(sc->ord_perm);
             sc->ord_cost = nullptr; sc->ord_class = nullptr; sc->ord_perm = nullptr; sc->ord_tiles = sc->ord_blocks = 0; sc->ord_valid = false;
-            HIP_TRY(hipMalloc((void **)&sc->ord_cost, (size_t)MAX_BATCH * P.n_tiles * sizeof(uint16_t)));     // (every frame of a batch writes its costs)
-            HIP_TRY(hipMalloc((void **)&sc->ord_class, (size_t)P.n_tiles));
-            HIP_TRY(hipMalloc((void **)&sc->ord_perm, (size_t)plan.grid.x * sizeof(uint32_t)));
+            HIP_TRY(device_alloc((void **)&sc->ord_cost, (size_t)MAX_BATCH * P.n_tiles * sizeof(uint16_t)));     // (every frame of a batch writes its costs)
+            HIP_TRY(device_alloc((void **)&sc->ord_class, (size_t)P.n_tiles));
+            HIP_TRY(device_alloc((void **)&sc->ord_perm, (size_t)plan.grid.x * sizeof(uint32_t)));
             sc->ord_tiles = P.n_tiles; sc->ord_blocks = plan.grid.x;
         }
         if (memcmp(sig, sc->ord_sig, sizeof sig) != 0) { sc->ord_valid = false; memcpy(sc->ord_sig, sig, sizeof sig); }
@@ -699,7 +699,7 @@ extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t 
     size_t need = (size_t)width * rows * nb;
     if (need > s->frame_cap) {
         if (s->d_frame) { (void)hipFree(s->d_frame); s->d_frame = nullptr; s->frame_cap = 0; }
-        HIP_TRY(hipMalloc((void **)&s->d_frame, need * sizeof(float4)));
+        HIP_TRY(device_alloc((void **)&s->d_frame, need * sizeof(float4)));
         s->frame_cap = need;
     }
     if (!banded) {
@@ -757,7 +757,7 @@ extern "C" int sdfhip_render_path(sdfhip_scene *s, const sdfhip_info *info, cons
     size_t need = (size_t)width * height;
     if (need > s->frame_cap) {
         if (s->d_frame) { (void)hipFree(s->d_frame); s->d_frame = nullptr; s->frame_cap = 0; }
-        HIP_TRY(hipMalloc((void **)&s->d_frame, need * sizeof(float4)));
+        HIP_TRY(device_alloc((void **)&s->d_frame, need * sizeof(float4)));
         s->frame_cap = need;
     }
     RenderCall c;

@@ -6,6 +6,7 @@
 #include "upload_kernels.h"
 #include "scene.h"
 
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -88,8 +89,8 @@ bool sdfhip::build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_
     TopCell *d_coarse = nullptr, *d_fine = nullptr;
     bool ok = false;
     do {
-        if (hipMalloc((void **)&d_coarse, ncell * sizeof(TopCell)) != hipSuccess) break;
-        if (hipMalloc((void **)&d_chunks, ((size_t)n_chunks + 1) * 4) != hipSuccess) break;
+        if (device_alloc((void **)&d_coarse, ncell * sizeof(TopCell)) != hipSuccess) break;
+        if (device_alloc((void **)&d_chunks, ((size_t)n_chunks + 1) * 4) != hipSuccess) break;
         const uint32_t tb = (uint32_t)((ncell + 255) / 256 < 8192 ? (ncell + 255) / 256 : 8192);
         hipLaunchKernelGGL(k_top_grid, dim3(tb), dim3(256), 0, s->stream, s->nodes, d_coarse, C, 2);
         // number the internal cells in cell order (deterministic: a prefix sum) and count them
@@ -103,8 +104,8 @@ bool sdfhip::build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_
         const uint64_t fine_bytes = (uint64_t)(nblocks << (3 * FB)) * sizeof(TopCell);
         if (fine_bytes > max_fine_bytes || (nblocks << (3 * FB)) >= ((size_t)1 << 31)) break;
         if (nblocks) {
-            if (hipMalloc((void **)&d_fine, fine_bytes) != hipSuccess) break;
-            if (hipMalloc((void **)&d_block_node, nblocks * 4) != hipSuccess) break;
+            if (device_alloc((void **)&d_fine, fine_bytes) != hipSuccess) break;
+            if (device_alloc((void **)&d_block_node, nblocks * 4) != hipSuccess) break;
             hipLaunchKernelGGL(k_split_assign, dim3(cb), dim3(256), 0, s->stream, d_coarse, (uint32_t)ncell, n_chunks, d_chunks, d_block_node, FB);
             const size_t nfine = nblocks << (3 * FB);
             const uint32_t fb = (uint32_t)((nfine + 255) / 256 < 16384 ? (nfine + 255) / 256 : 16384);
@@ -141,8 +142,25 @@ extern "C" void sdfhip_upload_options_default(sdfhip_upload_options *opt)
 extern "C" int sdfhip_scene_upload_ex(int device, const int32_t *structs, const uint8_t *values, uint32_t n,
                                       const sdfhip_upload_options *opt, sdfhip_scene **out)
 {
-    if (opt && opt->size != sizeof *opt)
-        return fail(SDFHIP_ERR_ARG, "scene_upload_ex: options of %u bytes (this library's are %zu: start from sdfhip_upload_options_default)", opt->size, sizeof *opt);
+    // `size` is what lets the struct grow: a caller built against an OLDER header passes a smaller struct -- its fields are
+    // taken and the ones it does not know stay at -1 ("choose"); a caller built against a NEWER header passes a larger one -- accepted
+    // when the part this library does not know is all -1, i.e. asks for nothing it cannot give.  Version 1 ends behind scatter_order.
+    constexpr uint32_t V1_BYTES = (uint32_t)(offsetof(sdfhip_upload_options, scatter_order) + sizeof(int32_t));
+    sdfhip_upload_options local;
+    if (opt) {
+        if (opt->size < V1_BYTES)
+            return fail(SDFHIP_ERR_ARG, "scene_upload_ex: options of %u bytes (version 1 has %u: start from sdfhip_upload_options_default)", opt->size, V1_BYTES);
+        memset(&local, 0xFF, sizeof local);                  // every field -1
+        const size_t take = opt->size < sizeof local ? opt->size : sizeof local;
+        memcpy(&local, opt, take);
+        local.size = (uint32_t)sizeof local;
+        for (size_t i = sizeof local; i + sizeof(int32_t) <= opt->size; i += sizeof(int32_t)) {
+            int32_t v;
+            memcpy(&v, reinterpret_cast<const char *>(opt) + i, sizeof v);
+            if (v != -1) return fail(SDFHIP_ERR_ARG, "scene_upload_ex: options of %u bytes set a field at offset %zu that this library (%zu bytes) does not know", opt->size, i, sizeof local);
+        }
+        opt = &local;
+    }
     if (opt && (opt->top_grid_level < -1 || opt->top_grid_level > 10 || opt->top_grid_split < -1 || opt->top_grid_split > 8 ||
                 opt->scatter_grid < -1 || opt->scatter_grid > 4 || opt->scatter_order < -1 || opt->scatter_order > 1))
         return fail(SDFHIP_ERR_ARG, "scene_upload_ex: an option out of range (top_grid_level -1..10, top_grid_split -1..8, scatter_grid -1..4, scatter_order -1..1)");
@@ -197,14 +215,14 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
     hipError_t e;
     const size_t bytes = (size_t)n * 8;
     if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-    if ((e = hipMalloc(&s->alloc, (size_t)n * 16 + 128)) != hipSuccess) return bail(e, "hipMalloc(records)");
+    if ((e = device_alloc(&s->alloc, (size_t)n * 16 + 128)) != hipSuccess) return bail(e, "device_alloc(records)");
     s->nodes = reinterpret_cast<NodeRec *>(static_cast<char *>(s->alloc) + 112);
-    if ((e = hipMalloc((void **)&s->d_verdict, 2 * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(verdict)");
+    if ((e = device_alloc((void **)&s->d_verdict, 2 * sizeof(uint32_t))) != hipSuccess) return bail(e, "device_alloc(verdict)");
     if (resident) {
         d_s = const_cast<int32_t *>(structs); d_v = const_cast<uint8_t *>(values);
     } else {
-        if ((e = hipMalloc(&d_s, bytes)) != hipSuccess) return bail(e, "hipMalloc(structs)");
-        if ((e = hipMalloc(&d_v, bytes)) != hipSuccess) return bail(e, "hipMalloc(values)");
+        if ((e = device_alloc(&d_s, bytes)) != hipSuccess) return bail(e, "device_alloc(structs)");
+        if ((e = device_alloc(&d_v, bytes)) != hipSuccess) return bail(e, "device_alloc(values)");
         if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
         if ((e = hipMemcpyAsync(d_v, values, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(values)");
     }
@@ -297,7 +315,7 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
     }
     if (s->stack_ok && top_level > 0 && !split_built) {
         // the grid is an accelerator, not part of the scene: without memory for it, shrink it
-        while (top_level > 0 && hipMalloc((void **)&s->d_top, sizeof(TopCell) << (3 * top_level)) != hipSuccess) {
+        while (top_level > 0 && device_alloc((void **)&s->d_top, sizeof(TopCell) << (3 * top_level)) != hipSuccess) {
             (void)hipGetLastError();
             s->d_top = nullptr;
             top_level--;
@@ -419,7 +437,7 @@ int sdfhip::get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_
         *sc = sdfhip_scene::Scratch();
         sc->stream = st;
         HIP_TRY(hipEventCreateWithFlags(&sc->idle, hipEventDisableTiming));
-        { const hipError_t em = hipMalloc((void **)&sc->ctl, sdfhip_scene::CTL_BYTES); if (em != hipSuccess) { (void)hipEventDestroy(sc->idle); sc->idle = nullptr; return fail(SDFHIP_ERR_DEVICE, "hipMalloc(scratch) failed: %s", hipGetErrorString(em)); } }
+        { const hipError_t em = device_alloc((void **)&sc->ctl, sdfhip_scene::CTL_BYTES); if (em != hipSuccess) { (void)hipEventDestroy(sc->idle); sc->idle = nullptr; return fail(SDFHIP_ERR_DEVICE, "device_alloc(scratch) failed: %s", hipGetErrorString(em)); } }
         // zeroed IN the stream that will use it: a hipMemset on the null stream is not ordered against a non-blocking
         // stream (the first frame on a new scratch would, now and then, have met counters that were not zero yet)
         s->n_scratch++;
@@ -429,7 +447,7 @@ int sdfhip::get_scratch(sdfhip_scene *s, hipStream_t st, size_t records, sdfhip_
     if (records > sc->records) {
         HIP_TRY(hipStreamSynchronize(st));
         if (sc->hit_buf) { (void)hipFree(sc->hit_buf); sc->hit_buf = nullptr; sc->records = 0; }
-        HIP_TRY(hipMalloc((void **)&sc->hit_buf, records * 64));
+        HIP_TRY(device_alloc((void **)&sc->hit_buf, records * 64));
         sc->records = records;
     }
     *out = sc;
@@ -445,7 +463,7 @@ int sdfhip::get_pt_scratch(sdfhip_scene *s, hipStream_t st, size_t bytes, sdfhip
     if (bytes > sc->pt_bytes) {
         HIP_TRY(hipStreamSynchronize(st));
         if (sc->pt_buf) { (void)hipFree(sc->pt_buf); sc->pt_buf = nullptr; sc->pt_bytes = 0; }
-        HIP_TRY(hipMalloc((void **)&sc->pt_buf, bytes));
+        HIP_TRY(device_alloc((void **)&sc->pt_buf, bytes));
         sc->pt_bytes = bytes;
     }
     return SDFHIP_OK;

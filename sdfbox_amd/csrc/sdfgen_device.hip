@@ -808,7 +808,9 @@ struct ChunkPool {
     {
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (enabled() && held + size <= POOL_MAX_BYTES) { items.push_back(Item{device, base, size}); held += size; return; }
+            size_t held_here = 0;                            // the limit is per device, as include/sdfhip.h says
+            for (const Item &it : items) if (it.device == device) held_here += it.size;
+            if (enabled() && held_here + size <= POOL_MAX_BYTES) { items.push_back(Item{device, base, size}); held += size; return; }
         }
         (void)hipFree(base);
     }
@@ -1121,6 +1123,16 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
     } catch (const std::bad_alloc &) {
         return fail(SDFHIP_ERR_NOMEM, "sdfgen: out of host memory");
     }
+}
+
+hipError_t sdfhip::device_alloc_bytes(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || g_pool.trim(device) == 0) return e;       // nothing to give back: the failure stands
+    return hipMalloc(p, bytes);
 }
 
 extern "C" int sdfhip_sdfgen_trim(void)

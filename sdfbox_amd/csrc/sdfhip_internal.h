@@ -34,3 +34,15 @@ double det_sin(double x);
 double det_cos(double x);
 
 }  // namespace sdfhip
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+namespace sdfhip {
+// hipMalloc -- and, when the device is out of memory, once more after the point-cloud builder's chunk pool (sdfgen_device.hip: up to
+// 24 GB per device kept between builds) has given back what it holds on the current device.  Every allocation of the scene, the
+// render scratch and the multi-device handle goes through it: a pool that sits on the memory must not make an upload fall back to a
+// smaller grid, or a render fail.
+hipError_t device_alloc_bytes(void **p, size_t bytes);
+template <class T> inline hipError_t device_alloc(T **p, size_t bytes) { return device_alloc_bytes(reinterpret_cast<void **>(p), bytes); }
+}  // namespace sdfhip
+#endif

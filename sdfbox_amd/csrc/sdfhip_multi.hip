@@ -283,7 +283,7 @@ int grow(uint8_t **p, size_t *cap, size_t need, hipStream_t drain)
     if (need <= *cap) return SDFHIP_OK;
     if (drain) M_TRY(hipStreamSynchronize(drain));
     if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
-    M_TRY(hipMalloc((void **)p, need));
+    M_TRY(device_alloc((void **)p, need));
     *cap = need;
     return SDFHIP_OK;
 }
@@ -724,7 +724,7 @@ extern "C" int sdfhip_multi_selftest(sdfhip_multi *m, sdfhip_multi_link *links)
     std::vector<uint8_t> pattern(BYTES), back(BYTES);
     Slot &S = m->slots[0];
     uint8_t *d_rx = nullptr;
-    { DevGuard g0(m->devices[0]); M_TRY(hipMalloc((void **)&d_rx, BYTES)); }
+    { DevGuard g0(m->devices[0]); M_TRY(device_alloc((void **)&d_rx, BYTES)); }
     int rc = SDFHIP_OK;
     char first[256] = { 0 };
     for (uint32_t r = 0; r < m->n; r++) {
@@ -748,7 +748,7 @@ extern "C" int sdfhip_multi_selftest(sdfhip_multi *m, sdfhip_multi_link *links)
             {
                 DevGuard g(m->devices[r]);
                 RankBuf &B = S.rb[r];
-                if ((e = hipMalloc((void **)&d_tx, BYTES)) == hipSuccess &&
+                if ((e = device_alloc((void **)&d_tx, BYTES)) == hipSuccess &&
                     (e = hipMemcpyAsync(d_tx, pattern.data(), BYTES, hipMemcpyHostToDevice, B.stream)) == hipSuccess) {
                     { DevGuard g0(m->devices[0]); e = hipMemsetAsync(d_rx, 0, BYTES, S.rb[0].stream); if (e == hipSuccess) e = hipStreamSynchronize(S.rb[0].stream); }
                     if (e == hipSuccess) e = hipEventRecord(B.ev_start, B.stream);

@@ -28,7 +28,10 @@ def load():
         try:
             spec.loader.exec_module(mod)
         except BaseException:
-            del sys.modules[_NAME]
+            # a failed import leaves nothing behind: the package AND the submodules it had imported so far (sdfbox_amd_lab._lib ...),
+            # or a second load() would meet a half-initialised package
+            for name in [k for k in sys.modules if k == _NAME or k.startswith(_NAME + ".")]:
+                del sys.modules[name]
             raise
     finally:
         if saved is None:

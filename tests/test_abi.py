@@ -3,6 +3,7 @@ struct layouts match the reference's; errors are status codes + messages."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -190,3 +191,33 @@ def test_csharp_stub_matches_the_header():
             assert _cs_class(a) == _c_class(c), f"{cname}: C# `{a}` against C `{c}`"
         want = "IntPtr" if "*" in cret else {"int": "int", "void": "void", "float": "float"}[cret.split()[-1]]
         assert ret == want, f"{cname}: returns {ret} in C#, {cret} in C"
+
+
+def test_a_failed_load_of_the_laboratory_package_leaves_nothing_behind(monkeypatch):
+    # sdfbox_amd.lab.load() imports the package a second time against libsdfhip_lab.so; when that import fails half-way the package
+    # and the submodules it had already imported must leave sys.modules, or a retry meets a half-initialised package
+    import importlib.util
+    import sdfbox_amd.lab as lab
+    saved = {k: v for k, v in sys.modules.items() if k == lab._NAME or k.startswith(lab._NAME + ".")}
+    for k in saved:
+        del sys.modules[k]
+    real = importlib.util.module_from_spec
+
+    def broken(spec):
+        mod = real(spec)
+        sys.modules[lab._NAME + "._lib"] = object()            # "a submodule was imported before the failure"
+
+        class Loader:
+            def exec_module(self, m):
+                raise RuntimeError("import failed half-way")
+        spec.loader = Loader()
+        return mod
+    monkeypatch.setattr(importlib.util, "module_from_spec", broken)
+    try:
+        with pytest.raises(RuntimeError):
+            lab.load()
+        assert not [k for k in sys.modules if k == lab._NAME or k.startswith(lab._NAME + ".")]
+    finally:
+        monkeypatch.undo()
+        sys.modules.update(saved)
+    assert lab.load()._lib.EXPERIMENTS                         # and a load after the failure works
