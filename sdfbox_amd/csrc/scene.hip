@@ -170,7 +170,7 @@ extern "C" int sdfhip_scene_upload_ex(int device, const int32_t *structs, const 
 // structs / values on the host (sdfhip_scene_upload), or already in `device`'s memory (sdfhip_sdfgen_scene: the tree the GPU
 // builder has just made never leaves HBM)
 int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t *values, uint32_t n, bool resident, const sdfhip_upload_options *opt,
-                              sdfhip_scene **out)
+                              sdfhip_scene **out, int trusted_depth)
 {
     // the grid choices: the caller's (sdfhip_scene_upload_ex), else -- laboratory library only -- the environment's, else ours
     auto choice = [](int32_t given, const char *env_name, int lo, int hi) {
@@ -226,7 +226,14 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
         if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
         if ((e = hipMemcpyAsync(d_v, values, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(values)");
     }
-    {   // validation (sdfhip_octdata_validate's verdicts, on the device: see k_validate)
+    if (resident && trusted_depth >= 0) {
+        // the point-cloud builder's own tree (sdfhip_sdfgen_scene): every block of eight children was appended by k_emit under its
+        // parent, the depth is the number of levels it built -- nothing to find out (0.3 ms of a 10 ms build, and a wait on the stream)
+        consistent = 1;
+        depth = (uint32_t)trusted_depth;
+        s->depth = depth;
+        s->stack_ok = depth <= (uint32_t)LM ? 1 : 0;
+    } else {   // validation (sdfhip_octdata_validate's verdicts, on the device: see k_validate)
         uint32_t *d_verdict = s->d_verdict, verdict[2] = { 0u, 0u };
         if ((e = hipMemsetAsync(d_verdict, 0, sizeof verdict, s->stream)) != hipSuccess) return bail(e, "hipMemset(verdict)");
         // (scratch: the allocation of the fused records, 16 bytes per node, not written before k_fuse)

@@ -694,9 +694,12 @@ __global__ __launch_bounds__(SCAN_CHUNK) void k_scan_sums(const uint32_t *__rest
 // What the host waits for at the two points of a level where it must know a total before it can go on (the size of the next
 // lists; the number of nodes of the next level, and whether a cell ran out of candidates): written by the scan's last thread
 // straight into page-locked host memory -- one stream synchronisation per point instead of a blocking copy per word.
-struct Report { unsigned long long total; uint32_t err, pad; };
+// What the host waits for twice per level, in page-locked memory it can read without a call: the scan's total, the error word, and
+// `seq` -- the number the host gave this scan, written LAST behind a system-scope fence: the host spins on it instead of
+// synchronising the stream (a round trip through the runtime's wait costs tens of microseconds; 21 of them per build).
+struct Report { unsigned long long total; uint32_t err; volatile uint32_t seq; };
 __global__ __launch_bounds__(SCAN_CHUNK) void k_scan_apply(const uint32_t *__restrict__ in, const uint32_t *__restrict__ sums,
-                                                            uint32_t *__restrict__ out, uint32_t n, const uint32_t *err, Report *report)
+                                                            uint32_t *__restrict__ out, uint32_t n, const uint32_t *err, Report *report, uint32_t seq)
 {
     __shared__ uint32_t wsum[SCAN_CHUNK / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -718,7 +721,11 @@ __global__ __launch_bounds__(SCAN_CHUNK) void k_scan_apply(const uint32_t *__res
     uint32_t woff = 0;
     for (uint32_t w = 0; w < wave; w++) woff += wsum[w];
     if (i < n) out[i] = (uint32_t)(before + woff + x - v);
-    if (i == n - 1) { report->total = before + woff + x; report->err = *err; }
+    if (i == n - 1) {
+        report->total = before + woff + x; report->err = *err;
+        __threadfence_system();
+        report->seq = seq;
+    }
 }
 
 // ---- the reference's node order, on the GPU ------------------------------------------------------
@@ -877,14 +884,29 @@ bool alloc_level(Arena &scratch, Arena &keep, LevelArrays &L, size_t n)
            L.center_value && L.pcount && L.vals && L.split && L.block_of;
 }
 
-bool scan_u32(Arena &scratch, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_err, sdfhip::Report *report)
+bool scan_u32(Arena &scratch, const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_err, sdfhip::Report *report, uint32_t seq)
 {
     const uint32_t chunks = (n + sdfhip::SCAN_CHUNK - 1) / sdfhip::SCAN_CHUNK;
     uint32_t *sums = scratch.alloc<uint32_t>(chunks);
     if (!sums) return false;
     hipLaunchKernelGGL(sdfhip::k_scan_sums, dim3(chunks), dim3(sdfhip::SCAN_CHUNK), 0, 0, in, sums, n);
-    hipLaunchKernelGGL(sdfhip::k_scan_apply, dim3(chunks), dim3(sdfhip::SCAN_CHUNK), 0, 0, in, sums, out, n, d_err, report);
+    hipLaunchKernelGGL(sdfhip::k_scan_apply, dim3(chunks), dim3(sdfhip::SCAN_CHUNK), 0, 0, in, sums, out, n, d_err, report, seq);
     return true;
+}
+
+// Wait for the scan numbered `seq` to have reported: spin on the page-locked word (the kernels in front of it are microseconds to a
+// millisecond of work); after 20 ms of that, ask the runtime -- a kernel that faulted never reports, and the runtime says why.
+hipError_t wait_report(const sdfhip::Report *report, uint32_t seq)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        if (report->seq == seq) return hipSuccess;
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+    const hipError_t e = hipStreamSynchronize(0);
+    if (e != hipSuccess) return e;
+    return report->seq == seq ? hipSuccess : hipErrorUnknown;
 }
 
 constexpr uint32_t WIDE_LEVEL = 16384;
@@ -932,6 +954,7 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
         static thread_local Report *report = nullptr;
         if (!report) GEN_TRY(hipHostMalloc((void **)&report, sizeof(Report) + BOUNDS_WG * 6 * sizeof(float), hipHostMallocPortable | hipHostMallocMapped));
         float *bounds = reinterpret_cast<float *>(report + 1);
+        uint32_t report_seq = report->seq;                   // (the scans of this build are numbered on from the last build's)
         Cand *cand = lists[0].alloc<Cand>(n);
         if (!d_verts || !d_err || !cand) return GEN_NOMEM();
         GEN_TRY(hipMemcpy(d_verts, verts6, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
@@ -1005,8 +1028,8 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             unsigned long long total = 0;
             Cand *possible = nullptr;
             if (!last_level) {
-                if (!scan_u32(mine, L.pcount, poff, n_nodes, d_err, report)) return GEN_NOMEM();
-                GEN_TRY(hipStreamSynchronize(0));
+                if (!scan_u32(mine, L.pcount, poff, n_nodes, d_err, report, ++report_seq)) return GEN_NOMEM();
+                GEN_TRY(wait_report(report, report_seq));
                 total = ((volatile Report *)report)->total;
                 if (total > 0xFFFFFFF0ull) return fail(SDFHIP_ERR_NOMEM, "sdfgen: candidate lists of level %d exceed 2^32 entries", lvl);
                 lists[(lvl + 1) & 1].reset();             // the lists of level lvl-1: dead since k_children of lvl-1
@@ -1022,8 +1045,8 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
                 hipLaunchKernelGGL(k_corners_seg, dim3((n_nodes * A.S + 7u) & ~7u), dim3(SEG_BT), 0, 0, P, L, A, cand, poff, possible, n_nodes);
                 hipLaunchKernelGGL(k_corners_fin, dim3((8 * n_nodes + 255) / 256), dim3(256), 0, 0, P, L, A, cand, n_nodes, d_err);
             }
-            if (!scan_u32(mine, L.split, L.block_of, n_nodes, d_err, report)) return GEN_NOMEM();
-            GEN_TRY(hipStreamSynchronize(0));
+            if (!scan_u32(mine, L.split, L.block_of, n_nodes, d_err, report, ++report_seq)) return GEN_NOMEM();
+            GEN_TRY(wait_report(report, report_seq));
             struct { unsigned long long n_split; uint32_t err; } back;
             back.n_split = ((volatile Report *)report)->total;
             back.err = ((volatile Report *)report)->err;
@@ -1090,7 +1113,8 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
             // the viewer's generate -> upload flow (Program.cs:613-650 -> :147-152) without the round trip: the scene's records
             // and grids are made from the arrays the builder has just written (12 ms of copy to the host and 8 ms back, at depth 10)
             GEN_TRY(hipDeviceSynchronize());
-            const int rc = sdfhip::scene_from_arrays(device, d_S, d_V, (uint32_t)total_nodes, true, nullptr, scene_out);
+            const int rc = sdfhip::scene_from_arrays(device, d_S, d_V, (uint32_t)total_nodes, true, nullptr, scene_out,
+                                                     (int)levels.size() - 1);     // (the depth it built: levels 0 .. size - 1)
             if (rc != SDFHIP_OK) return rc;
             lap("scene made on the device");
         }

@@ -22,8 +22,9 @@ inline const char *lab_env(const char *) { return nullptr; }
 #endif
 
 // sdfhip_scene_upload[_ex], or the same from arrays that are already in `device`'s memory (sdfhip_sdfgen_scene); opt may be null
+// trusted_depth >= 0: the arrays are the GPU builder's own output -- consistent by construction, that deep -- and are not validated again
 int scene_from_arrays(int device, const int32_t *structs, const uint8_t *values, uint32_t n, bool resident, const sdfhip_upload_options *opt,
-                      sdfhip_scene **out);
+                      sdfhip_scene **out, int trusted_depth = -1);
 // true when find() on this scene is a grid lookup (a dense grid as deep as the tree, or a split one): the default kernel
 // k_march renders it and can write sparse wire shares (sdfhip_render_sparse_device)
 bool scene_has_full_depth_grid(const sdfhip_scene *scene);
