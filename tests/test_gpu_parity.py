@@ -1319,12 +1319,13 @@ def test_upload_options_are_arguments_and_the_environment_is_the_laboratorys(sb,
         _fields_ = [("size", ctypes.c_uint32), ("top_grid_level", ctypes.c_int32), ("top_grid_split", ctypes.c_int32),
                     ("scatter_grid", ctypes.c_int32), ("scatter_order", ctypes.c_int32), ("a_later_field", ctypes.c_int32), ("another", ctypes.c_int32)]
     newer = NewerOptions(ctypes.sizeof(NewerOptions), 3, -1, -1, -1, -1, -1)
-    assert L.lib.sdfhip_scene_upload_ex(0, od.Structs.ctypes.data, od.Values.ctypes.data, od.Length, ctypes.byref(newer), ctypes.byref(h)) == L.OK
+    as_ours = ctypes.cast(ctypes.pointer(newer), ctypes.POINTER(L.UploadOptions))      # (the binding names this library's struct)
+    assert L.lib.sdfhip_scene_upload_ex(0, od.Structs.ctypes.data, od.Values.ctypes.data, od.Length, as_ours, ctypes.byref(h)) == L.OK
     level, nbytes = ctypes.c_int32(), ctypes.c_uint64()
     assert L.lib.sdfhip_scene_top_grid(h, ctypes.byref(level), ctypes.byref(nbytes)) == L.OK and level.value == 3
     assert L.lib.sdfhip_scene_free(h) == L.OK
     newer.another = 1
-    assert L.lib.sdfhip_scene_upload_ex(0, od.Structs.ctypes.data, od.Values.ctypes.data, od.Length, ctypes.byref(newer), ctypes.byref(h)) == L.ERR_ARG
+    assert L.lib.sdfhip_scene_upload_ex(0, od.Structs.ctypes.data, od.Values.ctypes.data, od.Length, as_ours, ctypes.byref(h)) == L.ERR_ARG
     d = L.UploadOptions(1, 2, 3, 0)
     L.lib.sdfhip_upload_options_default(ctypes.byref(d))
     assert (d.size, d.top_grid_level, d.top_grid_split, d.scatter_grid, d.scatter_order) == (ctypes.sizeof(L.UploadOptions), -1, -1, -1, -1)
