@@ -1,9 +1,9 @@
 #!/bin/bash
 # The round's bench lines (GPU box, via gpurun): gpurun_out/bench_lines/<tag>_<name>.json -> copy to profiles/bench_lines/
-R=${1:-r04}; O=gpurun_out/bench_lines; mkdir -p $O
+R=${1:-r05}; O=gpurun_out/bench_lines; mkdir -p $O
 run() { n=$1; shift; python bench.py "$@" > $O/${R}_$n.json 2> $O/${R}_$n.err || echo "$n failed"; }
 run 1080p_default
-run 1080p_driver_style --steps 20 --warmup 5
+run driver_line_with_configs --steps 20 --warmup 5
 run 1080p_one_frame_in_flight --no-cpu-baseline --frames-in-flight 1
 run 1080p_shadow_queue --no-cpu-baseline --lab --shadow-queue
 run 1080p_shadow_queue_single --no-cpu-baseline --lab --shadow-queue --frames-in-flight 1
@@ -38,7 +38,7 @@ import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
     r = d["roofline"]
-    print(sys.argv[1].split("/")[-1], d["value"], "Mray/s", d["ms_per_step"], "ms/step, latency", d["latency_ms"], "frac", r["frac"], r["binding"], "hbm_frac", r.get("hbm_frac"), "valu of spec", r.get("valu_frac_of_spec"))
+    print(sys.argv[1].split("/")[-1], d["value"], "Mray/s", d["ms_per_step"], "ms/step, latency", d["latency_ms"], "hbm_frac", r.get("hbm_frac"), "of measured", r.get("hbm_frac_of_measured"), "valu of spec", r.get("valu_frac_of_spec"), "limiting", r.get("limiting"))
 except Exception as e: print(sys.argv[1], "unreadable", e)
 PY
 done

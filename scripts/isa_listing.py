@@ -2,7 +2,7 @@
 "Depth=1" loop of the kernel (header block to the block after its last one) with static instruction counts.
 Usage: python scripts/isa_listing.py [mangled-kernel-name]   (default: k_march<CUR_STACK_SPLIT, false, OUT_RGBA32F, false>, the bench
 frame's kernel: loop 1 = primary march, loop 2 = shadow march)
-The committed profiles/r02_isa_k_march.txt is this output under a hand-written header holding the dynamic counts."""
+The committed profiles/r05_isa_k_march.txt is this output under a hand-written header holding the dynamic counts."""
 import os
 import re
 import subprocess

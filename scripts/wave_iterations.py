@@ -1,7 +1,7 @@
 """Dev script (GPU): wave-iterations of k_march on the bench frame = sum over the 8x8 tiles of the iterations their wave ran
 (the longest primary march of the tile, low byte; the longest shadow march of the tile, high byte), from the kernel's own
 per-tile cost output.  PMC instruction counts per launch divided by this give VALU / SALU per wave-iteration
-(profiles/r02_isa_k_march.txt)."""
+(profiles/r05_isa_k_march.txt)."""
 import ctypes, sys
 sys.path.insert(0, ".")
 import numpy as np, torch
