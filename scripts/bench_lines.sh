@@ -2,8 +2,8 @@
 # The round's bench lines (GPU box, via gpurun): gpurun_out/bench_lines/<tag>_<name>.json -> copy to profiles/bench_lines/
 R=${1:-r05}; O=gpurun_out/bench_lines; mkdir -p $O
 run() { n=$1; shift; python bench.py "$@" > $O/${R}_$n.json 2> $O/${R}_$n.err || echo "$n failed"; }
-run 1080p_default
 run driver_line_with_configs --steps 20 --warmup 5
+run 1080p_default
 run 1080p_one_frame_in_flight --no-cpu-baseline --frames-in-flight 1
 run 1080p_shadow_queue --no-cpu-baseline --lab --shadow-queue
 run 1080p_shadow_queue_single --no-cpu-baseline --lab --shadow-queue --frames-in-flight 1
