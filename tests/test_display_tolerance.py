@@ -45,3 +45,18 @@ def test_displayed_frame_is_within_one_level_of_every_reading_of_the_shader(sb, 
                           f"{float((d == 0).mean()):.5f} identical")
             assert frac >= FLOOR[v][col], report[-1]
     print("\n".join(report))
+
+
+def test_device_bandwidth_is_a_streaming_rate(sb):
+    # sdfhip_device_bandwidth: the roofline's measured denominator -- copy, triad and read-only rates of the library's
+    # own kernels.  On an MI355X each is a few TB/s (the guide: 6.3 achievable of 8 nameplate); bad arguments are refused with a message.
+    import ctypes
+    c, t, r = sb.device_bandwidth(0, 512 << 20, 5)
+    for name, v in (("copy", c), ("triad", t), ("read", r)):
+        assert 2000.0 < v < 8000.0, (name, v)
+    L = sb._lib
+    x = ctypes.c_double()
+    assert L.lib.sdfhip_device_bandwidth(0, 512 << 20, 3, None, None, ctypes.byref(x)) == L.OK and 2000.0 < x.value < 8000.0   # read only: one array
+    assert L.lib.sdfhip_device_bandwidth(0, 1 << 10, 3, ctypes.byref(x), None, None) == L.ERR_ARG       # arrays below 1 MiB
+    assert L.lib.sdfhip_device_bandwidth(0, 512 << 20, 3, None, None, None) == L.ERR_ARG                # nothing asked for
+    assert L.lib.sdfhip_device_bandwidth(99, 512 << 20, 3, ctypes.byref(x), None, None) == L.ERR_DEVICE and b"device" in L.lib.sdfhip_last_error()
