@@ -26,6 +26,8 @@ ap.add_argument("--order", action="store_true")
 ap.add_argument("--worlds", default="2,4,8")
 ap.add_argument("--deal", default="cost", choices=["cost", "weight"])
 ap.add_argument("--verbose", action="store_true")
+ap.add_argument("--no-readback", action="store_true", help="experiment: without the share counter's pinned copy + event per group")
+ap.add_argument("--even", action="store_true", help="experiment: the even round-robin deal only (rank 0 a whole share)")
 ap.add_argument("--fixed", type=float, default=4.0, help="band_costs: a tile's fixed part, in iterations")
 ap.add_argument("--band-order", action="store_true", help="experiment: a share's bands in descending order of their cost (the expansion scrambles rows: timing only)")
 args = ap.parse_args()
@@ -90,16 +92,17 @@ def measure(world, G, nbuf, lay):
         k = 0
         while k < nframes:
             g = min(G, nframes - k); slot = (k // G) % nbuf
-            if k >= G * nbuf:            # the slot's previous group is complete by now: its counter has arrived (finish() in bench.py)
+            if k >= G * nbuf and not args.no_readback:   # the slot's previous group is complete by now: its counter has arrived (finish() in bench.py)
                 evs[slot].synchronize(); base[slot] = int(own[slot].item()) & 0xFFFFFFFF
             h0 = time.perf_counter()
             call(groups[g], ptr[slot], base[slot], stream=streams[slot].cuda_stream)
             if expand:
                 expand_call(slot, ptrs[slot], frames_ptr, frames=g, stream=streams[slot].cuda_stream)
             host[0] += time.perf_counter() - h0; host[1] += 1
-            with torch.cuda.stream(streams[slot]):
-                own[slot].copy_(own_src[slot], non_blocking=True)
-                evs[slot].record(streams[slot])
+            if not args.no_readback:
+                with torch.cuda.stream(streams[slot]):
+                    own[slot].copy_(own_src[slot], non_blocking=True)
+                    evs[slot].record(streams[slot])
             k += g
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / nframes * 1e3
     warm = 2 * G * nbuf
@@ -132,7 +135,7 @@ for world in (int(w) for w in args.worlds.split(",")):
                 if r0b <= p1b and r0 <= p1 and frac > 0:
                     break
         else:
-            for weight in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4):
+            for weight in ((1.0,) if args.even else (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4)):
                 r0, p1, r0b, p1b = measure(world, G, nbuf, BandLayout(H, world, 16, weight))
                 rows.append((max(r0b, p1b), f"{weight:.1f} of a peer's share", r0, p1, r0b, p1b))
                 if r0b <= p1b and r0 <= p1:
