@@ -67,7 +67,10 @@ extern "C" int sdfhip_device_bandwidth(int device, uint64_t bytes, uint32_t reps
     if (triad_gbs) *triad_gbs = 0.0;
     if (read_gbs) *read_gbs = 0.0;
     DeviceGuard g(device);
-    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "device_bandwidth: no device %d", device);
+    if (!g.ok) {
+        (void)hipGetLastError();     // (the runtime keeps a failed call's error for the next hipGetLastError(): a later launch check would report it as its own)
+        return fail(SDFHIP_ERR_DEVICE, "device_bandwidth: no device %d", device);
+    }
     const size_t n = (size_t)(bytes / sizeof(f4));
     f4 *buf[3] = { nullptr, nullptr, nullptr };
     float *sink = nullptr;

@@ -46,7 +46,7 @@ int sdfhip::deinterleave_impl(int device, const void *d_gathered, void *d_frame,
     if (rows_per_rank < need_rows)
         return fail(SDFHIP_ERR_ARG, "deinterleave: rows_per_rank %u < %u needed for %u bands over %u ranks", rows_per_rank, need_rows, nbands, world);
     DeviceGuard g(device);
-    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "deinterleave: hipSetDevice(%d) failed", device);
+    if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "deinterleave: hipSetDevice(%d) failed", device);
     if (nbands <= (uint32_t)MAX_BAND_LIST && world <= 64 && (pixel_bytes == 16 || pixel_bytes == 4)) {
         // the frame's geometry in the launch grid (k_deinterleave_rows): a round-robin deal gets its band map here
         if (!M.n) {
@@ -149,7 +149,7 @@ extern "C" int sdfhip_deinterleave_sparse2_device(int device, const void *const 
         S.p[r] = static_cast<const uint8_t *>(d_shares[r]);
     }
     DeviceGuard g(device);
-    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "deinterleave_sparse2: hipSetDevice(%d) failed", device);
+    if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "deinterleave_sparse2: hipSetDevice(%d) failed", device);
     const Sparse2Layout L = sparse2_layout(width, rows_per_rank, frames, capacity);
     const size_t total = (size_t)width * height * frames;
     const uint32_t blocks = (uint32_t)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);

@@ -209,7 +209,7 @@ extern "C" int sdfhip_wire_compact_device(int device, const void *d_wire, void *
         return fail(SDFHIP_ERR_ARG, "wire_compact: null or zero argument");
     if (((size_t)rows * width) % 4 != 0) return fail(SDFHIP_ERR_ARG, "wire_compact: rows * width must be a multiple of 4");
     DeviceGuard g(device);
-    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "wire_compact: hipSetDevice(%d) failed", device);
+    if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "wire_compact: hipSetDevice(%d) failed", device);
     const SparseLayout L = sparse_layout(width, rows, capacity);
     const dim3 grid((L.tiles + 3) / 4, frames);
     hipLaunchKernelGGL(k_sparse_masks, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)d_wire, (uint8_t *)d_sparse, L);
@@ -248,7 +248,7 @@ extern "C" int sdfhip_deinterleave_sparse_device(int device, const void *d_gathe
     if (rows_per_rank < need_rows)
         return fail(SDFHIP_ERR_ARG, "deinterleave_sparse: rows_per_rank %u < %u needed", rows_per_rank, need_rows);
     DeviceGuard g(device);
-    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "deinterleave_sparse: hipSetDevice(%d) failed", device);
+    if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "deinterleave_sparse: hipSetDevice(%d) failed", device);
     const SparseLayout L = sparse_layout(width, rows_per_rank, capacity);
     size_t total = (size_t)width * height * frames;
     uint32_t blocks = (uint32_t)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
@@ -271,7 +271,7 @@ extern "C" int sdfhip_debug_step_classes(sdfhip_scene *s, void *stream, uint64_t
     if (!s || !out6) return fail(SDFHIP_ERR_ARG, "debug_step_classes: null argument");
     std::lock_guard<std::mutex> lk(s->lock);
     DeviceGuard g(s->device);
-    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "debug_step_classes: hipSetDevice(%d) failed", s->device);
+    if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "debug_step_classes: hipSetDevice(%d) failed", s->device);
     for (int i = 0; i < s->n_scratch; i++)
         if (s->scratch[i].stream == (hipStream_t)stream) {
             HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -286,7 +286,7 @@ extern "C" int sdfhip_debug_unorm_table(int device, float *out256)
 {
     if (!out256) return fail(SDFHIP_ERR_ARG, "debug_unorm_table: null argument");
     DeviceGuard g(device);
-    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "debug_unorm_table: hipSetDevice(%d) failed", device);
+    if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "debug_unorm_table: hipSetDevice(%d) failed", device);
     float *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 256 * sizeof(float)));
     hipLaunchKernelGGL(k_unorm_table, dim3(1), dim3(256), 0, 0, d);

@@ -191,7 +191,7 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
     if (device < 0 || device >= ndev)
         return fail(SDFHIP_ERR_DEVICE, "scene_upload: device %d of %d does not exist", device, ndev);
     DeviceGuard g(device);
-    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "scene_upload: hipSetDevice(%d) failed", device);
+    if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "scene_upload: hipSetDevice(%d) failed", device);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -409,7 +409,7 @@ extern "C" int sdfhip_scene_prepare_path(sdfhip_scene *s)
     if (!s) return fail(SDFHIP_ERR_ARG, "scene_prepare_path: null scene");
     std::lock_guard<std::mutex> lk(s->lock);
     DeviceGuard g(s->device);
-    if (!g.ok) return fail(SDFHIP_ERR_DEVICE, "scene_prepare_path: hipSetDevice(%d) failed", s->device);
+    if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "scene_prepare_path: hipSetDevice(%d) failed", s->device);
     ensure_scatter_grid(s);
     return SDFHIP_OK;
 }

@@ -918,8 +918,10 @@ struct KeptLevel { LevelArrays L; uint32_t n; uint32_t *cnt, *rank; int32_t *ind
 #define GEN_TRY(expr)                                                                           \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
+        if (e_ != hipSuccess) {                                                             \
+            (void)hipGetLastError();   /* the runtime's record of it: a later launch check must not report it as its own */ \
             return fail(SDFHIP_ERR_DEVICE, "sdfgen: %s failed: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                                   \
     } while (0)
 #define GEN_NOMEM() fail(SDFHIP_ERR_NOMEM, "sdfgen: out of device memory")
 

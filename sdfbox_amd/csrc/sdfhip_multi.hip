@@ -50,8 +50,10 @@ constexpr uint32_t MAX_GROUP = 8;          // frames per launch (sdfhip_render_b
 #define M_TRY(expr)                                                                           \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
+        if (e_ != hipSuccess) {                                                             \
+            (void)hipGetLastError();   /* the runtime's record of it: a later launch check must not report it as its own */ \
             return fail(SDFHIP_ERR_DEVICE, "multi: %s failed: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                                   \
     } while (0)
 
 // ---- RCCL, loaded on demand ---------------------------------------------------------------------------------------
@@ -249,7 +251,7 @@ namespace {
 
 struct DevGuard {
     int prev = -1;
-    explicit DevGuard(int d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(d); }
+    explicit DevGuard(int d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (hipSetDevice(d) != hipSuccess) (void)hipGetLastError(); }
     ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
