@@ -600,9 +600,9 @@ __global__ __launch_bounds__(64, PLAIN_WAVES_PER_SIMD) void k_march(RenderParams
     // grid: x = 8 tiles_x (XCD label in the low three bits, tile column above), y = frame of the batch, z = groups of eight tile rows:
     // tile_of_block's mapping (XCD k renders tile rows k, k + 8, ...) read off the block's coordinates, without its division
     // (round 5: the frame is y and the row group z, not the other way round -- the dispatcher walks x, then y, then z, so the
-    // frames of a batch are neighbours in the dispatch order and a row group of ALL frames starts before the next one: with the
-    // share's expensive bands first in its buffer, the batch's longest waves start first.)  Or, for a launch in tile order
-    // (P.tile_perm): x = XCD label, y = frame, z = order slot.
+    // frames of a batch are neighbours in the dispatch order and a row group of ALL frames starts before the next one: the last
+    // frame's long waves no longer start when seven eighths of the launch have been dispatched.  A rank's 20-step burst at 8 ranks
+    // 5.43 -> 5.79x.)  Or, for a launch in tile order (P.tile_perm): x = XCD label, y = frame, z = order slot.
     const uint32_t f = blockIdx.y;
     FrameInfo I = P.frames[f];
     // the scalars every march step reads stay in SGPRs: left alone, the compiler reloads them

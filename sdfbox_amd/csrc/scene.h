@@ -101,8 +101,10 @@ struct sdfhip_scene {
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
+        if (e_ != hipSuccess) {                                                             \
+            (void)hipGetLastError();   /* the runtime's record of it: a later launch check must not report it as its own */ \
             return sdfhip::fail(SDFHIP_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+        }                                                                                   \
     } while (0)
 
 namespace sdfhip {
@@ -113,8 +115,11 @@ struct DeviceGuard {
     bool ok = false;
     explicit DeviceGuard(int dev)
     {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
         ok = hipSetDevice(dev) == hipSuccess;
+        // (a failed runtime call leaves its error for the next hipGetLastError(): a later launch check -- "k_validate launch failed:
+        // invalid device ordinal" -- would report THIS failure as its own.  The caller reports it; the runtime's record is cleared.)
+        if (!ok) (void)hipGetLastError();
     }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
