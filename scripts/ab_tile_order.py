@@ -48,6 +48,21 @@ def long_first_perm(c, threshold):
         t = tiles[real]; long = c[t] >= threshold
         out[idx] = np.concatenate([t[long], t[~long], tiles[~real]])
     return out
+def mixed_perm(c, threshold, ratio):
+    # the long tiles (>= threshold iterations), in descending order of cost, spread over the FRONT of the launch with `ratio` other
+    # tiles (in their default order) between two of them; the rest behind: the long waves start early without all running at once
+    out = base.copy()
+    for x in range(8):
+        idx = np.nonzero((np.arange(nblk) & 7) == x)[0]
+        tiles = base[idx]; real = tiles != 0xFFFFFFFF
+        t = tiles[real]; long = c[t] >= threshold
+        H = t[long][np.argsort(-c[t[long]].astype(np.int64), kind="stable")]; L = t[~long]
+        seq = []; li = 0
+        for h in H:
+            seq.append(h); seq.extend(L[li:li + ratio]); li += ratio
+        seq.extend(L[li:])
+        out[idx] = np.concatenate([np.array(seq, dtype=np.uint32), tiles[~real]])
+    return out
 def row_perm(c, key):
     # whole tile rows stay together (neighbouring tiles share cells); each XCD's rows k, k+8, ... are launched in
     # descending order of the previous frame's row cost
@@ -67,7 +82,8 @@ def dilate(c, R):
 for mode in ("default order", "previous frame's cost, descending per XCD", "previous cost dilated 1", "previous cost dilated 2", "previous cost dilated 4",
              "same frame's cost (oracle for the idea)",
              "rows by previous frame's summed cost", "rows by previous frame's max cost",
-             "long tiles first, threshold 60", "long tiles first, threshold 90", "long tiles first, threshold 110"):
+             "long tiles first, threshold 60", "long tiles first, threshold 90", "long tiles first, threshold 110",
+             "mixed 1:1 from 40", "mixed 1:2 from 40", "mixed 1:3 from 40", "mixed 1:2 from 60", "mixed 1:4 from 30"):
     times = []
     check(lib.sdfhip_debug_tile_order(sc._h, None, ctypes.c_void_p(cost.data_ptr())))
     frame(camera(0))
@@ -81,7 +97,8 @@ for mode in ("default order", "previous frame's cost, descending per XCD", "prev
             if "dilated" in mode:
                 c = dilate(c, int(mode.split()[-1]))
             p = row_perm(c, "sum") if "summed" in mode else row_perm(c, "max") if "rows" in mode else \
-                long_first_perm(c, int(mode.split()[-1])) if mode.startswith("long") else sorted_perm(c)
+                long_first_perm(c, int(mode.split()[-1])) if mode.startswith("long") else \
+                mixed_perm(c, int(mode.split()[-1]), int(mode.split()[1].split(":")[1])) if mode.startswith("mixed") else sorted_perm(c)
             perm.copy_(torch.from_numpy(pack(p).view(np.int32)))
             check(lib.sdfhip_debug_tile_order(sc._h, ctypes.c_void_p(perm.data_ptr()), ctypes.c_void_p(cost.data_ptr())))
         times.append(frame(cam))
@@ -94,7 +111,8 @@ check(lib.sdfhip_debug_tile_order(sc._h, None, ctypes.c_void_p(cost.data_ptr()))
 c = cost.cpu().numpy().view(np.uint16); c = ((c & 0xFF) + (c >> 8)).astype(np.uint16)
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in streams]
-for name, p in (("default order", None), ("by cost, descending per XCD", sorted_perm(c)), ("long tiles first, threshold 60", long_first_perm(c, 60))):
+for name, p in (("default order", None), ("by cost, descending per XCD", sorted_perm(c)), ("long tiles first, threshold 60", long_first_perm(c, 60)),
+                ("mixed 1:2 from 40", mixed_perm(c, 40, 2))):
     if p is not None:
         perm.copy_(torch.from_numpy(pack(p).view(np.int32)))
     check(lib.sdfhip_debug_tile_order(sc._h, ctypes.c_void_p(perm.data_ptr()) if p is not None else None, None))
