@@ -1074,6 +1074,21 @@ def test_bench_frame_equals_the_oracle_on_every_pixel(sb, oracle_mod, dragon):
     assert st.n_nodes == 433305936 and st.n_samples == 52988750          # the figures DESIGN.md section 6 quotes
 
 
+def test_cfg3_frame_equals_the_oracle_on_every_pixel(sb, oracle_mod, dragon):
+    # BASELINE cfg-3 / cfg-4's frame -- 3840x2160, the depth-9 stand-in, the bench camera -- against the oracle on all 8 294 400
+    # pixels (a second of CPU time on the box's 16 CPUs), with the default kernel and with wavefront ray compaction on, and the
+    # four algorithmic counters; the 4K frame sharded over repeated device lists is held against it in tests/test_multi.py
+    od, sc = dragon
+    W, H = 3840, 2160
+    cam = sb.Logic(W, H); cam.Position = (0.5, 0.5, -0.35); cam.Heading = (-0.2, 0.35)
+    ref, cnt = oracle_mod.render(od.Structs, od.Values, cam.State, W, H, nthreads=min(64, os.cpu_count() or 8))
+    img, st = sc.Draw(cam, W, H, sb.FLAG_COUNT, want_stats=True)
+    assert_frames_identical(img, ref, "cfg-3 frame, default kernel")
+    assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
+    assert_frames_identical(sc.Draw(cam, W, H, sb.FLAG_COMPACT), ref, "cfg-3 frame, SDFHIP_FLAG_COMPACT")
+    assert_frames_identical(sc.Draw(cam, W, H, sb.FLAG_TILE_ORDER), ref, "cfg-3 frame, tile-order flag (ignored above 65 536 tiles)")
+
+
 def test_host_frames_in_page_locked_memory(sb, dragon):
     # sdfhip_host_alloc / sdfhip_host_register: below 4 M pixels sdfhip_render's kernel stores its pixels straight into the
     # host's array (no device frame, no copy), above it the band copies go into it.  Both must leave the frame a pageable
