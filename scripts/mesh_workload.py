@@ -1,6 +1,6 @@
 """The reference's mesh import flow (Program.cs:613-650 -> dllmain.cpp:295-319) at dragon scale, end to end on the GPU box:
 a 1 M-point .ply -> sdfhip_load_ply -> sdfhip_sdfgen (depth 9 and Model.MaxDepth = 10) -> .asdf -> bench.py --asdf.
-Writes the bench lines to gpurun_out/mesh/ (committed copies: profiles/bench_lines/r04_mesh_knot_d*.json).
+Writes the bench lines to gpurun_out/mesh/ (committed copies: profiles/bench_lines/r05_mesh_knot_d*.json).
     python scripts/mesh_workload.py [points]"""
 import json, os, subprocess, sys, time
 sys.path.insert(0, ".")
@@ -25,5 +25,5 @@ for depth in (9, 10):
         if not line:
             print(r.stderr[-2000:]); raise SystemExit(1)
         j = json.loads(line[-1]); j["mesh_import"] = info
-        json.dump(j, open(f"{out}/r04_mesh_knot_d{depth}{tag}.json", "w"))
+        json.dump(j, open(f"{out}/r05_mesh_knot_d{depth}{tag}.json", "w"))
         print(f"depth {depth}{tag}: {j['ms_per_step']} ms/frame, {j['value']} Mray/s, latency {j['latency_ms']} ms", flush=True)
