@@ -27,6 +27,11 @@ def burst(n):
         g = min(G, n - k); slot = (k // G) % nbuf
         call(groups[g], shares[slot].data_ptr(), 0, stream=streams[slot].cuda_stream); k += g
     torch.cuda.synchronize(); return (time.perf_counter() - t0) * 1e6
+if "--whole" in sys.argv:       # (scripts/share_pmc.sh: whole-frame launches beside the share's, for the counters)
+    wf = torch.zeros((H, W, 4), device="cuda")
+    for _ in range(8):
+        sc.DrawDevice(cam, W, H, wf.data_ptr(), stream=streams[0].cuda_stream)
+    torch.cuda.synchronize()
 burst(64)
 for _ in range(6):
     print(f"burst of {STEPS}: {burst(STEPS):.1f} us", flush=True)
