@@ -329,17 +329,14 @@ class SparseShareCall:
         self._cap, self._flags = int(capacity), int(flags)
         self._infos = (Info * max_frames)()
         self._max = max_frames
-        self._last = None                      # the states of the last call: a camera at rest is not copied again
         self._size = ctypes.sizeof(Info)
 
     def __call__(self, states, share_ptr, count_base, stream=None, flags=None):
         n = len(states)
         if n > self._max:
             raise ValueError("SparseShareCall: more frames than it was made for")
-        if states is not self._last:
-            for i, st in enumerate(states):
-                ctypes.memmove(ctypes.addressof(self._infos) + i * self._size, ctypes.addressof(getattr(st, "State", st)), self._size)
-            self._last = states
+        for i, st in enumerate(states):              # (always: a camera may have moved in place since the last call; 112 bytes each)
+            ctypes.memmove(ctypes.addressof(self._infos) + i * self._size, ctypes.addressof(getattr(st, "State", st)), self._size)
         check(lib.sdfhip_render_sparse_device(self._h, self._infos, n, self._w, self._h_frame, self._band_rows, self._bands, self._nb,
                                               self._rows, self._cap, int(count_base) & 0xFFFFFFFF, self._flags if flags is None else int(flags),
                                               ctypes.c_void_p(int(share_ptr)), ctypes.c_void_p(int(stream)) if stream else None))
