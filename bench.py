@@ -407,6 +407,8 @@ def main():
 
     batched = sharded and pt is None and not compact     # one launch per group (else one per frame)
 
+    host_t = {"launch": 0.0, "gather": 0.0, "finish": 0.0, "groups": 0}     # host seconds in the timed region's calls, by part
+
     def finish(slot):
         """Complete the gather issued from group buffer `slot`; rank 0 puts the rows of its G frames
         back in order."""
@@ -415,7 +417,10 @@ def main():
             return
         st = streams[slot]
         if sparse2:
-            return finish_sparse2(slot, w, st)
+            t_f = time.perf_counter()
+            finish_sparse2(slot, w, st)
+            host_t["finish"] += time.perf_counter() - t_f
+            return
         if nccl:
             with torch.cuda.stream(st):
                 w.wait()                              # the group's stream waits for its gather
@@ -496,7 +501,10 @@ def main():
             group = group_of(k, within + 1)
             if sparse2:
                 s2["n"][slot] = len(group)
+                t_l = time.perf_counter()
                 s2["call"](group, s2["ptr"][slot], s2["base"][slot], stream=s.cuda_stream, flags=flags)
+                host_t["launch"] += time.perf_counter() - t_l
+                host_t["groups"] += 1
             else:
                 render_bands_batch(scene, group, W, layout, rank, local[slot].data_ptr(), flags=flags, stream=s.cuda_stream)
             if timed:
@@ -515,6 +523,7 @@ def main():
         if not sharded or not group_ends:
             return
         if sparse2:
+            t_g = time.perf_counter()
             if rank != 0:                             # this rank's own counter, for finish()
                 with torch.cuda.stream(s):
                     s2["own"][slot].copy_(s2["own_src"][slot], non_blocking=True)
@@ -533,6 +542,7 @@ def main():
                 dist.gather(host, glist, dst=0)
                 pending[slot] = glist if rank == 0 else True
                 finish(slot)
+            host_t["gather"] += time.perf_counter() - t_g
             return
         # one collective for the whole group (a partial last group is gathered whole, too)
         if nccl:
@@ -645,6 +655,7 @@ def main():
     barrier()
     wd.phase("timed region", quiet=True)              # (no print between the barrier and the clock)
     resent_before = resent                    # (the moving-camera passes above resend tails by design; the timed region should not)
+    host_t.update(launch=0.0, gather=0.0, finish=0.0, groups=0)
     t_start = time.perf_counter()
     for k in range(args.steps):
         step(k, timed=True, last=(k == args.steps - 1))
@@ -764,6 +775,10 @@ def main():
                 "gather_pixel_bytes": (round(s2["prefix"] / (rows_local * W * G), 3) if sparse2 else px_bytes) if sharded else None,
                 "gather_format": ("sparse shares written by the march kernel" if sparse2 else "frame pixels") if sharded else None,
                 "shares_in_tile_order": bool(flags & sb.FLAG_TILE_ORDER) if sharded else None,
+                # rank 0's host time per gather group in the timed region, by part (the sparse-share pipeline): the launch call, issuing the
+                # gather (+ a peer's counter copy), and finish() -- the wait for the slot's previous group, its expansion call, the counters
+                "host_us_per_group": ({k: round(host_t[k] / max(1, host_t["groups"]) * 1e6, 1) for k in ("launch", "gather", "finish")}
+                                      if sparse2 and host_t["groups"] else None),
                 "float_tails_sent_again": resent if sparse2 else None,
                 "float_tails_sent_again_in_the_timed_region": (resent - resent_before) if sparse2 else None,
                 "output": "RGBA8, display pass fused (DisplayFrag.hlsl)" if args.display else "RGBA32F, alpha = step count",
