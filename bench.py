@@ -28,6 +28,13 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+# The driver's path is this file; what the line says about a measurement, the other configurations and the N > 1 machinery are
+# modules beside it (their names stay importable from here: tests and scripts say bench.roofline, bench.orbit_cameras, ...).
+from bench_report import (HBM_PEAK_GBS, KERNEL_SOURCES, VALU_PEAK_GINSTR, VALU_PEAK_SPEC_GINSTR, configs_summary, cpu_baseline,  # noqa: E402,F401
+                          kernel_source_hash, load_pmc, measured_hbm_bandwidth, roofline)
+from bench_configs import bench_camera, grid_suffix, load_package, orbit_cameras, run_configs  # noqa: E402,F401
+from bench_sharded import Watchdog, main_single_process, measure_band_deal, measure_rank0_weight, spawn_ranks  # noqa: E402,F401
+
 # Wavefront ray compaction is measured 2-3 % slower than the plain kernel on this workload
 # (DESIGN.md section 4.4), so it is off unless asked for.
 DEFAULT_COMPACT = False
@@ -114,48 +121,6 @@ def parse():
                     help="load the experiments flavour of the library (libsdfhip_lab.so, include/sdfhip_experimental.h): needed by the A/B "
                          "forms --one-kernel and --shadow-queue")
     return ap.parse_args()
-
-
-class Watchdog:
-    """First contact with N GPUs must end in bounded time and say where it stopped: a daemon thread that
-    writes `[bench rank r] phase ..., s in it` to stderr every `every` seconds while the run is in a phase that can block on
-    another rank, and ends THIS process with os._exit(3) -- a fresh exit, no re-exec, no clean-up that could block in turn --
-    once the run has taken `budget` seconds (or a phase its own limit).  The launcher then ends the other ranks."""
-
-    def __init__(self, rank, budget, every=5.0):
-        import threading
-        self.rank, self.budget, self.every = rank, budget, every
-        self.t0 = self.t_phase = time.monotonic()
-        self.name, self.limit, self.quiet = "start", None, True
-        self.lock = threading.Lock()
-        self.thread = None
-        if budget > 0:
-            self.thread = threading.Thread(target=self._run, name="bench-watchdog", daemon=True)
-            self.thread.start()
-
-    def phase(self, name, limit=None, quiet=False):
-        """enter a phase; `limit` = seconds this phase alone may take; quiet phases are not logged while they run"""
-        with self.lock:
-            self.name, self.limit, self.quiet, self.t_phase = name, limit, quiet, time.monotonic()
-        if self.budget > 0 and not quiet:
-            print(f"[bench rank {self.rank}] phase: {name}", file=sys.stderr, flush=True)
-
-    def _run(self):
-        while True:
-            time.sleep(min(self.every, 1.0))
-            now = time.monotonic()
-            with self.lock:
-                name, limit, quiet, in_phase = self.name, self.limit, self.quiet, now - self.t_phase
-            total = now - self.t0
-            over = total > self.budget or (limit is not None and in_phase > limit)
-            if over:
-                why = (f"phase '{name}' has taken {in_phase:.0f} s (limit {limit:.0f})" if (limit is not None and in_phase > limit)
-                       else f"the run has taken {total:.0f} s (budget {self.budget:.0f}), in phase '{name}' for {in_phase:.0f} s")
-                print(f"[bench rank {self.rank}] WATCHDOG: {why}: giving up with exit code 3", file=sys.stderr, flush=True)
-                os._exit(3)
-            if not quiet and in_phase >= self.every and int(in_phase / self.every) != int((in_phase - min(self.every, 1.0)) / self.every):
-                print(f"[bench rank {self.rank}] still in phase '{name}' after {in_phase:.0f} s ({total:.0f} s of {self.budget:.0f})",
-                      file=sys.stderr, flush=True)
 
 
 def main():
@@ -819,776 +784,6 @@ def main():
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def load_package(args):
-    """sdfbox_amd against the product library, or -- for the A/B forms -- against the experiments flavour"""
-    if args.lab or args.one_kernel or args.shadow_queue:
-        if not args.lab:
-            raise SystemExit("--one-kernel / --shadow-queue are A/B forms of the experiments build: add --lab")
-        import sdfbox_amd.lab
-        return sdfbox_amd.lab.load()
-    import sdfbox_amd
-    return sdfbox_amd
-
-
-
-def main_single_process(args, json_fd):
-    """`--single-process`: the N-device frame behind the library's one call (sdfhip_multi_submit / _wait): one process, one
-    host thread and one stream per device inside libsdfhip.so, sparse shares written by the march kernel, pushed into
-    device 0 over the peers' own links, assembled there.  Same workload, same JSON line; `config.parallelism` says which
-    of the two things it measures."""
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")           # (see main())
-    import torch
-
-    sb = load_package(args)
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
-    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
-    ndev = torch.cuda.device_count()
-    if max(devices) >= ndev:
-        raise SystemExit(f"--devices {devices}: this box has {ndev} GPU(s)")
-    W, H = (int(v) for v in args.size.lower().split("x"))
-    t0 = time.time()
-    if args.asdf:
-        od = sb.OctData.LoadAsdf(args.asdf)
-        scene_name = os.path.basename(args.asdf)
-    else:
-        od = sb.dragon_standin(args.depth, nthreads=max(1, min(32, os.cpu_count() or 1)))
-        scene_name = f"dragon_standin_d{args.depth}"
-    t_gen = time.time() - t0
-    torch.cuda.set_device(devices[0])
-    ms = sb.MultiScene(od, devices)                  # (create runs sdfhip_multi_selftest: a link that does not deliver fails here)
-    links = ms.selftest()
-    if args.band_rows != 16 or args.rank0_weight > 0:
-        ms.configure(band_rows=args.band_rows, rank0_weight=args.rank0_weight if args.rank0_weight > 0 else 1.0)
-    cam = sb.Logic(W, H)
-    cam.Position = (0.5, 0.5, -0.35)
-    cam.Heading = (-0.2, 0.35)
-    cams = orbit_cameras(sb, W, H, args.orbit) if args.orbit > 0 else [cam]
-    pt = sb.PathTrace(spp=args.spp) if args.spp > 0 else None
-    flags = (sb.FLAG_DISPLAY if args.display else 0) | (sb.FLAG_TILE_ORDER if args.tile_order else 0)
-    frame_mode = args.multi_mode == "frame" or pt is not None
-    G = 1 if frame_mode else (args.gather_every if args.gather_every > 0 else (8 if len(devices) >= 8 else 4))
-    nslots = 1 if frame_mode else min(4, args.frames_in_flight if args.frames_in_flight > 0 else 4)
-
-    def sync_all():
-        for d in sorted(set(devices)):
-            torch.cuda.synchronize(d)
-
-    inflight = [None] * nslots              # the step index of the group a slot holds
-    stats_seen = []
-
-    def run(n, collect=False):
-        """n steps (frames) through the slots; returns the host time"""
-        for k in range(nslots):
-            if inflight[k] is not None:
-                ms.Wait(k); inflight[k] = None
-        sync_all()
-        t = time.perf_counter()
-        k = 0
-        while k < n:
-            g = min(G, n - k)
-            slot = (k // G) % nslots
-            if inflight[slot] is not None:
-                _, st = ms.Wait(slot, want_stats=True)
-                if collect:
-                    stats_seen.append(st)
-            ms.Submit(slot, [cams[(k + i) % len(cams)] for i in range(g)], W, H, flags=flags, pt=pt)
-            inflight[slot] = k
-            if frame_mode:
-                _, st = ms.Wait(slot, want_stats=True)
-                inflight[slot] = None
-                if collect:
-                    stats_seen.append(st)
-            k += g
-        for q in range(nslots):
-            if inflight[q] is not None:
-                _, st = ms.Wait(q, want_stats=True)
-                inflight[q] = None
-                if collect:
-                    stats_seen.append(st)
-        sync_all()
-        return time.perf_counter() - t
-
-    run(args.warmup if args.warmup > 0 else 1)
-    elapsed = run(args.steps, collect=True)
-    # one frame alone across the devices: submit + wait, nothing else in flight (median)
-    lat = []
-    for j in range(20 if pt is None else 3):
-        sync_all()
-        t = time.perf_counter()
-        ms.Submit(0, cams[j % len(cams)], W, H, flags=flags, pt=pt)
-        ms.Wait(0)
-        lat.append(time.perf_counter() - t)
-    latency_ms = float(np.median(lat)) * 1e3
-    # the frame to a HOST array, one call (what the C# host makes): sdfhip_multi_render
-    host = np.empty((H, W, 4), dtype=np.uint8 if args.display else np.float32)
-    hl = []
-    for j in range(8 if pt is None else 2):
-        t = time.perf_counter()
-        ms.Draw(cams[j % len(cams)], W, H, flags=flags, pt=pt, out=host)
-        hl.append(time.perf_counter() - t)
-    host_ms = float(np.median(hl[1:])) * 1e3
-
-    check_ok = None
-    one = sb.Scene(od, device=devices[0])
-    st = sb.Stats()
-    ref = torch.zeros((H, W) if args.display else (H, W, 4), dtype=torch.int32 if args.display else torch.float32, device=f"cuda:{devices[0]}")
-    main_stream = torch.cuda.current_stream().cuda_stream
-    if pt is not None:
-        one.DrawPathDevice(cam, W, H, ref.data_ptr(), pt=pt, flags=sb.FLAG_COUNT, stream=main_stream, stats=st)
-    else:
-        one.DrawDevice(cam, W, H, ref.data_ptr(), flags=sb.FLAG_COUNT, stream=main_stream, stats=st)
-    torch.cuda.synchronize()
-    if args.check:
-        check_ok = True
-        for j in range(min(len(cams), 6)):
-            if pt is not None:
-                one.DrawPathDevice(cams[j], W, H, ref.data_ptr(), pt=pt, stream=main_stream)
-            else:
-                one.DrawDevice(cams[j], W, H, ref.data_ptr(), flags=flags & ~sb.FLAG_TILE_ORDER, stream=main_stream)
-            torch.cuda.synchronize()
-            ms.Draw(cams[j], W, H, flags=flags, pt=pt, out=host)
-            check_ok = check_ok and bool(np.array_equal(host.view(np.uint32 if not args.display else np.uint8),
-                                                        ref.cpu().numpy().view(np.uint32 if not args.display else np.uint8).reshape(host.shape)))
-    sec_per_step = elapsed / args.steps
-    px_bytes = 4 if args.display else 16
-    ref_bytes = 8 * st.n_nodes + 8 * st.n_samples + px_bytes * W * H
-    own_bytes = 16 * st.n_loads + px_bytes * W * H
-    roof = roofline(sec_per_step, own_bytes, ref_bytes, None, measured_hbm_bandwidth(sb, devices[0]))
-    roof.update({"time_ms": round(sec_per_step * 1e3, 4), "note": "no PMC pass exists for a multi-device run: no fraction, only the demand figures"})
-    n_st = max(1, len(stats_seen))
-    out = {
-        "metric": "Mray/s (primary rays; frame W*H / time per frame)",
-        "value": round(W * H * max(1, args.spp) / sec_per_step / 1e6, 2),
-        "unit": "Mray/s",
-        "n_gpus": len(devices),
-        "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(sec_per_step * 1e3, 4),
-        "latency_ms": round(latency_ms, 4),
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {
-            "workload": (f"{W}x{H} path trace, {args.spp} spp, 3 diffuse bounces, seed 0x5DFB0C5, " if pt is not None else
-                         f"{W}x{H} primary-ray sphere trace + shadow march, ") + f"{scene_name} (N={od.Length} nodes, {od.nbytes / 1e6:.1f} MB), "
-                        "camera (0.5,0.5,-0.35) yaw 0.35 pitch -0.2" + (f", moving 1 degree per frame ({len(cams)} cameras)" if args.orbit > 0 else ""),
-            "parallelism": f"single process, devices {devices} through sdfhip_multi_submit/_wait (one host thread + stream per device, "
-                           f"{args.band_rows}-row bands, sparse shares written by the march kernel, gather by {ms.transport} into device {devices[0]})",
-            "ranks_seen": len(links), "pci_bus_ids": [l["pci_bus_id"] for l in links], "distinct_gpus": len({l["pci_bus_id"] for l in links}),
-            "transport": "RCCL ncclSend / ncclRecv inside the library" if ms.transport == "rccl" else "hipMemcpyPeerAsync on the senders' streams",
-            "links": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in l.items()} for l in links],
-            "measures": ("one frame at a time across all devices, submit to completion: the viewer's latency (strong scaling of ONE frame)"
-                         if frame_mode else
-                         f"throughput of groups: {G} frames per launch and gather, {nslots} groups in flight ({G * nslots} frames in flight)"),
-            "frames_per_gather": G, "groups_in_flight": nslots,
-            "gathered_bytes_per_frame": round(sum(s.gathered_bytes for s in stats_seen) / n_st / G, 1),
-            "float_tails_sent_again": int(sum(s.resends for s in stats_seen)),
-            "rank_ms_per_group": [round(sum(s.rank_ms[r] for s in stats_seen) / n_st, 4) for r in range(len(devices))],
-            "host_frame_ms": round(host_ms, 4),
-            "output": "RGBA8, display pass at assembly" if args.display else "RGBA32F, alpha = step count",
-            "scene_build_s": round(t_gen, 2),
-        },
-        "latency": {"frames": 1, "ms": round(latency_ms, 4), "to_host_array_ms": round(host_ms, 4)},
-        "roofline": roof,
-    }
-    if check_ok is not None:
-        out["config"]["assembled_frame_equals_whole_frame_render"] = check_ok
-    sys.stdout.flush()
-    os.write(json_fd, (json.dumps(out) + "\n").encode())
-    one.close()
-    ms.close()
-
-
-def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_shape, px_dtype, px_bytes, rank, nccl, pt, compact,
-                         G, nbuf, sparse2=False):
-    """Rank 0 also assembles the frame (de-interleave, or the expansion of all ranks' sparse shares), so an
-    even deal makes it the slowest rank.  Before anything is timed, rank 0 tries layouts that give it
-    0.3 .. 1.0 of a peer's share: for each it times its own work (render + assembly) and the largest
-    peer share (rank 1's, which it can render itself: the scene is replicated), and every rank then
-    receives the weight with the smallest max of the two."""
-    import torch
-    import torch.distributed as dist
-    T = sb.tiles
-    w = torch.ones(1, dtype=torch.float64)
-    if rank == 0:
-        streams = [torch.cuda.Stream() for _ in range(nbuf)]
-        full_shape, full_dtype = ((), torch.int32) if px_bytes == 4 else ((4,), torch.float32)
-        frame = torch.zeros((G, H, W) + full_shape, dtype=full_dtype, device="cuda")
-        n = 3 if pt is not None else 16
-
-        def work(lay, r, local, gathered):
-            def one(k):
-                s = streams[k % nbuf].cuda_stream
-                if sparse2:          # the march kernel writes the share; rank 0 expands `world` of them (its own stands in for the peers')
-                    share = local[k % nbuf]
-                    with torch.cuda.stream(streams[k % nbuf]):
-                        share[:4].zero_()
-                    T.render_sparse2(scene, [cam] * G, W, lay, r, share.data_ptr(), lay.rows_per_rank * W * G, 0, flags=flags, stream=s)
-                    if r == 0:
-                        T.deinterleave_sparse2(torch.cuda.current_device(), [share.data_ptr()] * world, frame.data_ptr(), W, lay,
-                                               lay.rows_per_rank * W * G, frames=G, stream=s)
-                    return
-                if pt is None and not compact:
-                    T.render_bands_batch(scene, [cam] * G, W, lay, r, local[k % nbuf].data_ptr(), flags=flags, stream=s)
-                else:
-                    for f in range(G):
-                        T.render_bands(scene, cam, W, lay, r, local[k % nbuf][f].data_ptr(), flags=flags, stream=s, pt=pt)
-                if r == 0:
-                    T.deinterleave(torch.cuda.current_device(), gathered.data_ptr(), frame.data_ptr(), W, lay,
-                                   stream=s, pixel_bytes=px_bytes, frames=G)
-            best = 1e9
-            for _ in range(2):
-                one(0); torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for k in range(n):
-                    one(k)
-                torch.cuda.synchronize()
-                best = min(best, (time.perf_counter() - t0) / (n * G))
-            return best
-
-        tried = []
-        for cand in (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3):
-            lay = T.BandLayout(H, world, band_rows, cand)
-            if sparse2:
-                local = [torch.zeros(T.sparse2_bytes(lay.rows_per_rank, W, G, lay.rows_per_rank * W * G), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-                gathered = torch.zeros(1, dtype=torch.uint8, device="cuda")
-            else:
-                local = [torch.zeros((G,) + share_shape(lay.rows_per_rank), dtype=px_dtype, device="cuda") for _ in range(nbuf)]
-                gathered = torch.zeros((world, G) + share_shape(lay.rows_per_rank), dtype=px_dtype, device="cuda")
-            t0, t1 = work(lay, 0, local, gathered), work(lay, 1, local, gathered)
-            tried.append((max(t0, t1), cand, t0, t1))
-            del local, gathered
-            if t0 <= t1:                               # rank 0 is no longer the slowest: a smaller share only loads the peers
-                break
-        _, best, t0, t1 = min(tried)
-        w[0] = best
-        print("[bench] rank-0 share search: " + ", ".join(f"w={c:.2f}: rank0 {a * 1e3:.4f} / peer {b * 1e3:.4f} ms" for _, c, a, b in tried)
-              + f" -> {best:.2f}", file=sys.stderr)
-        torch.cuda.empty_cache()
-    if nccl:
-        w = w.cuda()
-    dist.broadcast(w, src=0)
-    return float(w.item())
-
-
-def measure_band_deal(sb, scene, cam, W, H, world, band_rows, flags, rank, nccl, G, nbuf, steps):
-    """The frame's bands dealt by their measured COST (tiles.balanced_owner), with rank 0 -- which also expands all shares into
-    the frame -- charged for that work.  Before anything is timed, rank 0 renders the frame once, prices every band from the
-    step counts (tiles.band_costs), and tries deals that charge it 0 .. 20 % of the frame's cost for the assembly: for each it
-    times its own job (its share + the expansion of `world` shares, its own standing in for the peers') and two peers' shares
-    (the scene is replicated: it can render them itself), in the shape the run will have (a short run -- the driver's scaling run
-    times 20 steps -- is timed as that burst).  Every rank then receives the deal with the smallest maximum.  -> owner[band]."""
-    import torch
-    import torch.distributed as dist
-    T = sb.tiles
-    n_bands = (H + band_rows - 1) // band_rows
-    owner = torch.zeros(n_bands, dtype=torch.uint8)
-    if rank == 0:
-        streams = [torch.cuda.Stream() for _ in range(nbuf)]
-        whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-        scene.DrawDevice(cam, W, H, whole.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        costs = T.band_costs(whole[..., 3], band_rows)
-        del whole
-        total = sum(costs)
-        frames = torch.zeros((G, H, W, 4), dtype=torch.float32, device="cuda")
-        burst = 0 < steps <= 64
-        n_frames = steps if burst else 16 * G
-
-        def job(lay, r, shares, expand):
-            full = lay.rows_per_rank * W * G
-
-            def run():
-                for sh in shares:
-                    sh[:4].zero_()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                k = 0
-                while k < n_frames:
-                    g = min(G, n_frames - k)
-                    slot = (k // G) % nbuf
-                    if k >= G * nbuf:                         # (the share's counter starts at 0 again: its floats are stored as in the run)
-                        with torch.cuda.stream(streams[slot]):
-                            shares[slot][:4].zero_()
-                    T.render_sparse2(scene, [cam] * g, W, lay, r, shares[slot].data_ptr(), full, 0, flags=flags, stream=streams[slot].cuda_stream)
-                    if expand:
-                        T.deinterleave_sparse2(torch.cuda.current_device(), [shares[slot].data_ptr()] * world, frames.data_ptr(), W, lay, full,
-                                               frames=g, stream=streams[slot].cuda_stream)
-                    k += g
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t0) / n_frames
-            run()                                             # (and, with SDFHIP_FLAG_TILE_ORDER, the order every stream's launches will use)
-            return min(run() for _ in range(5 if burst else 2))
-
-        tried = []
-        for frac in (0.0, 0.04, 0.07, 0.10, 0.13, 0.16, 0.20):
-            own = T.balanced_owner(costs, world, extra0=frac * total)
-            lay = T.BandLayout(H, world, band_rows, owner=own)
-            full = lay.rows_per_rank * W * G
-            shares = [torch.zeros(T.sparse2_bytes(lay.rows_per_rank, W, G, full), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-            t0 = job(lay, 0, shares, True)
-            t1 = max(job(lay, r, shares, False) for r in sorted({1, world - 1}))
-            tried.append((max(t0, t1), frac, t0, t1, own))
-            del shares
-            if t0 <= t1 and frac > 0:                     # rank 0 is no longer the slowest: charging it more only loads the peers
-                break
-        _, frac, t0, t1, own = min(tried, key=lambda e: e[0])
-        owner = torch.tensor(own, dtype=torch.uint8)
-        print("[bench] band deal by cost (" + ("%d-step burst" % steps if burst else "steady state") + "): " +
-              ", ".join(f"assembly charged {f:.2f}: rank0 {a * 1e3:.4f} / peers {b * 1e3:.4f} ms" for _, f, a, b, _ in tried) + f" -> {frac:.2f}",
-              file=sys.stderr)
-        del frames
-        torch.cuda.empty_cache()
-    if nccl:
-        owner = owner.cuda()
-    dist.broadcast(owner, src=0)
-    return [int(v) for v in owner.cpu().tolist()]
-
-
-def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run and relay
-    its JSON line and exit code.  This process has not touched the GPU (no torch import yet) and never will."""
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
-    lines = [l for l in child.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
-    if lines:
-        sys.stdout.write(lines[-1] + "\n")
-        sys.stdout.flush()
-    return child.returncode if child.returncode or lines else 1
-
-
-def orbit_cameras(sb, W, H, n, step_deg=1.0):
-    """n cameras, step_deg (one degree) apart, on the horizontal circle through the cfg-2 camera position about the scene's
-    centre, each turned by its angle (yaw convention of Matrix4x4.CreateFromYawPitchRoll: forward = (sin yaw, ., cos yaw))."""
-    import math
-    out = []
-    r = 0.5 + 0.35
-    for k in range(n):
-        phi = math.radians(k * step_deg)
-        c = sb.Logic(W, H)
-        c.Position = (0.5 - r * math.sin(phi), 0.5, 0.5 - r * math.cos(phi))
-        c.Heading = (-0.2, 0.35 + phi)
-        out.append(c)
-    return out
-
-
-# the kernel sources of the frame's pipeline (device code only: host-side edits do not change what the counters measured)
-KERNEL_SOURCES = ("raymarch_device.h", "raymarch_kernels.h", "upload_kernels.h", "tile_order_kernels.h",
-                  # (ADVICE r4) what else decides the counters: COMPACT_MIN_LANES and march_grid (scene.h), the launch shapes, hit_cap
-                  # and shade_grid (render.hip), the sparse-share kernels (gather_kernels.h)
-                  "scene.h", "render.hip", "gather_kernels.h")
-
-
-def kernel_source_hash():
-    """What the PMC figures in profiles/hbm_traffic.json were measured on (scripts/summarise_profile.py)."""
-    h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        with open(os.path.join(REPO, "sdfbox_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
-
-
-def load_pmc(key):
-    """rocprofv3 PMC figures of this workload (HBM bytes, issued VALU / SALU wave instructions and VALU-busy quad-cycles per
-    frame), or a dict {"dropped": reason}.  bench.py cannot run rocprofv3 on itself: scripts/profile.sh collects the
-    separate --pmc passes of this very command and scripts/summarise_profile.py writes profiles/hbm_traffic.json together
-    with the hash of the kernel sources they were measured on; figures of another build are not reported, and the line
-    says so."""
-    try:
-        with open(os.path.join(REPO, "profiles", "hbm_traffic.json")) as f:
-            e = json.load(f).get(key)
-    except (OSError, ValueError):
-        return {"dropped": "profiles/hbm_traffic.json is missing or unreadable"}
-    if not isinstance(e, dict):
-        return {"dropped": f"no PMC pass of workload '{key}' under profiles/ (scripts/profile.sh)"}
-    here = kernel_source_hash()
-    if e.get("kernel_source_sha") != here:
-        return {"dropped": f"the PMC pass of '{key}' ({e.get('profile')}) was measured on kernel sources {e.get('kernel_source_sha')}; "
-                           f"this build is {here}: figures of another build are not reported"}
-    return e
-
-
-# VALU issue ceilings, in wave64 instructions per second chip-wide:
-#   spec      256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles: a SIMD retires 32 lanes per clock (the 157.3 TFLOP/s fp32 vector figure
-#             = 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flops), so a wave64 instruction takes two
-#   measured  / 2.35 cycles: the cheapest instruction on this chip with 8 waves per SIMD (v_mov_b32; v_and / v_add / v_sub /
-#             v_mul / v_fmac 2.4-2.6; shifts, compares, conversions, v_fma_f32 (VOP3), min3 / med3 4.0-4.4; a packed fp32
-#             instruction 4.4-4.7 for two results: scripts/micro/valu_mix.hip, profiles/r03_micro_valu_mix.txt)
-# Both bound ANY instruction mix from above; `valu_busy` below is the measured utilisation.
-VALU_PEAK_SPEC_GINSTR = 256 * 4 * 2.4 / 2.0
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.35
-HBM_PEAK_GBS = 8000.0                    # HBM3E spec (MI355X_MICROARCH.md)
-N_SIMD, CLOCK_GHZ = 256 * 4, 2.4
-
-
-def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, measured):
-    """The frame against its two roofs, both from the rocprofv3 counters of THIS build and workload (profiles/hbm_traffic.json;
-    the PMC passes serialise launches -- one frame in flight while they count -- which changes times, not counts), over the
-    steady-state time per frame (the driver-verifiable ms_per_step; with frames in flight the launch durations overlap):
-      frac = hbm_frac   HBM bytes per frame (2 x FETCH_SIZE + WRITE_SIZE, separate passes, the guide's gfx950 correction) / time
-                        / 8 TB/s.  THIS is the fraction SURVEY.md 8d and BASELINE's "% of HBM roofline" ask for, so it is the
-                        object's `frac`, with bound = "hbm", achieved / peak in GB/s and `traffic` the counter bytes.
-                        hbm_frac_of_measured: the same over `measured` -- the box's own streaming rate (the library's float4
-                        copy / triad, sdfhip_device_bandwidth), SURVEY 8d's "measured device bandwidth" denominator.
-      valu_frac_of_spec issued VALU wave instructions per frame (SQ_INSTS_VALU) / time against the chip's SPEC issue rate, 1 228.8 G
-                        wave64 instructions per second (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles); valu_frac_of_measured_ceiling:
-                        against the cheapest instruction as measured here (2.35 cycles, scripts/micro/valu_mix.hip).  The PEER of
-                        hbm_frac, not a substitute: `limiting` names the larger of the two -- "valu" on the primary-ray frames
-                        (the march is instruction-issue bound: its lookups mostly hit L1 / L2), "hbm" on cfg-5 and the depth-10 scene.
-      valu_busy         SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles: the instruction count priced at 4 cycles each, NOT a utilisation.
-    pmc_stale = true: the committed PMC pass was measured on other kernel sources (or there is none): no fraction, only `demand`.
-    `demand`: the bytes this kernel's own algorithm asks of the MEMORY SYSTEM per frame (16 B per cell a LANE loads + the pixel
-    store, by the counting build) and the bytes the REFERENCE algorithm would read for the same pixels (8 B per node
-    visit of find(), Compute.hlsl:88-108, 8 B per sample, the store), each over 8 TB/s x time.  Both exceed 1 on the bench
-    frames: they are ratios, not fractions of a roof -- a lookup grid built at upload replaces the descent (1.1 loads per step
-    instead of 8.2), and L1 / L2 serve most of the kernel's own loads."""
-    dropped = pmc.get("dropped") if isinstance(pmc, dict) else None
-    if dropped:
-        pmc = None
-    best_gbs = measured.get("best_gbs") if isinstance(measured, dict) else measured
-    traffic = hbm = valu = valu_busy = None
-    if pmc:
-        traffic = int(pmc["hbm_bytes_per_frame"])
-        ach = traffic / sec_per_frame / 1e9
-        hbm = {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": traffic, "frac": round(ach / HBM_PEAK_GBS, 4),
-               "frac_of_measured": round(ach / best_gbs, 4) if best_gbs else None}
-        if pmc.get("valu_insts_per_frame"):
-            ach = pmc["valu_insts_per_frame"] / sec_per_frame / 1e9
-            valu = {"achieved": round(ach, 1), "peak": round(VALU_PEAK_SPEC_GINSTR, 1),
-                    "peak_is": "spec: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
-                    "measured_ceiling": round(VALU_PEAK_GINSTR, 1),
-                    "measured_ceiling_is": "the cheapest VALU instruction on this chip, 2.35 cycles (scripts/micro/valu_mix.hip)",
-                    "frac": round(ach / VALU_PEAK_SPEC_GINSTR, 4), "frac_of_measured_ceiling": round(ach / VALU_PEAK_GINSTR, 4),
-                    "unit": "G wave-instr/s", "per_frame": int(pmc["valu_insts_per_frame"])}
-        if pmc.get("valu_active_quad_cycles_per_frame"):
-            valu_busy = round(pmc["valu_active_quad_cycles_per_frame"] * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9 * sec_per_frame), 4)
-    cands = {k: v for k, v in (("hbm-traffic", hbm), ("valu", valu)) if v}
-    limiting = max(cands, key=lambda k: cands[k]["frac"]) if cands else None
-    own_over, ref_over = own_bytes / sec_per_frame / 1e9 / HBM_PEAK_GBS, ref_bytes / sec_per_frame / 1e9 / HBM_PEAK_GBS
-    return {
-        # the contract's object: the HBM roof, which is what SURVEY 8d / BASELINE ask the fraction of
-        "bound": "hbm" if hbm else None,
-        "achieved": hbm["achieved"] if hbm else None, "peak": hbm["peak"] if hbm else None, "unit": hbm["unit"] if hbm else None,
-        "frac": hbm["frac"] if hbm else None,
-        "frac_is": "hbm_frac: counter HBM bytes / time / 8 TB/s -- the fraction SURVEY.md 8d asks for; valu_frac_of_spec is its peer, "
-                   "`limiting` the larger of the two",
-        "traffic": traffic,
-        "pmc_stale": not cands,
-        "hbm_frac": hbm["frac"] if hbm else None,
-        "hbm_frac_of_measured": hbm["frac_of_measured"] if hbm else None,
-        "valu_frac_of_spec": valu["frac"] if valu else None,
-        "valu_frac_of_measured_ceiling": valu["frac_of_measured_ceiling"] if valu else None,
-        "limiting": None if limiting is None else ("hbm" if limiting.startswith("hbm") else "valu"),
-        "valu_busy": valu_busy,
-        "valu_busy_is": "SQ_ACTIVE_INST_VALU x 4 cycles over the SIMD-cycles of the frame: every instruction is charged one quad-cycle, "
-                        "so this is the instruction count at 4 cycles each, not a measured utilisation",
-        "traffic_source": ({"profile": pmc.get("profile"), "kernel_source_sha": pmc.get("kernel_source_sha"),
-                            "frames_in_flight_while_counting": 1} if pmc else
-                           (dropped or "no PMC pass of this build and workload under profiles/ (scripts/profile.sh)")),
-        "candidates": cands,
-        "demand": {"own_bytes_per_frame": int(own_bytes), "own_demand_over_hbm_peak": round(own_over, 3),
-                   "reference_bytes_per_frame": int(ref_bytes), "reference_demand_over_hbm_peak": round(ref_over, 3),
-                   "note": "requests to the memory system over 8 TB/s x time, NOT roofline fractions: the lookup grid built at upload replaces "
-                           "the reference's descent and L1 / L2 serve most of the kernel's own loads (see roofline() in bench.py)"},
-        "measured_hbm_gbs": measured,
-    }
-
-
-def configs_summary(out, cfgs):
-    """<= 600 characters that carry every configuration's time, rays and fractions: the LAST key of the line, so that the last
-    2 000 characters of it (what the driver's record keeps) hold all of them.  ms per frame / Mray/s / hbm_frac (of 8 TB/s) /
-    hbm_frac_of_measured / valu_frac_of_spec; '-' where there is no PMC pass of this build."""
-    names = {"cfg3_4k": "cfg3", "cfg3_4k_compact": "cfg3c", "cfg5_4k_spp16": "cfg5", "cfg2_depth10": "d10", "cfg2_mesh_knot_d10": "mesh"}
-
-    def f(v, nd):
-        return "-" if v is None else f"{v:.{nd}f}"
-
-    def one(tag, e, r):
-        if "error" in e:
-            return f"{tag} ERR {str(e['error'])[:40]}"
-        return f"{tag} {f(e.get('ms_per_step'), 4)}/{f(e.get('value'), 0)}/{f(r.get('hbm_frac'), 2)}/{f(r.get('hbm_frac_of_measured'), 2)}/{f(r.get('valu_frac_of_spec'), 2)}"
-    parts = [one("cfg2", out, out.get("roofline") or {})]
-    if isinstance(cfgs, dict):
-        if "error" in cfgs and not any(k in cfgs for k in names):
-            parts.append("configs ERR " + str(cfgs["error"])[:60])
-        for k, e in cfgs.items():
-            if isinstance(e, dict) and k != "error":
-                parts.append(one(names.get(k, k[:10]), e, e))
-    return ("ms/Mray/hbm/hbm_meas/valu: " + "; ".join(parts))[:600]
-
-
-def bench_camera(sb, W, H):
-    """SURVEY.md 8d cfg-2's camera"""
-    cam = sb.Logic(W, H)
-    cam.Position = (0.5, 0.5, -0.35)
-    cam.Heading = (-0.2, 0.35)            # (X = pitch, Y = yaw), Logic.cs:53
-    return cam
-
-
-def grid_suffix(scene, pt=None):
-    """The part of a PMC key that names the scene's grid: "grid9" dense, "grid8+blocks" split (SDFHIP_TOP_GRID_LEVEL / _SPLIT change it)"""
-    lvl, gbytes = scene.top_grid_level, scene.top_grid_bytes
-    return f":grid{lvl}" + ("+blocks" if lvl and gbytes > (16 << (3 * lvl)) and pt is None else "")
-
-
-def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared_streams=None):
-    """BASELINE.json's other single-GPU configurations, timed in this process behind the headline: the same
-    clock (host time around `steps` frames, synchronised on both sides, frames in flight on their own streams), the HIP-event
-    time of a launch beside it, and the counter fractions from the committed PMC pass of the SAME command line
-    (profiles/hbm_traffic.json -> profiles/<tag>_pmc.json, formulas in profiles/README.md) when it was measured on this build's
-    kernel sources -- else pmc_stale and no fraction."""
-    out = {}
-    suffix9 = grid_suffix(scene)                      # (before the path-traced mode adds its second grid to the byte count)
-
-    def measure(name, sc, sname, W, H, mode, suffix, flags=0, pt=None, steps=60, warmup=12, nbuf=4, note=None):
-        cam = bench_camera(sb, W, H)
-        bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-        # the headline's streams again: which hardware queue a stream gets is the runtime's business, and these are known to have
-        # queues of their own (fresh streams for every configuration: the 4K frame took 0.328 ms where the same run alone takes 0.313)
-        streams = (list(shared_streams[:nbuf]) if shared_streams and len(shared_streams) >= nbuf else []) or [torch.cuda.Stream() for _ in range(nbuf)]
-
-        def launch(k):
-            s = streams[k % nbuf].cuda_stream
-            if pt is not None:
-                sc.DrawPathDevice(cam, W, H, bufs[k % nbuf].data_ptr(), pt=pt, flags=flags, stream=s)
-            else:
-                sc.DrawDevice(cam, W, H, bufs[k % nbuf].data_ptr(), flags=flags, stream=s)
-        for k in range(warmup):
-            launch(k)
-        torch.cuda.synchronize()
-        ev = []
-        t0 = time.perf_counter()
-        for k in range(steps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(streams[k % nbuf])
-            launch(k)
-            e1.record(streams[k % nbuf])
-            ev.append((e0, e1))
-        torch.cuda.synchronize()
-        sec = (time.perf_counter() - t0) / steps
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        spp = pt.spp if pt is not None else 1
-        key = f"{W}x{H}:{sname}:{mode}{suffix}"
-        pmc = load_pmc(key)
-        stale = "dropped" in pmc
-        e = {"workload": f"{W}x{H}, {sname}, " + (f"path trace {spp} spp, 3 diffuse bounces" if pt is not None else
-                                                   "primary-ray sphere trace + shadow march") + (", " + note if note else ""),
-             "ms_per_step": round(sec * 1e3, 4), "value": round(W * H * spp / sec / 1e6, 2), "unit": "Mray/s",
-             "steps": steps, "warmup": warmup, "frames_in_flight": nbuf, "kernel_ms": round(kernel_ms, 4),
-             "pmc_key": key, "pmc_stale": stale,
-             "hbm_frac": None, "valu_frac_of_spec": None, "traffic": None, "valu_insts_per_frame": None,
-             "profile": None if stale else pmc.get("profile"), "kernel_source_sha": kernel_source_hash()}
-        if stale:
-            e["pmc_dropped"] = pmc["dropped"]
-        else:
-            e["traffic"] = int(pmc["hbm_bytes_per_frame"])
-            e["hbm_frac"] = round(e["traffic"] / sec / 1e9 / HBM_PEAK_GBS, 4)
-            best_gbs = copy_gbs.get("best_gbs") if isinstance(copy_gbs, dict) else copy_gbs
-            e["hbm_frac_of_measured"] = round(e["traffic"] / sec / 1e9 / best_gbs, 4) if best_gbs else None
-            if pmc.get("valu_insts_per_frame"):
-                e["valu_insts_per_frame"] = int(pmc["valu_insts_per_frame"])
-                e["valu_frac_of_spec"] = round(pmc["valu_insts_per_frame"] / sec / 1e9 / VALU_PEAK_SPEC_GINSTR, 4)
-            e["limiting"] = "hbm" if (e["hbm_frac"] or 0) >= (e["valu_frac_of_spec"] or 0) else "valu"
-        out[name] = e
-        del bufs, streams
-        torch.cuda.empty_cache()
-
-    W4, H4, W2, H2 = 3840 // scale, 2160 // scale, 1920 // scale, 1080 // scale
-
-    def guarded(name, fn):                 # a configuration that fails is reported as such; the others are still measured
-        try:
-            fn()
-        except Exception as e:
-            out[name] = {"error": f"{type(e).__name__}: {e}"}
-            torch.cuda.empty_cache()
-
-    guarded("cfg3_4k", lambda: measure("cfg3_4k", scene, scene_name, W4, H4, "default", suffix9,
-            note="BASELINE cfg-3's frame with compaction OFF (the default kernel: faster than every form of compaction built)"))
-    guarded("cfg3_4k_compact", lambda: measure("cfg3_4k_compact", scene, scene_name, W4, H4, "compact", suffix9, flags=sb.FLAG_COMPACT,
-            note="BASELINE cfg-3 as named: wavefront ray compaction ON (SDFHIP_FLAG_COMPACT: the shadow rays of waves that hold fewer than 32 "
-                 "compacted by ballot / prefix into a queue and marched 64 to a wave by a second kernel)"))
-
-    def cfg5():
-        pt = sb.PathTrace(spp=16)
-        sb._lib.check(sb._lib.lib.sdfhip_scene_prepare_path(scene._h))       # the bounce levels' grid, at load time
-        measure("cfg5_4k_spp16", scene, scene_name, W4, H4, "spp16", grid_suffix(scene, pt), pt=pt, steps=9, warmup=3, nbuf=3,
-                note="BASELINE cfg-5 on one GPU")
-    guarded("cfg5_4k_spp16", cfg5)
-
-    def depth10():                         # cfg-2 at the reference application's default depth (Model.MaxDepth = 10, SdfBox/Model.cs:18)
-        t0 = time.time()
-        od10 = sb.dragon_standin(depth + 1, nthreads=max(1, min(32, os.cpu_count() or 1)))
-        t_gen = time.time() - t0
-        with sb.Scene(od10, device=scene.device) as sc10:
-            measure("cfg2_depth10", sc10, f"dragon_standin_d{depth + 1}", W2, H2, "default", grid_suffix(sc10),
-                    note=f"N={od10.Length} nodes, {od10.nbytes / 1e6:.0f} MB, built in {t_gen:.1f} s")
-    guarded("cfg2_depth10", depth10)
-    # ... and on a MESH-derived scene at that depth: the reference's import flow (Program.cs:613-650: .ply -> SdfGen(depth 10) -> upload)
-    # on a 1 M-point cloud (a torus-knot tube: no mesh ships with the reference), the tree built by the GPU builder and never
-    # leaving HBM (sdfhip_sdfgen_scene)
-    def mesh():
-        pts = sb.knot_point_cloud(1_000_000)
-        sb.Scene.FromPoints(pts[:2000], 3).close()                       # (module load)
-        t0 = time.time()
-        scm, stg = sb.Scene.FromPoints(pts, depth + 1, device=scene.device, want_stats=True)
-        t_build = time.time() - t0
-        with scm:
-            measure("cfg2_mesh_knot_d10", scm, f"knot_d{depth + 1}.asdf", W2, H2, "default", grid_suffix(scm),
-                    note=f"1 M-point cloud -> sdfhip_sdfgen_scene: N={scm.Length} nodes in {t_build * 1e3:.0f} ms wall ({stg.total_ms:.0f} ms in the library)")
-    if scale == 1:
-        guarded("cfg2_mesh_knot_d10", mesh)
-    return out
-
-
-def measured_hbm_bandwidth(sb, device=0, nbytes=2 << 30, reps=10):
-    """SURVEY.md 8d's denominator: what this box's HBM delivers to a streaming kernel -- the library's own float4 copy, STREAM
-    triad and read-only sum over 2 GiB arrays (sdfhip_device_bandwidth, csrc/bandwidth.hip; the kernel shapes chosen by
-    scripts/micro/bw_variants.hip), bytes read + written per second in GB/s; `best_gbs` = the largest of the three, the roof no
-    kernel of this repository beats.  -> dict or None.  (Until round 5 this was a torch `copy_` of 1 GiB, which reaches
-    4.8-5.3 TB/s -- below what the frame's own kernels sustain on cfg-5, so fractions of it exceeded 1.)"""
-    try:
-        c, t, r = sb.device_bandwidth(device, nbytes, reps)
-    except Exception as e:                       # (out of memory beside a large scene: the line goes on without the figure)
-        print(f"[bench] measured_hbm_bandwidth: {type(e).__name__}: {e}", file=sys.stderr)
-        return None
-    return {"copy_gbs": round(c, 1), "triad_gbs": round(t, 1), "read_gbs": round(r, 1), "best_gbs": round(max(c, t, r), 1), "array_bytes": nbytes,
-            "reps": reps,
-            "is": "sdfhip_device_bandwidth: float4 copy (2 x array bytes moved), triad a = b + s c (3 x) and a read-only sum (1 x) over arrays far "
-                  "larger than the 256 MiB Infinity Cache, HIP-event time; best_gbs = the largest of the three"}
-
-
-def cpu_limits():
-    """What this process may use of the host: the CPUs of its affinity mask and the cgroup's CPU quota (cpu.max of cgroup v2, or
-    cfs_quota_us / cfs_period_us of v1) in CPUs -- None when there is no quota."""
-    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    quota = None
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            q, period = f.read().split()[:2]
-            if q != "max":
-                quota = int(q) / int(period)
-    except (OSError, ValueError):
-        try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
-                q, period = int(f.read()), int(g.read())
-                if q > 0:
-                    quota = q / period
-        except (OSError, ValueError):
-            pass
-    return affinity, quota
-
-
-def cpu_baseline(od, cam, W, H, target_seconds):
-    """The CPU oracle (the build's C restatement of Compute.hlsl: the reference has no CPU path) timed on this
-    host over bounded samples of the same frame (every `step`-th row), built here with -O3 -march=native -- same
-    source, same -ffp-contract=off, its rows compared bit for bit with the portable build the parity tests use.  Timed by
-    oracle_bench_rows: a pool of threads pinned to the CPUs of this process's affinity mask, dealt over the NUMA nodes, each
-    node reading its own copy of the scene, all waiting at a barrier before the clock (read inside the C function) starts;
-    pixels dealt in chunks of 64 from one counter.  The thread count is SWEPT (1, 16, 64, 128, 256, the affinity mask's size and
-    the cgroup quota, whichever the mask allows) and the best is the reported value; `limits` says what the host let this
-    process use -- a quota of 16 CPUs caps every thread count at 16 CPUs' worth of cycles."""
-    import oracle
-    oracle.build()
-    native = oracle.build_native()                     # None when the host has no compiler: then only the portable build is timed
-    affinity, quota = cpu_limits()
-    usable = min(affinity, int(quota + 0.999)) if quota else affinity
-    cands = sorted({n for n in (1, 16, 64, 128, 256, affinity, usable) if 1 <= n <= affinity})
-    # calibrate one thread on a sparse sample of the frame (rows spread top to bottom), on both builds: the faster one is swept
-    # (-O3 -march=native is not always it; the other's one-thread figure is printed beside it)
-    step0 = max(1, H // 8)
-    builds = {"gcc -O2 -march=x86-64-v2 (+ an fma clone) -ffp-contract=off": False}
-    if native is not None:
-        builds["gcc -O3 -march=native -ffp-contract=off, built on this host"] = True
-    calib = {}
-    for name, nat in builds.items():
-        _, _, sec0, _ = oracle.bench_rows(od.Structs, od.Values, cam.State, W, H, row_step=step0, nthreads=1, store=False, native=nat)
-        calib[name] = sec0 / ((H + step0 - 1) // step0)
-    build_used = min(calib, key=calib.get)
-    kw = {"native": builds[build_used]}
-    per_row1 = calib[build_used]
-    budget = target_seconds / len(cands)
-    sweep, best, best_img, best_step = [], None, None, 1
-    for nt in cands:
-        # rows for ~budget seconds if the threads scaled perfectly up to what the host lets this process use; when the whole frame
-        # is not enough (a cgroup grants CPU time in 100 ms periods: a quota shows in a timed region of seconds, not in a burst of
-        # 0.2 s) the frame is rendered several times over
-        want = budget * min(nt, usable) / max(per_row1, 1e-9)
-        rows = int(min(H, max(8, want)))
-        step = max(1, H // rows)
-        nrows = (H + step - 1) // step
-        repeat = max(1, int(round(want / nrows)))
-        img, _, sec, topo = oracle.bench_rows(od.Structs, od.Values, cam.State, W, H, row_step=step, nthreads=nt, repeat=repeat, **kw)
-        e = {"threads": topo["threads"], "value": round(repeat * nrows * W / sec / 1e6, 3), "numa_nodes": topo["numa_nodes"],
-             "scene_copies": topo["scene_copies"],
-             "sample": f"every {step}th row = {nrows * W} pixels" + (f", {repeat} times over," if repeat > 1 else "") + f" in {sec:.2f} s"}
-        sweep.append(e)
-        if best is None or e["value"] > best["value"]:
-            best, best_img, best_step = e, img, step
-    other = {name: {"one_thread_ms_per_row": round(v * 1e3, 3)} for name, v in calib.items()}
-    same = None
-    if kw["native"]:                                   # a few of the best run's rows through the portable build: identical bits
-        nrows = best_img.shape[0]
-        k = max(1, nrows // 8)
-        ref, _ = oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=(nrows + k - 1) // k, row_step=best_step * k,
-                               nthreads=min(usable, 32))
-        a, b = best_img[::k].view(np.uint32), ref.view(np.uint32)
-        same = bool(((a == b) | (np.isnan(best_img[::k]) & np.isnan(ref))).all())
-    one = next(e for e in sweep if e["threads"] == 1)
-    model, physical = host_cpu()
-    ratio = best["value"] / one["value"] if one["value"] else None
-    return {
-        "value": best["value"],
-        "unit": "Mray/s",
-        "cores": best["threads"],
-        "kind": "port",
-        "cpu_model": model,
-        "physical_cores": physical,
-        "limits": {"affinity_cpus": affinity, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count(),
-                   "note": ("the cgroup lets this process use %.1f CPUs' worth of cycles: more threads than that share them" % quota)
-                           if quota and quota < affinity else None},
-        "build": build_used,
-        "builds_tried_one_thread": other,
-        "native_build_equals_portable_build": same,
-        "sample": best["sample"] + f" of the same {W}x{H} frame; oracle/sdf_oracle.c::oracle_bench_rows, {best['threads']} pinned pthreads over "
-                  f"{best['numa_nodes']} NUMA node(s) ({best['scene_copies']} node-local scene copies), started before the clock, 64-pixel chunks from one counter",
-        "sweep": sweep,
-        "speedup_over_one_thread": round(ratio, 1) if ratio else None,
-        "one_thread": {"value": one["value"], "unit": "Mray/s", "sample": one["sample"]},
-    }
-
-
-def host_cpu():
-    """(model name, physical cores) from /proc/cpuinfo; (None, None) when it cannot be read."""
-    try:
-        model, cores = None, set()
-        phys = core = None
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                k, _, v = line.partition(":")
-                k, v = k.strip(), v.strip()
-                if k == "model name" and model is None:
-                    model = v
-                elif k == "physical id":
-                    phys = v
-                elif k == "core id":
-                    core = v
-                elif not k and phys is not None and core is not None:
-                    cores.add((phys, core)); phys = core = None
-        if phys is not None and core is not None:
-            cores.add((phys, core))
-        return model, (len(cores) or None)
-    except OSError:
-        return None, None
 
 
 if __name__ == "__main__":

@@ -1,0 +1,301 @@
+"""bench_report.py -- what bench.py's line says ABOUT a measurement: the roofline object from the committed rocprofv3 counter passes
+(load_pmc, roofline), the line's last key (configs_summary), the box's own HBM rate (measured_hbm_bandwidth) and the CPU baseline
+(the oracle timed on the host's cores: the one place outside tests/ and smoke() that may touch oracle/).  No GPU work is timed here
+except the bandwidth kernels of the library.  Split out of bench.py in round 6 without a change of behaviour."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+
+
+# the kernel sources of the frame's pipeline (device code only: host-side edits do not change what the counters measured)
+KERNEL_SOURCES = ("raymarch_device.h", "raymarch_kernels.h", "upload_kernels.h", "tile_order_kernels.h",
+                  #  what else decides the counters: COMPACT_MIN_LANES and march_grid (scene.h), the launch shapes, hit_cap
+                  # and shade_grid (render.hip), the sparse-share kernels (gather_kernels.h)
+                  "scene.h", "render.hip", "gather_kernels.h")
+
+
+def kernel_source_hash():
+    """What the PMC figures in profiles/hbm_traffic.json were measured on (scripts/summarise_profile.py)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(REPO, "sdfbox_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(key):
+    """rocprofv3 PMC figures of this workload (HBM bytes, issued VALU / SALU wave instructions and VALU-busy quad-cycles per
+    frame), or a dict {"dropped": reason}.  bench.py cannot run rocprofv3 on itself: scripts/profile.sh collects the
+    separate --pmc passes of this very command and scripts/summarise_profile.py writes profiles/hbm_traffic.json together
+    with the hash of the kernel sources they were measured on; figures of another build are not reported, and the line
+    says so."""
+    try:
+        with open(os.path.join(REPO, "profiles", "hbm_traffic.json")) as f:
+            e = json.load(f).get(key)
+    except (OSError, ValueError):
+        return {"dropped": "profiles/hbm_traffic.json is missing or unreadable"}
+    if not isinstance(e, dict):
+        return {"dropped": f"no PMC pass of workload '{key}' under profiles/ (scripts/profile.sh)"}
+    here = kernel_source_hash()
+    if e.get("kernel_source_sha") != here:
+        return {"dropped": f"the PMC pass of '{key}' ({e.get('profile')}) was measured on kernel sources {e.get('kernel_source_sha')}; "
+                           f"this build is {here}: figures of another build are not reported"}
+    return e
+
+
+# VALU issue ceilings, in wave64 instructions per second chip-wide:
+#   spec      256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles: a SIMD retires 32 lanes per clock (the 157.3 TFLOP/s fp32 vector figure
+#             = 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flops), so a wave64 instruction takes two
+#   measured  / 2.35 cycles: the cheapest instruction on this chip with 8 waves per SIMD (v_mov_b32; v_and / v_add / v_sub /
+#             v_mul / v_fmac 2.4-2.6; shifts, compares, conversions, v_fma_f32 (VOP3), min3 / med3 4.0-4.4; a packed fp32
+#             instruction 4.4-4.7 for two results: scripts/micro/valu_mix.hip, profiles/r03_micro_valu_mix.txt)
+# Both bound ANY instruction mix from above; `valu_busy` below is the measured utilisation.
+VALU_PEAK_SPEC_GINSTR = 256 * 4 * 2.4 / 2.0
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.35
+HBM_PEAK_GBS = 8000.0                    # HBM3E spec (MI355X_MICROARCH.md)
+N_SIMD, CLOCK_GHZ = 256 * 4, 2.4
+
+
+def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, measured):
+    """The frame against its two roofs, both from the rocprofv3 counters of THIS build and workload (profiles/hbm_traffic.json;
+    the PMC passes serialise launches -- one frame in flight while they count -- which changes times, not counts), over the
+    steady-state time per frame (the driver-verifiable ms_per_step; with frames in flight the launch durations overlap):
+      frac = hbm_frac   HBM bytes per frame (2 x FETCH_SIZE + WRITE_SIZE, separate passes, the guide's gfx950 correction) / time
+                        / 8 TB/s.  THIS is the fraction SURVEY.md 8d and BASELINE's "% of HBM roofline" ask for, so it is the
+                        object's `frac`, with bound = "hbm", achieved / peak in GB/s and `traffic` the counter bytes.
+                        hbm_frac_of_measured: the same over `measured` -- the box's own streaming rate (the library's float4
+                        copy / triad, sdfhip_device_bandwidth), SURVEY 8d's "measured device bandwidth" denominator.
+      valu_frac_of_spec issued VALU wave instructions per frame (SQ_INSTS_VALU) / time against the chip's SPEC issue rate, 1 228.8 G
+                        wave64 instructions per second (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles); valu_frac_of_measured_ceiling:
+                        against the cheapest instruction as measured here (2.35 cycles, scripts/micro/valu_mix.hip).  The PEER of
+                        hbm_frac, not a substitute: `limiting` names the larger of the two -- "valu" on the primary-ray frames
+                        (the march is instruction-issue bound: its lookups mostly hit L1 / L2), "hbm" on cfg-5 and the depth-10 scene.
+      valu_busy         SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles: the instruction count priced at 4 cycles each, NOT a utilisation.
+    pmc_stale = true: the committed PMC pass was measured on other kernel sources (or there is none): no fraction, only `demand`.
+    `demand`: the bytes this kernel's own algorithm asks of the MEMORY SYSTEM per frame (16 B per cell a LANE loads + the pixel
+    store, by the counting build) and the bytes the REFERENCE algorithm would read for the same pixels (8 B per node
+    visit of find(), Compute.hlsl:88-108, 8 B per sample, the store), each over 8 TB/s x time.  Both exceed 1 on the bench
+    frames: they are ratios, not fractions of a roof -- a lookup grid built at upload replaces the descent (1.1 loads per step
+    instead of 8.2), and L1 / L2 serve most of the kernel's own loads."""
+    dropped = pmc.get("dropped") if isinstance(pmc, dict) else None
+    if dropped:
+        pmc = None
+    best_gbs = measured.get("best_gbs") if isinstance(measured, dict) else measured
+    traffic = hbm = valu = valu_busy = None
+    if pmc:
+        traffic = int(pmc["hbm_bytes_per_frame"])
+        ach = traffic / sec_per_frame / 1e9
+        hbm = {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "per_frame": traffic, "frac": round(ach / HBM_PEAK_GBS, 4),
+               "frac_of_measured": round(ach / best_gbs, 4) if best_gbs else None}
+        if pmc.get("valu_insts_per_frame"):
+            ach = pmc["valu_insts_per_frame"] / sec_per_frame / 1e9
+            valu = {"achieved": round(ach, 1), "peak": round(VALU_PEAK_SPEC_GINSTR, 1),
+                    "peak_is": "spec: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction",
+                    "measured_ceiling": round(VALU_PEAK_GINSTR, 1),
+                    "measured_ceiling_is": "the cheapest VALU instruction on this chip, 2.35 cycles (scripts/micro/valu_mix.hip)",
+                    "frac": round(ach / VALU_PEAK_SPEC_GINSTR, 4), "frac_of_measured_ceiling": round(ach / VALU_PEAK_GINSTR, 4),
+                    "unit": "G wave-instr/s", "per_frame": int(pmc["valu_insts_per_frame"])}
+        if pmc.get("valu_active_quad_cycles_per_frame"):
+            valu_busy = round(pmc["valu_active_quad_cycles_per_frame"] * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9 * sec_per_frame), 4)
+    cands = {k: v for k, v in (("hbm-traffic", hbm), ("valu", valu)) if v}
+    limiting = max(cands, key=lambda k: cands[k]["frac"]) if cands else None
+    own_over, ref_over = own_bytes / sec_per_frame / 1e9 / HBM_PEAK_GBS, ref_bytes / sec_per_frame / 1e9 / HBM_PEAK_GBS
+    return {
+        # the contract's object: the HBM roof, which is what SURVEY 8d / BASELINE ask the fraction of
+        "bound": "hbm" if hbm else None,
+        "achieved": hbm["achieved"] if hbm else None, "peak": hbm["peak"] if hbm else None, "unit": hbm["unit"] if hbm else None,
+        "frac": hbm["frac"] if hbm else None,
+        "frac_is": "hbm_frac: counter HBM bytes / time / 8 TB/s -- the fraction SURVEY.md 8d asks for; valu_frac_of_spec is its peer, "
+                   "`limiting` the larger of the two",
+        "traffic": traffic,
+        "pmc_stale": not cands,
+        "hbm_frac": hbm["frac"] if hbm else None,
+        "hbm_frac_of_measured": hbm["frac_of_measured"] if hbm else None,
+        "valu_frac_of_spec": valu["frac"] if valu else None,
+        "valu_frac_of_measured_ceiling": valu["frac_of_measured_ceiling"] if valu else None,
+        "limiting": None if limiting is None else ("hbm" if limiting.startswith("hbm") else "valu"),
+        "valu_busy": valu_busy,
+        "valu_busy_is": "SQ_ACTIVE_INST_VALU x 4 cycles over the SIMD-cycles of the frame: every instruction is charged one quad-cycle, "
+                        "so this is the instruction count at 4 cycles each, not a measured utilisation",
+        "traffic_source": ({"profile": pmc.get("profile"), "kernel_source_sha": pmc.get("kernel_source_sha"),
+                            "frames_in_flight_while_counting": 1} if pmc else
+                           (dropped or "no PMC pass of this build and workload under profiles/ (scripts/profile.sh)")),
+        "candidates": cands,
+        "demand": {"own_bytes_per_frame": int(own_bytes), "own_demand_over_hbm_peak": round(own_over, 3),
+                   "reference_bytes_per_frame": int(ref_bytes), "reference_demand_over_hbm_peak": round(ref_over, 3),
+                   "note": "requests to the memory system over 8 TB/s x time, NOT roofline fractions: the lookup grid built at upload replaces "
+                           "the reference's descent and L1 / L2 serve most of the kernel's own loads (see roofline() in bench.py)"},
+        "measured_hbm_gbs": measured,
+    }
+
+
+def configs_summary(out, cfgs):
+    """<= 600 characters that carry every configuration's time, rays and fractions: the LAST key of the line, so that the last
+    2 000 characters of it (what the driver's record keeps) hold all of them.  ms per frame / Mray/s / hbm_frac (of 8 TB/s) /
+    hbm_frac_of_measured / valu_frac_of_spec; '-' where there is no PMC pass of this build."""
+    names = {"cfg3_4k": "cfg3", "cfg3_4k_compact": "cfg3c", "cfg5_4k_spp16": "cfg5", "cfg2_depth10": "d10", "cfg2_mesh_knot_d10": "mesh"}
+
+    def f(v, nd):
+        return "-" if v is None else f"{v:.{nd}f}"
+
+    def one(tag, e, r):
+        if "error" in e:
+            return f"{tag} ERR {str(e['error'])[:40]}"
+        return f"{tag} {f(e.get('ms_per_step'), 4)}/{f(e.get('value'), 0)}/{f(r.get('hbm_frac'), 2)}/{f(r.get('hbm_frac_of_measured'), 2)}/{f(r.get('valu_frac_of_spec'), 2)}"
+    parts = [one("cfg2", out, out.get("roofline") or {})]
+    if isinstance(cfgs, dict):
+        if "error" in cfgs and not any(k in cfgs for k in names):
+            parts.append("configs ERR " + str(cfgs["error"])[:60])
+        for k, e in cfgs.items():
+            if isinstance(e, dict) and k != "error":
+                parts.append(one(names.get(k, k[:10]), e, e))
+    return ("ms/Mray/hbm/hbm_meas/valu: " + "; ".join(parts))[:600]
+
+
+def measured_hbm_bandwidth(sb, device=0, nbytes=2 << 30, reps=10):
+    """SURVEY.md 8d's denominator: what this box's HBM delivers to a streaming kernel -- the library's own float4 copy, STREAM
+    triad and read-only sum over 2 GiB arrays (sdfhip_device_bandwidth, csrc/bandwidth.hip; the kernel shapes chosen by
+    scripts/micro/bw_variants.hip), bytes read + written per second in GB/s; `best_gbs` = the largest of the three, the roof no
+    kernel of this repository beats.  -> dict or None.  (Until round 5 this was a torch `copy_` of 1 GiB, which reaches
+    4.8-5.3 TB/s -- below what the frame's own kernels sustain on cfg-5, so fractions of it exceeded 1.)"""
+    try:
+        c, t, r = sb.device_bandwidth(device, nbytes, reps)
+    except Exception as e:                       # (out of memory beside a large scene: the line goes on without the figure)
+        print(f"[bench] measured_hbm_bandwidth: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
+    return {"copy_gbs": round(c, 1), "triad_gbs": round(t, 1), "read_gbs": round(r, 1), "best_gbs": round(max(c, t, r), 1), "array_bytes": nbytes,
+            "reps": reps,
+            "is": "sdfhip_device_bandwidth: float4 copy (2 x array bytes moved), triad a = b + s c (3 x) and a read-only sum (1 x) over arrays far "
+                  "larger than the 256 MiB Infinity Cache, HIP-event time; best_gbs = the largest of the three"}
+
+
+def cpu_limits():
+    """What this process may use of the host: the CPUs of its affinity mask and the cgroup's CPU quota (cpu.max of cgroup v2, or
+    cfs_quota_us / cfs_period_us of v1) in CPUs -- None when there is no quota."""
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    return affinity, quota
+
+
+def cpu_baseline(od, cam, W, H, target_seconds):
+    """The CPU oracle (the build's C restatement of Compute.hlsl: the reference has no CPU path) timed on this
+    host over bounded samples of the same frame (every `step`-th row), built here with -O3 -march=native -- same
+    source, same -ffp-contract=off, its rows compared bit for bit with the portable build the parity tests use.  Timed by
+    oracle_bench_rows: a pool of threads pinned to the CPUs of this process's affinity mask, dealt over the NUMA nodes, each
+    node reading its own copy of the scene, all waiting at a barrier before the clock (read inside the C function) starts;
+    pixels dealt in chunks of 64 from one counter.  The thread count is SWEPT (1, 16, 64, 128, 256, the affinity mask's size and
+    the cgroup quota, whichever the mask allows) and the best is the reported value; `limits` says what the host let this
+    process use -- a quota of 16 CPUs caps every thread count at 16 CPUs' worth of cycles."""
+    import oracle
+    oracle.build()
+    native = oracle.build_native()                     # None when the host has no compiler: then only the portable build is timed
+    affinity, quota = cpu_limits()
+    usable = min(affinity, int(quota + 0.999)) if quota else affinity
+    cands = sorted({n for n in (1, 16, 64, 128, 256, affinity, usable) if 1 <= n <= affinity})
+    # calibrate one thread on a sparse sample of the frame (rows spread top to bottom), on both builds: the faster one is swept
+    # (-O3 -march=native is not always it; the other's one-thread figure is printed beside it)
+    step0 = max(1, H // 8)
+    builds = {"gcc -O2 -march=x86-64-v2 (+ an fma clone) -ffp-contract=off": False}
+    if native is not None:
+        builds["gcc -O3 -march=native -ffp-contract=off, built on this host"] = True
+    calib = {}
+    for name, nat in builds.items():
+        _, _, sec0, _ = oracle.bench_rows(od.Structs, od.Values, cam.State, W, H, row_step=step0, nthreads=1, store=False, native=nat)
+        calib[name] = sec0 / ((H + step0 - 1) // step0)
+    build_used = min(calib, key=calib.get)
+    kw = {"native": builds[build_used]}
+    per_row1 = calib[build_used]
+    budget = target_seconds / len(cands)
+    sweep, best, best_img, best_step = [], None, None, 1
+    for nt in cands:
+        # rows for ~budget seconds if the threads scaled perfectly up to what the host lets this process use; when the whole frame
+        # is not enough (a cgroup grants CPU time in 100 ms periods: a quota shows in a timed region of seconds, not in a burst of
+        # 0.2 s) the frame is rendered several times over
+        want = budget * min(nt, usable) / max(per_row1, 1e-9)
+        rows = int(min(H, max(8, want)))
+        step = max(1, H // rows)
+        nrows = (H + step - 1) // step
+        repeat = max(1, int(round(want / nrows)))
+        img, _, sec, topo = oracle.bench_rows(od.Structs, od.Values, cam.State, W, H, row_step=step, nthreads=nt, repeat=repeat, **kw)
+        e = {"threads": topo["threads"], "value": round(repeat * nrows * W / sec / 1e6, 3), "numa_nodes": topo["numa_nodes"],
+             "scene_copies": topo["scene_copies"],
+             "sample": f"every {step}th row = {nrows * W} pixels" + (f", {repeat} times over," if repeat > 1 else "") + f" in {sec:.2f} s"}
+        sweep.append(e)
+        if best is None or e["value"] > best["value"]:
+            best, best_img, best_step = e, img, step
+    other = {name: {"one_thread_ms_per_row": round(v * 1e3, 3)} for name, v in calib.items()}
+    same = None
+    if kw["native"]:                                   # a few of the best run's rows through the portable build: identical bits
+        nrows = best_img.shape[0]
+        k = max(1, nrows // 8)
+        ref, _ = oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=(nrows + k - 1) // k, row_step=best_step * k,
+                               nthreads=min(usable, 32))
+        a, b = best_img[::k].view(np.uint32), ref.view(np.uint32)
+        same = bool(((a == b) | (np.isnan(best_img[::k]) & np.isnan(ref))).all())
+    one = next(e for e in sweep if e["threads"] == 1)
+    model, physical = host_cpu()
+    ratio = best["value"] / one["value"] if one["value"] else None
+    return {
+        "value": best["value"],
+        "unit": "Mray/s",
+        "cores": best["threads"],
+        "kind": "port",
+        "cpu_model": model,
+        "physical_cores": physical,
+        "limits": {"affinity_cpus": affinity, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count(),
+                   "note": ("the cgroup lets this process use %.1f CPUs' worth of cycles: more threads than that share them" % quota)
+                           if quota and quota < affinity else None},
+        "build": build_used,
+        "builds_tried_one_thread": other,
+        "native_build_equals_portable_build": same,
+        "sample": best["sample"] + f" of the same {W}x{H} frame; oracle/sdf_oracle.c::oracle_bench_rows, {best['threads']} pinned pthreads over "
+                  f"{best['numa_nodes']} NUMA node(s) ({best['scene_copies']} node-local scene copies), started before the clock, 64-pixel chunks from one counter",
+        "sweep": sweep,
+        "speedup_over_one_thread": round(ratio, 1) if ratio else None,
+        "one_thread": {"value": one["value"], "unit": "Mray/s", "sample": one["sample"]},
+    }
+
+
+def host_cpu():
+    """(model name, physical cores) from /proc/cpuinfo; (None, None) when it cannot be read."""
+    try:
+        model, cores = None, set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model is None:
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None and core is not None:
+                    cores.add((phys, core)); phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        return model, (len(cores) or None)
+    except OSError:
+        return None, None

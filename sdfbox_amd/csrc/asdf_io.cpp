@@ -3,7 +3,7 @@
 // File format (SdfGen/dllmain.cpp:250-292): 'a','s','d','f', uint32 N
 // (little-endian), N x {int32 Parent, int32 Children}, N x uint8[8]; no
 // version field (dllmain.cpp:285-286 is commented out).  8 + 16*N bytes.
-#include "sdfhip_internal.h"
+#include "abi_guard.h"
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -12,7 +12,7 @@
 using namespace sdfhip;
 
 extern "C" int sdfhip_asdf_load(const char *path, sdfhip_octdata *out)
-{
+try {
     if (!path || !out) return fail(SDFHIP_ERR_ARG, "asdf_load: null argument");
     out->length = 0; out->structs = nullptr; out->values = nullptr;
     FILE *f = fopen(path, "rb");
@@ -34,9 +34,10 @@ extern "C" int sdfhip_asdf_load(const char *path, sdfhip_octdata *out)
     out->length = n; out->structs = s; out->values = v;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_asdf_load)
 
 extern "C" int sdfhip_asdf_save(const sdfhip_octdata *d, const char *path)
-{
+try {
     if (!d || !path || !d->structs || !d->values || d->length == 0)
         return fail(SDFHIP_ERR_ARG, "asdf_save: null or empty octdata");
     FILE *f = fopen(path, "wb");
@@ -51,20 +52,22 @@ extern "C" int sdfhip_asdf_save(const sdfhip_octdata *d, const char *path)
     if (!ok) return fail(SDFHIP_ERR_IO, "asdf_save: short write to %s", path);
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_asdf_save)
 
 extern "C" void sdfhip_octdata_free(sdfhip_octdata *d)
-{
+try {
     if (!d) return;
     free(d->structs); free(d->values);
     d->structs = nullptr; d->values = nullptr; d->length = 0;
 }
+SDFHIP_ABI_CATCH_VOID(sdfhip_octdata_free)
 
 // Bounds check (mandatory for any kernel: no out-of-range node index is ever
 // dereferenced on the GPU) + depth + parent/child consistency (gates the
 // cursor-stack kernel, which derives parents from its own descent path).
 extern "C" int sdfhip_octdata_validate(const int32_t *structs, uint32_t n, uint32_t *depth_out,
                                        int *consistent_out)
-{
+try {
     if (!structs || n == 0) return fail(SDFHIP_ERR_ARG, "validate: null or empty structs");
     bool consistent = structs[0] < 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -148,3 +151,4 @@ extern "C" int sdfhip_octdata_validate(const int32_t *structs, uint32_t n, uint3
     if (consistent_out) *consistent_out = consistent ? 1 : 0;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_octdata_validate)

@@ -11,6 +11,7 @@
 // one float4 per thread and no loop reaches 6.25 (the guide's 6.29), the read-only stream 6.3.  The rate is the bytes the
 // kernel moves / its HIP-event time.
 #include "scene.h"
+#include "abi_guard.h"
 
 using namespace sdfhip;
 
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(BW_THREADS) void k_bw_fill(f4 *p, size_t n, float v
 }  // namespace
 
 extern "C" int sdfhip_device_bandwidth(int device, uint64_t bytes, uint32_t reps, double *copy_gbs, double *triad_gbs, double *read_gbs)
-{
+try {
     clear_error();
     if (!copy_gbs && !triad_gbs && !read_gbs) return fail(SDFHIP_ERR_ARG, "device_bandwidth: nothing asked for");
     if (bytes < (1ull << 20) || bytes > (64ull << 30) || reps == 0 || reps > 1000)
@@ -125,3 +126,4 @@ extern "C" int sdfhip_device_bandwidth(int device, uint64_t bytes, uint32_t reps
     cleanup();
     return rc;
 }
+SDFHIP_ABI_CATCH(sdfhip_device_bandwidth)

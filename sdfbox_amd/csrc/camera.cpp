@@ -17,7 +17,7 @@
 // (Quaternion.CreateFromYawPitchRoll followed by Matrix4x4.CreateFromQuaternion).
 // No reference test pins it; tests/test_camera.py pins the
 // identity and quarter-turn cases by hand.
-#include "sdfhip_internal.h"
+#include "abi_guard.h"
 #include <cmath>
 #include <cstring>
 
@@ -38,7 +38,7 @@ static void yaw_pitch_roll(float yaw, float pitch, float roll, float M[3][3])
 }
 
 extern "C" void sdfhip_info_set_heading(sdfhip_info *info, float heading_x, float heading_y)
-{
+try {
     if (!info) return;
     float M[3][3];
     // CreateFromYawPitchRoll(heading.Y, heading.X, 0), Logic.cs:53
@@ -51,9 +51,10 @@ extern "C" void sdfhip_info_set_heading(sdfhip_info *info, float heading_x, floa
         info->heading[r][3] = 0.0f;
     }
 }
+SDFHIP_ABI_CATCH_VOID(sdfhip_info_set_heading)
 
 extern "C" void sdfhip_info_set_position(sdfhip_info *info, float x, float y, float z)
-{
+try {
     if (!info) return;
     info->position[0] = x; info->position[1] = y; info->position[2] = z;
     float furthest = 0.0f;
@@ -64,9 +65,10 @@ extern "C" void sdfhip_info_set_position(sdfhip_info *info, float x, float y, fl
     }
     info->limit = furthest;
 }
+SDFHIP_ABI_CATCH_VOID(sdfhip_info_set_position)
 
 extern "C" void sdfhip_info_default(sdfhip_info *info, float width, float height)
-{
+try {
     if (!info) return;
     memset(info, 0, sizeof *info);
     info->light[0] = info->light[1] = info->light[2] = 0.0f;
@@ -79,9 +81,10 @@ extern "C" void sdfhip_info_default(sdfhip_info *info, float width, float height
     sdfhip_info_set_heading(info, 0.0f, 0.0f);
     sdfhip_info_set_position(info, 0.5f, 0.5f, 0.1f);
 }
+SDFHIP_ABI_CATCH_VOID(sdfhip_info_default)
 
 extern "C" void sdfhip_camera_update(sdfhip_info *info, float *heading_xy, float m_speed, uint32_t keys, float seconds)
-{
+try {
     if (!info || !heading_xy) return;
     const float t_speed = 0.1f;                      // tSpeed, Logic.cs:29
     const float transform = m_speed * m_speed * seconds;
@@ -111,18 +114,21 @@ extern "C" void sdfhip_camera_update(sdfhip_info *info, float *heading_xy, float
     if (keys & SDFHIP_KEY_CONTROL) p[1] = p[1] + 1.0f * transform;
     sdfhip_info_set_position(info, p[0], p[1], p[2]);
 }
+SDFHIP_ABI_CATCH_VOID(sdfhip_camera_update)
 
 extern "C" void sdfhip_camera_mouse_move(sdfhip_info *info, float *heading_xy, float dx, float dy)
-{
+try {
     if (!info || !heading_xy) return;
     heading_xy[0] += -dy / 512.0f * 4.0f;             // Heading += new Vector2(-diff.Y, diff.X) / 512 * 4
     heading_xy[1] += dx / 512.0f * 4.0f;
     sdfhip_info_set_heading(info, heading_xy[0], heading_xy[1]);
 }
+SDFHIP_ABI_CATCH_VOID(sdfhip_camera_mouse_move)
 
 extern "C" float sdfhip_camera_mouse_wheel(float m_speed, float wheel_delta)
-{
+try {
     if ((wheel_delta > 0 && m_speed < 1) || (wheel_delta < 0 && m_speed > 0.05))
         m_speed += wheel_delta * 0.05f;
     return m_speed;
 }
+SDFHIP_ABI_CATCH_AS(sdfhip_camera_mouse_wheel, 0.0f)

@@ -2,6 +2,7 @@
 // order, and the expansion of the sparse shares the ranks' march kernels write (sdfhip_render_sparse_device, render.hip).
 #include "gather_kernels.h"
 #include "scene.h"
+#include "abi_guard.h"
 
 #include <cmath>
 #include <cstring>
@@ -88,37 +89,41 @@ extern "C" int sdfhip_deinterleave_device(int device, const void *d_gathered, vo
                                           uint32_t width, uint32_t height, uint32_t band_rows,
                                           uint32_t world, uint32_t rows_per_rank, uint32_t pixel_bytes,
                                           uint32_t frames, void *stream)
-{
+try {
     return deinterleave_impl(device, d_gathered, d_frame, width, height, band_rows, world, rows_per_rank, nullptr,
                              pixel_bytes, frames, stream);
 }
+SDFHIP_ABI_CATCH(sdfhip_deinterleave_device)
 
 extern "C" int sdfhip_deinterleave_bands_device(int device, const void *d_gathered, void *d_frame,
                                                 uint32_t width, uint32_t height, uint32_t band_rows,
                                                 uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
                                                 uint32_t pixel_bytes, uint32_t frames, void *stream)
-{
+try {
     if (!owner) return fail(SDFHIP_ERR_ARG, "deinterleave_bands: null owner table");
     return deinterleave_impl(device, d_gathered, d_frame, width, height, band_rows, world, rows_per_rank, owner,
                              pixel_bytes, frames, stream);
 }
+SDFHIP_ABI_CATCH(sdfhip_deinterleave_bands_device)
 
 // ---- sparse shares written by the march kernel itself (OUT_SPARSE) ---------------------------------------------
 extern "C" uint64_t sdfhip_sparse2_bytes(uint32_t width, uint32_t rows, uint32_t frames, uint32_t capacity)
-{
+try {
     return (uint64_t)sparse2_layout(width, rows, frames, capacity).bytes;
 }
+SDFHIP_ABI_CATCH_AS(sdfhip_sparse2_bytes, 0)
 
 extern "C" uint64_t sdfhip_sparse2_floats_offset(uint32_t width, uint32_t rows, uint32_t frames)
-{
+try {
     return (uint64_t)sparse2_layout(width, rows, frames, 0).off_floats;
 }
+SDFHIP_ABI_CATCH_AS(sdfhip_sparse2_floats_offset, 0)
 
 extern "C" int sdfhip_deinterleave_sparse2_device(int device, const void *const *d_shares, void *d_frame, uint32_t width,
                                                   uint32_t height, uint32_t band_rows, uint32_t world, uint32_t rows_per_rank,
                                                   const uint8_t *owner, uint32_t capacity, uint32_t frames, uint32_t flags,
                                                   int only_rank, uint32_t *counts_out, void *stream)
-{
+try {
     if (frames == 0 || frames > (uint32_t)MAX_BATCH || !d_shares || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
         return fail(SDFHIP_ERR_ARG, "deinterleave_sparse2: null or zero argument");
     if (world > MULTI_MAX_RANKS) return fail(SDFHIP_ERR_ARG, "deinterleave_sparse2: %u ranks (at most %u)", world, MULTI_MAX_RANKS);
@@ -182,3 +187,4 @@ extern "C" int sdfhip_deinterleave_sparse2_device(int device, const void *const 
     HIP_TRY(hipGetLastError());
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_deinterleave_sparse2_device)

@@ -7,6 +7,7 @@
 #endif
 #include "lab_kernels.h"
 #include "scene.h"
+#include "abi_guard.h"
 #include "../../include/sdfhip_experimental.h"
 
 #include <cstdlib>
@@ -187,24 +188,27 @@ extern "C" int sdfhip_deinterleave_share_device(int device, const void *d_share,
                                                 uint32_t width, uint32_t height, uint32_t band_rows,
                                                 uint32_t world, uint32_t rows_per_rank, const uint8_t *owner,
                                                 uint32_t rank, uint32_t pixel_bytes, uint32_t frames, void *stream)
-{
+try {
     return sdfhip::deinterleave_impl(device, d_share, d_frame, width, height, band_rows, world, rows_per_rank, owner,
                              pixel_bytes, frames, stream, rank);
 }
+SDFHIP_ABI_CATCH(sdfhip_deinterleave_share_device)
 
 extern "C" uint64_t sdfhip_wire_sparse_bytes(uint32_t width, uint32_t rows, uint32_t capacity)
-{
+try {
     return (uint64_t)sparse_layout(width, rows, capacity).bytes;
 }
+SDFHIP_ABI_CATCH_AS(sdfhip_wire_sparse_bytes, 0)
 
 extern "C" uint64_t sdfhip_wire_sparse_head_offset(uint32_t width, uint32_t rows, uint32_t capacity)
-{
+try {
     return (uint64_t)sparse_layout(width, rows, capacity).off_head;
 }
+SDFHIP_ABI_CATCH_AS(sdfhip_wire_sparse_head_offset, 0)
 
 extern "C" int sdfhip_wire_compact_device(int device, const void *d_wire, void *d_sparse, uint32_t width, uint32_t rows,
                                           uint32_t frames, uint32_t capacity, void *stream)
-{
+try {
     if (!d_wire || !d_sparse || width == 0 || rows == 0 || frames == 0)
         return fail(SDFHIP_ERR_ARG, "wire_compact: null or zero argument");
     if (((size_t)rows * width) % 4 != 0) return fail(SDFHIP_ERR_ARG, "wire_compact: rows * width must be a multiple of 4");
@@ -218,12 +222,13 @@ extern "C" int sdfhip_wire_compact_device(int device, const void *d_wire, void *
     HIP_TRY(hipGetLastError());
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_wire_compact_device)
 
 extern "C" int sdfhip_deinterleave_sparse_device(int device, const void *d_gathered, void *d_frame, uint32_t width,
                                                  uint32_t height, uint32_t band_rows, uint32_t world,
                                                  uint32_t rows_per_rank, const uint8_t *owner, uint32_t capacity,
                                                  uint32_t frames, uint32_t *d_overflow, void *stream)
-{
+try {
     if (frames == 0 || !d_gathered || !d_frame || width == 0 || height == 0 || band_rows == 0 || world == 0)
         return fail(SDFHIP_ERR_ARG, "deinterleave_sparse: null or zero argument");
     if (band_rows % 8 != 0 || rows_per_rank % 8 != 0)
@@ -257,17 +262,19 @@ extern "C" int sdfhip_deinterleave_sparse_device(int device, const void *d_gathe
     HIP_TRY(hipGetLastError());
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_deinterleave_sparse_device)
 
 extern "C" int sdfhip_debug_tile_order(sdfhip_scene *s, const uint32_t *d_perm, uint16_t *d_cost)
-{
+try {
     if (!s) return fail(SDFHIP_ERR_ARG, "debug_tile_order: null scene");
     std::lock_guard<std::mutex> lk(s->lock);
     s->dbg_tile_perm = d_perm; s->dbg_tile_cost = d_cost;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_debug_tile_order)
 
 extern "C" int sdfhip_debug_step_classes(sdfhip_scene *s, void *stream, uint64_t *out6)
-{
+try {
     if (!s || !out6) return fail(SDFHIP_ERR_ARG, "debug_step_classes: null argument");
     std::lock_guard<std::mutex> lk(s->lock);
     DeviceGuard g(s->device);
@@ -281,9 +288,10 @@ extern "C" int sdfhip_debug_step_classes(sdfhip_scene *s, void *stream, uint64_t
         }
     return fail(SDFHIP_ERR_ARG, "debug_step_classes: no counting render has run on that stream of this scene");
 }
+SDFHIP_ABI_CATCH(sdfhip_debug_step_classes)
 
 extern "C" int sdfhip_debug_unorm_table(int device, float *out256)
-{
+try {
     if (!out256) return fail(SDFHIP_ERR_ARG, "debug_unorm_table: null argument");
     DeviceGuard g(device);
     if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "debug_unorm_table: hipSetDevice(%d) failed", device);
@@ -295,3 +303,4 @@ extern "C" int sdfhip_debug_unorm_table(int device, float *out256)
     if (e != hipSuccess) return fail(SDFHIP_ERR_DEVICE, "debug_unorm_table: %s", hipGetErrorString(e));
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_debug_unorm_table)

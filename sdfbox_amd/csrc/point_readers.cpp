@@ -9,7 +9,7 @@
 //                     vertices no face mentions keep the normal (0,0,0)); `#`, `o`, `s`,
 //                     `vt` lines are skipped; anything else is an error.
 // Out-of-range face indices are errors here (the reference indexes without a check).
-#include "sdfhip_internal.h"
+#include "abi_guard.h"
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
@@ -25,23 +25,25 @@ static int hand_over(const std::vector<float> &v, sdfhip_points *out)
     out->count = (uint32_t)(v.size() / 6);
     out->data = (float *)malloc(v.empty() ? 4 : v.size() * sizeof(float));
     if (!out->data) return fail(SDFHIP_ERR_NOMEM, "point reader: out of memory");
-    memcpy(out->data, v.data(), v.size() * sizeof(float));
+    if (!v.empty()) memcpy(out->data, v.data(), v.size() * sizeof(float));
     return SDFHIP_OK;
 }
 
 extern "C" void sdfhip_points_free(sdfhip_points *p)
-{
+try {
     if (!p) return;
     free(p->data);
     p->data = nullptr; p->count = 0;
 }
+SDFHIP_ABI_CATCH_VOID(sdfhip_points_free)
 
 extern "C" int sdfhip_load_ply(const char *path, sdfhip_points *out)
-{
+try {
     if (!path || !out) return fail(SDFHIP_ERR_ARG, "load_ply: null argument");
     out->count = 0; out->data = nullptr;
     std::ifstream file(path, std::ios::binary);
     if (!file.is_open()) return fail(SDFHIP_ERR_IO, "load_ply: could not open %s", path);
+    file.exceptions(std::ios::badbit);            // (an extraction that runs out of memory must not read as "end of file": see load_obj)
     std::string word;
     auto bad = [&]() { return fail(SDFHIP_ERR_IO, "load_ply: %s: file format is unsupported or invalid", path); };
     if (!(file >> word) || word != "ply") return bad();
@@ -66,13 +68,18 @@ extern "C" int sdfhip_load_ply(const char *path, sdfhip_points *out)
         return fail(SDFHIP_ERR_NOMEM, "load_ply: out of memory for %lld vertices", count);
     }
 }
+SDFHIP_ABI_CATCH(sdfhip_load_ply)
 
 extern "C" int sdfhip_load_obj(const char *path, sdfhip_points *out)
-{
+try {
     if (!path || !out) return fail(SDFHIP_ERR_ARG, "load_obj: null argument");
     out->count = 0; out->data = nullptr;
     std::ifstream file(path);
     if (!file.is_open()) return fail(SDFHIP_ERR_IO, "load_obj: could not open %s", path);
+    // iostreams swallow an exception inside an extraction and set badbit: a std::getline that cannot grow its string would end the
+    // loop below like the end of the file, and a truncated cloud would be handed over as a success (found by
+    // tests/host_fault_injection.cpp).  With badbit in the mask the stream throws the original exception again.
+    file.exceptions(std::ios::badbit);
     try {
         std::vector<float> verts;      // 6 per vertex
         std::vector<float> normals;    // 3 per normal
@@ -122,5 +129,8 @@ extern "C" int sdfhip_load_obj(const char *path, sdfhip_points *out)
         return hand_over(verts, out);
     } catch (const std::bad_alloc &) {
         return fail(SDFHIP_ERR_NOMEM, "load_obj: out of memory");
+    } catch (const std::ios_base::failure &) {
+        return fail(SDFHIP_ERR_IO, "load_obj: %s: read error", path);
     }
 }
+SDFHIP_ABI_CATCH(sdfhip_load_obj)

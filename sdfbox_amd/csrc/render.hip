@@ -15,6 +15,7 @@
 #include "raymarch_kernels.h"
 #include "tile_order_kernels.h"
 #include "scene.h"
+#include "abi_guard.h"
 #ifdef SDFHIP_EXPERIMENTS
 #include "../../include/sdfhip_experimental.h"
 #endif
@@ -511,7 +512,7 @@ extern "C" int sdfhip_render_device(sdfhip_scene *s, const sdfhip_info *info, ui
                                     uint32_t height, uint32_t band_rows, uint32_t band_first,
                                     uint32_t band_stride, uint32_t nrows_out, uint32_t flags,
                                     float *d_rgba_out, void *stream, sdfhip_stats *stats)
-{
+try {
     if (!s || !info || !d_rgba_out) return fail(SDFHIP_ERR_ARG, "render_device: null argument");
     RenderCall c;
     c.info = info; c.width = width; c.height = height; c.band_rows = band_rows; c.band_first = band_first; c.band_stride = band_stride;
@@ -519,37 +520,40 @@ extern "C" int sdfhip_render_device(sdfhip_scene *s, const sdfhip_info *info, ui
     c.st = (hipStream_t)stream;             // NULL = the HIP default stream, as everywhere in HIP
     return render_resident(s, c, stats, "render_device");
 }
+SDFHIP_ABI_CATCH(sdfhip_render_device)
 
 extern "C" int sdfhip_render_batch_device(sdfhip_scene *s, const sdfhip_info *infos, uint32_t n_frames,
                                           uint32_t width, uint32_t height, uint32_t band_rows,
                                           uint32_t band_first, uint32_t band_stride, uint32_t nrows_out,
                                           uint32_t flags, float *d_rgba_out, void *stream, sdfhip_stats *stats)
-{
+try {
     if (!s || !infos || !d_rgba_out) return fail(SDFHIP_ERR_ARG, "render_batch_device: null argument");
     RenderCall c;
     c.info = infos; c.n_frames = n_frames; c.width = width; c.height = height; c.band_rows = band_rows; c.band_first = band_first;
     c.band_stride = band_stride; c.nrows_out = nrows_out; c.flags = flags; c.d_out = d_rgba_out; c.st = (hipStream_t)stream;
     return render_resident(s, c, stats, "render_batch_device");
 }
+SDFHIP_ABI_CATCH(sdfhip_render_batch_device)
 
 extern "C" int sdfhip_render_path_device(sdfhip_scene *s, const sdfhip_info *info, const sdfhip_pathtrace *pt,
                                          uint32_t width, uint32_t height, uint32_t band_rows,
                                          uint32_t band_first, uint32_t band_stride, uint32_t nrows_out,
                                          uint32_t flags, float *d_rgba_out, void *stream, sdfhip_stats *stats)
-{
+try {
     if (!s || !info || !pt || !d_rgba_out) return fail(SDFHIP_ERR_ARG, "render_path_device: null argument");
     RenderCall c;
     c.info = info; c.pt = pt; c.width = width; c.height = height; c.band_rows = band_rows; c.band_first = band_first;
     c.band_stride = band_stride; c.nrows_out = nrows_out; c.flags = flags; c.d_out = d_rgba_out; c.st = (hipStream_t)stream;
     return render_resident(s, c, stats, "render_path_device");
 }
+SDFHIP_ABI_CATCH(sdfhip_render_path_device)
 
 extern "C" int sdfhip_render_bands_device(sdfhip_scene *s, const sdfhip_info *infos, uint32_t n_frames,
                                           const sdfhip_pathtrace *pt, uint32_t width, uint32_t height,
                                           uint32_t band_rows, const uint16_t *bands, uint32_t n_bands,
                                           uint32_t nrows_out, uint32_t flags, float *d_rgba_out, void *stream,
                                           sdfhip_stats *stats)
-{
+try {
     if (!s || !infos || !bands || !d_rgba_out) return fail(SDFHIP_ERR_ARG, "render_bands_device: null argument");
     if (pt && n_frames != 1) return fail(SDFHIP_ERR_ARG, "render_bands_device: the path-traced mode renders one frame per launch");
     RenderCall c;
@@ -557,11 +561,12 @@ extern "C" int sdfhip_render_bands_device(sdfhip_scene *s, const sdfhip_info *in
     c.bands = bands; c.n_bands = n_bands; c.nrows_out = nrows_out; c.flags = flags; c.d_out = d_rgba_out; c.st = (hipStream_t)stream;
     return render_resident(s, c, stats, "render_bands_device");
 }
+SDFHIP_ABI_CATCH(sdfhip_render_bands_device)
 
 extern "C" int sdfhip_render_sparse_device(sdfhip_scene *s, const sdfhip_info *infos, uint32_t n_frames, uint32_t width,
                                            uint32_t height, uint32_t band_rows, const uint16_t *bands, uint32_t n_bands,
                                            uint32_t nrows_out, uint32_t capacity, uint32_t count_base, uint32_t flags, void *d_share, void *stream)
-{
+try {
     if (!s || !infos || !bands || !d_share) return fail(SDFHIP_ERR_ARG, "render_sparse_device: null argument");
     if (capacity == 0) return fail(SDFHIP_ERR_ARG, "render_sparse_device: capacity 0");
     RenderCall c;
@@ -570,6 +575,7 @@ extern "C" int sdfhip_render_sparse_device(sdfhip_scene *s, const sdfhip_info *i
     c.sparse = true; c.sparse_cap = capacity; c.sparse_base = count_base;
     return render_resident(s, c, nullptr, "render_sparse_device");
 }
+SDFHIP_ABI_CATCH(sdfhip_render_sparse_device)
 
 // ---- host frames the copy engine can write by itself ---------------------------------------------------------------------
 // A copy into pageable memory is staged by the runtime inside the copy call: the host sits in it, and the copies of a frame's
@@ -606,7 +612,7 @@ int host_range_add(void *p, size_t bytes, bool ours, const char *what)
 }
 }
 extern "C" int sdfhip_host_alloc(uint64_t bytes, void **out)
-{
+try {
     if (!out || bytes == 0) return fail(SDFHIP_ERR_ARG, "host_alloc: null or zero argument");
     void *p = nullptr;
     hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped);
@@ -616,15 +622,17 @@ extern "C" int sdfhip_host_alloc(uint64_t bytes, void **out)
     *out = p;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_host_alloc)
 extern "C" int sdfhip_host_register(void *p, uint64_t bytes)
-{
+try {
     if (!p || bytes == 0) return fail(SDFHIP_ERR_ARG, "host_register: null or zero argument");
     hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(SDFHIP_ERR_DEVICE, "host_register: hipHostRegister(%llu bytes) failed: %s", (unsigned long long)bytes, hipGetErrorString(e)); }
     return host_range_add(p, (size_t)bytes, false, "host_register");
 }
+SDFHIP_ABI_CATCH(sdfhip_host_register)
 extern "C" int sdfhip_host_release(void *p)
-{
+try {
     if (!p) return SDFHIP_OK;
     HostRange r{0, 0, 0, false};
     {
@@ -637,10 +645,11 @@ extern "C" int sdfhip_host_release(void *p)
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(SDFHIP_ERR_DEVICE, "host_release: %s", hipGetErrorString(e)); }
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_host_release)
 
 extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t width,
                              uint32_t height, uint32_t flags, float *rgba_out, sdfhip_stats *stats)
-{
+try {
     if (!s || !info || !rgba_out) return fail(SDFHIP_ERR_ARG, "render: null argument");
     if (width == 0 || height == 0) return fail(SDFHIP_ERR_ARG, "render: zero-sized frame");
 #ifdef SDFHIP_EXPERIMENTS
@@ -743,11 +752,12 @@ extern "C" int sdfhip_render(sdfhip_scene *s, const sdfhip_info *info, uint32_t 
     for (uint32_t b = 0; b < nb && b * rows < height; b++) HIP_TRY(hipStreamSynchronize(s->band_stream[b]));
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_render)
 
 extern "C" int sdfhip_render_path(sdfhip_scene *s, const sdfhip_info *info, const sdfhip_pathtrace *pt,
                                   uint32_t width, uint32_t height, uint32_t flags, float *rgba_out,
                                   sdfhip_stats *stats)
-{
+try {
     if (!s || !info || !pt || !rgba_out) return fail(SDFHIP_ERR_ARG, "render_path: null argument");
     if (width == 0 || height == 0) return fail(SDFHIP_ERR_ARG, "render_path: zero-sized frame");
     std::lock_guard<std::mutex> lk(s->lock);
@@ -783,12 +793,14 @@ extern "C" int sdfhip_render_path(sdfhip_scene *s, const sdfhip_info *info, cons
     if (overflow) return fail(SDFHIP_ERR_NOMEM, "render_path: a hit queue of the path-traced pipeline overflowed; the frame is incomplete");
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_render_path)
 
 extern "C" int sdfhip_render_display(sdfhip_scene *s, const sdfhip_info *info, uint32_t width,
                                      uint32_t height, uint32_t flags, int debug, uint8_t *rgba8_out,
                                      sdfhip_stats *stats)
-{
+try {
     flags = (flags & ~(uint32_t)(SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG)) |
             (debug ? SDFHIP_FLAG_DISPLAY_DEBUG : SDFHIP_FLAG_DISPLAY);
     return sdfhip_render(s, info, width, height, flags, reinterpret_cast<float *>(rgba8_out), stats);
 }
+SDFHIP_ABI_CATCH(sdfhip_render_display)

@@ -5,6 +5,7 @@
 //   SdfBox/Program.cs:543-572,147-152     StructBuffer/ValueTexture + binding -> sdfhip_scene_upload
 #include "upload_kernels.h"
 #include "scene.h"
+#include "abi_guard.h"
 
 #include <cstddef>
 #include <cstdlib>
@@ -22,23 +23,25 @@ using namespace sdfhip;
 #endif
 
 extern "C" int sdfhip_device_count(int *count)
-{
+try {
     if (!count) return fail(SDFHIP_ERR_ARG, "device_count: null argument");
     *count = 0;
     HIP_TRY(hipGetDeviceCount(count));
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_device_count)
 
 extern "C" int sdfhip_device_pci_bus_id(int device, char *out, uint32_t len)
-{
+try {
     if (!out || len < 16) return fail(SDFHIP_ERR_ARG, "device_pci_bus_id: the buffer must hold 16 bytes");
     out[0] = 0;
     HIP_TRY(hipDeviceGetPCIBusId(out, (int)len, device));
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_device_pci_bus_id)
 
 extern "C" int sdfhip_scene_free(sdfhip_scene *s)
-{
+try {
     if (!s) return SDFHIP_OK;
     {
         DeviceGuard g(s->device);
@@ -78,6 +81,7 @@ extern "C" int sdfhip_scene_free(sdfhip_scene *s)
     delete s;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_scene_free)
 
 // (see scene.h)
 bool sdfhip::build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_t max_fine_bytes, TopCell **coarse_out, TopCell **fine_out,
@@ -128,20 +132,22 @@ bool sdfhip::build_split_grid(sdfhip_scene *s, int C, int FB, int order, uint64_
 
 extern "C" int sdfhip_scene_upload(int device, const int32_t *structs, const uint8_t *values,
                                    uint32_t n, sdfhip_scene **out)
-{
+try {
     return sdfhip::scene_from_arrays(device, structs, values, n, false, nullptr, out);
 }
+SDFHIP_ABI_CATCH(sdfhip_scene_upload)
 
 extern "C" void sdfhip_upload_options_default(sdfhip_upload_options *opt)
-{
+try {
     if (!opt) return;
     opt->size = (uint32_t)sizeof *opt;
     opt->top_grid_level = opt->top_grid_split = opt->scatter_grid = opt->scatter_order = -1;
 }
+SDFHIP_ABI_CATCH_VOID(sdfhip_upload_options_default)
 
 extern "C" int sdfhip_scene_upload_ex(int device, const int32_t *structs, const uint8_t *values, uint32_t n,
                                       const sdfhip_upload_options *opt, sdfhip_scene **out)
-{
+try {
     // `size` is what lets the struct grow: a caller built against an OLDER header passes a smaller struct -- its fields are
     // taken and the ones it does not know stay at -1 ("choose"); a caller built against a NEWER header passes a larger one -- accepted
     // when the part this library does not know is all -1, i.e. asks for nothing it cannot give.  Version 1 ends behind scatter_order.
@@ -166,6 +172,7 @@ extern "C" int sdfhip_scene_upload_ex(int device, const int32_t *structs, const 
         return fail(SDFHIP_ERR_ARG, "scene_upload_ex: an option out of range (top_grid_level -1..10, top_grid_split -1..8, scatter_grid -1..4, scatter_order -1..1)");
     return sdfhip::scene_from_arrays(device, structs, values, n, false, opt, out);
 }
+SDFHIP_ABI_CATCH(sdfhip_scene_upload_ex)
 
 // structs / values on the host (sdfhip_scene_upload), or already in `device`'s memory (sdfhip_sdfgen_scene: the tree the GPU
 // builder has just made never leaves HBM)
@@ -347,7 +354,7 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
 }
 
 extern "C" int sdfhip_scene_top_grid(const sdfhip_scene *s, int32_t *level, uint64_t *bytes)
-{
+try {
     if (!s) return fail(SDFHIP_ERR_ARG, "scene_top_grid: null scene");
     if (level) *level = s->d_top ? s->top_level : 0;
     uint64_t extra = s->top2_bytes;
@@ -357,6 +364,7 @@ extern "C" int sdfhip_scene_top_grid(const sdfhip_scene *s, int32_t *level, uint
     if (bytes) *bytes = s->d_top ? ((uint64_t)sizeof(TopCell) << (3 * s->top_level)) + s->fine_bytes + extra : 0;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_scene_top_grid)
 
 bool sdfhip::scene_has_full_depth_grid(const sdfhip_scene *s)
 {
@@ -365,7 +373,7 @@ bool sdfhip::scene_has_full_depth_grid(const sdfhip_scene *s)
 
 extern "C" int sdfhip_scene_info(const sdfhip_scene *s, uint32_t *n, uint32_t *depth,
                                  int *stack_kernel_ok, int *device)
-{
+try {
     if (!s) return fail(SDFHIP_ERR_ARG, "scene_info: null scene");
     if (n) *n = s->n;
     if (depth) *depth = s->depth;
@@ -373,6 +381,7 @@ extern "C" int sdfhip_scene_info(const sdfhip_scene *s, uint32_t *n, uint32_t *d
     if (device) *device = s->device;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_scene_info)
 
 // Beside the scene's own grid, the bounce levels of the path-traced pipeline read a split grid of the same cells with larger,
 // sub-cube-ordered blocks -- unless the scene's grid already has that coarse level.  Built once: by
@@ -405,7 +414,7 @@ void sdfhip::ensure_scatter_grid(sdfhip_scene *s)
 }
 
 extern "C" int sdfhip_scene_prepare_path(sdfhip_scene *s)
-{
+try {
     if (!s) return fail(SDFHIP_ERR_ARG, "scene_prepare_path: null scene");
     std::lock_guard<std::mutex> lk(s->lock);
     DeviceGuard g(s->device);
@@ -413,6 +422,7 @@ extern "C" int sdfhip_scene_prepare_path(sdfhip_scene *s)
     ensure_scatter_grid(s);
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_scene_prepare_path)
 
 // The scratch of stream `st` on this scene, with room for `records` hit records (0: control words only).
 // Created on a stream's first render; grown (after the stream has drained) when a larger frame comes.

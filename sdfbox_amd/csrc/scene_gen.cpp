@@ -15,7 +15,8 @@
 // subtrees are built by several threads and spliced in the same order the
 // serial recursion would have produced (the output bytes do not depend on the
 // thread count).
-#include "sdfhip_internal.h"
+#include "abi_guard.h"
+#include <memory>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -185,7 +186,7 @@ using namespace sdfhip;
 
 extern "C" int sdfhip_generate(int shape, const float *params, int nparams, int max_depth,
                                int nthreads, sdfhip_octdata *out)
-{
+try {
     if (!out || !params) return fail(SDFHIP_ERR_ARG, "generate: null argument");
     out->length = 0; out->structs = nullptr; out->values = nullptr;
     static const int need[] = { 4, 5, 6 };
@@ -220,7 +221,13 @@ extern "C" int sdfhip_generate(int shape, const float *params, int nparams, int 
                     } catch (...) { err[s] = 1; }
                 }
             };
-            for (int i = 0; i < nthreads; i++) pool.emplace_back(work);
+            // a thread the system refuses (std::system_error) or a pool that cannot grow is not an error: the threads that did
+            // start, and this one, build the seeds (which thread builds a seed changes nothing: every seed has its own tree)
+            try {
+                pool.reserve((size_t)nthreads);
+                for (int i = 0; i < nthreads - 1; i++) pool.emplace_back(work);
+            } catch (...) { }
+            work();
             for (auto &th : pool) th.join();
             for (int e : err) if (e) throw std::bad_alloc();
         }
@@ -232,9 +239,12 @@ extern "C" int sdfhip_generate(int shape, const float *params, int nparams, int 
         size_t total = top.size();
         for (auto &sd : seeds) total += sd.sub.size() - 1;
         if (total > 0xFFFFFFF0ull / 2) return fail(SDFHIP_ERR_NOMEM, "generate: %zu nodes exceed the 32-bit index space", total);
-        int32_t *S = (int32_t *)malloc(total * 8);
-        uint8_t *V = (uint8_t *)malloc(total * 8);
-        if (!S || !V) { free(S); free(V); return fail(SDFHIP_ERR_NOMEM, "generate: out of memory for %zu nodes", total); }
+        // (owned until the hand-over at the end: the vectors of the splice below may throw)
+        std::unique_ptr<int32_t, void (*)(void *)> S_own((int32_t *)malloc(total * 8), free);
+        std::unique_ptr<uint8_t, void (*)(void *)> V_own((uint8_t *)malloc(total * 8), free);
+        int32_t *S = S_own.get();
+        uint8_t *V = V_own.get();
+        if (!S || !V) return fail(SDFHIP_ERR_NOMEM, "generate: out of memory for %zu nodes", total);
 
         if (seeds.empty()) {
             memcpy(S, top.structs.data(), total * 8);
@@ -273,9 +283,10 @@ extern "C" int sdfhip_generate(int shape, const float *params, int nparams, int 
                 }
             }
         }
-        out->length = (uint32_t)total; out->structs = S; out->values = V;
+        out->length = (uint32_t)total; out->structs = S_own.release(); out->values = V_own.release();
         return SDFHIP_OK;
     } catch (const std::bad_alloc &) {
         return fail(SDFHIP_ERR_NOMEM, "generate: out of memory");
     }
 }
+SDFHIP_ABI_CATCH(sdfhip_generate)

@@ -24,7 +24,7 @@
 // in the same order, no contraction (-ffp-contract=off), IEEE sqrt and divide; ties in the
 // nearest-point search go to the earliest list position, as the reference's strict `<`
 // scan does; `minDistance < 0.015` is a double comparison, as there.
-#include "sdfhip_internal.h"
+#include "abi_guard.h"
 
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -1162,21 +1162,24 @@ hipError_t sdfhip::device_alloc_bytes(void **p, size_t bytes)
 }
 
 extern "C" int sdfhip_sdfgen_trim(void)
-{
+try {
     (void)g_pool.trim(-1);
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_sdfgen_trim)
 
 extern "C" int sdfhip_sdfgen(int device, const float *verts6, uint32_t n, int32_t depth, sdfhip_octdata *out,
                              sdfhip_sdfgen_stats *stats)
-{
+try {
     if (!out) return fail(SDFHIP_ERR_ARG, "sdfgen: null argument or empty point cloud");
     return sdfgen_impl(device, verts6, n, depth, out, nullptr, stats);
 }
+SDFHIP_ABI_CATCH(sdfhip_sdfgen)
 
 extern "C" int sdfhip_sdfgen_scene(int device, const float *verts6, uint32_t n, int32_t depth, sdfhip_scene **scene,
                                    sdfhip_octdata *out, sdfhip_sdfgen_stats *stats)
-{
+try {
     if (!scene) return fail(SDFHIP_ERR_ARG, "sdfgen_scene: null argument");
     return sdfgen_impl(device, verts6, n, depth, out, scene, stats);
 }
+SDFHIP_ABI_CATCH(sdfhip_sdfgen_scene)

@@ -23,7 +23,7 @@
 //
 // Everything here is written against the library's own C ABI (sdfhip_render_sparse_device, sdfhip_deinterleave_*): the
 // multi-device layer adds no kernel.
-#include "sdfhip_internal.h"
+#include "abi_guard.h"
 
 #include <hip/hip_runtime.h>
 
@@ -37,6 +37,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 using namespace sdfhip;
@@ -117,21 +118,34 @@ struct Worker {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) return false;
         }
     }
-    void run()
+    // The thread's body.  Nothing may leave it as an exception (that would be std::terminate in the host's process, the crash the
+    // C ABI promises not to cause: abi_guard.h): a job that throws is a job that failed, and a lock or a wait that throws
+    // (std::system_error) fails the job in hand and is tried again.
+    void run() noexcept
     {
         uint32_t seen = 0;
         for (;;) {
-            if (!spin(posted, seen, &quit)) {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit.load(); });
+            try {
+                if (!spin(posted, seen, &quit)) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit.load(); });
+                }
+                if (quit.load()) return;
+                seen = posted.load(std::memory_order_acquire);
+                int r;
+                try { r = fn(arg, rank); } catch (...) { r = abi_caught("sdfhip_multi: a rank's job"); }
+                rc = r;
+                if (r != SDFHIP_OK) { strncpy(err, sdfhip_last_error(), sizeof err - 1); err[sizeof err - 1] = 0; }
+                { std::lock_guard<std::mutex> lk(mu); finished.store(seen, std::memory_order_release); }
+                cv.notify_all();
+            } catch (...) {
+                rc = abi_caught("sdfhip_multi: a rank's worker thread");
+                strncpy(err, sdfhip_last_error(), sizeof err - 1); err[sizeof err - 1] = 0;
+                seen = posted.load(std::memory_order_acquire);
+                finished.store(seen, std::memory_order_release);
+                if (quit.load()) return;
+                usleep(1000);
             }
-            if (quit.load()) return;
-            seen = posted.load(std::memory_order_acquire);
-            const int r = fn(arg, rank);
-            rc = r;
-            if (r != SDFHIP_OK) { strncpy(err, sdfhip_last_error(), sizeof err - 1); err[sizeof err - 1] = 0; }
-            { std::lock_guard<std::mutex> lk(mu); finished.store(seen, std::memory_order_release); }
-            cv.notify_all();
         }
     }
     void post(int (*f)(void *, uint32_t), void *a)
@@ -592,7 +606,7 @@ int wait_locked(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_st
 }  // namespace
 
 extern "C" int sdfhip_multi_free(sdfhip_multi *m)
-{
+try {
     if (!m) return SDFHIP_OK;
     for (uint32_t r = 1; r < m->n; r++) {
         Worker *w = m->workers[r];
@@ -631,10 +645,11 @@ extern "C" int sdfhip_multi_free(sdfhip_multi *m)
     delete m;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_free)
 
 extern "C" int sdfhip_multi_create(const int *devices, uint32_t n_devices, const int32_t *structs, const uint8_t *values,
                                    uint32_t n, sdfhip_multi **out)
-{
+try {
     if (!devices || !structs || !values || !out || n == 0 || n_devices == 0)
         return fail(SDFHIP_ERR_ARG, "multi_create: null argument, empty scene or empty device list");
     *out = nullptr;
@@ -658,7 +673,8 @@ extern "C" int sdfhip_multi_create(const int *devices, uint32_t n_devices, const
         if (!w) return bail(fail(SDFHIP_ERR_NOMEM, "multi_create: out of host memory"));
         w->rank = r;
         m->workers[r] = w;
-        w->th = std::thread([w] { w->run(); });
+        try { w->th = std::thread([w] { w->run(); }); }
+        catch (...) { return bail(abi_caught("multi_create: the worker thread of a rank")); }     // (std::system_error: no more threads)
     }
     // peer access into rank 0's memory (the gather writes there)
     for (uint32_t r = 1; r < n_devices; r++) {
@@ -714,9 +730,10 @@ extern "C" int sdfhip_multi_create(const int *devices, uint32_t n_devices, const
     *out = m;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_create)
 
 extern "C" int sdfhip_multi_selftest(sdfhip_multi *m, sdfhip_multi_link *links)
-{
+try {
     if (!m) return fail(SDFHIP_ERR_ARG, "multi_selftest: null handle");
     std::lock_guard<std::mutex> lk(m->lock);
     for (uint32_t k = 0; k < MAX_SLOTS; k++)
@@ -808,9 +825,10 @@ extern "C" int sdfhip_multi_selftest(sdfhip_multi *m, sdfhip_multi_link *links)
     { DevGuard g0(m->devices[0]); (void)hipFree(d_rx); }
     return rc == SDFHIP_OK ? SDFHIP_OK : fail(rc, "%s", first);
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_selftest)
 
 extern "C" int sdfhip_multi_configure(sdfhip_multi *m, uint32_t band_rows, float rank0_weight)
-{
+try {
     if (!m) return fail(SDFHIP_ERR_ARG, "multi_configure: null handle");
     if (band_rows == 0 || band_rows % 8 != 0) return fail(SDFHIP_ERR_ARG, "multi_configure: band_rows %u must be a positive multiple of 8 (whole 8x8 wave tiles per band)", band_rows);
     if (!(rank0_weight > 0.0f && rank0_weight <= 1.0f)) return fail(SDFHIP_ERR_ARG, "multi_configure: rank0_weight must be in (0, 1]");
@@ -820,20 +838,22 @@ extern "C" int sdfhip_multi_configure(sdfhip_multi *m, uint32_t band_rows, float
     m->band_rows = band_rows; m->rank0_weight = rank0_weight;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_configure)
 
 #ifdef SDFHIP_EXPERIMENTS
 #include "../../include/sdfhip_experimental.h"
 extern "C" int sdfhip_multi_debug_floats_sent(sdfhip_multi *m, uint32_t floats)
-{
+try {
     if (!m) return fail(SDFHIP_ERR_ARG, "multi_debug_floats_sent: null handle");
     std::lock_guard<std::mutex> lk(m->lock);
     for (uint32_t r = 0; r < MAX_RANKS; r++) m->est[r] = floats;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_debug_floats_sent)
 #endif
 
 extern "C" int sdfhip_multi_info(const sdfhip_multi *m, uint32_t *n_devices, int *devices, uint32_t *band_rows, float *rank0_weight, int *transport)
-{
+try {
     if (!m) return fail(SDFHIP_ERR_ARG, "multi_info: null handle");
     if (n_devices) *n_devices = m->n;
     if (devices) for (uint32_t r = 0; r < m->n; r++) devices[r] = m->devices[r];
@@ -842,29 +862,33 @@ extern "C" int sdfhip_multi_info(const sdfhip_multi *m, uint32_t *n_devices, int
     if (transport) *transport = m->use_rccl ? 1 : 0;
     return SDFHIP_OK;
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_info)
 
 extern "C" int sdfhip_multi_submit(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint32_t n_frames, uint32_t width,
                                    uint32_t height, uint32_t flags, void *d_frames_out)
-{
+try {
     if (!m) return fail(SDFHIP_ERR_ARG, "multi_submit: null handle");
     std::lock_guard<std::mutex> lk(m->lock);
     return submit_locked(m, slot, infos, n_frames, nullptr, width, height, flags, d_frames_out);
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_submit)
 
 extern "C" int sdfhip_multi_submit_path(sdfhip_multi *m, uint32_t slot, const sdfhip_info *info, const sdfhip_pathtrace *pt,
                                         uint32_t width, uint32_t height, uint32_t flags, void *d_frame_out)
-{
+try {
     if (!m || !pt) return fail(SDFHIP_ERR_ARG, "multi_submit_path: null argument");
     std::lock_guard<std::mutex> lk(m->lock);
     return submit_locked(m, slot, info, 1, pt, width, height, flags, d_frame_out);
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_submit_path)
 
 extern "C" int sdfhip_multi_wait(sdfhip_multi *m, uint32_t slot, void **d_frames, sdfhip_multi_stats *stats)
-{
+try {
     if (!m) return fail(SDFHIP_ERR_ARG, "multi_wait: null handle");
     std::lock_guard<std::mutex> lk(m->lock);
     return wait_locked(m, slot, d_frames, stats);
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_wait)
 
 static int multi_render_host(sdfhip_multi *m, const sdfhip_info *info, const sdfhip_pathtrace *pt, uint32_t width, uint32_t height,
                              uint32_t flags, void *out, sdfhip_multi_stats *stats)
@@ -890,13 +914,15 @@ static int multi_render_host(sdfhip_multi *m, const sdfhip_info *info, const sdf
 
 extern "C" int sdfhip_multi_render(sdfhip_multi *m, const sdfhip_info *info, uint32_t width, uint32_t height, uint32_t flags,
                                    float *rgba_out, sdfhip_multi_stats *stats)
-{
+try {
     return multi_render_host(m, info, nullptr, width, height, flags, rgba_out, stats);
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_render)
 
 extern "C" int sdfhip_multi_render_path(sdfhip_multi *m, const sdfhip_info *info, const sdfhip_pathtrace *pt, uint32_t width,
                                         uint32_t height, uint32_t flags, float *rgba_out, sdfhip_multi_stats *stats)
-{
+try {
     if (!pt) return fail(SDFHIP_ERR_ARG, "multi_render_path: null argument");
     return multi_render_host(m, info, pt, width, height, flags, rgba_out, stats);
 }
+SDFHIP_ABI_CATCH(sdfhip_multi_render_path)

@@ -221,3 +221,38 @@ def test_a_failed_load_of_the_laboratory_package_leaves_nothing_behind(monkeypat
         monkeypatch.undo()
         sys.modules.update(saved)
     assert lab.load()._lib.EXPERIMENTS                         # and a load after the failure works
+
+
+def test_every_entry_point_is_behind_the_exception_firewall():
+    """the C ABI never throws or aborts across the boundary.  Every `extern "C"` DEFINITION under csrc/ (both flavours of
+    the library) is a function-try-block closed by one of csrc/abi_guard.h's macros naming that entry point -- so a std::bad_alloc,
+    a std::system_error or anything else a callee throws comes back as a status code -- and every thread the library starts has a
+    noexcept body or catches everything.  The one exception is sdfhip_last_error (it returns a thread-local array).  What the
+    guard DOES under failure is tests/test_host_sanitizers.py::test_injected_failures_come_back_as_status_codes."""
+    src = os.path.join(REPO, "sdfbox_amd", "csrc")
+    guarded, unguarded = set(), []
+    for f in sorted(os.listdir(src)):
+        if not f.endswith((".cpp", ".hip", ".h")):
+            continue
+        text = open(os.path.join(src, f)).read()
+        for m in re.finditer(r'^extern "C"[^;{]*?\b(sdfhip_\w+)\s*\([^;{]*?\)\s*(try\s*)?\{', text, re.M | re.S):
+            name, is_try = m.group(1), bool(m.group(2))
+            if name == "sdfhip_last_error":
+                continue
+            # the block's end: the first line that is exactly "}" after the opening, then the macro with this very name
+            end = re.compile(r"^\}\n(SDFHIP_ABI_CATCH(?:_VOID|_AS)?)\((\w+)", re.M).search(text, m.end())
+            if not is_try or not end or end.group(2) != name:
+                unguarded.append(f"{f}: {name}")
+            guarded.add(name)
+        # threads: std::thread bodies must not let an exception out
+        for m in re.finditer(r"std::thread\(\[[^\]]*\]\s*\{([^}]*)\}", text):
+            body = m.group(1)
+            assert "run()" in body, f"{f}: a thread body the firewall test does not know: {body!r}"
+        if "void run()" in text:
+            assert "void run() noexcept" in text, f"{f}: Worker::run must be noexcept with a catch-all inside"
+    assert not unguarded, "entry points outside the firewall: " + ", ".join(unguarded)
+    declared = set(declared_symbols()) | set(declared_symbols("sdfhip_experimental.h"))
+    assert declared - {"sdfhip_last_error"} <= guarded, sorted(declared - guarded)
+    # the scene builder's pool: its threads' bodies catch everything themselves
+    gen = open(os.path.join(src, "scene_gen.cpp")).read()
+    assert "catch (...) { err[s] = 1; }" in gen

@@ -29,3 +29,21 @@ def test_threaded_builder_under_tsan(tmp_path):
                           ["-o", exe, "-lpthread"])
     out = subprocess.run([exe, str(tmp_path / "y.asdf")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ThreadSanitizer" not in out.stderr, out.stdout + out.stderr
+
+
+def test_injected_failures_come_back_as_status_codes(tmp_path):
+    """"never throw/abort across the boundary" (the reference does: SdfGen/pch.h:20-26, dllmain.cpp:112-115).  operator
+    new fails at every allocation of sdfhip_octdata_validate, sdfhip_load_obj / _ply, sdfhip_generate (serial and threaded) and
+    sdfhip_asdf_load in turn, and pthread_create refuses every thread: each call returns SDFHIP_ERR_NOMEM with a message (or
+    succeeds where the library copes), never std::terminate (tests/host_fault_injection.cpp; UBSan on)."""
+    src = os.path.join(REPO, "sdfbox_amd", "csrc")
+    exe = str(tmp_path / "host_fault")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=undefined", "-fno-sanitize-recover=all", "-ffp-contract=off",
+                           "-I", os.path.join(REPO, "include"), os.path.join(REPO, "tests", "host_fault_injection.cpp")] +
+                          [os.path.join(src, f) for f in ("errors.cpp", "asdf_io.cpp", "camera.cpp", "scene_gen.cpp", "point_readers.cpp")] +
+                          ["-o", exe, "-lpthread", "-ldl"])
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "fault injection run ok" in out.stdout
+    for entry in ("sdfhip_octdata_validate", "sdfhip_load_obj", "sdfhip_load_ply", "sdfhip_generate (4 threads)", "sdfhip_generate (no threads)"):
+        assert entry in out.stdout
