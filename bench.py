@@ -33,6 +33,7 @@ sys.path.insert(0, REPO)
 from bench_report import (HBM_PEAK_GBS, KERNEL_SOURCES, VALU_PEAK_GINSTR, VALU_PEAK_SPEC_GINSTR, configs_summary, cpu_baseline,  # noqa: E402,F401
                           kernel_source_hash, load_pmc, measured_hbm_bandwidth, roofline)
 from bench_configs import bench_camera, grid_suffix, load_package, orbit_cameras, run_configs  # noqa: E402,F401
+from bench_sustained import GpuTelemetry, at_observed_clock, sustained_leg, sustained_seconds  # noqa: E402,F401
 from bench_sharded import Watchdog, main_single_process, measure_band_deal, measure_rank0_weight, spawn_ranks  # noqa: E402,F401
 
 # Wavefront ray compaction is measured 2-3 % slower than the plain kernel on this workload
@@ -117,6 +118,11 @@ def parse():
     ap.add_argument("--watchdog-seconds", type=float, default=-1.0,
                     help="a daemon thread writes the run's phase to stderr every few seconds and ends the process with exit code 3 once "
                          "the whole run has taken this long (-1 = default: 420 for N > 1, off for N = 1; 0 = off)")
+    ap.add_argument("--sustained", default="auto",
+                    help="continuous-operation legs behind the headline (bench_sustained.py): 'cfg2,cfg3,orbit' seconds of wall time, e.g. "
+                         "'5,3,2' -- the cfg-2 frame pipelined for >= 5 s, the 4K frame (in the `configs` block) for >= 3 s, the cfg-2 frame "
+                         "with a camera that moves every frame for >= 2 s, the GPU's clock / power / temperature sampled every 100 ms.  "
+                         "auto: 5,3,2 when the command is the headline's, else off; 0 or off: none")
     ap.add_argument("--lab", action="store_true",
                     help="load the experiments flavour of the library (libsdfhip_lab.so, include/sdfhip_experimental.h): needed by the A/B "
                          "forms --one-kernel and --shadow-queue")
@@ -682,6 +688,47 @@ def main():
         roof.update({"time_ms": round(sec_per_step * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch,
                      "kernel_ms_is": "average HIP-event time around one launch on its stream; with several frames in flight the launches overlap, "
                                      "so this is longer than time_ms (the steady-state time per frame, which the fractions divide by)"})
+        headline = (world == 1 and not sharded and (W, H) == (1920, 1080) and args.depth == 9 and not args.asdf and pt is None and not compact
+                    and not args.display and not args.one_kernel and not args.shadow_queue and not args.tile_order and args.orbit == 0
+                    and args.kernel == "auto")
+        # ---- continuous operation: the same frames, pipelined the same way, for seconds; clocks sampled ----
+        sus_s = sustained_seconds(args.sustained, headline)
+        sustained = telemetry = None
+        if any(sus_s) and world == 1 and not sharded and pt is None:
+            wd.phase("sustained legs (continuous rendering, clock / power / temperature sampled every 100 ms)", quiet=True)
+            telemetry = GpuTelemetry(bus_ids[0])
+            valu_pf = pmc.get("valu_insts_per_frame") if isinstance(pmc, dict) else None
+            sustained = {"is": "the timed region's frames rendered without a stop for >= `seconds` (Program.cs:58-74 never stops): device time "
+                               "from HIP events at chunk boundaries on every stream, nothing synchronised inside a leg; telemetry from "
+                               + str(telemetry.source or telemetry.error)}
+
+            def leg(camlist, seconds):
+                r = sustained_leg(torch, lambda k, si: render(local[si][0], streams[si].cuda_stream, c=camlist[k % len(camlist)]),
+                                  streams, seconds, telemetry)
+                clk = ((r.get("telemetry") or {}).get("sclk_mhz") or {}).get("mean")
+                r["valu_frac_of_spec_2400mhz"] = (round(valu_pf / (r["ms_per_step"] * 1e-3) / 1e9 / VALU_PEAK_SPEC_GINSTR, 4) if valu_pf else None)
+                r["valu_frac_at_observed_clock"] = at_observed_clock(valu_pf, r["ms_per_step"], clk)
+                r["mray_per_s"] = round(W * H / (r["ms_per_step"] * 1e-3) / 1e6, 1)
+                return r
+            try:
+                if sus_s[0] > 0:
+                    sustained["cfg2"] = leg([cam], sus_s[0])
+                if sus_s[2] > 0:
+                    sustained["cfg2_orbit"] = leg(orbit, sus_s[2])
+            except Exception as e:
+                sustained["error"] = f"{type(e).__name__}: {e}"
+            flat = sustained.get("cfg2")
+            if flat:                               # flat scalars in `roofline`: the driver's record keeps that object's scalars
+                tl = flat.get("telemetry") or {}
+                roof.update({"sustained_ms_per_step": flat["ms_per_step"], "sustained_seconds": flat["seconds"], "sustained_frames": flat["frames"],
+                             "sustained_ms_per_step_first_20": flat["ms_per_step_first_20"],
+                             "sustained_ms_per_step_last_1000": flat["ms_per_step_last_1000"],
+                             "sustained_sclk_mhz_min": (tl.get("sclk_mhz") or {}).get("min"),
+                             "sustained_sclk_mhz_mean": (tl.get("sclk_mhz") or {}).get("mean"),
+                             "sustained_power_w_mean": (tl.get("power_w") or {}).get("mean"),
+                             "sustained_temp_c_max": (tl.get("temp_c") or {}).get("max"),
+                             "sustained_valu_frac_of_spec": flat["valu_frac_of_spec_2400mhz"],
+                             "sustained_valu_frac_at_observed_clock": flat["valu_frac_at_observed_clock"]})
         out = {
             "metric": "Mray/s (primary rays; frame W*H / time per frame)",
             "value": round(W * H * max(1, args.spp) / sec_per_step / 1e6, 2),
@@ -759,16 +806,16 @@ def main():
         }
         if check_ok is not None:
             out["config"]["assembled_frame_equals_whole_frame_render"] = check_ok
-        headline = (world == 1 and not sharded and (W, H) == (1920, 1080) and args.depth == 9 and not args.asdf and pt is None and not compact
-                    and not args.display and not args.one_kernel and not args.shadow_queue and not args.tile_order and args.orbit == 0
-                    and args.kernel == "auto")
+        if sustained is not None:
+            out["sustained"] = sustained
         if args.configs == "all" or (args.configs == "auto" and headline):
             # (the headline's buffers are not needed any more: the path-traced configuration wants 30 GB of queues)
             local = send = frame = gathered = None
             torch.cuda.empty_cache()
             # (a configuration that fails says so in its own entry: the headline above has been measured and is printed regardless)
             try:
-                out["configs"] = run_configs(sb, torch, scene, scene_name, copy_gbs, args.configs_scale, args.depth, streams)
+                out["configs"] = run_configs(sb, torch, scene, scene_name, copy_gbs, args.configs_scale, args.depth, streams,
+                                             sustained_4k_seconds=sus_s[1] if sustained is not None else 0.0, telemetry=telemetry)
             except Exception as e:
                 out["configs"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:

@@ -14,6 +14,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 
 from bench_report import HBM_PEAK_GBS, VALU_PEAK_SPEC_GINSTR, kernel_source_hash, load_pmc
+from bench_sustained import at_observed_clock, sustained_leg
 
 
 def load_package(args):
@@ -56,7 +57,7 @@ def grid_suffix(scene, pt=None):
     return f":grid{lvl}" + ("+blocks" if lvl and gbytes > (16 << (3 * lvl)) and pt is None else "")
 
 
-def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared_streams=None):
+def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared_streams=None, sustained_4k_seconds=0.0, telemetry=None):
     """BASELINE.json's other single-GPU configurations, timed in this process behind the headline: the same
     clock (host time around `steps` frames, synchronised on both sides, frames in flight on their own streams), the HIP-event
     time of a launch beside it, and the counter fractions from the committed PMC pass of the SAME command line
@@ -65,7 +66,7 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
     out = {}
     suffix9 = grid_suffix(scene)                      # (before the path-traced mode adds its second grid to the byte count)
 
-    def measure(name, sc, sname, W, H, mode, suffix, flags=0, pt=None, steps=60, warmup=12, nbuf=4, note=None):
+    def measure(name, sc, sname, W, H, mode, suffix, flags=0, pt=None, steps=60, warmup=12, nbuf=4, note=None, sustained=0.0):
         cam = bench_camera(sb, W, H)
         bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
         # the headline's streams again: which hardware queue a stream gets is the runtime's business, and these are known to have
@@ -114,6 +115,18 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
                 e["valu_insts_per_frame"] = int(pmc["valu_insts_per_frame"])
                 e["valu_frac_of_spec"] = round(pmc["valu_insts_per_frame"] / sec / 1e9 / VALU_PEAK_SPEC_GINSTR, 4)
             e["limiting"] = "hbm" if (e["hbm_frac"] or 0) >= (e["valu_frac_of_spec"] or 0) else "valu"
+        if sustained > 0 and pt is None:
+            # the same frames without a stop, the GPU's clocks sampled (bench_sustained.py)
+            try:
+                r = sustained_leg(torch, lambda k, si: launch(k), streams, sustained, telemetry)
+                clk = ((r.get("telemetry") or {}).get("sclk_mhz") or {}).get("mean")
+                r["valu_frac_of_spec_2400mhz"] = (round(e["valu_insts_per_frame"] / (r["ms_per_step"] * 1e-3) / 1e9 / VALU_PEAK_SPEC_GINSTR, 4)
+                                                  if e.get("valu_insts_per_frame") else None)
+                r["valu_frac_at_observed_clock"] = at_observed_clock(e.get("valu_insts_per_frame"), r["ms_per_step"], clk)
+                r["mray_per_s"] = round(W * H * spp / (r["ms_per_step"] * 1e-3) / 1e6, 1)
+                e["sustained"] = r
+            except Exception as ex:
+                e["sustained"] = {"error": f"{type(ex).__name__}: {ex}"}
         out[name] = e
         del bufs, streams
         torch.cuda.empty_cache()
@@ -128,7 +141,8 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
             torch.cuda.empty_cache()
 
     guarded("cfg3_4k", lambda: measure("cfg3_4k", scene, scene_name, W4, H4, "default", suffix9,
-            note="BASELINE cfg-3's frame with compaction OFF (the default kernel: faster than every form of compaction built)"))
+            note="BASELINE cfg-3's frame with compaction OFF (the default kernel: faster than every form of compaction built)",
+            sustained=sustained_4k_seconds))
     guarded("cfg3_4k_compact", lambda: measure("cfg3_4k_compact", scene, scene_name, W4, H4, "compact", suffix9, flags=sb.FLAG_COMPACT,
             note="BASELINE cfg-3 as named: wavefront ray compaction ON (SDFHIP_FLAG_COMPACT: the shadow rays of waves that hold fewer than 32 "
                  "compacted by ballot / prefix into a queue and marched 64 to a wave by a second kernel)"))

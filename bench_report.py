@@ -138,8 +138,8 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, measured):
 
 
 def configs_summary(out, cfgs):
-    """<= 600 characters that carry every configuration's time, rays and fractions: the LAST key of the line, so that the last
-    2 000 characters of it (what the driver's record keeps) hold all of them.  ms per frame / Mray/s / hbm_frac (of 8 TB/s) /
+    """<= 600 characters that carry every configuration's time, rays and fractions (+ <= 380 for the sustained legs): the LAST key of
+    the line, so that the last 2 000 characters of it (what the driver's record keeps) hold all of them.  ms per frame / Mray/s / hbm_frac (of 8 TB/s) /
     hbm_frac_of_measured / valu_frac_of_spec; '-' where there is no PMC pass of this build."""
     names = {"cfg3_4k": "cfg3", "cfg3_4k_compact": "cfg3c", "cfg5_4k_spp16": "cfg5", "cfg2_depth10": "d10", "cfg2_mesh_knot_d10": "mesh"}
 
@@ -157,7 +157,26 @@ def configs_summary(out, cfgs):
         for k, e in cfgs.items():
             if isinstance(e, dict) and k != "error":
                 parts.append(one(names.get(k, k[:10]), e, e))
-    return ("ms/Mray/hbm/hbm_meas/valu: " + "; ".join(parts))[:600]
+    text = ("ms/Mray/hbm/hbm_meas/valu: " + "; ".join(parts))[:600]
+    # continuous operation (bench_sustained.py): ms per frame over the leg / its seconds / frames, first 20 and last 1000 frames,
+    # the shader clock (min-mean MHz) and the mean socket power while it ran, VALU issue at the observed clock -- <= 360 characters more
+    def sus(tag, r):
+        if not isinstance(r, dict) or "ms_per_step" not in r:
+            return None
+        t = r.get("telemetry") or {}
+        clk, pw = t.get("sclk_mhz") or {}, t.get("power_w") or {}
+        return (f"{tag} {f(r['ms_per_step'], 4)}ms/{f(r.get('seconds'), 1)}s/{r.get('frames')}f first20 {f(r.get('ms_per_step_first_20'), 4)} "
+                f"last1000 {f(r.get('ms_per_step_last_1000'), 4)} sclk {f(clk.get('min'), 0)}-{f(clk.get('mean'), 0)}MHz {f(pw.get('mean'), 0)}W "
+                f"valu@clk {f(r.get('valu_frac_at_observed_clock'), 2)}")
+    legs = []
+    for tag, key in (("cfg2", "cfg2"), ("orbit", "cfg2_orbit")):
+        legs.append(sus(tag, (out.get("sustained") or {}).get(key)))
+    if isinstance(cfgs, dict) and isinstance(cfgs.get("cfg3_4k"), dict):
+        legs.append(sus("cfg3", cfgs["cfg3_4k"].get("sustained")))
+    legs = [l for l in legs if l]
+    if legs:
+        text += " | sustained: " + "; ".join(legs)
+    return text[:980]
 
 
 def measured_hbm_bandwidth(sb, device=0, nbytes=2 << 30, reps=10):

@@ -216,6 +216,71 @@ def test_configs_summary_is_short_and_names_every_config():
     assert "cfg5 ERR" in text and "d10 3.3066/27012/-/-/-" in text
 
 
+def test_sustained_block_reaches_the_summary_and_prices_the_observed_clock():
+    # the sustained legs' figures sit in the line's last key (what the driver's record keeps) and
+    # valu_frac is recomputed at the clock the leg ran at
+    sys.path.insert(0, REPO)
+    import bench
+    import bench_sustained as bs
+    leg = {"ms_per_step": 0.0871, "seconds": 5.02, "frames": 57632, "ms_per_step_first_20": 0.0932, "ms_per_step_last_1000": 0.0869,
+           "telemetry": {"sclk_mhz": {"min": 2085.0, "mean": 2240.5, "max": 2400.0}, "power_w": {"min": 900.0, "mean": 1011.0, "max": 1100.0}},
+           "valu_frac_at_observed_clock": bs.at_observed_clock(57_043_052, 0.0871, 2240.5)}
+    assert abs(leg["valu_frac_at_observed_clock"] - 57_043_052 / 0.0871e-3 / (1024 * 2240.5e6 / 2)) < 1e-4
+    assert bs.at_observed_clock(None, 0.1, 2000.0) is None and bs.at_observed_clock(1e6, 0.1, None) is None
+    cfgs = {"cfg3_4k": {"ms_per_step": 0.31, "value": 26775.0, "hbm_frac": 0.17, "hbm_frac_of_measured": 0.22, "valu_frac_of_spec": 0.53,
+                        "sustained": dict(leg, ms_per_step=0.3099, frames=9876, seconds=3.06)}}
+    text = bench.configs_summary({"ms_per_step": 0.0896, "value": 23135.0, "roofline": {"hbm_frac": 0.33, "hbm_frac_of_measured": 0.42,
+                                  "valu_frac_of_spec": 0.52}, "sustained": {"cfg2": leg, "cfg2_orbit": dict(leg, ms_per_step=0.0902)}}, cfgs)
+    assert len(text) <= 980
+    assert "| sustained: cfg2 0.0871ms/5.0s/57632f first20 0.0932 last1000 0.0869 sclk 2085-2240MHz 1011W valu@clk 0.57" in text
+    assert "orbit 0.0902ms" in text and "cfg3 0.3099ms/3.1s/9876f" in text
+    assert bs.sustained_seconds("auto", True) == (5.0, 3.0, 2.0) and bs.sustained_seconds("auto", False) == (0.0, 0.0, 0.0)
+    assert bs.sustained_seconds("off", True) == (0.0, 0.0, 0.0) and bs.sustained_seconds("1.5,0.5", True) == (1.5, 0.5, 0.0)
+
+
+def test_telemetry_summary_and_the_leg_bookkeeping_without_a_gpu(monkeypatch):
+    # GpuTelemetry on a machine without a GPU names why it has no source and summarises nothing; with samples put in, the summary
+    # leaves the ramp out of the idle clock (the first 0.3 s) out of min / mean / max.  sustained_leg's bookkeeping (first 20,
+    # last >= 1000 frames, per second) is exercised against a stand-in for torch whose events carry a simulated device clock.
+    sys.path.insert(0, REPO)
+    import bench_sustained as bs
+    t = bs.GpuTelemetry("0000:ff:00.0")
+    if t.source is None:
+        assert t.error and t.start().stop()["samples"] == 0
+    t.source = "test"
+    t.samples = [(10.0, 95.0, 94.0, 97.0, 245.0, 46.0, 0.0), (10.1, 1200.0, 1100.0, 1300.0, 600.0, 50.0, 80.0)] + \
+                [(10.4 + 0.1 * i, 2100.0 + i, 2090.0, 2110.0 + i, 1000.0, 60.0 + i, 100.0) for i in range(10)]
+    sm = t.summary()
+    assert sm["samples"] == 12 and sm["sclk_mhz"] == {"min": 2100.0, "mean": 2104.5, "max": 2109.0} and sm["first_sample"]["sclk_mhz"] == 95.0
+    assert sm["sclk_mhz_slowest_xcd_min"] == 2090.0 and sm["temp_c"]["max"] == 69.0 and sm["power_w"]["mean"] == 1000.0
+
+    class Clock:                       # the simulated device: every launch takes 0.1 ms, four streams in parallel
+        now = 0.0
+    class Ev:
+        def __init__(self, enable_timing=True): self.t = None
+        def record(self, s): self.t = s.busy_until
+        def synchronize(self): pass
+        def elapsed_time(self, other): return other.t - self.t
+    class Stream:
+        def __init__(self): self.busy_until = 0.0
+    class Cuda:
+        Event = Ev
+        @staticmethod
+        def synchronize(): pass
+    class Torch:
+        cuda = Cuda
+    streams = [Stream() for _ in range(4)]
+
+    def launch(k, si):
+        streams[si].busy_until += 0.4 if k >= 20 else 0.8          # the first 20 frames twice as slow (a cold chip)
+    ticks = iter(range(10 ** 9))
+    monkeypatch.setattr(bs.time, "perf_counter", lambda: next(ticks) * 0.05)     # the host's clock: 0.05 s per look
+    r = bs.sustained_leg(Torch, launch, streams, 1.0, None, chunk=256)
+    assert r["frames"] >= 20 + 7 * 256 and r["frames"] % 256 == 20
+    assert abs(r["ms_per_step_first_20"] - 0.2) < 1e-9 and abs(r["ms_per_step_last_1000"] - 0.1) < 1e-9 and r["last_frames"] >= 1000
+    assert abs(r["ms_per_step"] - (20 * 0.2 + (r["frames"] - 20) * 0.1) / r["frames"]) < 1e-4 and r["telemetry"] is None
+
+
 def test_orbit_cameras_walk_round_the_scene():
     sys.path.insert(0, REPO)
     import bench
