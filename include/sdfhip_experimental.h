@@ -92,12 +92,26 @@ SDFHIP_API int sdfhip_deinterleave_sparse_device(int device, const void *d_gathe
  * of them): a small value forces the float tail of the next shares to be sent again (sdfhip_multi_stats.resends). */
 SDFHIP_API int sdfhip_multi_debug_floats_sent(sdfhip_multi *m, uint32_t floats);
 
-/* Experiment hook (scripts/ab_tile_order.py): the primary-march kernel of the following single-frame renders
- * on this scene takes workgroup b's tile from d_perm[b] (device array, one entry per workgroup of its grid =
- * 8 * ceil(tiles_y / 8) * tiles_x with 8x8 tiles; entries >= the tile count idle) and writes the march
- * iterations of every tile's wave to d_cost[tile] (device array): the primary loop's in the low byte, the
- * shadow loop's in the high byte.  NULL switches either off. */
+/* Experiment hook (scripts/ab_tile_order.py): the default kernel of the following single-frame renders on this scene takes its
+ * tiles from d_perm (device array of B = 8 * ceil(tiles_y / 8) * tiles_x entries, one per workgroup of a frame, 8x8 tiles), stored
+ * LABEL-MAJOR: entry [label * (B / 8) + slot] is the tile of the slot-th workgroup that carries XCD label `label` (0..7: the label
+ * is blockIdx.x of the launch, whose grid is (8, frames, B / 8)), PACKED as tile_row << 16 | tile_col; an entry whose row or
+ * column lies outside the frame idles.  The kernel writes the march iterations of every tile's wave to d_cost[tile_row * tiles_x
+ * + tile_col] (device array): the primary loop's in the low byte, the shadow loop's in the high byte.  NULL switches either off.
+ * Refused (SDFHIP_ERR_ARG at the render) for frames with more than 65 535 tile rows or columns or more than 8 * 65 535 workgroups
+ * (B / 8 is a grid dimension). */
 SDFHIP_API int sdfhip_debug_tile_order(sdfhip_scene *scene, const uint32_t *d_perm, uint16_t *d_cost);
+
+/* The compulsory bytes of this design: between _begin and _end every SDFHIP_FLAG_COUNT render on this scene
+ * marks, per XCD, the 128-byte lines of the lookup grid its find() touches.  A "phase" is what is counted on its own: a whole
+ * frame of the default / compact kernels; for sdfhip_render_path_device the camera segments and then each bounce level (each is a
+ * kernel launch of its own, reading the bounce levels' second grid when the scene has one).  _end synchronises the device and
+ * returns, per phase, out[8 * phase + ...] = {lines of the coarse array, lines of the fine array (distinct, chip-wide: one ideal
+ * cache), the same two summed over the 8 XCDs (eight ideal L2s that share nothing), which grid (0: the scene's own, 2: the
+ * bounce levels'), 0, 0, 0}; array_bytes4 (may be NULL) = the bytes of {coarse, fine, coarse2, fine2}.  Needs a scene whose grid
+ * is as deep as its tree.  The hook costs the counting kernels an atomic per new line; the product has no such code. */
+SDFHIP_API int sdfhip_debug_touch_begin(sdfhip_scene *scene);
+SDFHIP_API int sdfhip_debug_touch_end(sdfhip_scene *scene, uint64_t *out, uint32_t max_phases, uint32_t *n_phases, uint64_t *array_bytes4);
 
 /* Diagnostics: after a SDFHIP_FLAG_COUNT render of the default kernel on `stream` (the stream argument of the
  * sdfhip_render_device call that made it; synchronises with it), how many lane-steps sampled which kind of cell: out6 = {flat leaf at or above the grid's coarse level, flat leaf below it, non-flat at or above the coarse level,

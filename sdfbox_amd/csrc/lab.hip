@@ -127,6 +127,10 @@ int sdfhip::launch_experiment(sdfhip_scene *s, const RenderCall &c, RenderParams
     const uint32_t btsel = (flags >> SDFHIP_TUNE_BLOCK_SHIFT) & 0xF;
     const int bt = btsel == 3 ? 256 : (btsel == 2 ? 128 : 64);
     P.tile_perm = c.n_frames == 1 ? s->dbg_tile_perm : nullptr;      // (the experiment hook is for single frames: its arrays hold one frame's tiles)
+    //  the hook's entries pack tile_row << 16 | tile_col and its launch has grid.z = grid.x / 8: refuse what neither can hold
+    if (P.tile_perm && (P.tiles_x >= 65536u || P.tiles_y >= 65536u || grid.x / 8u > 65535u))
+        return fail(SDFHIP_ERR_ARG, "render: the tile-order hook (sdfhip_debug_tile_order) takes frames of at most 65 535 tile rows / columns and "
+                                    "8 x 65 535 workgroups (this one: %u x %u tiles, %u workgroups)", P.tiles_x, P.tiles_y, grid.x);
     P.perm_per_label = grid.x / 8u;                                  // (the hook's array: [XCD label][slot], as the library's own)
     P.tile_cost = c.n_frames == 1 ? s->dbg_tile_cost : nullptr;
     const bool grid_lookup = cur == CUR_STACK_FULL || cur == CUR_STACK_SPLIT;
@@ -272,6 +276,89 @@ try {
     return SDFHIP_OK;
 }
 SDFHIP_ABI_CATCH(sdfhip_debug_tile_order)
+
+// ---- sdfhip_debug_touch_*: the compulsory bytes of this design ------------------------------------------
+// What a frame MUST move is the distinct 128-byte lines of the grid its lookups touch (+ the frame it stores); the counters say
+// what it DID move.  The counting builds of the kernels mark every lookup's line in a bitmap per array and XCD.
+static void touch_release(sdfhip_scene *s)
+{
+    for (int a = 0; a < 4; a++) { if (s->touch.bits[a]) (void)hipFree(s->touch.bits[a]); s->touch.bits[a] = nullptr; s->touch.words[a] = 0; }
+    if (s->touch.result) (void)hipFree(s->touch.result);
+    s->touch.result = nullptr; s->touch.on = false; s->touch.phase = 0;
+}
+
+void sdfhip::touch_params(const sdfhip_scene *s, RenderParams &P, int pair)
+{
+    P.touch_top = s->touch.bits[pair]; P.touch_top_words = s->touch.words[pair];
+    P.touch_fine = s->touch.bits[pair + 1]; P.touch_fine_words = s->touch.words[pair + 1];
+}
+
+void sdfhip::touch_phase(sdfhip_scene *s, hipStream_t st, int pair)
+{
+    if (!s->touch.on || s->touch.phase >= sdfhip_scene::Touch::MAX_PHASES) return;
+    unsigned long long *out = s->touch.result + (size_t)s->touch.phase * 8;
+    const uint32_t most = s->touch.words[pair] > s->touch.words[pair + 1] ? s->touch.words[pair] : s->touch.words[pair + 1];
+    const uint32_t blocks = (most + 255u) / 256u < 4096u ? (most + 255u) / 256u : 4096u;
+    hipLaunchKernelGGL(k_touch_count, dim3(blocks ? blocks : 1u), dim3(256), 0, st, s->touch.bits[pair], s->touch.words[pair],
+                       s->touch.bits[pair + 1], s->touch.words[pair + 1], out);
+    const unsigned long long which = (unsigned long long)pair;
+    (void)hipMemcpyAsync(out + 4, &which, sizeof which, hipMemcpyHostToDevice, st);     // (pageable source: copied before the call returns)
+    s->touch.phase++;
+}
+
+extern "C" int sdfhip_debug_touch_begin(sdfhip_scene *s)
+try {
+    if (!s) return fail(SDFHIP_ERR_ARG, "debug_touch_begin: null scene");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "debug_touch_begin: hipSetDevice(%d) failed", s->device);
+    if (!s->d_top || s->top_level + s->fine_bits != (int)s->depth)
+        return fail(SDFHIP_ERR_ARG, "debug_touch_begin: the scene has no grid as deep as its tree (the lookups that are counted go through one)");
+    HIP_TRY(hipDeviceSynchronize());
+    touch_release(s);
+    const TopCell *arrays[4] = { s->d_top, s->d_fine, s->d_top2, s->d_fine2 };
+    const uint64_t bytes[4] = { (uint64_t)sizeof(TopCell) << (3 * s->top_level), s->fine_bytes,
+                                s->d_top2 ? (uint64_t)sizeof(TopCell) << (3 * s->top2_level) : 0,
+                                s->d_top2 ? s->top2_bytes - ((uint64_t)sizeof(TopCell) << (3 * s->top2_level)) : 0 };
+    for (int a = 0; a < 4; a++) {
+        if (!arrays[a] || !bytes[a]) continue;
+        if (reinterpret_cast<uintptr_t>(arrays[a]) % 128u) { touch_release(s); return fail(SDFHIP_ERR_DEVICE, "debug_touch_begin: grid array %d is not line-aligned", a); }
+        const uint64_t lines = (bytes[a] + 127) / 128, words = (lines + 31) / 32;
+        if (words > 0x7FFFFFFFull) { touch_release(s); return fail(SDFHIP_ERR_ARG, "debug_touch_begin: grid array %d is too large", a); }
+        s->touch.words[a] = (uint32_t)words;
+        hipError_t e = device_alloc((void **)&s->touch.bits[a], (size_t)words * 8 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(s->touch.bits[a], 0, (size_t)words * 8 * sizeof(uint32_t));
+        if (e != hipSuccess) { touch_release(s); (void)hipGetLastError(); return fail(SDFHIP_ERR_NOMEM, "debug_touch_begin: %s", hipGetErrorString(e)); }
+    }
+    const size_t rbytes = (size_t)sdfhip_scene::Touch::MAX_PHASES * 8 * sizeof(unsigned long long);
+    hipError_t e = device_alloc((void **)&s->touch.result, rbytes);
+    if (e == hipSuccess) e = hipMemset(s->touch.result, 0, rbytes);
+    if (e != hipSuccess) { touch_release(s); (void)hipGetLastError(); return fail(SDFHIP_ERR_NOMEM, "debug_touch_begin: %s", hipGetErrorString(e)); }
+    s->touch.on = true; s->touch.phase = 0;
+    return SDFHIP_OK;
+}
+SDFHIP_ABI_CATCH(sdfhip_debug_touch_begin)
+
+extern "C" int sdfhip_debug_touch_end(sdfhip_scene *s, uint64_t *out, uint32_t max_phases, uint32_t *n_phases, uint64_t *array_bytes4)
+try {
+    if (!s || !out || !n_phases) return fail(SDFHIP_ERR_ARG, "debug_touch_end: null argument");
+    std::lock_guard<std::mutex> lk(s->lock);
+    DeviceGuard g(s->device);
+    if (!g.ok) return (void)hipGetLastError(), fail(SDFHIP_ERR_DEVICE, "debug_touch_end: hipSetDevice(%d) failed", s->device);
+    if (!s->touch.on) return fail(SDFHIP_ERR_ARG, "debug_touch_end: sdfhip_debug_touch_begin has not been called on this scene");
+    HIP_TRY(hipDeviceSynchronize());
+    const uint32_t n = s->touch.phase < max_phases ? s->touch.phase : max_phases;
+    if (n) HIP_TRY(hipMemcpy(out, s->touch.result, (size_t)n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    *n_phases = n;
+    if (array_bytes4) {
+        array_bytes4[0] = (uint64_t)sizeof(TopCell) << (3 * s->top_level); array_bytes4[1] = s->fine_bytes;
+        array_bytes4[2] = s->d_top2 ? (uint64_t)sizeof(TopCell) << (3 * s->top2_level) : 0;
+        array_bytes4[3] = s->d_top2 ? s->top2_bytes - array_bytes4[2] : 0;
+    }
+    touch_release(s);
+    return SDFHIP_OK;
+}
+SDFHIP_ABI_CATCH(sdfhip_debug_touch_end)
 
 extern "C" int sdfhip_debug_step_classes(sdfhip_scene *s, void *stream, uint64_t *out6)
 try {

@@ -231,6 +231,31 @@ __global__ void k_deinterleave_sparse(const uint8_t *__restrict__ gathered, floa
     }
 }
 
+// sdfhip_debug_touch_*: the distinct lines of a pair of bitmaps ([8 XCDs][words] each) -> out[0..1] chip-wide (the OR over the
+// XCDs), out[2..3] summed over the XCDs; the bitmaps are cleared for the next phase
+__global__ __launch_bounds__(256) void k_touch_count(uint32_t *a, uint32_t words_a, uint32_t *b, uint32_t words_b, unsigned long long *out)
+{
+    unsigned long long any[2] = { 0, 0 }, sum[2] = { 0, 0 };
+    for (int k = 0; k < 2; k++) {
+        uint32_t *bits = k ? b : a;
+        const uint32_t words = k ? words_b : words_a;
+        if (!bits) continue;
+        for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
+            uint32_t u = 0;
+            for (uint32_t x = 0; x < 8; x++) {
+                const uint32_t v = bits[(size_t)x * words + w];
+                u |= v; sum[k] += (unsigned long long)__popc(v);
+                bits[(size_t)x * words + w] = 0u;
+            }
+            any[k] += (unsigned long long)__popc(u);
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        for (int o = 32; o > 0; o >>= 1) { any[k] += __shfl_down(any[k], o); sum[k] += __shfl_down(sum[k], o); }
+        if ((threadIdx.x & 63u) == 0u) { if (any[k]) atomicAdd(&out[k], any[k]); if (sum[k]) atomicAdd(&out[2 + k], sum[k]); }
+    }
+}
+
 __global__ void k_unorm_table(float *out)
 {
     out[threadIdx.x] = unorm8((float)threadIdx.x);

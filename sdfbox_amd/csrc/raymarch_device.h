@@ -55,8 +55,23 @@ struct GridRef {
     const TopCell *top; const TopCell *fine; int level; int fine_bits; int fine_order;
 #ifdef SDFHIP_EXPERIMENTS
     const uint32_t *d4 = nullptr; const uint4 *recs = nullptr;
+    // sdfhip_debug_touch_*: one bit per 128-byte line of `top` / `fine` and XCD ([8][words]), set by the COUNTING kernels' lookups
+    uint32_t *touch_top = nullptr, *touch_fine = nullptr; uint32_t touch_top_words = 0, touch_fine_words = 0;
 #endif
 };
+#ifdef SDFHIP_EXPERIMENTS
+// The line of cell `cell` (16-byte cells, 8 to a 128-byte line: the arrays are hipMalloc'ed, so line-aligned) is marked in the
+// bitmap of the XCD this wave runs on (HW_REG_XCC_ID, hwreg 20 bits 3:0).  Counting builds only: what a frame MUST fetch is
+// the distinct lines it touches -- chip-wide with one ideal cache, per XCD with eight ideal L2s that share nothing.
+__device__ __forceinline__ void touch_line(uint32_t *bits, uint32_t words, uint32_t cell)
+{
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+    const uint32_t line = cell >> 3;
+    uint32_t *w = bits + (size_t)xcc * words + (line >> 5);
+    const uint32_t bit = 1u << (line & 31u);
+    if (!(*reinterpret_cast<volatile uint32_t *>(w) & bit)) atomicOr(w, bit);
+}
+#endif
 __host__ __device__ __forceinline__ uint32_t fine_cell_index(uint32_t x, uint32_t y, uint32_t z, int FB, int order)
 {
     if (order == 0) return x | (y << FB) | (z << (2 * FB));
@@ -78,6 +93,8 @@ struct RenderParams {
 #ifdef SDFHIP_EXPERIMENTS
     const uint32_t *d4;        // the grid as 4-byte words (CursorFF): a flat leaf's distance, or where a non-flat leaf's sample record is; or null
     const uint4 *recs;         // ... the records, biased by the words' tag (see find_sample_ff)
+    uint32_t *touch_top, *touch_fine;            // sdfhip_debug_touch_*: see GridRef (null: off)
+    uint32_t touch_top_words, touch_fine_words;
 #endif
     float4 *out;               // compact rows: nrows_out x width
     uint32_t width, height;    // full frame
@@ -535,8 +552,12 @@ template <bool EXACT, bool SPLIT, bool ORDERED>
 __device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT, ORDERED> &c, const GridRef &g, int32_t Dx, int32_t Dy, int32_t Dz)
 {
     const int TG = g.level, sh = LM - TG;
-    uint4 e = reinterpret_cast<const uint4 *>(g.top)[top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG)];
+    const uint32_t ti = top_index((uint32_t)Dx >> sh, (uint32_t)Dy >> sh, (uint32_t)Dz >> sh, TG);
+    uint4 e = reinterpret_cast<const uint4 *>(g.top)[ti];
     c.loads++;
+#ifdef SDFHIP_EXPERIMENTS
+    if (EXACT && g.touch_top) touch_line(g.touch_top, g.touch_top_words, ti);
+#endif
     if (SPLIT) {
         // one 16-byte load for the whole cell (left alone, the compiler fetches level and children first
         // and the values in a second, dependent load)
@@ -546,6 +567,9 @@ __device__ __forceinline__ int load_cell(CursorFT<EXACT, SPLIT, ORDERED> &c, con
             const int FB = g.fine_bits, sh2 = sh - FB;
             const uint32_t m = (1u << FB) - 1u;
             const uint32_t local = fine_cell_index(((uint32_t)Dx >> sh2) & m, ((uint32_t)Dy >> sh2) & m, ((uint32_t)Dz >> sh2) & m, FB, ORDERED ? g.fine_order : 0);
+#ifdef SDFHIP_EXPERIMENTS
+            if (EXACT && g.touch_fine) touch_line(g.touch_fine, g.touch_fine_words, e.w + local);
+#endif
             e = reinterpret_cast<const uint4 *>(g.fine)[e.w + local];      // children = the block's first cell (32-bit: < 2^31 fine cells)
         }
     }

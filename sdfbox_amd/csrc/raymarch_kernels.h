@@ -46,7 +46,8 @@ template <bool COUNT> struct CursorOf<CUR_STACK_SPLIT, COUNT> { typedef CursorFT
 __device__ __forceinline__ GridRef grid_of(const RenderParams &P, const TopCell *top = nullptr)
 {
 #ifdef SDFHIP_EXPERIMENTS
-    return GridRef{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order, P.d4, P.recs};
+    return GridRef{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order, P.d4, P.recs,
+                   P.touch_top, P.touch_fine, P.touch_top_words, P.touch_fine_words};
 #else
     return GridRef{top ? top : P.top, P.fine, P.top_level, P.fine_bits, P.fine_order};
 #endif

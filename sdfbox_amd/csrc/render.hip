@@ -237,6 +237,7 @@ int launch_pt_pipeline(sdfhip_scene *s, dim3 grid, hipStream_t st, RenderParams 
         return fail(SDFHIP_ERR_DEVICE, "render_path: hipMemsetAsync failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL((k_pt_primary<CUR, COUNT>), grid, dim3(64), 0, st, P);
 #ifdef SDFHIP_EXPERIMENTS
+    if (COUNT && s->touch.on) touch_phase(s, st, 0);   // sdfhip_debug_touch_*: the camera segments' lines, counted on their own
     uint32_t pt_sort_from = 0;                          // SDFHIP_PT_SORT_FROM=b: only the levels from b on are ordered
     if (const char *env = getenv("SDFHIP_PT_SORT_FROM")) pt_sort_from = (uint32_t)atoi(env);
 #endif
@@ -264,8 +265,14 @@ int launch_pt_pipeline(sdfhip_scene *s, dim3 grid, hipStream_t st, RenderParams 
             hipLaunchKernelGGL((k_pt_scatter<0>), sort_grid, dim3(PT_SORT_THREADS), 0, st, Pb);
         }
 #endif
+#ifdef SDFHIP_EXPERIMENTS
+        if (COUNT && s->touch.on) touch_params(s, Pb, s->d_top2 ? 2 : 0);
+#endif
         if (s->d_top2) hipLaunchKernelGGL((k_pt_bounce<CUR_STACK_SPLIT, COUNT>), dim3(resident), dim3(64), 0, st, Pb);
         else           hipLaunchKernelGGL((k_pt_bounce<CUR, COUNT>), dim3(resident), dim3(64), 0, st, Pb);
+#ifdef SDFHIP_EXPERIMENTS
+        if (COUNT && s->touch.on) touch_phase(s, st, s->d_top2 ? 2 : 0);     // ... and every bounce level's
+#endif
     }
     const size_t npx = (size_t)P.nrows_out * P.width;
     const uint32_t rb = (uint32_t)((npx + 255) / 256 < 4096 ? (npx + 255) / 256 : 4096);
@@ -457,6 +464,9 @@ int sdfhip::render_impl(sdfhip_scene *s, const RenderCall &c, sdfhip_scene::Stat
         HIP_TRY(hipMemsetAsync(P.counters, 0, sdfhip_scene::CTL_COUNTER_WORDS * sizeof(uint32_t), st));
     }
     if (c.pt && plan.grid_lookup) ensure_scatter_grid(s);     // (before the clock)
+#ifdef SDFHIP_EXPERIMENTS
+    if (s->touch.on && plan.count) touch_params(s, P, 0);      // sdfhip_debug_touch_*: this render's lookups mark the lines they touch
+#endif
     if (ticket) HIP_TRY(hipEventRecord(ticket->ev0, st));
     bool launched = false;
 #ifdef SDFHIP_EXPERIMENTS
@@ -471,6 +481,9 @@ int sdfhip::render_impl(sdfhip_scene *s, const RenderCall &c, sdfhip_scene::Stat
         if (rc != SDFHIP_OK) return rc;
     }
     HIP_TRY(hipGetLastError());
+#ifdef SDFHIP_EXPERIMENTS
+    if (s->touch.on && plan.count && !(c.pt && plan.grid_lookup)) touch_phase(s, st, 0);    // (the path-traced pipeline closes a phase per kernel)
+#endif
     if (ticket) {
         ticket->kernel_used = (plan.use_stack ? SDFHIP_KERNEL_STACK : SDFHIP_KERNEL_GENERIC) | (plan.compact ? SDFHIP_FLAG_COMPACT : 0u);
         if (plan.count) {

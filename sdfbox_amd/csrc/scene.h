@@ -94,6 +94,19 @@ struct sdfhip_scene {
     uint64_t d4_bytes = 0;
     const uint32_t *dbg_tile_perm = nullptr;   // sdfhip_debug_tile_order: experiment hooks for k_march
     uint16_t *dbg_tile_cost = nullptr;
+    // sdfhip_debug_touch_begin / _end (lab.hip): the distinct 128-byte lines of the grid arrays that counting renders touch.
+    // bits[a]: [8 XCDs][words[a]] bitmaps of array a (0 top, 1 fine, 2 top2, 3 fine2: the bounce levels' grid); a "phase" is a
+    // kernel launch whose lines are counted on their own (a whole frame of the default kernel; the camera segments and every bounce
+    // level of the path-traced pipeline): result[phase][0..1] = lines of (top, fine) or (top2, fine2) chip-wide, [2..3] = the
+    // same summed over the XCDs, [4] = which pair (0 / 2)
+    struct Touch {
+        static constexpr uint32_t MAX_PHASES = 16;
+        uint32_t *bits[4] = { nullptr, nullptr, nullptr, nullptr };
+        uint32_t words[4] = { 0, 0, 0, 0 };
+        unsigned long long *result = nullptr;      // device, [MAX_PHASES][8]
+        uint32_t phase = 0;
+        bool on = false;
+    } touch;
 #endif
     std::mutex lock;                  // render on one handle is single-caller; this makes misuse safe
 };
@@ -181,6 +194,10 @@ void build_dense4(sdfhip_scene *s);
 // launched = true when one of them took the frame
 int launch_experiment(sdfhip_scene *s, const RenderCall &call, RenderParams &P, int cur, bool count, dim3 grid, bool *launched,
                       sdfhip_scene::Scratch **sc);
+// sdfhip_debug_touch_*: point P's lookups at the bitmaps of grid pair `pair` (0: the scene's own grid, 2: the bounce levels'), and
+// close a phase behind the launches issued so far on `st` (count the pair's lines into result[phase], clear its bitmaps)
+void touch_params(const sdfhip_scene *s, RenderParams &P, int pair);
+void touch_phase(sdfhip_scene *s, hipStream_t st, int pair);
 #endif
 
 }  // namespace sdfhip

@@ -52,6 +52,8 @@ try {
         if (s->d_fine) (void)hipFree(s->d_fine);
 #ifdef SDFHIP_EXPERIMENTS
         if (s->d_d4) (void)hipFree(s->d_d4);
+        for (int a = 0; a < 4; a++) if (s->touch.bits[a]) (void)hipFree(s->touch.bits[a]);      // (a sdfhip_debug_touch_begin without its _end)
+        if (s->touch.result) (void)hipFree(s->touch.result);
         if (s->d_recs) (void)hipFree(s->d_recs);
 #endif
         if (s->d_top2) (void)hipFree(s->d_top2);

@@ -228,6 +228,26 @@ class Scene:
         return dict(zip(("flat_coarse", "flat_fine", "nonflat_coarse", "nonflat_full_depth", "nonflat_between", "nonflat_outside"),
                         (int(v) for v in out)))
 
+    def touch_begin(self):
+        """From here to touch_end() every FLAG_COUNT render marks the 128-byte lines of the lookup grid its find() touches, per XCD
+        (sdfhip_debug_touch_begin; laboratory library)."""
+        _lib.need_lab("Scene.touch_begin")
+        check(lib.sdfhip_debug_touch_begin(self._h))
+
+    def touch_end(self):
+        """-> {"phases": [{"grid": "own" | "bounce", "coarse_lines", "fine_lines", "coarse_lines_xcd_sum", "fine_lines_xcd_sum"}, ...],
+        "array_bytes": {"coarse", "fine", "coarse2", "fine2"}}: the distinct lines each counted launch touched (a frame of the
+        default kernel is one phase; a path-traced frame is its camera segments and then one phase per bounce level), chip-wide and
+        summed over the XCDs (sdfhip_debug_touch_end)."""
+        _lib.need_lab("Scene.touch_end")
+        out = (ctypes.c_uint64 * (16 * 8))()
+        n = ctypes.c_uint32(0)
+        ab = (ctypes.c_uint64 * 4)()
+        check(lib.sdfhip_debug_touch_end(self._h, out, 16, ctypes.byref(n), ab))
+        phases = [{"grid": "own" if int(out[8 * i + 4]) == 0 else "bounce", "coarse_lines": int(out[8 * i]), "fine_lines": int(out[8 * i + 1]),
+                   "coarse_lines_xcd_sum": int(out[8 * i + 2]), "fine_lines_xcd_sum": int(out[8 * i + 3])} for i in range(n.value)]
+        return {"phases": phases, "array_bytes": dict(zip(("coarse", "fine", "coarse2", "fine2"), (int(v) for v in ab)))}
+
 
 class MultiScene:
     """A scene replicated on several GPUs of one node; a frame is ONE call (sdfhip_multi_*: bands dealt to the devices,
