@@ -34,7 +34,7 @@ from bench_report import (HBM_PEAK_GBS, KERNEL_SOURCES, VALU_PEAK_GINSTR, VALU_P
                           kernel_source_hash, load_pmc, measured_hbm_bandwidth, roofline)
 from bench_configs import bench_camera, grid_suffix, load_package, orbit_cameras, run_configs  # noqa: E402,F401
 from bench_sustained import GpuTelemetry, at_observed_clock, sustained_leg, sustained_seconds  # noqa: E402,F401
-from bench_sharded import Watchdog, main_single_process, measure_band_deal, measure_rank0_weight, spawn_ranks  # noqa: E402,F401
+from bench_sharded import Watchdog, link_check, main_single_process, measure_band_deal, measure_rank0_weight, spawn_ranks  # noqa: E402,F401
 
 # Wavefront ray compaction is measured 2-3 % slower than the plain kernel on this workload
 # (DESIGN.md section 4.4), so it is off unless asked for.
@@ -115,6 +115,9 @@ def parse():
                          "'frame' = one frame at a time across all devices, launch to completion (what a viewer waits for)")
     ap.add_argument("--init-timeout", type=float, default=90.0,
                     help="N > 1: seconds the rendezvous (init_process_group) and every later collective may take before it raises")
+    ap.add_argument("--link-timeout", type=float, default=10.0,
+                    help="N > 1: seconds a peer's first 1 MB message may take to reach rank 0 in the link check before every rank gives up "
+                         "(exit code 5, the link named)")
     ap.add_argument("--watchdog-seconds", type=float, default=-1.0,
                     help="a daemon thread writes the run's phase to stderr every few seconds and ends the process with exit code 3 once "
                          "the whole run has taken this long (-1 = default: 420 for N > 1, off for N = 1; 0 = off)")
@@ -184,8 +187,11 @@ def main():
             print(f"[bench rank {rank}] rendezvous failed after at most {args.init_timeout:.0f} s: not every one of the {world} ranks "
                   f"arrived ({type(e).__name__}: {str(e)[:300]})", file=sys.stderr, flush=True)
             raise SystemExit(4)
+    links = None
     if sharded and not nccl:
         rendezvous()                      # gloo needs no GPU: before anything touches one
+        if world > 1:                     # ... nor does the rehearsal of the link check (bench_sharded.link_check): through host buffers
+            links = link_check(torch, dist, rank, world, False, wd, ["host buffers"] * world, limit=args.link_timeout)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     ndev = torch.cuda.device_count()
@@ -202,6 +208,16 @@ def main():
         got = [None] * world
         dist.all_gather_object(got, bus_ids[0])
         bus_ids = got
+        if nccl:
+            # first contact with the links themselves, before the weight search times anything over them: 1 MB from every peer into
+            # rank 0, every byte compared, 10 s per link, a per-link table on stderr
+            peer = [None] * world
+            try:
+                mine = bool(torch.cuda.can_device_access_peer(device, 0 % ndev)) if device != 0 % ndev else True
+            except Exception:
+                mine = None
+            dist.all_gather_object(peer, mine)
+            links = link_check(torch, dist, rank, world, True, wd, bus_ids, limit=args.link_timeout, peer_access=peer)
 
     wd.phase("scene build + upload", quiet=True)
     # ---- scene: built on the host, resident in HBM before anything is timed ----------
@@ -278,7 +294,7 @@ def main():
     if sharded and world > 1 and w0 <= 0:
         if sparse2 and args.deal == "cost" and world <= n_bands_frame <= 512:
             # the bands dealt by their measured cost, rank 0 charged for the assembly (tiles.balanced_owner)
-            deal = measure_band_deal(sb, scene, cam, W, H, world, args.band_rows, flags, rank, nccl, G, nbuf, args.steps)
+            deal = measure_band_deal(sb, scene, cam, W, H, world, args.band_rows, flags, rank, nccl, G, nbuf, args.steps, burst=plan_ordered)
         else:
             w0 = measure_rank0_weight(sb, scene, cam, W, H, world, args.band_rows, flags, share_shape, px_dtype, px_bytes,
                                       rank, nccl, pt, compact, G, nbuf, sparse2)
@@ -373,6 +389,7 @@ def main():
             scene.DrawDevice(c, W, H, buf.data_ptr(), flags=f, stream=st, stats=stats)
 
     pending = [None] * nbuf
+    asm_ev = []                           # rank 0: (start, end, frames) HIP events around each assembly (expansion of all shares / de-interleave)
     ev = []                               # (start, end) HIP events around each timed launch
     rendered = 0                          # frames the timed launches rendered (= steps: a partial last group renders its own frames only)
 
@@ -396,7 +413,11 @@ def main():
             with torch.cuda.stream(st):
                 w.wait()                              # the group's stream waits for its gather
                 if rank == 0:
+                    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a0.record(st)
                     assemble(slot, st.cuda_stream)
+                    a1.record(st)
+                    asm_ev.append((a0, a1, G))
         elif rank == 0:                               # gloo rehearsal: through host buffers
             gathered[slot].copy_(torch.stack(w).cuda())
             assemble(slot, main)
@@ -411,7 +432,11 @@ def main():
             with torch.cuda.stream(st):
                 w.wait()
                 if rank == 0:
+                    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a0.record(st)
                     s2["expand"](slot, s2["ptrs"][slot], s2["frame_ptr"][slot], frames=n, counts_ptr=s2["counts_ptr"][slot], stream=st.cuda_stream)
+                    a1.record(st)
+                    asm_ev.append((a0, a1, n))
                     s2["ev"][slot].record(st)
         elif rank == 0:                                   # gloo rehearsal: through host buffers
             for r in range(1, world):
@@ -627,6 +652,7 @@ def main():
     wd.phase("timed region", quiet=True)              # (no print between the barrier and the clock)
     resent_before = resent                    # (the moving-camera passes above resend tails by design; the timed region should not)
     host_t.update(launch=0.0, gather=0.0, finish=0.0, groups=0)
+    del asm_ev[:]
     t_start = time.perf_counter()
     for k in range(args.steps):
         step(k, timed=True, last=(k == args.steps - 1))
@@ -644,6 +670,31 @@ def main():
     # stream each launch went to; with frames in flight the launches overlap each other)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in ev]))
     frames_per_launch = float(np.mean([n for _, _, n in ev]))
+    # every rank's OWN share time per frame (HIP events around its launches in the timed region: the launches of the groups in flight
+    # overlap, so this is a launch's duration, not the rank's throughput) and rank 0's assembly per frame -- one SCALE record shows an
+    # imbalance
+    per_rank_ms = [round(float(np.sum([a.elapsed_time(b) for a, b, _ in ev])) / max(1, sum(n for _, _, n in ev)), 5)]
+    rank0_assemble_ms = (round(float(np.sum([a.elapsed_time(b) for a, b, _ in asm_ev])) / max(1, sum(n for _, _, n in asm_ev)), 5)
+                         if (rank == 0 and asm_ev) else None)
+    if sharded and world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, per_rank_ms[0])
+        per_rank_ms = got
+    # ... and the run's STEADY STATE beside a short run's burst: a short sharded run (tiles.is_burst) deals its bands as that
+    # burst and launches in tile order; the same deal rendered for >= 16 fills of the pipeline in the default order is what a long run gets
+    steady = None
+    if sharded and world > 1 and pt is None and args.orbit == 0:
+        n_steady = max(args.steps, 16 * G * nbuf)
+        saved_flags = flags
+        if plan_ordered and not args.tile_order:
+            flags &= ~sb.FLAG_TILE_ORDER
+        try:
+            steady = {"ms_per_step": round(throughput_pass(cams, n_steady), 5), "steps": n_steady,
+                      "shares_in_tile_order": bool(flags & sb.FLAG_TILE_ORDER),
+                      "is": "the timed run's deal and buffers over >= 16 fills of the pipeline, in the launch order a long run uses "
+                            "(tiles.group_plan): the steady-state time per frame beside a short run's burst figure"}
+        finally:
+            flags = saved_flags
 
     wd.phase("check (assembled frames against a whole-frame render)")
     check_ok = None
@@ -667,7 +718,12 @@ def main():
                   for w in range(G) if g * G + w < args.steps]
         check_ok = all(bool(torch.equal(frame[sl][w].view(torch.int32), ref_of(k).view(torch.int32))) for sl, w, k in filled)
 
-    wd.phase("report (bandwidth, configs, cpu baseline on rank 0; the others wait at the last barrier)", quiet=world == 1)
+    # The ranks part HERE, before rank 0's report: nothing below is a collective, so a long report (the bandwidth kernels, with
+    # --configs all the other configurations) cannot run a peer's last barrier into the process group's timeout.
+    if sharded:
+        wd.phase("last barrier (every rank is done with its collectives)", limit=args.init_timeout + 60.0)
+        dist.barrier()
+    wd.phase("report (bandwidth, configs, cpu baseline: rank 0 alone, no collective)", quiet=world == 1)
     if rank == 0:
         sec_per_step = elapsed / args.steps
         copy_gbs = measured_hbm_bandwidth(sb, device)   # the box's own figure beside the nameplate
@@ -789,6 +845,16 @@ def main():
                 "shares_in_tile_order": bool(flags & sb.FLAG_TILE_ORDER) if sharded else None,
                 # rank 0's host time per gather group in the timed region, by part (the sparse-share pipeline): the launch call, issuing the
                 # gather (+ a peer's counter copy), and finish() -- the wait for the slot's previous group, its expansion call, the counters
+                # what a short run gets that a long one does not, from ONE predicate (tiles.is_burst): tile order on the batched launches,
+                # the band deal timed as that burst
+                "plan": ({"frames_per_gather": G, "groups_in_flight": nbuf, "burst": bool(plan_ordered),
+                          "band_deal_timed_as": (None if deal is None else f"{args.steps}-step burst" if plan_ordered else "steady state"),
+                          "shares_in_tile_order": bool(flags & sb.FLAG_TILE_ORDER)} if sharded else None),
+                "per_rank_ms": per_rank_ms if sharded else None,
+                "per_rank_ms_is": ("each rank's own launches in the timed region, HIP-event time per frame (groups in flight overlap: a launch's "
+                                   "duration, not a throughput)") if sharded else None,
+                "rank0_assemble_ms": rank0_assemble_ms,
+                "links": links,
                 "host_us_per_group": ({k: round(host_t[k] / max(1, host_t["groups"]) * 1e6, 1) for k in ("launch", "gather", "finish")}
                                       if sparse2 and host_t["groups"] else None),
                 "float_tails_sent_again": resent if sparse2 else None,
@@ -804,6 +870,9 @@ def main():
             "latency": latency,
             "roofline": roof,
         }
+        if steady is not None:
+            steady["value"] = round(W * H * max(1, args.spp) / (steady["ms_per_step"] * 1e-3) / 1e6, 2)
+            out["steady_state"] = steady
         if check_ok is not None:
             out["config"]["assembled_frame_equals_whole_frame_render"] = check_ok
         if sustained is not None:
@@ -829,7 +898,6 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     scene.close()
     if sharded:
-        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -230,6 +230,100 @@ def main_single_process(args, json_fd):
     ms.close()
 
 
+LINK_CHECK_EXIT = 5
+
+
+def link_check(torch, dist, rank, world, nccl, wd, names, limit=10.0, nbytes=1 << 20, peer_access=None):
+    """First contact with the LINKS, before anything depends on them (the library's own design has the same step
+    at create: sdfhip_multi_selftest).  Every peer sends rank 0 one `nbytes` message of a pattern that only it makes (the
+    direction every gather and every resent tail takes: over xGMI each peer has its own link into rank 0); rank 0 waits at most
+    `limit` seconds per link, compares every byte, prints a per-link table on stderr and tells everyone the verdict in a broadcast.
+    A link that is silent or delivers other bytes ends EVERY rank non-zero (exit code 5) with the link named; a rank that waits
+    for a verdict which never comes is ended by the watchdog (exit code 3) with this phase in its message.
+    names[r]: how rank r is called in the table (its PCI bus id, or 'host buffers' in the gloo rehearsal).  peer_access[r]: what
+    hipDeviceCanAccessPeer said about r's device and rank 0's (None: not asked).  -> the table's rows (rank 0) or None."""
+    import datetime
+    dev = "cuda" if nccl else "cpu"
+    # test hook (tests/test_first_contact.py): 'corrupt:R' -- rank R's payload is damaged on the way; 'silent:R' -- rank R never sends
+    fault = os.environ.get("SDFHIP_BENCH_LINK_FAULT", "")
+    fkind, _, frank = fault.partition(":")
+    frank = int(frank) if frank.strip().isdigit() else -1
+
+    def pattern(r):
+        i = torch.arange(nbytes, dtype=torch.int64, device=dev)
+        return ((i * 131 + r * 17 + (i >> 9)) % 251).to(torch.uint8)
+
+    def name(r):
+        return f"rank {r} ({names[r]})"
+    verdict = torch.zeros(world, dtype=torch.int32, device=dev)          # 0 ok, 1 other bytes, 2 nothing within the limit
+    rows = None
+    if rank == 0:
+        rows = []
+        for r in range(1, world):
+            wd.phase(f"link check: {name(r)} -> {name(0)}, {nbytes >> 10} KB, at most {limit:.0f} s", limit=limit + 20.0)
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            t0 = time.perf_counter()
+            work = dist.irecv(buf, src=r)
+            done = False
+            if nccl:                                                       # (a wait with a timeout does not bound a CUDA-side receive: poll its event)
+                while time.perf_counter() - t0 < limit:
+                    if work.is_completed():
+                        done = True
+                        break
+                    time.sleep(0.0005)
+                if done:
+                    work.wait()
+                    torch.cuda.synchronize()
+            else:                                                          # (gloo's receive completes inside wait(): the timeout goes there)
+                try:
+                    work.wait(datetime.timedelta(seconds=limit))
+                    done = True
+                except Exception:
+                    done = False
+            ms = (time.perf_counter() - t0) * 1e3
+            row = {"link": f"{name(r)} -> {name(0)}", "peer_access": None if peer_access is None else peer_access[r], "ms": round(ms, 3),
+                   "gb_per_s": round(nbytes / (ms * 1e-3) / 1e9, 3) if done else None, "verdict": "ok"}
+            if not done:
+                row["verdict"] = f"NOTHING ARRIVED within {limit:.0f} s"
+                rows.append(row)
+                _print_links(rows)
+                print(f"[bench rank 0] link check FAILED: {row['link']}: {row['verdict']} (exit code {LINK_CHECK_EXIT}; the other ranks are "
+                      "ended by the launcher or by their own watchdog)", file=sys.stderr, flush=True)
+                os._exit(LINK_CHECK_EXIT)                                   # (the process group is wedged: no collective can tell the others)
+            if not bool(torch.equal(buf, pattern(r))):
+                bad = int((buf != pattern(r)).sum().item())
+                row["verdict"] = f"{bad} of {nbytes} bytes differ from what rank {r} sent"
+                verdict[r] = 1
+            rows.append(row)
+        _print_links(rows)
+    else:
+        wd.phase(f"link check: {name(rank)} -> {name(0)} (send, then rank 0's verdict)", limit=limit * world + 30.0)
+        if not (fkind == "silent" and frank == rank):
+            payload = pattern(rank)
+            if fkind == "corrupt" and frank == rank:
+                payload[nbytes // 3] ^= 0x40
+            dist.send(payload, dst=0)
+            if nccl:
+                torch.cuda.synchronize()
+    dist.broadcast(verdict, src=0)
+    bad = [r for r, v in enumerate(verdict.tolist()) if v]
+    if bad:
+        for r in bad:
+            print(f"[bench rank {rank}] link check FAILED: {name(r)} -> {name(0)} delivered other bytes than were sent: every rank ends "
+                  f"with exit code {LINK_CHECK_EXIT}", file=sys.stderr, flush=True)
+        os._exit(LINK_CHECK_EXIT)
+    return rows
+
+
+def _print_links(rows):
+    print("[bench rank 0] link check (one message from every peer into rank 0, every byte compared):", file=sys.stderr)
+    for r in rows:
+        pa = "" if r["peer_access"] is None else f", peer access {'yes' if r['peer_access'] else 'NO (copies stage through the host)'}"
+        rate = "" if r["gb_per_s"] is None else f" = {r['gb_per_s']} GB/s incl. the channel's set-up"
+        print(f"[bench rank 0]   {r['link']}{pa}: {r['ms']} ms{rate}: {r['verdict']}", file=sys.stderr)
+    sys.stderr.flush()
+
+
 def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_shape, px_dtype, px_bytes, rank, nccl, pt, compact,
                          G, nbuf, sparse2=False):
     """Rank 0 also assembles the frame (de-interleave, or the expansion of all ranks' sparse shares), so an
@@ -302,13 +396,13 @@ def measure_rank0_weight(sb, scene, cam, W, H, world, band_rows, flags, share_sh
     return float(w.item())
 
 
-def measure_band_deal(sb, scene, cam, W, H, world, band_rows, flags, rank, nccl, G, nbuf, steps):
+def measure_band_deal(sb, scene, cam, W, H, world, band_rows, flags, rank, nccl, G, nbuf, steps, burst=None):
     """The frame's bands dealt by their measured COST (tiles.balanced_owner), with rank 0 -- which also expands all shares into
     the frame -- charged for that work.  Before anything is timed, rank 0 renders the frame once, prices every band from the
     step counts (tiles.band_costs), and tries deals that charge it 0 .. 20 % of the frame's cost for the assembly: for each it
     times its own job (its share + the expansion of `world` shares, its own standing in for the peers') and two peers' shares
-    (the scene is replicated: it can render them itself), in the shape the run will have (a short run -- the driver's scaling run
-    times 20 steps -- is timed as that burst).  Every rank then receives the deal with the smallest maximum.  -> owner[band]."""
+    (the scene is replicated: it can render them itself), in the shape the run will have (a short run -- tiles.is_burst: the driver's
+    scaling run times 20 steps -- is timed as that burst; the same predicate puts its launches in tile order).  Every rank then receives the deal with the smallest maximum.  -> owner[band]."""
     import torch
     import torch.distributed as dist
     T = sb.tiles
@@ -323,7 +417,8 @@ def measure_band_deal(sb, scene, cam, W, H, world, band_rows, flags, rank, nccl,
         del whole
         total = sum(costs)
         frames = torch.zeros((G, H, W, 4), dtype=torch.float32, device="cuda")
-        burst = 0 < steps <= 64
+        if burst is None:                                     # (one predicate for "a short run": tiles.is_burst, also behind the tile order)
+            burst = T.is_burst(world, steps)
         n_frames = steps if burst else 16 * G
 
         def job(lay, r, shares, expand):

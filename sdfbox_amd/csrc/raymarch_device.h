@@ -160,6 +160,7 @@ struct RenderParams {
     uint32_t *pt_perm;
     uint32_t *pt_hist;
     uint32_t pt_sort_bits;
+    uint32_t pt_sort_xcd;          // ... and each XCD walks a contiguous eighth of that order (SDFHIP_PT_SORT_XCD=1)
 #endif
     // k_march, optional: tile_perm[b] = the tile workgroup b renders, as tile row << 16 | tile column (a permutation of the
     // default order: the previous frame's expensive tiles first; all ones = idle); tile_cost[tile] = march iterations the tile's wave ran

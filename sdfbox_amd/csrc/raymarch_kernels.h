@@ -1412,12 +1412,19 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
     // ordered (P.pt_sort_bits, an A/B): chunk t = slots 64 t .. of the permutation; else the queue's own chunks
     const uint32_t n_sorted = P.pt_sort_bits ? P.pt_hist[8u << (3 * P.pt_sort_bits)] : 0u;
     const uint32_t nchunks = P.pt_sort_bits ? (n_sorted + 63u) >> 6 : C.nchunks;
+    // ... and (P.pt_sort_xcd, round 6's attempt at the bounce levels' refetch factor) every XCD walks a contiguous eighth of that order
+    // front to back instead of every eighth chunk of all of it: the workgroups that share an L2 work in the same part of the scene
+    // (blockIdx.x & 7 names the workgroups that share an XCD under round-robin placement: speed only)
+    const bool by_xcd = P.pt_sort_bits && P.pt_sort_xcd;
+    const uint32_t per_xcd = (nchunks + 7u) >> 3, t_first = by_xcd ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t t_end = by_xcd ? min(((blockIdx.x & 7u) + 1u) * per_xcd, nchunks) : nchunks, t_step = by_xcd ? gridDim.x >> 3 : gridDim.x;
 #else
     const uint32_t nchunks = C.nchunks;
+    const uint32_t t_first = blockIdx.x, t_end = nchunks, t_step = gridDim.x;
 #endif
     unsigned long long cn = 0, cs = 0, cr = 0, cl = 0;
     const float4 *Q = P.pt_q[qin];
-    for (uint32_t t = blockIdx.x; t < nchunks; t += gridDim.x) {
+    for (uint32_t t = t_first; t < t_end; t += t_step) {
         uint32_t e32;
 #ifdef SDFHIP_EXPERIMENTS
         if (P.pt_sort_bits) { const uint32_t slot = t * 64u + lane; e32 = slot < n_sorted ? P.pt_perm[slot] : 0xFFFFFFFFu; }

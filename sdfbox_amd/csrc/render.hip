@@ -317,6 +317,7 @@ int launch_path(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &pla
         P.pt_hist = reinterpret_cast<uint32_t *>(base + n_entries * 4);
         P.pt_key = reinterpret_cast<uint16_t *>(base + n_entries * 4 + (((size_t)8 << (3 * PT_SORT_MAX_BITS)) + 64) * 4);
         P.pt_sort_bits = sort_bits;
+        if (const char *env = getenv("SDFHIP_PT_SORT_XCD")) P.pt_sort_xcd = atoi(env) != 0 ? 1u : 0u;
     }
 #endif
     P.pt_q[0] = reinterpret_cast<float4 *>(sc->pt_buf);

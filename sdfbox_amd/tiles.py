@@ -166,8 +166,16 @@ def group_plan(world, steps=0):
     12.3 -> 13.7 us per frame in the steady state (scripts/rank_emulation.py, profiles/r05_rank_emulation.txt)."""
     G = 8 if world >= 8 else 4
     nbuf = 4
-    ordered = 0 < steps <= 4 * G * nbuf
-    return G, nbuf, ordered
+    return G, nbuf, is_burst(world, steps)
+
+
+def is_burst(world, steps):
+    """THE predicate of a short sharded run: `steps` frames are at most four fills of the pipeline (4 x frames per
+    launch x launches in flight).  Everything that treats a short run differently asks this one function: group_plan (tile order
+    on the batched launches) and bench.py's band deal (timed as that very burst instead of in the steady state).  The line prints
+    it (config.plan), and a steady-state figure beside the burst's (`steady_state`)."""
+    G = 8 if world >= 8 else 4
+    return 0 < steps <= 4 * G * 4
 
 
 def wire_shape(rows, width):

@@ -17,8 +17,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _start(rank, world, port, *args):
+def _start(rank, world, port, *args, **extra_env):
     env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.update(extra_env)
     return subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "2",
                              "--warmup", "1"] + [str(a) for a in args], env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
@@ -46,3 +47,53 @@ def test_the_watchdog_ends_a_stuck_run_with_exit_code_3_and_names_the_phase():
     assert time.time() - t0 < 45
     assert p.returncode == 3, (p.returncode, err[-1500:])
     assert "WATCHDOG" in err and "in phase 'rendezvous (gloo init_process_group, world 2" in err and "exit code 3" in err, err[-1500:]
+
+
+# ---- the link check (bench_sharded.link_check): one message from every peer into rank 0 before anything depends on a link ----------
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+def test_the_link_check_prints_a_table_and_lets_a_healthy_run_go_on():
+    # world 2 through gloo (host buffers): the check passes, rank 0 prints one row per peer; without a GPU the run then ends where the
+    # product says it has no CPU path -- after the check, not in it
+    port = _free_port()
+    procs = [_start(r, 2, port, "--init-timeout", 30, "--watchdog-seconds", 60) for r in (0, 1)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    err0 = outs[0][1]
+    assert "link check (one message from every peer into rank 0, every byte compared)" in err0, err0[-2000:]
+    assert "rank 1 (host buffers) -> rank 0 (host buffers)" in err0 and ": ok" in err0, err0[-2000:]
+    if _no_gpu():
+        for p, (out, err) in zip(procs, outs):
+            assert p.returncode not in (0, 3, 4, 5) and "no CPU path" in err, (p.returncode, err[-1500:])
+
+
+def test_a_link_that_delivers_other_bytes_ends_every_rank_with_the_link_named():
+    # rank 1's payload is damaged on the way (test hook SDFHIP_BENCH_LINK_FAULT): rank 0 finds the bytes that differ, tells everyone
+    # in the verdict's broadcast, and ALL THREE ranks end with exit code 5 naming the link -- also rank 2, whose own link is fine
+    port = _free_port()
+    t0 = time.time()
+    procs = [_start(r, 3, port, "--init-timeout", 30, "--watchdog-seconds", 60, SDFHIP_BENCH_LINK_FAULT="corrupt:1") for r in (0, 1, 2)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert time.time() - t0 < 120
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 5, (r, p.returncode, err[-1500:])
+        assert "link check FAILED: rank 1 (host buffers) -> rank 0 (host buffers) delivered other bytes" in err, (r, err[-1500:])
+        assert not [l for l in out.splitlines() if l.startswith("{")]
+    assert "1 of 1048576 bytes differ from what rank 1 sent" in outs[0][1]
+    assert "rank 2 (host buffers) -> rank 0 (host buffers)" in outs[0][1]          # the table still holds the healthy link's row
+
+
+def test_a_silent_link_ends_rank_0_inside_the_limit_and_the_peer_non_zero():
+    # rank 1 never sends: rank 0 waits --link-timeout seconds, prints the table with that row and leaves with exit code 5; rank 1 is
+    # left in the verdict's broadcast, which fails once rank 0 is gone (or its watchdog ends it): non-zero either way
+    port = _free_port()
+    t0 = time.time()
+    procs = [_start(r, 2, port, "--init-timeout", 30, "--link-timeout", 3, "--watchdog-seconds", 25, SDFHIP_BENCH_LINK_FAULT="silent:1")
+             for r in (0, 1)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert time.time() - t0 < 120
+    assert procs[0].returncode == 5, (procs[0].returncode, outs[0][1][-1500:])
+    assert "NOTHING ARRIVED within 3 s" in outs[0][1] and "link check FAILED: rank 1 (host buffers) -> rank 0 (host buffers)" in outs[0][1]
+    assert procs[1].returncode != 0, outs[1][1][-1500:]
