@@ -31,7 +31,7 @@ sys.path.insert(0, REPO)
 # The driver's path is this file; what the line says about a measurement, the other configurations and the N > 1 machinery are
 # modules beside it (their names stay importable from here: tests and scripts say bench.roofline, bench.orbit_cameras, ...).
 from bench_report import (HBM_PEAK_GBS, KERNEL_SOURCES, VALU_PEAK_GINSTR, VALU_PEAK_SPEC_GINSTR, configs_summary, cpu_baseline,  # noqa: E402,F401
-                          kernel_source_hash, load_pmc, measured_hbm_bandwidth, roofline)
+                          kernel_source_hash, load_compulsory, load_pmc, measured_hbm_bandwidth, roofline)
 from bench_configs import bench_camera, grid_suffix, load_package, orbit_cameras, run_configs  # noqa: E402,F401
 from bench_sustained import GpuTelemetry, at_observed_clock, sustained_leg, sustained_seconds  # noqa: E402,F401
 from bench_sharded import Watchdog, link_check, main_single_process, measure_band_deal, measure_rank0_weight, spawn_ranks  # noqa: E402,F401
@@ -735,9 +735,17 @@ def main():
         if sharded:
             mode += ":sharded"                         # other kernel instances (sparse shares, bands): no PMC pass of its own
         # ... and of the same grid (SDFHIP_TOP_GRID_LEVEL / _SPLIT change it): "grid9" dense, "grid8+blocks" split
-        mode += grid_suffix(scene, pt)
-        pmc = load_pmc(f"{W}x{H}:{scene_name}:{mode}") if world == 1 else None
-        roof = roofline(sec_per_step, own_bytes_rank, ref_bytes_rank, pmc, copy_gbs)
+        if args.orbit > 0:
+            mode += f":orbit{args.orbit}"                # a camera that moves every frame: counters of its own (profiles/*_orbit_pmc.json)
+        key_base, gsuf = f"{W}x{H}:{scene_name}:{mode}", grid_suffix(scene, pt)
+        mode += gsuf
+        pmc = load_pmc(key_base + gsuf) if world == 1 else None
+        comp = load_compulsory(key_base + gsuf) if world == 1 else None
+        # the headline also reports the counters of the same command under --orbit 90 (a new camera every frame), over that pass's time
+        orbit_pmc = None
+        if world == 1 and not sharded and args.orbit == 0 and "orbit_ms_per_step" in latency:
+            orbit_pmc = {"pmc": load_pmc(f"{key_base}:orbit{len(orbit)}{gsuf}"), "ms_per_step": latency["orbit_ms_per_step"], "cameras": len(orbit)}
+        roof = roofline(sec_per_step, own_bytes_rank, ref_bytes_rank, pmc, copy_gbs, compulsory=comp, latency_ms=latency["ms"], orbit=orbit_pmc)
         # what the fraction divides by, so that it can be recomputed from profiles/: per_frame / time_ms / peak.  kernel_ms is
         # the HIP-event time around one frame's launches on their stream (k_march; overlapping the other frame in
         # flight), and frac_over_kernel_ms the same fraction over that longer time

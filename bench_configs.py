@@ -13,7 +13,7 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 
-from bench_report import HBM_PEAK_GBS, VALU_PEAK_SPEC_GINSTR, kernel_source_hash, load_pmc
+from bench_report import HBM_PEAK_GBS, VALU_PEAK_SPEC_GINSTR, compulsory_fields, kernel_source_hash, load_compulsory, load_pmc
 from bench_sustained import at_observed_clock, sustained_leg
 
 
@@ -115,6 +115,7 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
                 e["valu_insts_per_frame"] = int(pmc["valu_insts_per_frame"])
                 e["valu_frac_of_spec"] = round(pmc["valu_insts_per_frame"] / sec / 1e9 / VALU_PEAK_SPEC_GINSTR, 4)
             e["limiting"] = "hbm" if (e["hbm_frac"] or 0) >= (e["valu_frac_of_spec"] or 0) else "valu"
+            e.update(compulsory_fields(e["traffic"], load_compulsory(key)))
         if sustained > 0 and pt is None:
             # the same frames without a stop, the GPU's clocks sampled (bench_sustained.py)
             try:

@@ -51,6 +51,37 @@ def load_pmc(key):
     return e
 
 
+def load_compulsory(key):
+    """The compulsory bytes of this design for workload `key` (profiles/compulsory_bytes.json, written by
+    scripts/compulsory_bytes.py from the laboratory library's line-touch bitmaps: every distinct 128-byte line of the lookup grid
+    that the frame's find() touches, once, + the frame it stores + -- path-traced mode -- the queues and per-path results between
+    its launches), or {"dropped": reason}.  Like the PMC figures it belongs to a build: other kernel sources, no figure."""
+    try:
+        with open(os.path.join(REPO, "profiles", "compulsory_bytes.json")) as f:
+            e = json.load(f).get(key)
+    except (OSError, ValueError):
+        return {"dropped": "profiles/compulsory_bytes.json is missing or unreadable"}
+    if not isinstance(e, dict):
+        return {"dropped": f"no line count of workload '{key}' under profiles/ (scripts/compulsory_bytes.py)"}
+    here = kernel_source_hash()
+    if e.get("kernel_source_sha") != here:
+        return {"dropped": f"the line count of '{key}' was taken on kernel sources {e.get('kernel_source_sha')}; this build is {here}"}
+    return e
+
+
+def compulsory_fields(traffic, comp):
+    """-> the keys a roofline object / a `configs` entry carries about the compulsory bytes: what the frame MUST move (chip-wide: one
+    ideal cache in front of HBM; per XCD: eight ideal L2s that share nothing, the bound of the L2s' fabric-side counters given which
+    XCD renders what) and the counter traffic over each."""
+    if not isinstance(comp, dict) or "dropped" in comp or not comp.get("compulsory_bytes"):
+        return {"compulsory_bytes": None, "traffic_over_compulsory": None, "compulsory_bytes_per_xcd": None, "traffic_over_compulsory_per_xcd": None,
+                "compulsory_dropped": (comp or {}).get("dropped") if isinstance(comp, dict) else "no line count"}
+    c, cx = int(comp["compulsory_bytes"]), int(comp["compulsory_bytes_per_xcd"])
+    return {"compulsory_bytes": c, "traffic_over_compulsory": round(traffic / c, 3) if traffic else None,
+            "compulsory_bytes_per_xcd": cx, "traffic_over_compulsory_per_xcd": round(traffic / cx, 3) if traffic else None,
+            "compulsory_lines": comp.get("distinct_lines"), "compulsory_lines_summed_over_xcds": comp.get("distinct_lines_summed_over_xcds")}
+
+
 # VALU issue ceilings, in wave64 instructions per second chip-wide:
 #   spec      256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles: a SIMD retires 32 lanes per clock (the 157.3 TFLOP/s fp32 vector figure
 #             = 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flops), so a wave64 instruction takes two
@@ -64,7 +95,7 @@ HBM_PEAK_GBS = 8000.0                    # HBM3E spec (MI355X_MICROARCH.md)
 N_SIMD, CLOCK_GHZ = 256 * 4, 2.4
 
 
-def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, measured):
+def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, measured, compulsory=None, latency_ms=None, orbit=None):
     """The frame against its two roofs, both from the rocprofv3 counters of THIS build and workload (profiles/hbm_traffic.json;
     the PMC passes serialise launches -- one frame in flight while they count -- which changes times, not counts), over the
     steady-state time per frame (the driver-verifiable ms_per_step; with frames in flight the launch durations overlap):
@@ -108,7 +139,28 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, measured):
     cands = {k: v for k, v in (("hbm-traffic", hbm), ("valu", valu)) if v}
     limiting = max(cands, key=lambda k: cands[k]["frac"]) if cands else None
     own_over, ref_over = own_bytes / sec_per_frame / 1e9 / HBM_PEAK_GBS, ref_bytes / sec_per_frame / 1e9 / HBM_PEAK_GBS
-    return {
+    extra = compulsory_fields(traffic, compulsory)
+    # one frame at a time (what the reference's loop does): the same counter bytes over the LATENCY of a frame alone on the chip --
+    # the PMC passes serialise launches, so this is the condition the bytes were counted under
+    extra["hbm_frac_latency"] = round(traffic / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and latency_ms) else None
+    extra["valu_frac_of_spec_latency"] = (round(pmc["valu_insts_per_frame"] / (latency_ms * 1e-3) / 1e9 / VALU_PEAK_SPEC_GINSTR, 4)
+                                          if (pmc and pmc.get("valu_insts_per_frame") and latency_ms) else None)
+    extra["pmc_serialises_launches"] = ("rocprofv3 --pmc runs one launch at a time: the counts are a frame's, whatever is in flight in the timed "
+                                        "run; hbm_frac divides them by the pipelined time per frame, hbm_frac_latency by one frame's own time")
+    # the same passes with a camera that moves every frame (bench.py --orbit 90; profiles/*_orbit_pmc.json), over that run's time
+    if isinstance(orbit, dict) and orbit.get("pmc") and "dropped" not in orbit["pmc"] and orbit.get("ms_per_step"):
+        op, osec = orbit["pmc"], orbit["ms_per_step"] * 1e-3
+        extra["orbit"] = {"cameras": orbit.get("cameras"), "ms_per_step": orbit["ms_per_step"], "traffic": int(op["hbm_bytes_per_frame"]),
+                          "hbm_frac": round(op["hbm_bytes_per_frame"] / osec / 1e9 / HBM_PEAK_GBS, 4),
+                          "valu_insts_per_frame": int(op.get("valu_insts_per_frame") or 0),
+                          "valu_frac_of_spec": (round(op["valu_insts_per_frame"] / osec / 1e9 / VALU_PEAK_SPEC_GINSTR, 4)
+                                                if op.get("valu_insts_per_frame") else None),
+                          "profile": op.get("profile")}
+        extra["hbm_frac_orbit"] = extra["orbit"]["hbm_frac"]
+        extra["valu_frac_of_spec_orbit"] = extra["orbit"]["valu_frac_of_spec"]
+    elif isinstance(orbit, dict):
+        extra["orbit"] = {"dropped": (orbit.get("pmc") or {}).get("dropped", "no orbit pass")}
+    return {**{
         # the contract's object: the HBM roof, which is what SURVEY 8d / BASELINE ask the fraction of
         "bound": "hbm" if hbm else None,
         "achieved": hbm["achieved"] if hbm else None, "peak": hbm["peak"] if hbm else None, "unit": hbm["unit"] if hbm else None,
@@ -134,7 +186,7 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, measured):
                    "note": "requests to the memory system over 8 TB/s x time, NOT roofline fractions: the lookup grid built at upload replaces "
                            "the reference's descent and L1 / L2 serve most of the kernel's own loads (see roofline() in bench.py)"},
         "measured_hbm_gbs": measured,
-    }
+    }, **extra}
 
 
 def configs_summary(out, cfgs):
@@ -176,7 +228,18 @@ def configs_summary(out, cfgs):
     legs = [l for l in legs if l]
     if legs:
         text += " | sustained: " + "; ".join(legs)
-    return text[:980]
+    # traffic over the compulsory bytes of this design (scripts/compulsory_bytes.py): one ideal cache / eight unshared ideal L2s
+    ratios = []
+    r0 = out.get("roofline") or {}
+    if r0.get("traffic_over_compulsory"):
+        ratios.append(f"cfg2 {f(r0['traffic_over_compulsory'], 2)}/{f(r0.get('traffic_over_compulsory_per_xcd'), 2)}")
+    if isinstance(cfgs, dict):
+        for k, e in cfgs.items():
+            if isinstance(e, dict) and e.get("traffic_over_compulsory"):
+                ratios.append(f"{names.get(k, k[:10])} {f(e['traffic_over_compulsory'], 2)}/{f(e.get('traffic_over_compulsory_per_xcd'), 2)}")
+    if ratios:
+        text += " | traffic/compulsory (chip/per-XCD): " + "; ".join(ratios)
+    return text[:1400]
 
 
 def measured_hbm_bandwidth(sb, device=0, nbytes=2 << 30, reps=10):

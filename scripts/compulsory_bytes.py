@@ -13,7 +13,7 @@ per-path results that one launch writes and the next reads.  Two denominators:
                                request counters (FETCH_SIZE) could at best show, given which XCD renders which tile
 
 Writes profiles/<round>_compulsory_bytes.json keyed like profiles/hbm_traffic.json (bench.py reads both and prints
-roofline.compulsory_bytes / traffic_over_compulsory).  GPU:  gpurun -- python scripts/compulsory_bytes.py r06 [--only cfg2,...]
+roofline.compulsory_bytes / traffic_over_compulsory).  GPU:  gpurun -- python scripts/compulsory_bytes.py r06 [--only cfg2,...]; then here: python scripts/compulsory_bytes.py r06 --install
 """
 import json
 import os
@@ -22,6 +22,29 @@ import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+
+
+def install(tag):
+    """here, after the GPU run: gpurun_out/<tag>_compulsory_bytes.json -> profiles/<tag>_compulsory_bytes.json and the entries of
+    profiles/compulsory_bytes.json (what bench.py reads: like hbm_traffic.json, every entry names the build it belongs to)"""
+    got = json.load(open(os.path.join(REPO, "gpurun_out", f"{tag}_compulsory_bytes.json")))
+    with open(os.path.join(REPO, "profiles", f"{tag}_compulsory_bytes.json"), "w") as f:
+        json.dump(got, f, indent=1, sort_keys=True)
+        f.write("\n")
+    cur_path = os.path.join(REPO, "profiles", "compulsory_bytes.json")
+    cur = json.load(open(cur_path)) if os.path.exists(cur_path) else {}
+    for k, e in got.items():
+        cur[k] = dict(e, profile=f"profiles/{tag}_compulsory_bytes.json")
+    with open(cur_path, "w") as f:
+        json.dump(cur, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("installed", len(got), "entries of", tag)
+
+
+if "--install" in sys.argv:
+    install(sys.argv[1])
+    sys.exit(0)
+
 import torch  # noqa: E402
 
 import bench  # noqa: E402

@@ -15,6 +15,9 @@ for SPEC in 0:0 3:0 3:1; do
     rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${SPEC/:/_}_$C" -- python3 scripts/pt_xcd_order_ab.py one $SPEC 2 > /dev/null 2> "$OUT/pmc_${SPEC/:/_}_$C.err" || echo "pmc pass $SPEC $C failed"
   done
 done
+for SPEC in 0:0 3:0 3:1; do
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_${SPEC/:/_}" -- python3 scripts/pt_xcd_order_ab.py one $SPEC 3 > /dev/null 2> "$OUT/trace_${SPEC/:/_}.err" || echo "trace pass $SPEC failed"
+done
 python3 - "$OUT" <<'PY' | tee "$OUT/summary.txt"
 import collections, csv, glob, os, re, sys
 out = sys.argv[1]
@@ -33,4 +36,20 @@ for spec in ("0_0", "3_0", "3_1"):
         frames = n.get("k_pt_primary", 1) or 1
         row.append(f"{c}" + (" (doubled)" if mult == 2 else "") + ": " + ", ".join(f"{k} {v * 1024 * mult / frames / 1e9:.2f} GB" for k, v in sorted(agg.items())))
     print(f"SORT={spec.replace('_', ' XCD=')}: per frame: " + "; ".join(row))
+    fs = glob.glob(f"{out}/trace_{spec}/*/*_kernel_trace.csv")
+    if fs:
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
+            m = re.match(r"(?:void )?(?:sdfhip::)?(k_pt_\w+)", r["Kernel_Name"])
+            if m:
+                per[m.group(1)].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        frames = len(per.get("k_pt_primary", [])) or 1
+        parts = []
+        for k, v in sorted(per.items()):
+            v.sort()
+            parts.append(f"{k} {sum(x[1] for x in v) / frames / 1e6:.3f}")
+            if k == "k_pt_bounce":
+                lv = len(v) // frames
+                parts.append("(levels " + " ".join(f"{sum(x[1] for x in v[i::lv]) / frames / 1e6:.3f}" for i in range(lv)) + ")")
+        print(f"    kernel ms per frame (3 frames in flight under the tracer): " + ", ".join(parts))
 PY
