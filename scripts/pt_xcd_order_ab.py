@@ -40,7 +40,7 @@ def main():
     pt = sb.PathTrace(spp=16)
     with sb.Scene(od, device=0) as sc:
         sb._lib.check(sb._lib.lib.sdfhip_scene_prepare_path(sc._h))
-        nbuf = 3
+        nbuf = int(os.environ.get("PT_AB_FRAMES_IN_FLIGHT", "3"))
         streams = [torch.cuda.Stream() for _ in range(nbuf)]
         bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
 

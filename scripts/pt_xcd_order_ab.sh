@@ -16,7 +16,7 @@ for SPEC in 0:0 3:0 3:1; do
   done
 done
 for SPEC in 0:0 3:0 3:1; do
-  rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_${SPEC/:/_}" -- python3 scripts/pt_xcd_order_ab.py one $SPEC 3 > /dev/null 2> "$OUT/trace_${SPEC/:/_}.err" || echo "trace pass $SPEC failed"
+  PT_AB_FRAMES_IN_FLIGHT=1 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_${SPEC/:/_}" -- python3 scripts/pt_xcd_order_ab.py one $SPEC 3 > /dev/null 2> "$OUT/trace_${SPEC/:/_}.err" || echo "trace pass $SPEC failed"
 done
 python3 - "$OUT" <<'PY' | tee "$OUT/summary.txt"
 import collections, csv, glob, os, re, sys
@@ -51,5 +51,5 @@ for spec in ("0_0", "3_0", "3_1"):
             if k == "k_pt_bounce":
                 lv = len(v) // frames
                 parts.append("(levels " + " ".join(f"{sum(x[1] for x in v[i::lv]) / frames / 1e6:.3f}" for i in range(lv)) + ")")
-        print(f"    kernel ms per frame (3 frames in flight under the tracer): " + ", ".join(parts))
+        print(f"    kernel ms per frame (one frame in flight under the tracer): " + ", ".join(parts))
 PY

@@ -158,6 +158,12 @@ try {
     if (opt) {
         if (opt->size < V1_BYTES)
             return fail(SDFHIP_ERR_ARG, "scene_upload_ex: options of %u bytes (version 1 has %u: start from sdfhip_upload_options_default)", opt->size, V1_BYTES);
+        //  ... but `size` is also the one field a caller can leave uninitialised: a struct this library does not know is
+        // scanned up to `size` below, so a garbage value must not send that scan through the caller's memory.  No header of this
+        // library will be 16 times today's.
+        if (opt->size > 16u * (uint32_t)sizeof local)
+            return fail(SDFHIP_ERR_ARG, "scene_upload_ex: options of %u bytes (this library's are %zu; start from sdfhip_upload_options_default)",
+                        opt->size, sizeof local);
         memset(&local, 0xFF, sizeof local);                  // every field -1
         const size_t take = opt->size < sizeof local ? opt->size : sizeof local;
         memcpy(&local, opt, take);
@@ -235,7 +241,15 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
         if ((e = hipMemcpyAsync(d_s, structs, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(structs)");
         if ((e = hipMemcpyAsync(d_v, values, bytes, hipMemcpyHostToDevice, s->stream)) != hipSuccess) return bail(e, "hipMemcpy(values)");
     }
-    if (resident && trusted_depth >= 0) {
+    //  the laboratory library does not take the builder's word: it validates the builder's tree like any other and
+    // refuses a scene whose verdict differs from what the builder said -- every GPU test of the builder runs on both flavours, so
+    // a regression there is SDFHIP_ERR_BAD_TREE in the test suite, not wrong pixels behind a grid sized for another depth
+#ifdef SDFHIP_EXPERIMENTS
+    const bool trust = false;
+#else
+    const bool trust = resident && trusted_depth >= 0;
+#endif
+    if (trust) {
         // the point-cloud builder's own tree (sdfhip_sdfgen_scene): every block of eight children was appended by k_emit under its
         // parent, the depth is the number of levels it built -- nothing to find out (0.3 ms of a 10 ms build, and a wait on the stream)
         consistent = 1;
@@ -276,6 +290,11 @@ int sdfhip::scene_from_arrays(int device, const int32_t *structs, const uint8_t 
         }
         consistent = (verdict[0] & 2u) ? 0 : 1;
         depth = consistent ? verdict[1] : 0xFFFFFFFFu;
+        if (resident && trusted_depth >= 0 && (!consistent || depth != (uint32_t)trusted_depth)) {
+            sdfhip_scene_free(s);
+            return fail(SDFHIP_ERR_BAD_TREE, "scene_from_arrays: the builder says its tree is consistent and %d levels deep; the validation finds it %s, depth %u",
+                        trusted_depth, consistent ? "consistent" : "INCONSISTENT", depth);
+        }
         s->depth = depth;
         s->stack_ok = (consistent && depth <= (uint32_t)LM) ? 1 : 0;   // LM: the shader's own descent limit (Compute.hlsl:98)
     }

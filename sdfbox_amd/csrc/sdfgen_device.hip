@@ -34,6 +34,7 @@
 #include <sys/mman.h>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 namespace sdfhip {
@@ -901,7 +902,11 @@ hipError_t wait_report(const sdfhip::Report *report, uint32_t seq)
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0;; spins++) {
         if (report->seq == seq) return hipSuccess;
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
         if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
     }
     const hipError_t e = hipStreamSynchronize(0);
@@ -954,7 +959,14 @@ static int sdfgen_impl(int device, const float *verts6, uint32_t n, int32_t dept
         uint32_t *d_err = keep.alloc<uint32_t>(1);
         // (page-locked and mapped; one per host thread, kept for the life of the process: allocating one costs as much as a level)
         static thread_local Report *report = nullptr;
-        if (!report) GEN_TRY(hipHostMalloc((void **)&report, sizeof(Report) + BOUNDS_WG * 6 * sizeof(float), hipHostMallocPortable | hipHostMallocMapped));
+        if (!report) {
+            //  COHERENT, said explicitly: the host spins on `seq` while the kernel is still running -- without fine-grained
+            // coherence (HIP_HOST_COHERENT=0 makes that the default) every wait would burn its whole spin budget before the stream
+            // synchronisation behind it; and the numbering starts from zeroed bytes, not from whatever the allocation held
+            GEN_TRY(hipHostMalloc((void **)&report, sizeof(Report) + BOUNDS_WG * 6 * sizeof(float),
+                                  hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+            memset(report, 0, sizeof(Report) + BOUNDS_WG * 6 * sizeof(float));
+        }
         float *bounds = reinterpret_cast<float *>(report + 1);
         uint32_t report_seq = report->seq;                   // (the scans of this build are numbered on from the last build's)
         Cand *cand = lists[0].alloc<Cand>(n);

@@ -113,7 +113,11 @@ struct Worker {
         for (;;) {
             for (int i = 0; i < 64; i++) {
                 if (a.load(std::memory_order_acquire) != seen || (stop && stop->load(std::memory_order_acquire))) return true;
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
+#else
+                std::this_thread::yield();
+#endif
             }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) return false;
         }

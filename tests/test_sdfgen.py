@@ -231,3 +231,40 @@ def test_points_to_scene_without_leaving_the_device(sb):
             only.close()
     with pytest.raises(sb.SdfHipError):
         sb.Scene.FromPoints(np.full((10, 6), np.nan, np.float32), 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flavour", ["product", "lab"])
+def test_builder_scene_agrees_with_the_uploaded_tree_on_edge_clouds(flavour):
+    # sdfhip_sdfgen_scene hands its own tree to the scene without validating it again (the product; the laboratory
+    # library validates it and refuses a verdict that differs from the builder's word).  On the clouds where a builder could
+    # stop early or build a single node, the scene it makes must be the scene an upload of the same tree makes: depth, kernel
+    # choice, grid, pixels -- or both ways must fail.
+    from conftest import assert_frames_identical, make_camera
+    if flavour == "lab":
+        import sdfbox_amd.lab
+        sb = sdfbox_amd.lab.load()
+    else:
+        import sdfbox_amd as sb
+    one = np.array([[0.1, 0.2, 0.3, 0.0, 0.0, 1.0]], np.float32)
+    cases = {"one point": (one, 3), "two coincident points": (np.repeat(one, 2, 0), 4),
+             "eight points, depth 10": (fib_sphere(8), 10), "depth 0: the root alone": (fib_sphere(500), 0),
+             "depth 1": (fib_sphere(500), 1), "a flat cloud (one plane)": (np.concatenate([fib_sphere(300)[:, :2], np.zeros((300, 1), np.float32),
+                                                                           np.tile(np.float32([0, 0, 1]), (300, 1))], 1), 6)}
+    for name, (v, depth) in cases.items():
+        try:
+            od = sb.OctData.SdfGen(v, depth)
+        except sb.SdfHipError:
+            with pytest.raises(sb.SdfHipError):
+                sb.Scene.FromPoints(v, depth)
+            continue
+        sc = sb.Scene.FromPoints(v, depth)
+        try:
+            with sb.Scene(od) as ref:
+                assert (sc.Length, sc.depth, sc.stack_kernel_ok) == (ref.Length, ref.depth, ref.stack_kernel_ok), name
+                assert (sc.top_grid_level, sc.top_grid_bytes) == (ref.top_grid_level, ref.top_grid_bytes), name
+                assert od.validate() == (sc.depth, True), name
+                cam = make_camera("rotated", 96, 64)
+                assert_frames_identical(sc.Draw(cam, 96, 64), ref.Draw(cam, 96, 64), name)
+        finally:
+            sc.close()
