@@ -113,6 +113,13 @@ SDFHIP_API int sdfhip_debug_tile_order(sdfhip_scene *scene, const uint32_t *d_pe
 SDFHIP_API int sdfhip_debug_touch_begin(sdfhip_scene *scene);
 SDFHIP_API int sdfhip_debug_touch_end(sdfhip_scene *scene, uint64_t *out, uint32_t max_phases, uint32_t *n_phases, uint64_t *array_bytes4);
 
+/* Test hook (tests/test_gpu_fault_injection.py): the countdown-th allocation that THIS library's own host code makes from now on
+ * (operator new: containers, handles, threads' state) throws std::bad_alloc; countdown < 0 switches the injector off.
+ * *thrown_so_far (may be NULL) receives how many allocations have been failed since the library was loaded.  Whatever entry
+ * point the failure lands in must return a status code (SDFHIP_ERR_NOMEM) with sdfhip_last_error() set -- the firewall of
+ * csrc/abi_guard.h -- and leave the library usable.  The product has no such code. */
+SDFHIP_API int sdfhip_debug_fail_host_allocations(int64_t countdown, uint64_t *thrown_so_far);
+
 /* Diagnostics: after a SDFHIP_FLAG_COUNT render of the default kernel on `stream` (the stream argument of the
  * sdfhip_render_device call that made it; synchronises with it), how many lane-steps sampled which kind of cell: out6 = {flat leaf at or above the grid's coarse level, flat leaf below it, non-flat at or above the coarse level,
  * non-flat as deep as the grid, non-flat in between, non-flat with the position outside the cube (or NaN)}.  What the

@@ -242,6 +242,7 @@ _SIG_LAB = {
     "sdfhip_debug_unorm_table": (_c.c_int, [_c.c_int, _vp]),
     "sdfhip_debug_step_classes": (_c.c_int, [_vp, _vp, _c.POINTER(_c.c_uint64)]),
     "sdfhip_multi_debug_floats_sent": (_c.c_int, [_vp, _c.c_uint32]),
+    "sdfhip_debug_fail_host_allocations": (_c.c_int, [_c.c_int64, _c.POINTER(_c.c_uint64)]),
     "sdfhip_debug_touch_begin": (_c.c_int, [_vp]),
     "sdfhip_debug_touch_end": (_c.c_int, [_vp, _c.POINTER(_c.c_uint64), _c.c_uint32, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint64)]),
 }

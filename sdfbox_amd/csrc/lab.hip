@@ -10,8 +10,10 @@
 #include "abi_guard.h"
 #include "../../include/sdfhip_experimental.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 using namespace sdfhip;
 
@@ -359,6 +361,44 @@ try {
     return SDFHIP_OK;
 }
 SDFHIP_ABI_CATCH(sdfhip_debug_touch_end)
+
+// ---- sdfhip_debug_fail_host_allocations: the exception firewall of the DEVICE half, under injected failures ---------------------
+// tests/host_fault_injection.cpp fails operator new under the host half of the library on the CPU.  The entry points that need a
+// GPU (upload, render, the multi-device handle, the point-cloud builder) allocate too -- vectors, threads' state, the scene handle
+// -- and can only be exercised on the box: the LABORATORY library carries its own operator new (hidden visibility: it replaces the
+// allocations made from this library's own code, inlined container code included, and nobody else's), which throws std::bad_alloc
+// at the k-th allocation from now when the hook below has armed it.  Every entry point must come back with a status code.
+static std::atomic<long long> g_alloc_countdown{-1};      // < 0: off
+static std::atomic<unsigned long long> g_alloc_thrown{0};
+static void *lab_alloc(size_t n)
+{
+    long long c = g_alloc_countdown.load(std::memory_order_relaxed);
+    while (c >= 0) {
+        if (g_alloc_countdown.compare_exchange_weak(c, c - 1)) {
+            if (c == 0) { g_alloc_thrown.fetch_add(1); throw std::bad_alloc(); }
+            break;
+        }
+    }
+    void *p = malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+// (kept inside this library by its link map, lab.map: <new> declares them with default visibility, and an exported definition would
+// neither bind this library's own calls -- the process's first operator new, libstdc++'s, would -- nor stay out of the host's)
+void *operator new(size_t n) { return lab_alloc(n); }
+void *operator new[](size_t n) { return lab_alloc(n); }
+void operator delete(void *p) noexcept { free(p); }
+void operator delete[](void *p) noexcept { free(p); }
+void operator delete(void *p, size_t) noexcept { free(p); }
+void operator delete[](void *p, size_t) noexcept { free(p); }
+
+extern "C" int sdfhip_debug_fail_host_allocations(int64_t countdown, uint64_t *thrown_so_far)
+try {
+    if (thrown_so_far) *thrown_so_far = g_alloc_thrown.load();
+    g_alloc_countdown.store(countdown < 0 ? -1 : (long long)countdown);
+    return SDFHIP_OK;
+}
+SDFHIP_ABI_CATCH(sdfhip_debug_fail_host_allocations)
 
 extern "C" int sdfhip_debug_step_classes(sdfhip_scene *s, void *stream, uint64_t *out6)
 try {

@@ -6,6 +6,7 @@
  *   c_frames_in_flight [frames = 2000] [streams = 4] [depth = 9]      cfg-2's frame: 1920x1080, the gyroid stand-in
  * exit 0 ok, 3 = no usable GPU. */
 #define __HIP_PLATFORM_AMD__ 1
+#define _GNU_SOURCE 1
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
@@ -20,6 +21,8 @@ int main(int argc, char **argv)
     const int frames = argc > 1 ? atoi(argv[1]) : 2000, ns = argc > 2 ? atoi(argv[2]) : 4, depth = argc > 3 ? atoi(argv[3]) : 9;
     const unsigned W = 1920, H = 1080;
     if (frames < 1 || ns < 1 || ns > 8) { fprintf(stderr, "usage: %s [frames] [streams 1..8] [depth]\n", argv[0]); return 2; }
+    /* a 4th argument "setenv": export the variable from main(), before the first call that touches the GPU (does the runtime still see it?) */
+    if (argc > 4 && argv[4][0] == 's') setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const char *q = getenv("GPU_MAX_HW_QUEUES");
     const float gyroid[6] = { 0.5f, 0.5f, 0.5f, 0.42f, (float)(12.0 * M_PI), 0.004f };
     sdfhip_octdata od;
