@@ -9,6 +9,12 @@
  * Each entry point names the reference interface it replaces (paths are
  * relative to the tau-dev/SdfBox checkout).  INTEGRATION.md shows the C#
  * [DllImport] stub a maintainer would add.
+ *
+ * Loading the library has ONE side effect on its host: unless GPU_MAX_HW_QUEUES is already in the environment (any value: the
+ * host's word stands) or SDFHIP_KEEP_ENV is set, it exports GPU_MAX_HW_QUEUES=8 -- the HIP runtime reads that variable when the
+ * process makes its first HIP call, and a host that keeps four frames in flight on four streams renders 20 % slower on the
+ * runtime's default of four hardware queues (0.1014 against 0.0841 ms per 1080p frame: INTEGRATION.md section 3).  A process
+ * that has initialised HIP before it loads the library keeps what it had.
  */
 #ifndef SDFHIP_H
 #define SDFHIP_H
@@ -451,8 +457,8 @@ SDFHIP_API int sdfhip_deinterleave_sparse2_device(int device, const void *const 
  * sent, no Python.  The same device may appear several times (a rehearsal of the pipeline on one GPU; not with RCCL).
  * Environment, read at create: SDFHIP_MULTI_TRANSPORT (above), SDFHIP_RCCL_LIB (the RCCL library to dlopen, if not the system's),
  * SDFHIP_MULTI_RCCL_SELF=1 (with ONE device and the RCCL transport: its share travels through ncclSend / ncclRecv to itself -- all
- * of that transport a single GPU can run).  With SDFHIP_GEN_POOL these are the only variables the product library reads; every
- * other choice is an argument (sdfhip_upload_options, sdfhip_multi_configure).
+ * of that transport a single GPU can run).  With SDFHIP_GEN_POOL and SDFHIP_KEEP_ENV (the note at the top of this file) these are
+ * the only variables the product library reads; every other choice is an argument (sdfhip_upload_options, sdfhip_multi_configure).
  *   sdfhip_multi_render        one frame to a host array: the viewer's call (latency: every device works on this frame)
  *   sdfhip_multi_submit/_wait  groups of n_frames <= 8 frames (one camera block each, one launch per device), up to 4 groups
  *                              in flight (slot 0..3): throughput.  d_frames_out: device memory on devices[0] for

@@ -44,3 +44,18 @@ int abi_caught(const char *entry) noexcept
 }  // namespace sdfhip
 
 extern "C" const char *sdfhip_last_error(void) { return sdfhip::g_err; }     // (reads a thread-local array: nothing to guard)
+
+// ---- the hardware queues of the process that loads this library -------------------------------------------
+// The HIP runtime deals a process's streams onto GPU_MAX_HW_QUEUES hardware queues -- 4 unless the environment says otherwise -- and
+// streams that share a queue run their kernels one behind the other.  A host that keeps four frames in flight on four streams of
+// its own (what the frame pipeline of INTEGRATION.md section 2 does) renders cfg-2's frame in 0.1014 ms on the runtime's four queues
+// and in 0.0841 ms on eight: 20 % (tests/c_frames_in_flight.c, a plain C host; profiles/r06_hw_queues_c_host.txt).  The runtime
+// reads the variable when it initialises -- at the process's first HIP call, not when libamdhip64.so is mapped (the same file: a
+// program that exports it at the top of main() gets the eight queues) -- so the library exports it when IT is loaded, before its
+// own kernels are registered, unless the host has set the variable itself (any value: the host's word stands) or SDFHIP_KEEP_ENV
+// is set (the library then leaves the environment alone).  A process that initialised HIP before loading the library (a PyTorch
+// host) keeps what it had; bench.py exports the variable itself before it imports torch.
+__attribute__((constructor(101))) static void sdfhip_export_hw_queues(void)
+{
+    if (getenv("SDFHIP_KEEP_ENV") == nullptr) (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite*/ 0);
+}

@@ -13,8 +13,9 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void clear_error();
 
 // A measurement or test knob of the environment: read by the laboratory library only.  The product takes its choices through
-// its ABI (sdfhip_upload_options, sdfhip_multi_configure) and reads four variables in all, each named in include/sdfhip.h:
-// SDFHIP_MULTI_TRANSPORT, SDFHIP_RCCL_LIB, SDFHIP_MULTI_RCCL_SELF (the RCCL transport's self-test on one device), SDFHIP_GEN_POOL.
+// its ABI (sdfhip_upload_options, sdfhip_multi_configure) and reads five variables in all, each named in include/sdfhip.h:
+// SDFHIP_MULTI_TRANSPORT, SDFHIP_RCCL_LIB, SDFHIP_MULTI_RCCL_SELF (the RCCL transport's self-test on one device), SDFHIP_GEN_POOL,
+// SDFHIP_KEEP_ENV (errors.cpp: do not export GPU_MAX_HW_QUEUES at load).
 #ifdef SDFHIP_EXPERIMENTS
 inline const char *lab_env(const char *name) { return getenv(name); }
 #else

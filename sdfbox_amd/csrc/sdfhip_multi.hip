@@ -502,7 +502,11 @@ int submit_locked(sdfhip_multi *m, uint32_t slot, const sdfhip_info *infos, uint
         // another geometry: every slot must be idle (their buffers and the float estimates belong to the old one)
         for (uint32_t k = 0; k < MAX_SLOTS; k++)
             if (m->slots[k].busy) return fail(SDFHIP_ERR_ARG, "multi_submit: the frame geometry changed while slot %u is in flight", k);
-        deal_bands(m->lay, width, height, m->n, m->band_rows, m->rank0_weight);
+        // dealt into a layout of its own and moved over the handle's when it is complete: a deal that throws half-way (its vectors;
+        // found by tests/test_gpu_fault_injection.py) must not leave a layout that says "this geometry" and owns no rows
+        Layout fresh;
+        deal_bands(fresh, width, height, m->n, m->band_rows, m->rank0_weight);
+        m->lay = std::move(fresh);
         for (uint32_t r = 0; r < MAX_RANKS; r++) m->est[r] = 0;
     }
     const bool display = (flags & (SDFHIP_FLAG_DISPLAY | SDFHIP_FLAG_DISPLAY_DEBUG)) != 0;

@@ -256,3 +256,17 @@ def test_every_entry_point_is_behind_the_exception_firewall():
     # the scene builder's pool: its threads' bodies catch everything themselves
     gen = open(os.path.join(src, "scene_gen.cpp")).read()
     assert "catch (...) { err[s] = 1; }" in gen
+
+
+def test_loading_the_library_exports_the_hardware_queue_count_unless_the_host_decided(sb):
+    # a host that keeps frames in flight is 20 % slower on the runtime's four hardware queues; the runtime reads
+    # GPU_MAX_HW_QUEUES at the first HIP call, so the library exports 8 when it is loaded -- never over the host's own value, and
+    # not at all with SDFHIP_KEEP_ENV (csrc/errors.cpp)
+    import subprocess
+    prog = ("import ctypes, sys; ctypes.CDLL(sys.argv[1]); g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; "
+            "print(g(b'GPU_MAX_HW_QUEUES'))")
+    base = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "SDFHIP_KEEP_ENV")}
+    for path in (sb._lib.LIB_PATH, sb._lib.LAB_LIB_PATH):
+        for extra, want in (({}, "b'8'"), ({"GPU_MAX_HW_QUEUES": "2"}, "b'2'"), ({"SDFHIP_KEEP_ENV": "1"}, "None")):
+            out = subprocess.run([sys.executable, "-c", prog, path], env=dict(base, **extra), capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0 and out.stdout.strip() == want, (path, extra, out.stdout, out.stderr[-500:])
