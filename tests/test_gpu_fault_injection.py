@@ -86,8 +86,10 @@ def test_every_gpu_entry_point_returns_a_code_when_an_allocation_fails(lab, orac
     report["sdfhip_sdfgen_scene"] = _sweep(lab, "sdfgen_scene", lambda: fp.append(lab.Scene.FromPoints(cloud, 4)))
     print({k: f"{v[1]} allocations failed one by one, {v[0]} came back as codes" for k, v in report.items()})
     # allocation failures did land in the device half, and each became a code
-    assert report["sdfhip_scene_upload"][1] >= 1 and report["sdfhip_multi_create"][1] >= 3 and report["sdfhip_sdfgen"][1] >= 1, report
-    assert sum(v[0] for v in report.values()) >= 8, report
+    # (upload and the render calls allocate with nothrow new / malloc / hipMalloc and check the result: nothing of theirs can throw;
+    # the multi-device handle's vectors and threads and the builder's arenas and level list can)
+    assert report["sdfhip_multi_create"][1] >= 3 and report["sdfhip_multi_render"][1] >= 1 and report["sdfhip_sdfgen"][1] >= 1, report
+    assert sum(v[0] for v in report.values()) >= 10, report
     # ... and the library is whole: the same frames as before, from the handles that survived and from a fresh one
     assert_frames_identical(sc.Draw(cam, W, H), ref, "the scene that was uploaded under injection")
     assert_frames_identical(ms.Draw(cam, W, H), ref, "the multi-device handle that was created under injection")
