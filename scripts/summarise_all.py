@@ -2,7 +2,7 @@
 import subprocess, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G = "grid8+blocks"          # the default grid of both stand-in scenes: coarse level 8 + blocks (bench.py's key names it)
-for tag, key in [("1080p", f"1920x1080:dragon_standin_d9:default:{G}"), ("1080p_onekernel", f"1920x1080:dragon_standin_d9:one-kernel:{G}"),
+for tag, key in [("1080p", f"1920x1080:dragon_standin_d9:default:{G}"), ("1080p_orbit", f"1920x1080:dragon_standin_d9:default:orbit90:{G}"), ("1080p_onekernel", f"1920x1080:dragon_standin_d9:one-kernel:{G}"),
                  ("1080p_queue", f"1920x1080:dragon_standin_d9:default:shadow-queue:{G}"), ("4k_queue", f"3840x2160:dragon_standin_d9:default:shadow-queue:{G}"),
                  ("4k", f"3840x2160:dragon_standin_d9:default:{G}"), ("4k_compact", f"3840x2160:dragon_standin_d9:compact:{G}"),
                  ("1080p_display", f"1920x1080:dragon_standin_d9:display:{G}"), ("1080p_d10", f"1920x1080:dragon_standin_d10:default:{G}"),
