@@ -121,6 +121,10 @@ def parse():
     ap.add_argument("--watchdog-seconds", type=float, default=-1.0,
                     help="a daemon thread writes the run's phase to stderr every few seconds and ends the process with exit code 3 once "
                          "the whole run has taken this long (-1 = default: 420 for N > 1, off for N = 1; 0 = off)")
+    ap.add_argument("--only-timed", action="store_true",
+                    help="skip the passes that render OTHER frames than the timed region's before it (the moving-camera and tile-order latency "
+                         "figures): for a profiler pass, whose per-frame counters are averages over every launch of the process "
+                         "(scripts/profile.sh passes it; until round 6 its averages included those passes' frames)")
     ap.add_argument("--sustained", default="auto",
                     help="continuous-operation legs behind the headline (bench_sustained.py): 'cfg2,cfg3,orbit' seconds of wall time, e.g. "
                          "'5,3,2' -- the cfg-2 frame pipelined for >= 5 s, the 4K frame (in the `configs` block) for >= 3 s, the cfg-2 frame "
@@ -274,7 +278,7 @@ def main():
         G = 1 if not sharded else G            # those kernels render one frame per launch
     # in flight: 4 frames on one GPU, on hardware queues of their own (GPU_MAX_HW_QUEUES above): the long tail of a frame's last waves
     # runs under the body of the next ones -- 1080p 0.163 ms with one frame in flight, 0.0896 / 0.0872 / 0.0871 with two / three / four,
-    # 0.0998 with five (8 queues; profiles/r04_hw_queues.txt.  On the runtime's default of 4 queues: 0.0898 with four, 0.0881 with
+    # 0.0998 with five (8 queues; profiles/r04_hw_queues.txt in the history, commit 53ee955.  On the runtime's default of 4 queues: 0.0898 with four, 0.0881 with
     # six, 0.1136 with three); 3 for the path-traced mode (its buffers are gigabytes per stream; 21.6 / 20.9 / 20.9 / 20.8 ms per cfg-5 frame
     # with 2 / 3 / 4 / 5 -- on four hardware queues the third brought nothing); 4
     # groups of a sharded run (scripts/batch_sweep.py: a rank's share of 4 frames per launch needs 4 launches in flight to fill the
@@ -630,7 +634,7 @@ def main():
     wd.phase("latency passes (one group at a time)")
     n_lat = 5 if pt is not None else 40
     latency = {"frames": G, "ms": round(latency_pass(cams, n_lat), 4)}
-    if pt is None and not args.check:
+    if pt is None and not args.check and not args.only_timed:
         latency["orbit_cameras"] = len(orbit)
         latency["orbit_ms"] = round(latency_pass(orbit, n_lat), 4)
         latency["orbit_ms_per_step"] = round(throughput_pass(orbit, max(args.steps, 2 * len(orbit))), 4)

@@ -87,7 +87,7 @@ def compulsory_fields(traffic, comp):
 #             = 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flops), so a wave64 instruction takes two
 #   measured  / 2.35 cycles: the cheapest instruction on this chip with 8 waves per SIMD (v_mov_b32; v_and / v_add / v_sub /
 #             v_mul / v_fmac 2.4-2.6; shifts, compares, conversions, v_fma_f32 (VOP3), min3 / med3 4.0-4.4; a packed fp32
-#             instruction 4.4-4.7 for two results: scripts/micro/valu_mix.hip, profiles/r03_micro_valu_mix.txt)
+#             instruction 4.4-4.7 for two results: scripts/micro/valu_mix.hip, profiles/r03_micro_valu_mix.txt in the history, commit 53ee955)
 # Both bound ANY instruction mix from above; `valu_busy` below is the measured utilisation.
 VALU_PEAK_SPEC_GINSTR = 256 * 4 * 2.4 / 2.0
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.35

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the k_march variants of ROUND 4 (MARCH_AB=0..3 in raymarch_device.h find_units as of commit 818aed4; round 5 took the variants out of the
-# product header -- the numbers are profiles/r04_k_march_ab.txt): bench lines per build, A/B/A/B, then PMC.  Kept as the recipe of an A/B.
+# product header -- the numbers are profiles/r04_k_march_ab.txt (history: commit 53ee955)): bench lines per build, A/B/A/B, then PMC.  Kept as the recipe of an A/B.
 #   bash scripts/march_ab.sh        (on the GPU box)  -> gpurun_out/march_ab/
 set -u
 # the hardware queues bench.py asks for: under rocprofv3 --pmc the profiler has initialised the GPU before bench.py can set it

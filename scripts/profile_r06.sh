@@ -12,6 +12,7 @@ run ${R}_4k --size 3840x2160
 run ${R}_4k_compact --size 3840x2160 --compact 1
 fi
 if [ "$C" = 0 ] || [ "$C" = 2 ]; then
+[ "$C" = 2 ] && run ${R}_1080p          # (again: chunk 1's first run of it still had the sustained legs' frames in its passes)
 run ${R}_1080p_d10 --depth 10
 run ${R}_cfg5 --size 3840x2160 --spp 16
 fi

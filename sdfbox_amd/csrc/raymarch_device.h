@@ -152,7 +152,7 @@ struct RenderParams {
     float *pt_t;                    // [spp][pixels]
     uint32_t *pt_n;                 // [spp][pixels]
 #ifdef SDFHIP_EXPERIMENTS
-    // A/B (measured: no gain, profiles/r04_cfg5_sort_ab.txt): bounce levels with pt_sort_bits = R > 0: before a level's kernel its queue entries are ordered by the key
+    // A/B (measured: no gain, profiles/r04_cfg5_sort_ab.txt in the history (commit 53ee955); profiles/r06_cfg5_xcd_order_ab.txt): bounce levels with pt_sort_bits = R > 0: before a level's kernel its queue entries are ordered by the key
     // (Morton code of the hit's region, 2^R regions per axis) << 3 | octant of the OUTGOING direction -- the rays a wave marches
     // start in the same part of the scene and head the same way (k_pt_key, k_pt_scatter): pt_key[entry] = the key, pt_perm[slot] =
     // the entry a lane takes, pt_hist = the keys' counts, then their running slots ([keys + 1]: the last word is the entry total)
@@ -682,7 +682,7 @@ __device__ __forceinline__ int32_t cvt_floor(float u)
 //     without this every pixel's first step takes the exact rule.)
 // (Round 4 A/B'd three forms of this function with PMC -- the lattice branch told which way it usually goes, kept: the
 // __builtin_expect below; the coarse cell's load issued by hand before the lattice test: waits 5 % less, issues 13 % more, slower;
-// waves strictly inside the cube skipping the clamps: slower -- profiles/r04_k_march_ab.txt, docs/history.md section 4.6.)
+// waves strictly inside the cube skipping the clamps: slower -- profiles/r04_k_march_ab.txt (history: commit 53ee955), docs/history.md section 4.6.)
 template <bool SPLIT, bool FRESH, bool ORDERED>
 __device__ __forceinline__ uint32_t find_units(CursorFT<false, SPLIT, ORDERED> &c, const GridRef &g, float px, float py, float pz, Scaled &u)
 {

@@ -1265,10 +1265,14 @@ struct PtChunks {
 
 #ifdef SDFHIP_EXPERIMENTS
 // ---- LABORATORY (experiments build): the bounce levels' queue entries ordered by (region of the hit, octant of the outgoing direction) ----
-// MEASURED: NO GAIN (profiles/r04_cfg5_sort_ab.txt): the camera level's queue is already in screen-tile order, which
+// MEASURED: NO GAIN (profiles/r04_cfg5_sort_ab.txt in the history (commit 53ee955); profiles/r06_cfg5_xcd_order_ab.txt): the camera level's queue is already in screen-tile order, which
 // no key of this kind beats (level 0: 9.5 -> 10.6 ms ordered), and the deeper levels gain 0.5 ms of 13 for 0.7 ms of key + scatter:
 // what the bounce rays fetch is decided where they END, which no order of their starts can know.  Kept as a bit-identical A/B
 // (SDFHIP_PT_SORT=R, SDFHIP_PT_SORT_FROM=first level).
+// ROUND 6 (profiles/r06_cfg5_xcd_order_ab.txt): the order alone moves no byte because every XCD still takes every eighth chunk of it;
+// with each XCD walking a CONTIGUOUS eighth (SDFHIP_PT_SORT_XCD=1, k_pt_bounce) the bounce kernels read 77 GB instead of 113 per frame
+// and the lines summed over the XCDs halve -- and the frame is 10 % SLOWER (key + scatter 1.4 ms; the levels gain 0.9 ms, level 0 loses
+// 1.1 through the permutation): the levels sit at the latency of their dependent lookups, not at the bandwidth roof.  Dropped again.
 // The bounce levels are bound by the 64-byte sectors their incoherent rays fetch.  The queues hold the hits in
 // the order the waves of the level before pushed them; here a level's entries get a KEY -- where the ray starts and which way it
 // will go: the bounce direction is a function of the entry alone (the hit's normal from its cursor's cell, the counter-based RNG) --

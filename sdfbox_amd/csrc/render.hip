@@ -695,7 +695,7 @@ try {
     if (viewer) {
         // A page-locked destination (sdfhip_host_alloc / _register): the march can store its pixels into the host's array
         // itself -- no device frame, no copy: the stores cross PCIe while the other waves march.  Measured (scripts/host_frame.py
-        // --locked, profiles/r03_host_frame.txt): into the library's own allocation 1080p 0.676 ms against 0.711-0.731 with band
+        // --locked, profiles/r03_host_frame.txt in the history, commit 53ee955): into the library's own allocation 1080p 0.676 ms against 0.711-0.731 with band
         // copies into the same memory (RGBA8: 0.260 against 0.292); at 4K the copy engine's 55 GB/s beat the stores' 51 (2.47
         // against 2.58 ms), so frames of 4 M pixels and more go in bands.  Into the caller's own registered array (4 KB pages
         // wherever they happened to lie) the stores are slower -- 1080p RGBA32F 0.758 against 0.714 -- and are used for frames of

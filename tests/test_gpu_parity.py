@@ -367,7 +367,7 @@ def test_path_traced_mode_through_every_scatter_grid(sb, oracle_mod, scenes, blo
 
 
 def test_path_traced_bounce_levels_ordered_by_key(sb, oracle_mod, scenes):
-    # A/B of the experiments build (SDFHIP_PT_SORT=R, profiles/r04_cfg5_sort_ab.txt: measured without gain): before every bounce
+    # A/B of the experiments build (SDFHIP_PT_SORT=R, profiles/r04_cfg5_sort_ab.txt in the history (commit 53ee955); profiles/r06_cfg5_xcd_order_ab.txt: measured without gain): before every bounce
     # level its queue entries are ordered by (region of the hit, octant of the outgoing direction) and read through a permutation.
     # A path's results do not depend on where its entry sits in a queue: every ordering must give the oracle's frame, counters included
     lab_only(sb)
