@@ -445,8 +445,12 @@ def main():
         elif rank == 0:                                   # gloo rehearsal: through host buffers
             for r in range(1, world):
                 s2["gath"][slot][r][:s2["prefix"]].copy_(w[r].cuda())
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
             deinterleave_sparse2(device, s2_ptrs(slot), frame[slot].data_ptr(), W, layout, s2["full"], frames=n,
                                  counts_ptr=s2["counts"][slot].data_ptr(), stream=main)
+            a1.record()
+            asm_ev.append((a0, a1, n))
             torch.cuda.synchronize()
         if rank == 0:
             if nccl:
