@@ -265,15 +265,19 @@ def link_check(torch, dist, rank, world, nccl, wd, names, limit=10.0, nbytes=1 <
             t0 = time.perf_counter()
             work = dist.irecv(buf, src=r)
             done = False
-            if nccl:                                                       # (a wait with a timeout does not bound a CUDA-side receive: poll its event)
+            if nccl:
+                # A wait with a timeout does not bound a receive that runs on the GPU.  work.wait() only puts the receive in front of
+                # this thread's stream; an EVENT recorded behind it completes when the bytes are there, and querying an event never
+                # blocks -- so the limit holds whatever the state of the link (a peer that never even joins the transfer leaves this
+                # rank inside irecv: the watchdog's limit on this phase ends that case, naming the link).
+                work.wait()
+                arrived = torch.cuda.Event()
+                arrived.record()
                 while time.perf_counter() - t0 < limit:
-                    if work.is_completed():
+                    if arrived.query():
                         done = True
                         break
                     time.sleep(0.0005)
-                if done:
-                    work.wait()
-                    torch.cuda.synchronize()
             else:                                                          # (gloo's receive completes inside wait(): the timeout goes there)
                 try:
                     work.wait(datetime.timedelta(seconds=limit))

@@ -97,3 +97,58 @@ def test_a_silent_link_ends_rank_0_inside_the_limit_and_the_peer_non_zero():
     assert procs[0].returncode == 5, (procs[0].returncode, outs[0][1][-1500:])
     assert "NOTHING ARRIVED within 3 s" in outs[0][1] and "link check FAILED: rank 1 (host buffers) -> rank 0 (host buffers)" in outs[0][1]
     assert procs[1].returncode != 0, outs[1][1][-1500:]
+
+
+def test_the_nccl_branch_of_the_link_check_bounds_a_receive_by_an_event():
+    # No two GPUs here: the NCCL branch of bench_sharded.link_check is exercised against stand-ins for torch / torch.distributed.
+    # The receive is bounded by QUERYING an event recorded behind it (a wait with a timeout does not bound a receive on the GPU): a
+    # link whose event completes passes; one whose event never completes ends the process with exit code 5 inside the limit.
+    import subprocess
+    prog = r"""
+import sys, time, types
+sys.path.insert(0, %r)
+import torch as real_torch
+import bench_sharded as bs
+
+class Work:
+    def wait(self, *a): pass
+    def is_completed(self): raise AssertionError("the NCCL branch must not rely on is_completed()")
+class Dist:
+    sent = []
+    @staticmethod
+    def irecv(buf, src):
+        i = real_torch.arange(buf.numel(), dtype=real_torch.int64)
+        buf.copy_(((i * 131 + src * 17 + (i >> 9)) %% 251).to(real_torch.uint8))       # what rank `src` sends
+        return Work()
+    @staticmethod
+    def broadcast(t, src): pass
+class Event:
+    dead = %s
+    def __init__(self): self.t = None
+    def record(self): self.t = time.perf_counter()
+    def query(self): return (not Event.dead) and time.perf_counter() - self.t > 0.05     # the bytes arrive 50 ms after the post
+class Cuda:
+    Event = Event
+    @staticmethod
+    def synchronize(): pass
+class Torch:                       # torch with "cuda" tensors living on the CPU
+    cuda = Cuda
+    int64, int32, uint8 = real_torch.int64, real_torch.int32, real_torch.uint8
+    @staticmethod
+    def arange(n, dtype=None, device=None): return real_torch.arange(n, dtype=dtype)
+    @staticmethod
+    def zeros(*a, dtype=None, device=None): return real_torch.zeros(*a, dtype=dtype)
+    @staticmethod
+    def equal(a, b): return real_torch.equal(a, b)
+class Wd:
+    def phase(self, *a, **k): pass
+rows = bs.link_check(Torch, Dist, 0, 3, True, Wd(), ["0000:05:00.0", "0000:15:00.0", "0000:25:00.0"], limit=1.0, nbytes=1 << 16, peer_access=[True, True, False])
+print("ROWS", [(r["verdict"], r["peer_access"]) for r in rows])
+""" 
+    ok = subprocess.run([sys.executable, "-c", prog % (REPO, "False")], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and "ROWS [('ok', True), ('ok', False)]" in ok.stdout, ok.stdout + ok.stderr
+    assert "peer access NO (copies stage through the host)" in ok.stderr and "rank 2 (0000:25:00.0) -> rank 0 (0000:05:00.0)" in ok.stderr
+    t0 = time.time()
+    dead = subprocess.run([sys.executable, "-c", prog % (REPO, "True")], capture_output=True, text=True, timeout=120)
+    assert dead.returncode == 5 and time.time() - t0 < 30, (dead.returncode, dead.stderr[-800:])
+    assert "NOTHING ARRIVED within 1 s" in dead.stderr and "link check FAILED: rank 1 (0000:15:00.0) -> rank 0 (0000:05:00.0)" in dead.stderr
