@@ -270,3 +270,27 @@ def test_loading_the_library_exports_the_hardware_queue_count_unless_the_host_de
         for extra, want in (({}, "b'8'"), ({"GPU_MAX_HW_QUEUES": "2"}, "b'2'"), ({"SDFHIP_KEEP_ENV": "1"}, "None")):
             out = subprocess.run([sys.executable, "-c", prog, path], env=dict(base, **extra), capture_output=True, text=True, timeout=120)
             assert out.returncode == 0 and out.stdout.strip() == want, (path, extra, out.stdout, out.stderr[-500:])
+
+
+def test_the_binaries_carry_the_firewall(sb):
+    # ... and the same from the BINARIES ("nm shows no entry point without the guard"): every exported entry
+    # point's machine code -- its body or its .cold part -- calls sdfhip::abi_caught from its catch handler, except the few whose
+    # handler the compiler removed because nothing in them can throw (arithmetic on the caller's struct, free(), a thread-local
+    # array): that list is closed and spelled out here.
+    import subprocess
+    nothrow = {"sdfhip_last_error", "sdfhip_camera_mouse_wheel", "sdfhip_info_set_heading", "sdfhip_info_set_position", "sdfhip_octdata_free",
+               "sdfhip_points_free", "sdfhip_sparse2_bytes", "sdfhip_sparse2_floats_offset", "sdfhip_upload_options_default",
+               # laboratory only
+               "sdfhip_wire_sparse_bytes", "sdfhip_wire_sparse_head_offset", "sdfhip_debug_fail_host_allocations"}
+    for path in (sb._lib.LIB_PATH, sb._lib.LAB_LIB_PATH):
+        out = subprocess.run(["objdump", "-d", "--no-show-raw-insn", path], capture_output=True, text=True, check=True).stdout
+        cur, guarded = None, set()
+        for line in out.splitlines():
+            m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+            if m:
+                cur = re.sub(r"\.cold.*|\[clone.*", "", m.group(1)).strip()
+            elif cur and "abi_caught" in line and "call" in line:
+                guarded.add(cur)
+        exported = set(exported_symbols(path))
+        assert exported - guarded <= nothrow, (os.path.basename(path), sorted(exported - guarded - nothrow))
+        assert len(exported & guarded) >= 45
