@@ -30,7 +30,7 @@ sys.path.insert(0, REPO)
 
 # The driver's path is this file; what the line says about a measurement, the other configurations and the N > 1 machinery are
 # modules beside it (their names stay importable from here: tests and scripts say bench.roofline, bench.orbit_cameras, ...).
-from bench_report import (HBM_PEAK_GBS, KERNEL_SOURCES, VALU_PEAK_GINSTR, VALU_PEAK_SPEC_GINSTR, configs_summary, cpu_baseline,  # noqa: E402,F401
+from bench_report import (HBM_PEAK_GBS, KERNEL_SOURCES, VALU_PEAK_GINSTR, VALU_PEAK_SPEC_GINSTR, configs_summary,  # noqa: E402,F401
                           kernel_source_hash, load_compulsory, load_pmc, measured_hbm_bandwidth, roofline)
 from bench_configs import bench_camera, grid_suffix, load_package, orbit_cameras, run_configs  # noqa: E402,F401
 from bench_sustained import GpuTelemetry, at_observed_clock, sustained_leg, sustained_seconds  # noqa: E402,F401
@@ -915,6 +915,131 @@ def main():
     scene.close()
     if sharded:
         dist.destroy_process_group()
+
+
+# ---- the CPU baseline: the ONE leg of the bench that may touch oracle/ (it is the thing timed here, never the thing shipped) ----
+def cpu_limits():
+    """What this process may use of the host: the CPUs of its affinity mask and the cgroup's CPU quota (cpu.max of cgroup v2, or
+    cfs_quota_us / cfs_period_us of v1) in CPUs -- None when there is no quota."""
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    return affinity, quota
+
+
+def cpu_baseline(od, cam, W, H, target_seconds):
+    """The CPU oracle (the build's C restatement of Compute.hlsl: the reference has no CPU path) timed on this
+    host over bounded samples of the same frame (every `step`-th row), built here with -O3 -march=native -- same
+    source, same -ffp-contract=off, its rows compared bit for bit with the portable build the parity tests use.  Timed by
+    oracle_bench_rows: a pool of threads pinned to the CPUs of this process's affinity mask, dealt over the NUMA nodes, each
+    node reading its own copy of the scene, all waiting at a barrier before the clock (read inside the C function) starts;
+    pixels dealt in chunks of 64 from one counter.  The thread count is SWEPT (1, 16, 64, 128, 256, the affinity mask's size and
+    the cgroup quota, whichever the mask allows) and the best is the reported value; `limits` says what the host let this
+    process use -- a quota of 16 CPUs caps every thread count at 16 CPUs' worth of cycles."""
+    import oracle
+    oracle.build()
+    native = oracle.build_native()                     # None when the host has no compiler: then only the portable build is timed
+    affinity, quota = cpu_limits()
+    usable = min(affinity, int(quota + 0.999)) if quota else affinity
+    cands = sorted({n for n in (1, 16, 64, 128, 256, affinity, usable) if 1 <= n <= affinity})
+    # calibrate one thread on a sparse sample of the frame (rows spread top to bottom), on both builds: the faster one is swept
+    # (-O3 -march=native is not always it; the other's one-thread figure is printed beside it)
+    step0 = max(1, H // 8)
+    builds = {"gcc -O2 -march=x86-64-v2 (+ an fma clone) -ffp-contract=off": False}
+    if native is not None:
+        builds["gcc -O3 -march=native -ffp-contract=off, built on this host"] = True
+    calib = {}
+    for name, nat in builds.items():
+        _, _, sec0, _ = oracle.bench_rows(od.Structs, od.Values, cam.State, W, H, row_step=step0, nthreads=1, store=False, native=nat)
+        calib[name] = sec0 / ((H + step0 - 1) // step0)
+    build_used = min(calib, key=calib.get)
+    kw = {"native": builds[build_used]}
+    per_row1 = calib[build_used]
+    budget = target_seconds / len(cands)
+    sweep, best, best_img, best_step = [], None, None, 1
+    for nt in cands:
+        # rows for ~budget seconds if the threads scaled perfectly up to what the host lets this process use; when the whole frame
+        # is not enough (a cgroup grants CPU time in 100 ms periods: a quota shows in a timed region of seconds, not in a burst of
+        # 0.2 s) the frame is rendered several times over
+        want = budget * min(nt, usable) / max(per_row1, 1e-9)
+        rows = int(min(H, max(8, want)))
+        step = max(1, H // rows)
+        nrows = (H + step - 1) // step
+        repeat = max(1, int(round(want / nrows)))
+        img, _, sec, topo = oracle.bench_rows(od.Structs, od.Values, cam.State, W, H, row_step=step, nthreads=nt, repeat=repeat, **kw)
+        e = {"threads": topo["threads"], "value": round(repeat * nrows * W / sec / 1e6, 3), "numa_nodes": topo["numa_nodes"],
+             "scene_copies": topo["scene_copies"],
+             "sample": f"every {step}th row = {nrows * W} pixels" + (f", {repeat} times over," if repeat > 1 else "") + f" in {sec:.2f} s"}
+        sweep.append(e)
+        if best is None or e["value"] > best["value"]:
+            best, best_img, best_step = e, img, step
+    other = {name: {"one_thread_ms_per_row": round(v * 1e3, 3)} for name, v in calib.items()}
+    same = None
+    if kw["native"]:                                   # a few of the best run's rows through the portable build: identical bits
+        nrows = best_img.shape[0]
+        k = max(1, nrows // 8)
+        ref, _ = oracle.render(od.Structs, od.Values, cam.State, W, H, row0=0, nrows=(nrows + k - 1) // k, row_step=best_step * k,
+                               nthreads=min(usable, 32))
+        a, b = best_img[::k].view(np.uint32), ref.view(np.uint32)
+        same = bool(((a == b) | (np.isnan(best_img[::k]) & np.isnan(ref))).all())
+    one = next(e for e in sweep if e["threads"] == 1)
+    model, physical = host_cpu()
+    ratio = best["value"] / one["value"] if one["value"] else None
+    return {
+        "value": best["value"],
+        "unit": "Mray/s",
+        "cores": best["threads"],
+        "kind": "port",
+        "cpu_model": model,
+        "physical_cores": physical,
+        "limits": {"affinity_cpus": affinity, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count(),
+                   "note": ("the cgroup lets this process use %.1f CPUs' worth of cycles: more threads than that share them" % quota)
+                           if quota and quota < affinity else None},
+        "build": build_used,
+        "builds_tried_one_thread": other,
+        "native_build_equals_portable_build": same,
+        "sample": best["sample"] + f" of the same {W}x{H} frame; oracle/sdf_oracle.c::oracle_bench_rows, {best['threads']} pinned pthreads over "
+                  f"{best['numa_nodes']} NUMA node(s) ({best['scene_copies']} node-local scene copies), started before the clock, 64-pixel chunks from one counter",
+        "sweep": sweep,
+        "speedup_over_one_thread": round(ratio, 1) if ratio else None,
+        "one_thread": {"value": one["value"], "unit": "Mray/s", "sample": one["sample"]},
+    }
+
+
+def host_cpu():
+    """(model name, physical cores) from /proc/cpuinfo; (None, None) when it cannot be read."""
+    try:
+        model, cores = None, set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model is None:
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None and core is not None:
+                    cores.add((phys, core)); phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        return model, (len(cores) or None)
+    except OSError:
+        return None, None
 
 
 if __name__ == "__main__":

@@ -301,3 +301,15 @@ def test_bench_refuses_to_run_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, cwd=REPO)
     assert out.returncode != 0 and "no CPU path" in (out.stderr + out.stdout)
+
+
+def test_only_the_cpu_baseline_leg_of_bench_py_touches_the_oracle():
+    # the oracle is test infrastructure: outside tests/ and smoke() only bench.py's cpu_baseline leg may import it -- also after
+    # bench.py became four modules (the leg stayed in bench.py itself)
+    import re
+    for f in ("bench_report.py", "bench_configs.py", "bench_sharded.py", "bench_sustained.py"):
+        text = open(os.path.join(REPO, f)).read()
+        assert not re.search(r"^\s*(import|from)\s+oracle\b", text, re.M), f
+    text = open(os.path.join(REPO, "bench.py")).read()
+    hits = [m.start() for m in re.finditer(r"^\s*(import|from)\s+oracle\b", text, re.M)]
+    assert len(hits) == 1 and text.rfind("def cpu_baseline(", 0, hits[0]) > text.rfind("\ndef main(", 0, hits[0])
