@@ -424,7 +424,11 @@ def main():
                     asm_ev.append((a0, a1, G))
         elif rank == 0:                               # gloo rehearsal: through host buffers
             gathered[slot].copy_(torch.stack(w).cuda())
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
             assemble(slot, main)
+            a1.record()
+            asm_ev.append((a0, a1, G))
 
     def finish_sparse2(slot, w, st):
         """the gather of sparse2 shares: rank 0 expands them; a share whose floats did not all travel sends the tail again"""
