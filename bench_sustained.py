@@ -202,28 +202,41 @@ def sustained_leg(torch, launch, streams, seconds, telemetry, chunk=256, max_fra
     wall = time.perf_counter() - t0
     tele = telemetry.stop() if telemetry is not None else None
 
-    zero = start_ev                                               # device time of a mark = the latest of its streams' events
-    def at(evs):
-        return max(z.elapsed_time(e) for z, e in zip(zero, evs))  # ms since the leg's zero (each stream against its own zero event:
-        #                                                           the zeros were recorded back to back on an idle device)
-    times = [(kk, at(evs)) for kk, evs in marks]
-    total_ms = times[-1][1]
-    first20 = times[0][1] / times[0][0]
-    # the last >= 1000 frames
-    j = len(times) - 1
-    while j > 0 and times[-1][0] - times[j][0] < 1000:
+    # Device times.  The streams are not in lock step (each hardware queue runs its own frames; one may lag the others by a good part
+    # of a chunk), so "when had ALL streams passed mark m" is late by that lag at every mark but the last -- a window that ends at the
+    # leg's end would look short, one that starts at its beginning long.  Windows are therefore timed PER STREAM (a stream's events
+    # bracket exactly its own frames: frame k goes to stream k % ns) and the streams' rates added.
+    T = [[z.elapsed_time(e) for z, e in zip(start_ev, evs)] for _, evs in marks]      # T[m][s]: ms since stream s's zero at mark m
+    K = [kk for kk, _ in marks]
+
+    def own(s_idx, k0, k1):                                       # frames of stream s_idx among frames k0 .. k1 - 1
+        return (k1 - s_idx + ns - 1) // ns - (k0 - s_idx + ns - 1) // ns
+
+    def window(m0, m1):                                           # ms per frame between marks m0 (-1: the leg's zero) and m1
+        rate = 0.0
+        for s_idx in range(ns):
+            t0_, k0 = (0.0, 0) if m0 < 0 else (T[m0][s_idx], K[m0])
+            dt, n = T[m1][s_idx] - t0_, own(s_idx, k0, K[m1])
+            if n > 0 and dt > 0:
+                rate += n / dt
+        return 1.0 / rate if rate > 0 else float("nan")
+    total_ms = max(T[-1])                                         # the leg ends when its last frame does, whichever stream holds it
+    first20 = window(-1, 0)
+    j = len(marks) - 1
+    while j > 0 and K[-1] - K[j] < 1000:
         j -= 1
-    last = (times[-1][1] - times[j][1]) / max(1, times[-1][0] - times[j][0])
-    # per second of device time
-    per_second, edge, prev = [], 1000.0, (0, 0.0)
-    for kk, t in times:
+    last = window(j, len(marks) - 1)
+    times = [(kk, max(row)) for kk, row in zip(K, T)]
+    per_second, edge, prev = [], 1000.0, -1
+    for m, (kk, t) in enumerate(times):
         if t >= edge:
-            per_second.append(round((t - prev[1]) / max(1, kk - prev[0]), 4))
-            prev, edge = (kk, t), edge + 1000.0
+            per_second.append(round(window(prev, m), 4))
+            prev, edge = m, edge + 1000.0
     return {"frames": k, "seconds": round(total_ms / 1e3, 3), "wall_seconds": round(wall, 3),
             "ms_per_step": round(total_ms / k, 4),
             "ms_per_step_first_20": round(first20, 4),
-            "ms_per_step_last_1000": round(last, 4), "last_frames": times[-1][0] - times[j][0],
+            "ms_per_step_last_1000": round(last, 4), "last_frames": K[-1] - K[j],
+            "windows_are": "per stream (a stream's events bracket its own frames), the streams' rates added: the streams are not in lock step",
             "ms_per_step_each_second": per_second,
             "chunk_frames": chunk, "host_runs_ahead_by_at_most_chunks": 2,
             "gpu_before": idle, "telemetry": tele}

@@ -279,6 +279,16 @@ def test_telemetry_summary_and_the_leg_bookkeeping_without_a_gpu(monkeypatch):
     assert r["frames"] >= 20 + 7 * 256 and r["frames"] % 256 == 20
     assert abs(r["ms_per_step_first_20"] - 0.2) < 1e-9 and abs(r["ms_per_step_last_1000"] - 0.1) < 1e-9 and r["last_frames"] >= 1000
     assert abs(r["ms_per_step"] - (20 * 0.2 + (r["frames"] - 20) * 0.1) / r["frames"]) < 1e-4 and r["telemetry"] is None
+    # streams that are NOT in lock step (one hardware queue slower than the others): windows are timed per stream and the rates added
+    streams2 = [Stream() for _ in range(4)]
+
+    def launch2(k, si):
+        streams2[si].busy_until += 0.5 if si == 3 else 0.4
+    r2 = bs.sustained_leg(Torch, launch2, streams2, 1.0, None, chunk=256)
+    want = 1.0 / (3 / 0.4 + 1 / 0.5)
+    assert abs(r2["ms_per_step_last_1000"] - want) < 1e-4 and abs(r2["ms_per_step_first_20"] - want) < 1e-4
+    assert all(abs(v - want) < 2e-4 for v in r2["ms_per_step_each_second"])
+    assert abs(r2["seconds"] * 1e3 - 0.5 * ((r2["frames"] + 0) // 4)) < 1.0          # the leg ends with its slowest stream
 
 
 def test_orbit_cameras_walk_round_the_scene():
