@@ -222,10 +222,13 @@ def sustained_leg(torch, launch, streams, seconds, telemetry, chunk=256, max_fra
         return 1.0 / rate if rate > 0 else float("nan")
     total_ms = max(T[-1])                                         # the leg ends when its last frame does, whichever stream holds it
     first20 = window(-1, 0)
-    j = len(marks) - 1
-    while j > 0 and K[-1] - K[j] < 1000:
+    # the last >= 1000 frames BEFORE the drain: in the leg's final two chunks the streams that are ahead (they keep a lead of 5-12 ms
+    # over the slowest one) finish early and the others speed up -- an end effect of 1-2 % of the last 1000 frames, not the steady state
+    end = max(1, len(marks) - 3)
+    j = end
+    while j > 0 and K[end] - K[j] < 1000:
         j -= 1
-    last = window(j, len(marks) - 1)
+    last = window(j, end)
     times = [(kk, max(row)) for kk, row in zip(K, T)]
     per_second, edge, prev = [], 1000.0, -1
     for m, (kk, t) in enumerate(times):
@@ -235,7 +238,8 @@ def sustained_leg(torch, launch, streams, seconds, telemetry, chunk=256, max_fra
     return {"frames": k, "seconds": round(total_ms / 1e3, 3), "wall_seconds": round(wall, 3),
             "ms_per_step": round(total_ms / k, 4),
             "ms_per_step_first_20": round(first20, 4),
-            "ms_per_step_last_1000": round(last, 4), "last_frames": K[-1] - K[j],
+            "ms_per_step_last_1000": round(last, 4), "last_frames": K[end] - K[j],
+            "last_frames_are": "the last >= 1000 frames before the leg's final two chunks (the drain: the streams that are ahead finish early)",
             "windows_are": "per stream (a stream's events bracket its own frames), the streams' rates added: the streams are not in lock step",
             "ms_per_step_each_second": per_second,
             "chunk_frames": chunk, "host_runs_ahead_by_at_most_chunks": 2,
