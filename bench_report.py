@@ -169,6 +169,8 @@ def roofline(sec_per_frame, own_bytes, ref_bytes, pmc, measured, compulsory=None
         "valu_frac_of_spec": valu["frac"] if valu else None,
         "valu_frac_of_measured_ceiling": valu["frac_of_measured_ceiling"] if valu else None,
         "limiting": None if limiting is None else ("hbm" if limiting.startswith("hbm") else "valu"),
+        "limiting_is": "the larger of the two fractions -- a ranking, not a proof of the bound (cfg-5 ranks 'hbm' at 0.9 of the measured rate and is "
+                       "bound by the latency of its dependent lookups: a third fewer bytes bought no time, profiles/r06_cfg5_xcd_order_ab.txt)",
         "valu_busy": valu_busy,
         "valu_busy_is": "SQ_ACTIVE_INST_VALU x 4 cycles over the SIMD-cycles of the frame: every instruction is charged one quad-cycle, "
                         "so this is the instruction count at 4 cycles each, not a measured utilisation",
