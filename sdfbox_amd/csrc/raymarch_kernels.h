@@ -1517,6 +1517,188 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
     if (COUNT) flush_counters(P, cn, cs, 0, cr, cl);
 }
 
+#ifdef SDFHIP_EXPERIMENTS
+// ---- LABORATORY (round 6): a bounce level with LANE REFILL ------------------------------------------------------------------------
+// k_pt_bounce gives a lane one queue entry and the wave waits for its slowest lane twice (the shadow march, then the next segment):
+// lanes are on in 44 % of the VALU thread-cycles.  Here a wave is PERSISTENT over its chunks and a lane that has finished its
+// entry takes the next one (its wave's next unread queue slot) while the others march on: one loop, every active lane makes one
+// march step per iteration (of its shadow ray or of its segment), and the code between two marches -- loading an entry and shading
+// it, the light term and the bounce, the stores and the push -- runs under wave-uniform "does any lane need it" tests.
+// Every path's arithmetic is k_pt_bounce's, statement for statement (the cursor goes from the shadow march into the segment, as
+// there); only the ORDER of the pushes into the next queue differs, which no result depends on.  SDFHIP_PT_REFILL=1.
+template <int CUR, bool COUNT>
+__global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce_refill(RenderParams P)
+{
+    typedef typename ScatterCursorOf<CUR, COUNT>::type CursorT;
+    enum { ST_IDLE = 0, ST_SHADOW = 1, ST_SEGMENT = 2 };
+    const uint32_t lane = threadIdx.x, b = P.pt_level, qin = b & 1u, qout = qin ^ 1u;
+    FrameInfo I = P.frames[0];
+    asm volatile("" : "+s"(I.margin), "+s"(I.margin2), "+s"(I.limit));
+    const float margin = I.margin;
+    const size_t npx = (size_t)P.nrows_out * P.width, total = (size_t)HIT_QUEUES * P.pt_cap;
+    const PtChunks C(P, qin, lane);
+    const uint32_t nchunks = C.nchunks;
+    unsigned long long cn = 0, cs = 0, cr = 0, cl = 0;
+    const float4 *Q = P.pt_q[qin];
+    float Tb = 1.0f;
+    for (uint32_t lv = 0; lv < b; lv++) Tb *= P.pt_albedo;             // what the levels before this one multiplied onto 1, in their order
+    // the wave's reading position: slot `pos` of chunk `t` (64 slots per chunk; a chunk's last slots may hold no entry)
+    uint32_t t = blockIdx.x, pos = 0;
+    // lane state
+    int st = ST_IDLE;
+    RayState r;
+    CursorT c;
+    c.loads = 0;
+    r.px = r.py = r.pz = 0.0f; r.dx = r.dy = r.dz = 0.0f; r.prox = 1.0f; r.angle = 0.0f; r.dist = 1.0f; r.n = 0; r.base = 0; r.phase = PH_PRIMARY;
+    uint32_t pid = 0, nsteps = 0;
+    size_t o = 0;
+    float ux = 0, uy = 0, uz = 1, T = 0, angle = 0, hx = 0, hy = 0, hz = 0, n0 = 0, n1 = 0, n2 = 1;
+    bool flip = false;
+    for (;;) {
+        // ---- (A) idle lanes take the wave's next unread slots ---------------------------------------------------------------
+        bool fresh = false;
+        {
+            unsigned long long idle = __ballot(st == ST_IDLE);
+            while (idle && t < nchunks) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t room = 64u - pos, want = (uint32_t)__popcll(idle), take = want < room ? want : room;
+                const bool mine = st == ST_IDLE && !fresh && rank < take;
+                const uint32_t e32 = C.entry(P, t, mine ? pos + rank : 0u);          // (wave-wide inside: every lane calls it)
+                if (mine && e32 != 0xFFFFFFFFu) {
+                    const size_t e = e32;
+                    const float4 a = nt_load(&Q[e]), k = nt_load(&Q[total + e]), d = nt_load(&Q[2 * total + e]);
+                    r.px = a.x; r.py = a.y; r.pz = a.z; r.prox = a.w;
+                    c.loads = 0;
+                    c.unpack(pt_unpack_cursor(make_uint2(__float_as_uint(k.x), __float_as_uint(k.y))),
+                             CursorT::units_shift(P.top_level + (CUR == CUR_STACK_SPLIT ? P.fine_bits : 0)));
+                    c.v0 = __float_as_uint(k.z); c.v1 = __float_as_uint(k.w); pid = __float_as_uint(d.x);
+                    ux = d.y; uy = d.z; uz = d.w;
+                    fresh = true;
+                }
+                pos += take;
+                if (pos == 64u) { pos = 0; t += gridDim.x; }
+                idle = __ballot(st == ST_IDLE && !fresh);
+            }
+        }
+        // ---- (B) a fresh entry: shade it (Compute.hlsl:205-213), start its shadow ray -----------------------------------------
+        bool to_bounce = false;                       // this lane's shadow march is over (or there was none): light term, bounce
+        if (__ballot(fresh)) {
+            if (fresh) {
+                T = Tb;
+                const uint32_t pix = pid / P.pt_spp, s = pid - pix * P.pt_spp;
+                o = (size_t)s * npx + pix;
+                float lx = I.lightx - r.px, ly = I.lighty - r.py, lz = I.lightz - r.pz;
+                const float rl = 1.0f / sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+                const float L0 = lx * rl, L1 = ly * rl, L2 = lz * rl;
+                r.px = __builtin_fmaf(L0, margin, r.px); r.py = __builtin_fmaf(L1, margin, r.py); r.pz = __builtin_fmaf(L2, margin, r.pz);
+                float g0, g1, g2;
+                gradient(c.cell(), r.px, r.py, r.pz, g0, g1, g2);
+                const float rg = 1.0f / sqrtf(dot3(g0, g1, g2, g0, g1, g2));
+                n0 = g0 * rg; n1 = g1 * rg; n2 = g2 * rg;
+                angle = dot3(L0, L1, L2, n0, n1, n2);
+                flip = dot3(n0, n1, n2, ux, uy, uz) > 0.0f;        // (decided now: the incoming direction is overwritten below)
+                hx = r.px; hy = r.py; hz = r.pz;
+                nsteps = 0;
+                r.n = 0;
+                if (!(angle < 0.0f)) {
+                    lx = I.lightx - r.px; ly = I.lighty - r.py; lz = I.lightz - r.pz;
+                    r.dist = sqrtf(dot3(lx, ly, lz, lx, ly, lz)) / 2.0f;
+                    r.dx = L0; r.dy = L1; r.dz = L2; r.phase = PH_SHADOW;
+                    if (COUNT) cr += 1;
+                    st = ST_SHADOW;
+                } else {
+                    st = ST_SHADOW; to_bounce = true;              // no shadow ray: e_light = 0, zero shadow steps
+                }
+            }
+        }
+        // ---- (C) between two march steps: is this lane's march over? --------------------------------------------------------
+        bool lit = false;
+        if (st == ST_SHADOW && !to_bounce) {                       // Compute.hlsl:214-223, as shadow_march's loop head
+            const bool header = r.n < 40 && r.prox > -I.margin;
+            const float lo = __builtin_fminf(__builtin_fminf(r.px, r.py), r.pz), hi = __builtin_fmaxf(__builtin_fmaxf(r.px, r.py), r.pz);
+            const bool at_light = r.prox > r.dist || lo < 0.0f || hi > 1.0f;
+            bool go = header && !at_light;
+            if (go && r.prox < I.margin) {
+                float gx, gy, gz;
+                gradient(cell_of(c, P), r.px, r.py, r.pz, gx, gy, gz);
+                go = !(dot3(gx, gy, gz, r.dx, r.dy, r.dz) < 0.0f);
+            }
+            if (!go) { to_bounce = true; lit = header && at_light; }
+        }
+        bool seg_over = false, escaped = false;
+        if (__ballot(to_bounce)) {
+            if (to_bounce) {
+                const bool had_ray = !(angle < 0.0f);
+                const uint32_t shadow_steps = had_ray ? (uint32_t)r.n : 0u;
+                float e_light = 0.0f;
+                if (had_ray && lit) e_light = T * (P.pt_albedo * (angle / (r.dist * r.dist) * I.k_strength));
+                __builtin_nontemporal_store(e_light, &P.pt_e[(size_t)b * P.pt_spp * npx + o]);
+                nsteps = (__builtin_nontemporal_load(&P.pt_n[o]) & 0xFFFFu) + shadow_steps;
+                if (b < P.pt_bounces) {
+                    // diffuse bounce (o_pixel_pt): the normal facing the incoming ray, a direction by rejection in the cube
+                    if (flip) { n0 = -n0; n1 = -n1; n2 = -n2; }
+                    const uint32_t pix = pid / P.pt_spp, s = pid - pix * P.pt_spp;
+                    const uint32_t y_l = pix / P.width, x_l = pix - y_l * P.width;
+                    const uint32_t p = global_row(P, y_l) * P.width + x_l;          // the frame's pixel index seeds the RNG
+                    float u0 = n0, u1 = n1, u2 = n2, qq1 = 1.0f;
+                    for (uint32_t a2 = 0; a2 < 8; a2++) {
+                        const float c0 = rnd(P.pt_seed, p, s, b + 1, 3 * a2) * 2.0f - 1.0f;
+                        const float c1 = rnd(P.pt_seed, p, s, b + 1, 3 * a2 + 1) * 2.0f - 1.0f;
+                        const float c2 = rnd(P.pt_seed, p, s, b + 1, 3 * a2 + 2) * 2.0f - 1.0f;
+                        const float qq = dot3(c0, c1, c2, c0, c1, c2);
+                        if (qq <= 1.0f && qq > 1e-12f) { u0 = c0; u1 = c1; u2 = c2; qq1 = qq; break; }
+                    }
+                    const float ru = 1.0f / sqrtf(qq1);
+                    float d0 = __builtin_fmaf(u0, ru, n0), d1 = __builtin_fmaf(u1, ru, n1), d2 = __builtin_fmaf(u2, ru, n2);
+                    float qd = dot3(d0, d1, d2, d0, d1, d2);
+                    if (!(qd > 1e-12f)) { d0 = n0; d1 = n1; d2 = n2; qd = dot3(n0, n1, n2, n0, n1, n2); }
+                    const float rd = 1.0f / sqrtf(qd);
+                    ux = d0 * rd; uy = d1 * rd; uz = d2 * rd;
+                    const float off = margin * 4.0f;
+                    r.px = __builtin_fmaf(n0, off, hx); r.py = __builtin_fmaf(n1, off, hy); r.pz = __builtin_fmaf(n2, off, hz);
+                    T *= P.pt_albedo;
+                    r.dx = ux; r.dy = uy; r.dz = uz; r.prox = 1.0f; r.n = 0; r.phase = PH_PRIMARY;
+                    st = ST_SEGMENT;
+                } else {
+                    seg_over = true;                               // the last level: no next segment, nothing to push
+                    st = ST_IDLE;
+                    __builtin_nontemporal_store(nsteps | ((b + 1u) << 16), &P.pt_n[o]);
+                    if (COUNT) cl += c.loads;
+                }
+            }
+        }
+        bool push = false;
+        if (st == ST_SEGMENT) {                                    // pt_march's loop head
+            const bool marching = (r.prox > I.margin2 || r.prox < 0.0f) && r.n < 100;
+            const bool go_on = marching && !(dot3(r.px, r.py, r.pz, r.px, r.py, r.pz) > I.limit);
+            if (!go_on) {
+                escaped = marching;
+                nsteps += (uint32_t)r.n;
+                if (escaped) __builtin_nontemporal_store(T, &P.pt_t[o]);
+                __builtin_nontemporal_store(nsteps | ((b + 1u) << 16), &P.pt_n[o]);
+                if (COUNT) cl += c.loads;
+                push = !escaped;
+                seg_over = true;
+                st = ST_IDLE;
+            }
+        }
+        if (__ballot(seg_over))
+            pt_push(P, qout, blockIdx.x & (HIT_QUEUES - 1u), push, lane, r.px, r.py, r.pz, r.prox, c, pid, ux, uy, uz);
+        // ---- (D) done? else one march step of every lane that is marching ------------------------------------------------------
+        const unsigned long long active = __ballot(st != ST_IDLE);
+        if (!active) {
+            if (t >= nchunks) break;
+            continue;                                              // every lane idle, entries left: refill
+        }
+        if (st != ST_IDLE) {
+            uint32_t reads = march_step(P, I, r, c, nullptr, 0);
+            if (COUNT) { cn += reads; cs += 1; }
+        }
+    }
+    if (COUNT) flush_counters(P, cn, cs, 0, cr, cl);
+}
+#endif
+
 // Per pixel: o_pixel_pt's accumulation over samples and bounces, in its order; alpha = the march steps of all paths.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_pt_resolve(RenderParams P)

@@ -268,6 +268,14 @@ int launch_pt_pipeline(sdfhip_scene *s, dim3 grid, hipStream_t st, RenderParams 
 #ifdef SDFHIP_EXPERIMENTS
         if (COUNT && s->touch.on) touch_params(s, Pb, s->d_top2 ? 2 : 0);
 #endif
+#ifdef SDFHIP_EXPERIMENTS
+        // A/B (round 6): the level with lane refill (k_pt_bounce_refill: persistent waves, a lane that has finished its entry takes the next)
+        const bool refill = getenv("SDFHIP_PT_REFILL") && atoi(getenv("SDFHIP_PT_REFILL")) != 0;
+        if (refill && !Pb.pt_sort_bits) {
+            if (s->d_top2) hipLaunchKernelGGL((k_pt_bounce_refill<CUR_STACK_SPLIT, COUNT>), dim3(resident), dim3(64), 0, st, Pb);
+            else           hipLaunchKernelGGL((k_pt_bounce_refill<CUR, COUNT>), dim3(resident), dim3(64), 0, st, Pb);
+        } else
+#endif
         if (s->d_top2) hipLaunchKernelGGL((k_pt_bounce<CUR_STACK_SPLIT, COUNT>), dim3(resident), dim3(64), 0, st, Pb);
         else           hipLaunchKernelGGL((k_pt_bounce<CUR, COUNT>), dim3(resident), dim3(64), 0, st, Pb);
 #ifdef SDFHIP_EXPERIMENTS
