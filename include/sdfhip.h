@@ -116,8 +116,11 @@ typedef struct sdfhip_stats {
     uint64_t n_loads;       /* with SDFHIP_FLAG_COUNT: 16-byte node records / */
                             /* grid cells the kernels themselves loaded (one  */
                             /* per lane and load): their own algorithmic reads */
-    uint64_t n_hits;        /* (experiments build, queued-shadow A/B form: pixels */
-                            /* queued between its two kernels; else 0)         */
+    uint64_t n_hits;        /* with SDFHIP_FLAG_COUNT: entries that travelled     */
+                            /* through a queue between two kernels -- the path-   */
+                            /* traced pipeline's hits, summed over its levels (48 */
+                            /* bytes each, written once and read once); shadow    */
+                            /* rays queued by SDFHIP_FLAG_COMPACT; else 0         */
 } sdfhip_stats;
 
 /* ---- errors ------------------------------------------------------------ */

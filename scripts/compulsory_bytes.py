@@ -85,6 +85,8 @@ def entry(key, scene, W, H, pt=None, flags=0, note=None):
         # entry reads the step count and stores the light it received and the new count (12 B) and, when it escapes, the throughput
         # (counted for every entry: 4 B); the ordered sum reads count + throughput (8 B per path) and one light term per entry (4 B)
         E, npaths = st.n_hits, W * H * pt.spp
+        if E == 0:
+            raise SystemExit("the counting build reports no queue entries (sdfhip_stats.n_hits): a library older than round 6's")
         stream_bytes = 2 * PT_RECORD_BYTES * E + 8 * npaths + 16 * E + 8 * npaths + 4 * E
         stream_is = (f"{E} queue entries x (48 B written + 48 B read) + per-path results ({npaths} paths: 16 B each + 20 B per entry), "
                      "byte-granular (what is useful, not what a 128-byte line costs)")

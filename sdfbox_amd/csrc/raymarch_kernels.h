@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
     const uint32_t nchunks = C.nchunks;
     const uint32_t t_first = blockIdx.x, t_end = nchunks, t_step = gridDim.x;
 #endif
-    unsigned long long cn = 0, cs = 0, cr = 0, cl = 0;
+    unsigned long long cn = 0, cs = 0, cr = 0, cl = 0, ch = 0;     // ch: queue entries this level took (counting builds: sdfhip_stats.n_hits)
     const float4 *Q = P.pt_q[qin];
     for (uint32_t t = t_first; t < t_end; t += t_step) {
         uint32_t e32;
@@ -1510,11 +1510,11 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
                 if (escaped) __builtin_nontemporal_store(T, &P.pt_t[o]);
             }
             __builtin_nontemporal_store(nsteps | ((b + 1u) << 16), &P.pt_n[o]);
-            if (COUNT) cl += c.loads;
+            if (COUNT) { cl += c.loads; ch += 1; }
         }
         pt_push(P, qout, blockIdx.x & (HIT_QUEUES - 1u), have && next && !escaped, lane, r.px, r.py, r.pz, r.prox, c, pid, ux, uy, uz);
     }
-    if (COUNT) flush_counters(P, cn, cs, 0, cr, cl);
+    if (COUNT) flush_counters(P, cn, cs, 0, cr, cl, ch);
 }
 
 #ifdef SDFHIP_EXPERIMENTS
@@ -1526,6 +1526,10 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce(RenderPar
 // it, the light term and the bounce, the stores and the push -- runs under wave-uniform "does any lane need it" tests.
 // Every path's arithmetic is k_pt_bounce's, statement for statement (the cursor goes from the shadow march into the segment, as
 // there); only the ORDER of the pushes into the next queue differs, which no result depends on.  SDFHIP_PT_REFILL=1.
+// MEASURED: 66 % SLOWER (scripts/pt_refill_ab.py, profiles/r06_cfg5_refill_ab.txt: 20.8-21.1 -> 34.7-35.5 ms per cfg-5 frame, frames and
+// counters identical; same 72 VGPRs, occupancy 7).  What k_march taught in round 2 holds for incoherent rays too: the lane state
+// machine pays its phase tests and ballots in every iteration and its transition code whenever ANY lane needs it, and that costs more
+// than the idle lanes of two tight loops.  Kept as the record of the attempt.
 template <int CUR, bool COUNT>
 __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce_refill(RenderParams P)
 {
@@ -1538,7 +1542,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce_refill(Re
     const size_t npx = (size_t)P.nrows_out * P.width, total = (size_t)HIT_QUEUES * P.pt_cap;
     const PtChunks C(P, qin, lane);
     const uint32_t nchunks = C.nchunks;
-    unsigned long long cn = 0, cs = 0, cr = 0, cl = 0;
+    unsigned long long cn = 0, cs = 0, cr = 0, cl = 0, ch = 0;
     const float4 *Q = P.pt_q[qin];
     float Tb = 1.0f;
     for (uint32_t lv = 0; lv < b; lv++) Tb *= P.pt_albedo;             // what the levels before this one multiplied onto 1, in their order
@@ -1574,6 +1578,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce_refill(Re
                     c.v0 = __float_as_uint(k.z); c.v1 = __float_as_uint(k.w); pid = __float_as_uint(d.x);
                     ux = d.y; uy = d.z; uz = d.w;
                     fresh = true;
+                    if (COUNT) ch += 1;
                 }
                 pos += take;
                 if (pos == 64u) { pos = 0; t += gridDim.x; }
@@ -1695,7 +1700,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_pt_bounce_refill(Re
             if (COUNT) { cn += reads; cs += 1; }
         }
     }
-    if (COUNT) flush_counters(P, cn, cs, 0, cr, cl);
+    if (COUNT) flush_counters(P, cn, cs, 0, cr, cl, ch);
 }
 #endif
 

@@ -100,6 +100,9 @@ def test_touched_lines_of_a_path_traced_frame_come_per_launch(lab):
         assert ph[1]["coarse_lines"] + ph[1]["fine_lines"] > 0
         assert sum(p["coarse_lines"] + p["fine_lines"] for p in ph) <= st1.n_loads
         assert st1.n_loads == st0.n_loads and st1.n_hits == st0.n_hits
+        # n_hits: the entries that went through the hit queues, all levels -- at least the vertices that cast a shadow ray, at most
+        # every path once per level
+        assert st1.n_shadow_rays <= st1.n_hits <= W * H * pt.spp * (pt.max_bounces + 1)
 
 
 def test_the_product_has_no_touch_hook(sb):

@@ -372,7 +372,9 @@ def test_path_traced_bounce_levels_ordered_by_key(sb, oracle_mod, scenes):
     # A path's results do not depend on where its entry sits in a queue: every ordering must give the oracle's frame, counters included
     lab_only(sb)
     W, H = 96, 72
-    prev = {k: os.environ.get(k) for k in ("SDFHIP_PT_SORT", "SDFHIP_PT_SORT_FROM")}
+    # round 6: + every XCD walking a contiguous eighth of the order (SDFHIP_PT_SORT_XCD=1), and a level with lane refill
+    # (SDFHIP_PT_REFILL=1: k_pt_bounce_refill, persistent waves) -- both measured and dropped, both bit-identical
+    prev = {k: os.environ.get(k) for k in ("SDFHIP_PT_SORT", "SDFHIP_PT_SORT_FROM", "SDFHIP_PT_SORT_XCD", "SDFHIP_PT_REFILL")}
     try:
         for sname, cname in (("torus_d6", "rotated"), ("sphere_d4", "closeup")):
             od = scenes[sname]
@@ -381,12 +383,19 @@ def test_path_traced_bounce_levels_ordered_by_key(sb, oracle_mod, scenes):
             ref, cnt = oracle_mod.render_pt(od.Structs, od.Values, cam.State, W, H, spp=pt.spp, max_bounces=pt.max_bounces, seed=pt.seed,
                                             albedo=pt.albedo, nthreads=8)
             with sb.Scene(od) as sc:
-                for bits, first in (("1", "0"), ("2", "0"), ("3", "0"), ("3", "1"), ("2", "2"), ("9", "0")):     # (9: out of range = off)
+                hits = None
+                for bits, first, xcd, refill in (("1", "0", "0", "0"), ("2", "0", "0", "0"), ("3", "0", "0", "0"), ("3", "1", "0", "0"), ("2", "2", "0", "0"),
+                                                 ("9", "0", "0", "0"),                                     # (9: out of range = off)
+                                                 ("3", "0", "1", "0"), ("2", "1", "1", "0"), ("0", "0", "0", "1")):
                     os.environ["SDFHIP_PT_SORT"], os.environ["SDFHIP_PT_SORT_FROM"] = bits, first
+                    os.environ["SDFHIP_PT_SORT_XCD"], os.environ["SDFHIP_PT_REFILL"] = xcd, refill
+                    what = f"{sname}: bounce levels ordered with {bits} region bits from level {first}, XCD walk {xcd}, lane refill {refill}"
                     img, st = sc.DrawPath(cam, W, H, pt, flags=sb.FLAG_COUNT, want_stats=True)
-                    assert_frames_identical(img, ref, f"{sname}: bounce levels ordered with {bits} region bits from level {first}")
-                    assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt)
-                    assert_frames_identical(sc.DrawPath(cam, W, H, pt), ref, "not counting")
+                    assert_frames_identical(img, ref, what)
+                    assert (st.n_nodes, st.n_samples, st.n_steps, st.n_shadow_rays) == tuple(int(c) for c in cnt), what
+                    hits = st.n_hits if hits is None else hits
+                    assert st.n_hits == hits and st.n_shadow_rays <= st.n_hits <= W * H * pt.spp * (pt.max_bounces + 1), what    # the queues' entries
+                    assert_frames_identical(sc.DrawPath(cam, W, H, pt), ref, what + ", not counting")
     finally:
         for k, v in prev.items():
             if v is None:
