@@ -73,6 +73,8 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
         # queues of their own (fresh streams for every configuration: the 4K frame took 0.328 ms where the same run alone takes 0.313)
         streams = (list(shared_streams[:nbuf]) if shared_streams and len(shared_streams) >= nbuf else []) or [torch.cuda.Stream() for _ in range(nbuf)]
 
+        torch.cuda.synchronize()           # (the buffers' fills run on torch's stream, the renders on their own: not ordered by themselves)
+
         def launch(k):
             s = streams[k % nbuf].cuda_stream
             if pt is not None:

@@ -880,6 +880,9 @@ def test_tile_order_flag_changes_no_pixel(sb, oracle_mod, scenes, split):
 
         def draw(name, W, H, flags=F, stream=None):
             buf = torch.full((H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+            # (the fill runs on torch's stream, the render on its own -- torch's streams do not wait for the default stream: without
+            # this, a late part of the fill lands on rendered pixels.  Seen once the library gave its process eight hardware queues.)
+            torch.cuda.synchronize()
             st = sb.Stats()
             sc.DrawDevice(make_camera(name, W, H), W, H, buf.data_ptr(), flags=flags,
                           stream=stream.cuda_stream if stream is not None else None, stats=st if flags & sb.FLAG_COUNT else None)
@@ -925,6 +928,7 @@ def test_frames_in_flight_on_one_handle_do_not_share_scratch(sb, oracle_mod, sce
     streams = [torch.cuda.Stream() for _ in cams]
     for flags in (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_COMPACT, sb.KERNEL_STACK | sb.FLAG_TILE_ORDER) + ab(sb, sb.KERNEL_STACK | sb._lib.TUNE_SHADOW_QUEUE, sb.KERNEL_STACK | sb.TUNE_ONE_KERNEL):
         bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
+        torch.cuda.synchronize()                   # (the fills run on torch's stream, the renders on their own)
         for rep in range(8):                       # keep every stream busy so that the launches really overlap
             for c, b, st in zip(cams, bufs, streams):
                 scene.DrawDevice(c, W, H, b.data_ptr(), flags=flags, stream=st.cuda_stream)
@@ -944,6 +948,7 @@ def test_a_stream_per_frame_and_counters_per_stream(sb, oracle_mod, scenes):
     ref, cnt = oracle_mod.render(od.Structs, od.Values, cam.State, W, H, nthreads=8)
     with sb.Scene(od) as sc:
         buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()                   # (the fill runs on torch's stream, the renders on their own)
         for k in range(40):
             st = torch.cuda.Stream()
             flags = (sb.KERNEL_STACK, sb.KERNEL_STACK | sb.FLAG_TILE_ORDER, sb.KERNEL_STACK | (sb._lib.TUNE_SHADOW_QUEUE if sb._lib.EXPERIMENTS else sb.FLAG_COUNT), sb.KERNEL_STACK | sb.FLAG_COMPACT)[k % 4]
@@ -954,6 +959,7 @@ def test_a_stream_per_frame_and_counters_per_stream(sb, oracle_mod, scenes):
         a, b = torch.cuda.Stream(), torch.cuda.Stream()
         other = make_camera("closeup", W, H)
         bufb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         stats = sb.Stats()
         for _ in range(6):                         # stream b counts without ever reading its counters, while stream a's are read
             sc.DrawDevice(other, W, H, bufb.data_ptr(), flags=sb.KERNEL_STACK | sb.FLAG_COUNT, stream=b.cuda_stream)
