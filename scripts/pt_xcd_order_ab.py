@@ -1,6 +1,6 @@
 """Round 6's attempt at cfg-5's refetch factor (keep / drop rule: 5 % of the frame).
 
-scripts/compulsory_bytes.py: a cfg-5 frame must move 3.7 GB (every distinct line of every launch once, + its queues and results)
+scripts/compulsory_bytes.py: a cfg-5 frame must move 9.7 GB (every distinct line of every launch once: 1.5 GB, + its queues and results: 8.1 GB)
 and moves 120 GB; each bounce level touches 2.5-3.3 M lines (0.4 GB) chip-wide but 15-17 M summed over the XCDs -- every XCD
 walks nearly the whole object -- and fetches each of them ~14 times.  The attempt: the bounce levels' entries in the order of
 (region of the hit, octant of the outgoing direction) [round 4's key: SDFHIP_PT_SORT=R, no gain on its own], AND every XCD
