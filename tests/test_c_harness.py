@@ -43,3 +43,21 @@ def test_c_caller_renders_the_oracle_frame(tmp_path, sb, oracle_mod, scenes):
     assert_frames_identical(frame, ref, "C harness")
     assert f"{int(cnt[0])} node reads, {int(cnt[1])} samples, {int(cnt[2])} steps" in out.stdout
     assert "page-locked frame identical" in out.stdout            # sdfhip_host_alloc + the same sdfhip_render, from C
+
+
+@pytest.mark.gpu
+def test_c_host_with_frames_in_flight(tmp_path):
+    # tests/c_frames_in_flight.c (the measurement behind INTEGRATION.md section 3's hardware-queue paragraph: scripts/hw_queues_c_host.sh)
+    # stays buildable and runnable: plain C + four HIP streams + the C ABI, a small scene, a few frames per pass; and the library's
+    # export of GPU_MAX_HW_QUEUES reaches a host that set nothing (the program prints what its environment holds after the load)
+    exe = str(tmp_path / "c_frames_in_flight")
+    libdir = os.path.join(REPO, "sdfbox_amd")
+    subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Wall", "-I", os.path.join(REPO, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(REPO, "tests", "c_frames_in_flight.c"), "-o", exe, "-L", libdir, "-lsdfhip", "-L", "/opt/rocm/lib",
+                           "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "SDFHIP_KEEP_ENV")}
+    out = subprocess.run([exe, "40", "4", "6"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GPU_MAX_HW_QUEUES=8:" in out.stdout and "40 frames on 4 streams" in out.stdout, out.stdout
+    kept = subprocess.run([exe, "40", "4", "6"], capture_output=True, text=True, timeout=300, env=dict(env, SDFHIP_KEEP_ENV="1"))
+    assert kept.returncode == 0 and "GPU_MAX_HW_QUEUES=(unset: the runtime's 4)" in kept.stdout, kept.stdout + kept.stderr
