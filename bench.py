@@ -115,9 +115,10 @@ def parse():
                          "'frame' = one frame at a time across all devices, launch to completion (what a viewer waits for)")
     ap.add_argument("--init-timeout", type=float, default=90.0,
                     help="N > 1: seconds the rendezvous (init_process_group) and every later collective may take before it raises")
-    ap.add_argument("--link-timeout", type=float, default=10.0,
+    ap.add_argument("--link-timeout", type=float, default=30.0,
                     help="N > 1: seconds a peer's first 1 MB message may take to reach rank 0 in the link check before every rank gives up "
-                         "(exit code 5, the link named)")
+                         "(exit code 5, the link named).  Generous on purpose: the first message between two ranks also sets their channel up "
+                         "(hundreds of milliseconds on one GPU; unknown on eight), and a false alarm would cost the run")
     ap.add_argument("--watchdog-seconds", type=float, default=-1.0,
                     help="a daemon thread writes the run's phase to stderr every few seconds and ends the process with exit code 3 once "
                          "the whole run has taken this long (-1 = default: 420 for N > 1, off for N = 1; 0 = off)")
