@@ -502,22 +502,32 @@ __device__ __forceinline__ void sparse2_flush(const RenderParams &P, uint32_t f,
 // rays look up: with the stores non-temporal the 4K frame takes 0.292 instead of 0.304 ms (-4 %), the depth-10 stand-in 0.101-0.103
 // instead of 0.105-0.109, the mesh scene 0.055-0.057 instead of 0.058-0.063, 1080p 0.0847 instead of 0.0854 (A/B/A/B of two builds
 // of the library in one run; bit-identical frames: the same values, another cache policy).
-__device__ __forceinline__ void frame_store(float4 *p, const float4 &v)
+// NOT into page-locked HOST memory (sdfhip_render into a registered array: the march stores across PCIe): there the non-temporal
+// form is slower -- 1080p RGBA32F 0.676 -> 0.701 ms, the RGBA8 display frame 0.256 -> 0.366 (scripts/host_frame.py --locked, the same
+// A/B) -- so `host` (RenderParams::out_host, wave-uniform) selects plain stores.
+__device__ __forceinline__ void frame_store(float4 *p, const float4 &v, bool host = false)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(p));
+    if (host) *p = v;
+    else __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(p));
 }
-__device__ __forceinline__ void frame_store(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void frame_store(uint32_t *p, uint32_t v, bool host = false)
+{
+    if (host) *p = v;
+    else __builtin_nontemporal_store(v, p);
+}
 template <int MODE>
 struct PixelSink {
     float4 *out;             // frame f of the launch: RGBA32F pixels / uint32 pixels / the frame's wire planes
     uint8_t *codes;          // OUT_WIRE: the byte plane behind the float plane
     uint32_t sky8;
+    bool host;               // the frame lies in page-locked host memory: plain stores (frame_store)
     SparseLane *px;          // OUT_SPARSE: the lane's wire pixel stays in registers until the wave's flush (sparse2_flush)
     __device__ __forceinline__ PixelSink(const RenderParams &P, uint32_t f, SparseLane *lane_px = nullptr)
     {
         const size_t npx = (size_t)P.nrows_out * P.width;
         sky8 = P.sky8;
+        host = P.out_host != 0u;
         px = lane_px;
         if (MODE == OUT_SPARSE) { out = nullptr; codes = nullptr; }
         else if (MODE == OUT_RGBA32F) { out = P.out + f * npx; codes = nullptr; }
@@ -534,22 +544,22 @@ struct PixelSink {
     }
     __device__ __forceinline__ void sky(size_t idx, float steps) const
     {
-        if (MODE == OUT_RGBA32F) frame_store(&out[idx], make_float4(0.005f, 0.01f, 0.2f, steps));
+        if (MODE == OUT_RGBA32F) frame_store(&out[idx], make_float4(0.005f, 0.01f, 0.2f, steps), host);
         else if (MODE == OUT_WIRE || MODE == OUT_SPARSE) wire(idx, 0.0f, 255u - (uint32_t)steps);
-        else frame_store(&reinterpret_cast<uint32_t *>(out)[idx], MODE == OUT_HEAT8 ? heat8(steps) : (sky8 | alpha8(steps)));
+        else frame_store(&reinterpret_cast<uint32_t *>(out)[idx], MODE == OUT_HEAT8 ? heat8(steps) : (sky8 | alpha8(steps)), host);
     }
     __device__ __forceinline__ void grey(size_t idx, float a, float steps) const
     {
-        if (MODE == OUT_RGBA32F) frame_store(&out[idx], make_float4(a, a, a, steps));
+        if (MODE == OUT_RGBA32F) frame_store(&out[idx], make_float4(a, a, a, steps), host);
         else if (MODE == OUT_WIRE || MODE == OUT_SPARSE) wire(idx, a, (uint32_t)steps);
-        else if (MODE == OUT_HEAT8) frame_store(&reinterpret_cast<uint32_t *>(out)[idx], heat8(steps));
-        else { const uint32_t q = gamma8(a); frame_store(&reinterpret_cast<uint32_t *>(out)[idx], q | (q << 8) | (q << 16) | alpha8(steps)); }
+        else if (MODE == OUT_HEAT8) frame_store(&reinterpret_cast<uint32_t *>(out)[idx], heat8(steps), host);
+        else { const uint32_t q = gamma8(a); frame_store(&reinterpret_cast<uint32_t *>(out)[idx], q | (q << 8) | (q << 16) | alpha8(steps), host); }
     }
     __device__ __forceinline__ void black(size_t idx, float steps) const
     {
-        if (MODE == OUT_RGBA32F) frame_store(&out[idx], make_float4(0.0f, 0.0f, 0.0f, steps));
+        if (MODE == OUT_RGBA32F) frame_store(&out[idx], make_float4(0.0f, 0.0f, 0.0f, steps), host);
         else if (MODE == OUT_WIRE || MODE == OUT_SPARSE) wire(idx, 0.0f, (uint32_t)steps);
-        else frame_store(&reinterpret_cast<uint32_t *>(out)[idx], MODE == OUT_HEAT8 ? heat8(steps) : alpha8(steps));
+        else frame_store(&reinterpret_cast<uint32_t *>(out)[idx], MODE == OUT_HEAT8 ? heat8(steps) : alpha8(steps), host);
     }
 };
 
@@ -861,7 +871,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
             // stores, whose completion the wave waits for once (behind start_pixel's work)
             if (r.phase == PH_DONE) {
                 const size_t pidx = (size_t)(pix >> 16) * P.width + (pix & 0xFFFFu);
-                if (P.out_mode == 0u) frame_store(&P.out[pidx], out_lds[lane]);
+                if (P.out_mode == 0u) frame_store(&P.out[pidx], out_lds[lane], P.out_host != 0u);
                 else reinterpret_cast<uint32_t *>(P.out)[pidx] = display8(out_lds[lane], P.out_mode);
                 r.phase = PH_IDLE;
             }
@@ -1102,7 +1112,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
             it++;
         }
         const float inv = (float)P.pt_spp;
-        frame_store(&P.out[(size_t)yl * P.width + x], make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps));
+        frame_store(&P.out[(size_t)yl * P.width + x], make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps), P.out_host != 0u);
         if (COUNT) { ct = steps; cl = c.loads; }
     }
     if (COUNT) flush_counters(P, cn, cs, ct, cr, cl);
@@ -1738,7 +1748,7 @@ __global__ __launch_bounds__(256) void k_pt_resolve(RenderParams P)
             acc0 = __builtin_fmaf(T, 0.005f, acc0); acc1 = __builtin_fmaf(T, 0.01f, acc1); acc2 = __builtin_fmaf(T, 0.2f, acc2);
         }
         const float inv = (float)P.pt_spp;
-        frame_store(&P.out[pix], make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps));
+        frame_store(&P.out[pix], make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps), P.out_host != 0u);
         if (COUNT) ct += steps;
     }
     if (COUNT) flush_counters(P, 0, 0, ct, 0, 0);

@@ -102,6 +102,7 @@ int fill_params(sdfhip_scene *s, const RenderCall &c, RenderParams &P, Plan &pla
     memset(&P, 0, sizeof P);
     P.nodes = s->nodes; P.n_nodes = s->n; P.top = s->d_top; P.top_level = s->top_level; P.fine = s->d_fine; P.fine_bits = s->fine_bits; P.fine_order = 0;
     P.out = reinterpret_cast<float4 *>(c.d_out);
+    P.out_host = c.out_host ? 1u : 0u;
     P.width = c.width; P.height = c.height;
     P.band_rows = c.band_rows; P.band_first = c.band_first; P.band_stride = c.band_stride;
     P.band_shift = 32u;
@@ -714,7 +715,7 @@ try {
         const bool locked = known != nullptr;
         if (direct && (ours ? (size_t)width * height < ((size_t)4 << 20) : frame_bytes < ((size_t)16 << 20))) {
             RenderCall c = whole;
-            c.flags = flags | SDFHIP_FLAG_TILE_ORDER; c.d_out = reinterpret_cast<float *>(direct);
+            c.flags = flags | SDFHIP_FLAG_TILE_ORDER; c.d_out = reinterpret_cast<float *>(direct); c.out_host = true;
             int rc = render_impl(s, c, nullptr);
             if (rc != SDFHIP_OK) return rc;
             HIP_TRY(hipStreamSynchronize(s->stream));

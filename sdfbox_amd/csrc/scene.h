@@ -165,6 +165,7 @@ struct RenderCall {
     uint32_t n_bands = 0;
     bool sparse = false;
     uint32_t sparse_cap = 0, sparse_base = 0;
+    bool out_host = false;            // d_out is page-locked host memory: the kernels store the frame with plain stores (frame_store)
 };
 int render_impl(sdfhip_scene *s, const RenderCall &call, sdfhip_scene::StatsTicket *ticket);
 // k_march's launch grid: the workgroups of a frame's flat numbering (x: 8 * ceil(tiles_y / 8) * tiles_x, y: frames of the batch) as
