@@ -505,15 +505,17 @@ __device__ __forceinline__ void sparse2_flush(const RenderParams &P, uint32_t f,
 // NOT into page-locked HOST memory (sdfhip_render into a registered array: the march stores across PCIe): there the non-temporal
 // form is slower -- 1080p RGBA32F 0.676 -> 0.701 ms, the RGBA8 display frame 0.256 -> 0.366 (scripts/host_frame.py --locked, the same
 // A/B) -- so `host` (RenderParams::out_host, wave-uniform) selects plain stores.
+// (The host form is a VOLATILE store on purpose: two branches that store the same value to the same address are merged by the
+// compiler into ONE plain store -- the non-temporal hint is dropped and with it the 4 % -- and a volatile store cannot be merged.)
 __device__ __forceinline__ void frame_store(float4 *p, const float4 &v, bool host = false)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    if (host) *p = v;
+    if (host) *reinterpret_cast<volatile f32x4 *>(p) = (f32x4){v.x, v.y, v.z, v.w};
     else __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(p));
 }
 __device__ __forceinline__ void frame_store(uint32_t *p, uint32_t v, bool host = false)
 {
-    if (host) *p = v;
+    if (host) *reinterpret_cast<volatile uint32_t *>(p) = v;
     else __builtin_nontemporal_store(v, p);
 }
 template <int MODE>
