@@ -126,7 +126,8 @@ struct RenderParams {
     uint32_t sparse_cap;       // ... and the float slots it holds
     uint32_t sparse_base;      // ... and the value of its counter (header word 0) before this launch
     uint32_t sky8;             // the sky constant through the display pass (host-computed, alpha excluded)
-    uint32_t out_host;         // `out` is page-locked HOST memory (sdfhip_render into a registered array): plain stores, see frame_store
+    uint32_t out_host;         // `out` is page-locked HOST memory (sdfhip_render into a registered array): read by the HOST's launch code only,
+                               // which picks the instantiation that stores the frame with plain stores (frame_store, raymarch_kernels.h)
     // path-traced mode (k_path): samples per pixel, diffuse bounces, RNG seed, albedo
     uint32_t pt_spp, pt_bounces, pt_seed;
     float pt_albedo;

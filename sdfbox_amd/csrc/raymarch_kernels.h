@@ -497,39 +497,43 @@ __device__ __forceinline__ void sparse2_flush(const RenderParams &P, uint32_t f,
 
 // Where a finished pixel goes, by output mode (a template parameter: no dispatch at the store, and no
 // display-pass code in the RGBA32F kernels).  idx = pixel index within the launch's frame f.
-// A frame's pixels are written once and not read again by the kernel that writes them: stored past the caches (round 6).  As plain
-// stores the 33 MB (1080p) / 133 MB (4K) of a frame went through the XCDs' 4 MB L2s and took their lines from the grid cells the
-// rays look up: with the stores non-temporal the 4K frame takes 0.292 instead of 0.304 ms (-4 %), the depth-10 stand-in 0.101-0.103
-// instead of 0.105-0.109, the mesh scene 0.055-0.057 instead of 0.058-0.063, 1080p 0.0847 instead of 0.0854 (A/B/A/B of two builds
-// of the library in one run; bit-identical frames: the same values, another cache policy).
+// A frame's pixels are written once and not read again by the kernel that writes them: k_march / k_shadow store them past the
+// caches (round 6).  As plain stores the 33 MB (1080p) / 133 MB (4K) of a frame went through the XCDs' 4 MB L2s and took their lines
+// from the grid cells the rays look up: with the stores non-temporal the 4K frame takes 0.292 instead of 0.304 ms (-4 %), the
+// depth-10 stand-in 0.101-0.103 instead of 0.105-0.109, the mesh scene 0.055-0.057 instead of 0.058-0.063, 1080p 0.0847 instead of
+// 0.0854 (A/B/A/B of two builds of the library in one run; bit-identical frames: the same values, another cache policy).
 // NOT into page-locked HOST memory (sdfhip_render into a registered array: the march stores across PCIe): there the non-temporal
 // form is slower -- 1080p RGBA32F 0.676 -> 0.701 ms, the RGBA8 display frame 0.256 -> 0.366 (scripts/host_frame.py --locked, the same
-// A/B) -- so `host` (RenderParams::out_host, wave-uniform) selects plain stores.
-// (The host form is a VOLATILE store on purpose: two branches that store the same value to the same address are merged by the
-// compiler into ONE plain store -- the non-temporal hint is dropped and with it the 4 % -- and a volatile store cannot be merged.)
-__device__ __forceinline__ void frame_store(float4 *p, const float4 &v, bool host = false)
+// A/B) -- so that launch takes an instantiation of its own (output mode | OUT_HOST) with plain stores.  The policy is a TEMPLATE
+// parameter on purpose: a run-time "if (host) plain else non-temporal" is merged by the compiler into one store (both forms store
+// the same value to the same address) and the hint is lost -- measured: the 4 % were gone; a volatile host store keeps them apart
+// but is emitted as a system-scope write-through store that crosses PCIe at half the rate for the 4-byte display pixels (0.512 ms).
+constexpr int OUT_HOST = 8;
+template <bool HOST>
+__device__ __forceinline__ void frame_store(float4 *p, const float4 &v)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    if (host) *reinterpret_cast<volatile f32x4 *>(p) = (f32x4){v.x, v.y, v.z, v.w};
+    if (HOST) *p = v;
     else __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(p));
 }
-__device__ __forceinline__ void frame_store(uint32_t *p, uint32_t v, bool host = false)
+template <bool HOST>
+__device__ __forceinline__ void frame_store(uint32_t *p, uint32_t v)
 {
-    if (host) *reinterpret_cast<volatile uint32_t *>(p) = v;
+    if (HOST) *p = v;
     else __builtin_nontemporal_store(v, p);
 }
-template <int MODE>
+template <int MODE_>
 struct PixelSink {
+    static constexpr int MODE = MODE_ & (OUT_HOST - 1);       // the output mode proper
+    static constexpr bool HOST = (MODE_ & OUT_HOST) != 0;      // the frame lies in page-locked host memory: plain stores (frame_store)
     float4 *out;             // frame f of the launch: RGBA32F pixels / uint32 pixels / the frame's wire planes
     uint8_t *codes;          // OUT_WIRE: the byte plane behind the float plane
     uint32_t sky8;
-    bool host;               // the frame lies in page-locked host memory: plain stores (frame_store)
     SparseLane *px;          // OUT_SPARSE: the lane's wire pixel stays in registers until the wave's flush (sparse2_flush)
     __device__ __forceinline__ PixelSink(const RenderParams &P, uint32_t f, SparseLane *lane_px = nullptr)
     {
         const size_t npx = (size_t)P.nrows_out * P.width;
         sky8 = P.sky8;
-        host = P.out_host != 0u;
         px = lane_px;
         if (MODE == OUT_SPARSE) { out = nullptr; codes = nullptr; }
         else if (MODE == OUT_RGBA32F) { out = P.out + f * npx; codes = nullptr; }
@@ -546,22 +550,22 @@ struct PixelSink {
     }
     __device__ __forceinline__ void sky(size_t idx, float steps) const
     {
-        if (MODE == OUT_RGBA32F) frame_store(&out[idx], make_float4(0.005f, 0.01f, 0.2f, steps), host);
+        if (MODE == OUT_RGBA32F) frame_store<HOST>(&out[idx], make_float4(0.005f, 0.01f, 0.2f, steps));
         else if (MODE == OUT_WIRE || MODE == OUT_SPARSE) wire(idx, 0.0f, 255u - (uint32_t)steps);
-        else frame_store(&reinterpret_cast<uint32_t *>(out)[idx], MODE == OUT_HEAT8 ? heat8(steps) : (sky8 | alpha8(steps)), host);
+        else frame_store<HOST>(&reinterpret_cast<uint32_t *>(out)[idx], MODE == OUT_HEAT8 ? heat8(steps) : (sky8 | alpha8(steps)));
     }
     __device__ __forceinline__ void grey(size_t idx, float a, float steps) const
     {
-        if (MODE == OUT_RGBA32F) frame_store(&out[idx], make_float4(a, a, a, steps), host);
+        if (MODE == OUT_RGBA32F) frame_store<HOST>(&out[idx], make_float4(a, a, a, steps));
         else if (MODE == OUT_WIRE || MODE == OUT_SPARSE) wire(idx, a, (uint32_t)steps);
-        else if (MODE == OUT_HEAT8) frame_store(&reinterpret_cast<uint32_t *>(out)[idx], heat8(steps), host);
-        else { const uint32_t q = gamma8(a); frame_store(&reinterpret_cast<uint32_t *>(out)[idx], q | (q << 8) | (q << 16) | alpha8(steps), host); }
+        else if (MODE == OUT_HEAT8) frame_store<HOST>(&reinterpret_cast<uint32_t *>(out)[idx], heat8(steps));
+        else { const uint32_t q = gamma8(a); frame_store<HOST>(&reinterpret_cast<uint32_t *>(out)[idx], q | (q << 8) | (q << 16) | alpha8(steps)); }
     }
     __device__ __forceinline__ void black(size_t idx, float steps) const
     {
-        if (MODE == OUT_RGBA32F) frame_store(&out[idx], make_float4(0.0f, 0.0f, 0.0f, steps), host);
+        if (MODE == OUT_RGBA32F) frame_store<HOST>(&out[idx], make_float4(0.0f, 0.0f, 0.0f, steps));
         else if (MODE == OUT_WIRE || MODE == OUT_SPARSE) wire(idx, 0.0f, (uint32_t)steps);
-        else frame_store(&reinterpret_cast<uint32_t *>(out)[idx], MODE == OUT_HEAT8 ? heat8(steps) : alpha8(steps), host);
+        else frame_store<HOST>(&reinterpret_cast<uint32_t *>(out)[idx], MODE == OUT_HEAT8 ? heat8(steps) : alpha8(steps));
     }
 };
 
@@ -873,7 +877,7 @@ __global__ __launch_bounds__(64, COMPACT_WAVES_PER_SIMD) void k_compact(RenderPa
             // stores, whose completion the wave waits for once (behind start_pixel's work)
             if (r.phase == PH_DONE) {
                 const size_t pidx = (size_t)(pix >> 16) * P.width + (pix & 0xFFFFu);
-                if (P.out_mode == 0u) frame_store(&P.out[pidx], out_lds[lane], P.out_host != 0u);
+                if (P.out_mode == 0u) P.out[pidx] = out_lds[lane];
                 else reinterpret_cast<uint32_t *>(P.out)[pidx] = display8(out_lds[lane], P.out_mode);
                 r.phase = PH_IDLE;
             }
@@ -1114,7 +1118,7 @@ __global__ __launch_bounds__(64, PATH_WAVES_PER_SIMD) void k_path(RenderParams P
             it++;
         }
         const float inv = (float)P.pt_spp;
-        frame_store(&P.out[(size_t)yl * P.width + x], make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps), P.out_host != 0u);
+        P.out[(size_t)yl * P.width + x] = make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps);
         if (COUNT) { ct = steps; cl = c.loads; }
     }
     if (COUNT) flush_counters(P, cn, cs, ct, cr, cl);
@@ -1750,7 +1754,7 @@ __global__ __launch_bounds__(256) void k_pt_resolve(RenderParams P)
             acc0 = __builtin_fmaf(T, 0.005f, acc0); acc1 = __builtin_fmaf(T, 0.01f, acc1); acc2 = __builtin_fmaf(T, 0.2f, acc2);
         }
         const float inv = (float)P.pt_spp;
-        frame_store(&P.out[pix], make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps), P.out_host != 0u);
+        P.out[pix] = make_float4(acc0 / inv, acc1 / inv, acc2 / inv, (float)steps);
         if (COUNT) ct += steps;
     }
     if (COUNT) flush_counters(P, 0, 0, ct, 0, 0);

@@ -171,6 +171,14 @@ template <int CUR, bool COUNT>
 void launch_march(uint32_t mode, dim3 flat, hipStream_t st, const RenderParams &P)
 {
     const dim3 grid = march_grid(P, flat);
+    // the frame goes straight into page-locked host memory (sdfhip_render's direct path: never a counting render): the instantiations
+    // that store it with plain stores (frame_store in raymarch_kernels.h)
+    if (!COUNT && P.out_host && mode <= (uint32_t)OUT_HEAT8) {
+        if (mode == OUT_RGBA32F)     hipLaunchKernelGGL((k_march<CUR, false, OUT_RGBA32F | OUT_HOST, false>), grid, dim3(64), 0, st, P);
+        else if (mode == OUT_GAMMA8) hipLaunchKernelGGL((k_march<CUR, false, OUT_GAMMA8 | OUT_HOST, false>), grid, dim3(64), 0, st, P);
+        else                         hipLaunchKernelGGL((k_march<CUR, false, OUT_HEAT8 | OUT_HOST, false>), grid, dim3(64), 0, st, P);
+        return;
+    }
     if (mode == OUT_RGBA32F)     hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_RGBA32F, false>), grid, dim3(64), 0, st, P);
     else if (mode == OUT_GAMMA8) hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_GAMMA8, false>), grid, dim3(64), 0, st, P);
     else if (mode == OUT_HEAT8)  hipLaunchKernelGGL((k_march<CUR, COUNT, OUT_HEAT8, false>), grid, dim3(64), 0, st, P);
