@@ -1,5 +1,5 @@
 """One-off campaign: the GPU SdfGen builder against the CPU oracle on random point clouds (byte-identical
-structs and values expected).  python scripts/sdfgen_fuzz.py [cases]"""
+structs and values expected).  python scripts/sdfgen_fuzz.py [cases [first case]]"""
 import sys
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -8,8 +8,9 @@ sb = sdfbox_amd.lab.load()          # SDFHIP_GEN_WIDE is a knob of the laborator
 import oracle
 import os
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0
-for case in range(n_cases):
+for case in range(first, first + n_cases):
     # every third case: the sibling-block kernels on every level below the root (by default only levels of 16 384 nodes and more)
     if case % 3 == 0:
         os.environ["SDFHIP_GEN_WIDE"] = "8"
@@ -43,5 +44,5 @@ for case in range(n_cases):
     same = od.Length == len(o["structs"]) and (od.Structs == o["structs"]).all() and (od.Values == o["values"]).all()
     if not same:
         print(f"case {case}: kind {kind} n {n} depth {depth}: DIFFERENT ({od.Length} vs {len(o['structs'])} nodes)"); bad += 1
-print(f"{n_cases} clouds, {bad} differences")
+print(f"{n_cases} clouds (cases {first} .. {first + n_cases - 1}), {bad} differences")
 sys.exit(1 if bad else 0)

@@ -1258,8 +1258,12 @@ def test_pre_decoded_cells_of_split_grids(sb, oracle_mod, seed):
         os.environ.pop("SDFHIP_SAMPLE_RECORDS", None)
 
 
-# SDFHIP_FUZZ_SEEDS=n runs n seeds instead of 6 (a one-off campaign; the committed default stays small)
-@pytest.mark.parametrize("seed", sorted(set(range(int(os.environ.get("SDFHIP_FUZZ_SEEDS", "6")))) | {26}))
+# SDFHIP_FUZZ_SEEDS=n runs n seeds instead of 6 (a one-off campaign; the committed default stays small); SDFHIP_FUZZ_FIRST=f: the
+# n seeds f .. f + n - 1 (a second campaign over seeds the first one did not see)
+_FUZZ_FIRST = int(os.environ.get("SDFHIP_FUZZ_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", sorted(set(range(_FUZZ_FIRST, _FUZZ_FIRST + int(os.environ.get("SDFHIP_FUZZ_SEEDS", "6")))) | {26}))
 def test_fuzz_random_trees_and_on_grid_cameras(sb, oracle_mod, seed):
     rng = np.random.default_rng(1000 + seed)
     depth = [3, 5, 7, 9, 11, 12][seed % 6]
