@@ -33,6 +33,7 @@ sys.path.insert(0, REPO)
 from bench_report import (HBM_PEAK_GBS, KERNEL_SOURCES, VALU_PEAK_GINSTR, VALU_PEAK_SPEC_GINSTR, configs_summary,  # noqa: E402,F401
                           kernel_source_hash, load_compulsory, load_pmc, measured_hbm_bandwidth, roofline)
 from bench_configs import bench_camera, grid_suffix, load_package, orbit_cameras, run_configs  # noqa: E402,F401
+from bench_live_pmc import live_pmc, merged as merge_pmc  # noqa: E402
 from bench_sustained import GpuTelemetry, at_observed_clock, sustained_leg, sustained_seconds  # noqa: E402,F401
 from bench_sharded import Watchdog, link_check, main_single_process, measure_band_deal, measure_rank0_weight, spawn_ranks  # noqa: E402,F401
 
@@ -131,6 +132,11 @@ def parse():
                          "'5,3,2' -- the cfg-2 frame pipelined for >= 5 s, the 4K frame (in the `configs` block) for >= 3 s, the cfg-2 frame "
                          "with a camera that moves every frame for >= 2 s, the GPU's clock / power / temperature sampled every 100 ms.  "
                          "auto: 5,3,2 when the command is the headline's, else off; 0 or off: none")
+    ap.add_argument("--live-pmc", default="auto", choices=["auto", "on", "off"],
+                    help="the roofline's counters measured in this run (bench_live_pmc.py): after the timed region, the headline's command is run "
+                         "again as child processes under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE, the VALU counters: one pass each, 5 frames) and "
+                         "`roofline.traffic` comes from those passes, the committed figure beside it.  auto / on: when the command is the "
+                         "headline's and rocprofv3 is there (about 40 s more); off: the committed passes only (--only-timed implies off)")
     ap.add_argument("--lab", action="store_true",
                     help="load the experiments flavour of the library (libsdfhip_lab.so, include/sdfhip_experimental.h): needed by the A/B "
                          "forms --one-kernel and --shadow-queue")
@@ -753,6 +759,15 @@ def main():
         key_base, gsuf = f"{W}x{H}:{scene_name}:{mode}", grid_suffix(scene, pt)
         mode += gsuf
         pmc = load_pmc(key_base + gsuf) if world == 1 else None
+        headline = (world == 1 and not sharded and (W, H) == (1920, 1080) and args.depth == 9 and not args.asdf and pt is None and not compact
+                    and not args.display and not args.one_kernel and not args.shadow_queue and not args.tile_order and args.orbit == 0
+                    and args.kernel == "auto")
+        # the same counters measured NOW, by child processes under rocprofv3 --pmc (bench_live_pmc.py); the committed pass stays beside them
+        live_note = None
+        if headline and args.live_pmc != "off" and not args.only_timed and not args.lab:
+            wd.phase("live PMC passes (this command again, as children under rocprofv3 --pmc)", quiet=True)
+            torch.cuda.synchronize()
+            pmc, live_note = merge_pmc(live_pmc([], kernel_source_hash(), frames_per_launch), pmc)
         comp = load_compulsory(key_base + gsuf) if world == 1 else None
         # the headline also reports the counters of the same command under --orbit 90 (a new camera every frame), over that pass's time
         orbit_pmc = None
@@ -765,9 +780,10 @@ def main():
         roof.update({"time_ms": round(sec_per_step * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "frames_per_launch": frames_per_launch,
                      "kernel_ms_is": "average HIP-event time around one launch on its stream; with several frames in flight the launches overlap, "
                                      "so this is longer than time_ms (the steady-state time per frame, which the fractions divide by)"})
-        headline = (world == 1 and not sharded and (W, H) == (1920, 1080) and args.depth == 9 and not args.asdf and pt is None and not compact
-                    and not args.display and not args.one_kernel and not args.shadow_queue and not args.tile_order and args.orbit == 0
-                    and args.kernel == "auto")
+        if live_note is not None:
+            roof["live_pmc"] = live_note
+            if isinstance(roof.get("traffic_source"), dict):
+                roof["traffic_source"]["live"] = live_note.get("used") == "live"
         # ---- continuous operation: the same frames, pipelined the same way, for seconds; clocks sampled ----
         sus_s = sustained_seconds(args.sustained, headline)
         sustained = telemetry = None

@@ -1,5 +1,5 @@
-"""bench_report.py -- what bench.py's line says ABOUT a measurement: the roofline object from the committed rocprofv3 counter passes
-(load_pmc, load_compulsory, roofline), the line's last key (configs_summary) and the box's own HBM rate (measured_hbm_bandwidth).
+"""bench_report.py -- what bench.py's line says ABOUT a measurement: the roofline object from the rocprofv3 counter passes (the committed
+ones: load_pmc, load_compulsory; the headline's own live ones: bench_live_pmc.py; roofline), the line's last key (configs_summary) and the box's own HBM rate (measured_hbm_bandwidth).
 The CPU baseline -- the one leg that may touch oracle/ -- stays in bench.py itself.  No GPU work is timed here
 except the bandwidth kernels of the library.  Split out of bench.py in round 6 without a change of behaviour."""
 import hashlib
@@ -27,11 +27,11 @@ def kernel_source_hash():
 
 
 def load_pmc(key):
-    """rocprofv3 PMC figures of this workload (HBM bytes, issued VALU / SALU wave instructions and VALU-busy quad-cycles per
-    frame), or a dict {"dropped": reason}.  bench.py cannot run rocprofv3 on itself: scripts/profile.sh collects the
-    separate --pmc passes of this very command and scripts/summarise_profile.py writes profiles/hbm_traffic.json together
-    with the hash of the kernel sources they were measured on; figures of another build are not reported, and the line
-    says so."""
+    """The COMMITTED rocprofv3 PMC figures of this workload (HBM bytes, issued VALU / SALU wave instructions and VALU-busy quad-cycles per
+    frame), or a dict {"dropped": reason}.  scripts/profile.sh collects the separate --pmc passes of this very command and
+    scripts/summarise_profile.py writes profiles/hbm_traffic.json together with the hash of the kernel sources they were measured
+    on; figures of another build are not reported, and the line says so.  (The headline's command also measures the same counters
+    in its own run, through child processes: bench_live_pmc.py; this record then stands beside the live one.)"""
     try:
         with open(os.path.join(REPO, "profiles", "hbm_traffic.json")) as f:
             e = json.load(f).get(key)
@@ -236,7 +236,15 @@ def configs_summary(out, cfgs):
                 ratios.append(f"{names.get(k, k[:10])} {f(e['traffic_over_compulsory'], 2)}/{f(e.get('traffic_over_compulsory_per_xcd'), 2)}")
     if ratios:
         text += " | traffic/compulsory (chip/per-XCD): " + "; ".join(ratios)
-    return text[:1400]
+    # the headline's counters measured in this run (bench_live_pmc.py) against the committed pass of the same build
+    lp = r0.get("live_pmc")
+    if isinstance(lp, dict):
+        if lp.get("used") == "live":
+            text += (f" | live pmc (this run, {f(lp.get('seconds'), 0)}s): cfg2 {f((lp.get('hbm_bytes_per_frame') or 0) / 1e6, 1)}MB "
+                     f"{f((lp.get('valu_insts_per_frame') or 0) / 1e6, 2)}M valu = {f(lp.get('live_over_committed'), 4)} x committed bytes")
+        else:
+            text += " | live pmc dropped: " + str(lp.get("dropped"))[:80]
+    return text[:1500]
 
 
 def measured_hbm_bandwidth(sb, device=0, nbytes=2 << 30, reps=10):
