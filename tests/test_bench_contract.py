@@ -429,3 +429,20 @@ def test_run_group_ends_the_whole_group_at_its_timeout(tmp_path):
         except (ProcessLookupError, FileNotFoundError):
             pass
     assert L.run_group([sys.executable, "-c", "import sys; sys.stderr.write('x' * 1000); sys.exit(3)"], str(tmp_path), dict(os.environ), 30.0) == (3, "x" * 300)
+
+
+@pytest.mark.gpu
+def test_headline_counts_its_own_bytes_through_child_passes():
+    # the headline's command with everything behind the timed region switched off but the live counter passes: roofline.traffic comes
+    # from rocprofv3 --pmc children of this very run and agrees with the committed pass of the same build
+    j = run_bench("--steps", 5, "--warmup", 1, "--no-cpu-baseline", "--configs", "none", "--sustained", "off")
+    r = j["roofline"]
+    lp = r["live_pmc"]
+    if lp["used"] != "live":                                  # a box without a usable rocprofv3: the committed figure, and the reason
+        assert lp["dropped"] and r["traffic_source"]["live"] is False and not str(r["traffic_source"]["profile"]).startswith("live")
+        pytest.skip("no live pass on this box: " + str(lp["dropped"]))
+    assert r["traffic"] == lp["hbm_bytes_per_frame"] and r["traffic_source"]["live"] is True and r["traffic_source"]["profile"].startswith("live:")
+    assert [p["counters"] for p in lp["passes"]][:2] == [["FETCH_SIZE"], ["WRITE_SIZE"]] and all(p["exit"] == 0 and p["frames_counted"] >= 5 for p in lp["passes"])
+    assert 0.97 < lp["live_over_committed"] < 1.03, lp
+    assert lp["valu_insts_per_frame"] == lp["committed"]["valu_insts_per_frame"]          # the instruction count of a frame is deterministic
+    assert j["configs_summary"].endswith("x committed bytes")
