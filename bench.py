@@ -132,11 +132,13 @@ def parse():
                          "'5,3,2' -- the cfg-2 frame pipelined for >= 5 s, the 4K frame (in the `configs` block) for >= 3 s, the cfg-2 frame "
                          "with a camera that moves every frame for >= 2 s, the GPU's clock / power / temperature sampled every 100 ms.  "
                          "auto: 5,3,2 when the command is the headline's, else off; 0 or off: none")
-    ap.add_argument("--live-pmc", default="auto", choices=["auto", "on", "off"],
+    ap.add_argument("--live-pmc", default="auto", choices=["auto", "on", "all", "off"],
                     help="the roofline's counters measured in this run (bench_live_pmc.py): after the timed region, the headline's command is run "
                          "again as child processes under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE, the VALU counters: one pass each, 5 frames) and "
-                         "`roofline.traffic` comes from those passes, the committed figure beside it.  auto / on: when the command is the "
-                         "headline's and rocprofv3 is there (about 40 s more); off: the committed passes only (--only-timed implies off)")
+                         "`roofline.traffic` comes from those passes, the committed figure beside it.  on: the headline's command only (about 8 s "
+                         "more); auto / all: when the command is the headline's and rocprofv3 is there, also the moving-camera pass and every entry "
+                         "of the `configs` block, each through child passes of its own command line (about a minute more); off: the committed "
+                         "passes only (--only-timed implies off)")
     ap.add_argument("--lab", action="store_true",
                     help="load the experiments flavour of the library (libsdfhip_lab.so, include/sdfhip_experimental.h): needed by the A/B "
                          "forms --one-kernel and --shadow-queue")
@@ -764,15 +766,29 @@ def main():
                     and args.kernel == "auto")
         # the same counters measured NOW, by child processes under rocprofv3 --pmc (bench_live_pmc.py); the committed pass stays beside them
         live_note = None
+        live_state = {"broken": None}
+
+        def live(workload_args, fpl=1.0):
+            """one workload's passes; once a pass has HUNG (not merely failed) no further child is started in this run"""
+            if live_state["broken"]:
+                return {"dropped": "not run: " + live_state["broken"]}
+            r = live_pmc(workload_args, kernel_source_hash(), fpl)
+            if "did not end within" in str(r.get("dropped", "")):
+                live_state["broken"] = "an earlier pass of this run hung (" + r["dropped"] + ")"
+            return r
         if headline and args.live_pmc != "off" and not args.only_timed and not args.lab:
             wd.phase("live PMC passes (this command again, as children under rocprofv3 --pmc)", quiet=True)
             torch.cuda.synchronize()
-            pmc, live_note = merge_pmc(live_pmc([], kernel_source_hash(), frames_per_launch), pmc)
+            pmc, live_note = merge_pmc(live([], frames_per_launch), pmc)
+        live_all = live_note is not None and args.live_pmc in ("auto", "all")
         comp = load_compulsory(key_base + gsuf) if world == 1 else None
         # the headline also reports the counters of the same command under --orbit 90 (a new camera every frame), over that pass's time
         orbit_pmc = None
         if world == 1 and not sharded and args.orbit == 0 and "orbit_ms_per_step" in latency:
             orbit_pmc = {"pmc": load_pmc(f"{key_base}:orbit{len(orbit)}{gsuf}"), "ms_per_step": latency["orbit_ms_per_step"], "cameras": len(orbit)}
+            if live_all:
+                orbit_pmc["pmc"], orbit_note = merge_pmc(live(["--orbit", str(len(orbit))], frames_per_launch), orbit_pmc["pmc"])
+                live_note["orbit"] = {k: v for k, v in orbit_note.items() if k != "passes"}
         roof = roofline(sec_per_step, own_bytes_rank, ref_bytes_rank, pmc, copy_gbs, compulsory=comp, latency_ms=latency["ms"], orbit=orbit_pmc)
         # what the fraction divides by, so that it can be recomputed from profiles/: per_frame / time_ms / peak.  kernel_ms is
         # the HIP-event time around one frame's launches on their stream (k_march; overlapping the other frame in
@@ -921,7 +937,8 @@ def main():
             # (a configuration that fails says so in its own entry: the headline above has been measured and is printed regardless)
             try:
                 out["configs"] = run_configs(sb, torch, scene, scene_name, copy_gbs, args.configs_scale, args.depth, streams,
-                                             sustained_4k_seconds=sus_s[1] if sustained is not None else 0.0, telemetry=telemetry)
+                                             sustained_4k_seconds=sus_s[1] if sustained is not None else 0.0, telemetry=telemetry,
+                                             live=live if live_all else None)
             except Exception as e:
                 out["configs"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:

@@ -4,9 +4,11 @@ without a change of behaviour."""
 import hashlib
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -14,6 +16,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 
 from bench_report import HBM_PEAK_GBS, VALU_PEAK_SPEC_GINSTR, compulsory_fields, kernel_source_hash, load_compulsory, load_pmc
+from bench_live_pmc import merged as merge_pmc
 from bench_sustained import at_observed_clock, sustained_leg
 
 
@@ -57,16 +60,18 @@ def grid_suffix(scene, pt=None):
     return f":grid{lvl}" + ("+blocks" if lvl and gbytes > (16 << (3 * lvl)) and pt is None else "")
 
 
-def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared_streams=None, sustained_4k_seconds=0.0, telemetry=None):
+def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared_streams=None, sustained_4k_seconds=0.0, telemetry=None, live=None):
     """BASELINE.json's other single-GPU configurations, timed in this process behind the headline: the same
     clock (host time around `steps` frames, synchronised on both sides, frames in flight on their own streams), the HIP-event
     time of a launch beside it, and the counter fractions from the committed PMC pass of the SAME command line
     (profiles/hbm_traffic.json -> profiles/<tag>_pmc.json, formulas in profiles/README.md) when it was measured on this build's
-    kernel sources -- else pmc_stale and no fraction."""
+    kernel sources -- else pmc_stale and no fraction.  live (bench.py --live-pmc all): a function that runs a configuration's command
+    line as child processes under rocprofv3 --pmc (bench_live_pmc.live_pmc); the fractions then come from THIS run's counts, the
+    committed pass beside them (`live_pmc`)."""
     out = {}
     suffix9 = grid_suffix(scene)                      # (before the path-traced mode adds its second grid to the byte count)
 
-    def measure(name, sc, sname, W, H, mode, suffix, flags=0, pt=None, steps=60, warmup=12, nbuf=4, note=None, sustained=0.0):
+    def measure(name, sc, sname, W, H, mode, suffix, flags=0, pt=None, steps=60, warmup=12, nbuf=4, note=None, sustained=0.0, live_args=None):
         cam = bench_camera(sb, W, H)
         bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
         # the headline's streams again: which hardware queue a stream gets is the runtime's business, and these are known to have
@@ -98,6 +103,11 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
         spp = pt.spp if pt is not None else 1
         key = f"{W}x{H}:{sname}:{mode}{suffix}"
         pmc = load_pmc(key)
+        live_note = None
+        if live is not None and live_args is not None and scale == 1:
+            torch.cuda.synchronize()
+            pmc, live_note = merge_pmc(live(live_args() if callable(live_args) else live_args), pmc)
+            live_note = {k: v for k, v in live_note.items() if k != "passes"}           # (the headline's entry keeps the per-pass log)
         stale = "dropped" in pmc
         e = {"workload": f"{W}x{H}, {sname}, " + (f"path trace {spp} spp, 3 diffuse bounces" if pt is not None else
                                                    "primary-ray sphere trace + shadow march") + (", " + note if note else ""),
@@ -106,6 +116,8 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
              "pmc_key": key, "pmc_stale": stale,
              "hbm_frac": None, "valu_frac_of_spec": None, "traffic": None, "valu_insts_per_frame": None,
              "profile": None if stale else pmc.get("profile"), "kernel_source_sha": kernel_source_hash()}
+        if live_note is not None:
+            e["live_pmc"] = live_note
         if stale:
             e["pmc_dropped"] = pmc["dropped"]
         else:
@@ -145,16 +157,16 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
 
     guarded("cfg3_4k", lambda: measure("cfg3_4k", scene, scene_name, W4, H4, "default", suffix9,
             note="BASELINE cfg-3's frame with compaction OFF (the default kernel: faster than every form of compaction built)",
-            sustained=sustained_4k_seconds))
+            sustained=sustained_4k_seconds, live_args=["--size", f"{W4}x{H4}"]))
     guarded("cfg3_4k_compact", lambda: measure("cfg3_4k_compact", scene, scene_name, W4, H4, "compact", suffix9, flags=sb.FLAG_COMPACT,
             note="BASELINE cfg-3 as named: wavefront ray compaction ON (SDFHIP_FLAG_COMPACT: the shadow rays of waves that hold fewer than 32 "
-                 "compacted by ballot / prefix into a queue and marched 64 to a wave by a second kernel)"))
+                 "compacted by ballot / prefix into a queue and marched 64 to a wave by a second kernel)", live_args=["--size", f"{W4}x{H4}", "--compact", "1"]))
 
     def cfg5():
         pt = sb.PathTrace(spp=16)
         sb._lib.check(sb._lib.lib.sdfhip_scene_prepare_path(scene._h))       # the bounce levels' grid, at load time
         measure("cfg5_4k_spp16", scene, scene_name, W4, H4, "spp16", grid_suffix(scene, pt), pt=pt, steps=9, warmup=3, nbuf=3,
-                note="BASELINE cfg-5 on one GPU")
+                note="BASELINE cfg-5 on one GPU", live_args=["--size", f"{W4}x{H4}", "--spp", "16"])
     guarded("cfg5_4k_spp16", cfg5)
 
     def depth10():                         # cfg-2 at the reference application's default depth (Model.MaxDepth = 10, SdfBox/Model.cs:18)
@@ -163,7 +175,7 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
         t_gen = time.time() - t0
         with sb.Scene(od10, device=scene.device) as sc10:
             measure("cfg2_depth10", sc10, f"dragon_standin_d{depth + 1}", W2, H2, "default", grid_suffix(sc10),
-                    note=f"N={od10.Length} nodes, {od10.nbytes / 1e6:.0f} MB, built in {t_gen:.1f} s")
+                    note=f"N={od10.Length} nodes, {od10.nbytes / 1e6:.0f} MB, built in {t_gen:.1f} s", live_args=["--depth", str(depth + 1)])
     guarded("cfg2_depth10", depth10)
     # ... and on a MESH-derived scene at that depth: the reference's import flow (Program.cs:613-650: .ply -> SdfGen(depth 10) -> upload)
     # on a 1 M-point cloud (a torus-knot tube: no mesh ships with the reference), the tree built by the GPU builder and never
@@ -174,9 +186,21 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
         t0 = time.time()
         scm, stg = sb.Scene.FromPoints(pts, depth + 1, device=scene.device, want_stats=True)
         t_build = time.time() - t0
-        with scm:
-            measure("cfg2_mesh_knot_d10", scm, f"knot_d{depth + 1}.asdf", W2, H2, "default", grid_suffix(scm),
-                    note=f"1 M-point cloud -> sdfhip_sdfgen_scene: N={scm.Length} nodes in {t_build * 1e3:.0f} ms wall ({stg.total_ms:.0f} ms in the library)")
+        tmpd = []
+
+        def mesh_file():                    # the children load the same tree from a file (the builder's bytes are the oracle's: tests/test_sdfgen.py);
+            tmpd.append(tempfile.mkdtemp(prefix="sdfhip_live_mesh_", dir="/tmp"))      # written AFTER the timed frames: the GPU idles meanwhile
+            asdf = os.path.join(tmpd[0], f"knot_d{depth + 1}.asdf")
+            sb.OctData.SdfGen(pts, depth + 1).Save(asdf)
+            return ["--asdf", asdf]
+        try:
+            with scm:
+                measure("cfg2_mesh_knot_d10", scm, f"knot_d{depth + 1}.asdf", W2, H2, "default", grid_suffix(scm),
+                        note=f"1 M-point cloud -> sdfhip_sdfgen_scene: N={scm.Length} nodes in {t_build * 1e3:.0f} ms wall ({stg.total_ms:.0f} ms in the library)",
+                        live_args=mesh_file)
+        finally:
+            for d in tmpd:
+                shutil.rmtree(d, ignore_errors=True)
     if scale == 1:
         guarded("cfg2_mesh_knot_d10", mesh)
     return out

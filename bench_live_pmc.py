@@ -2,8 +2,8 @@
 committed file, not from the driver's run").
 
 bench.py cannot count its own launches -- rocprofv3 has to start the process it counts -- but it can start CHILDREN: after its timed
-region, rank 0 of the headline's command runs this very command again (5 frames, nothing but the timed region's frames:
---only-timed) under `rocprofv3 --pmc`, one pass per counter group as MI355X_MICROARCH.md's HBM section prescribes (FETCH_SIZE and
+region, the headline's command runs this very command again (5 frames, nothing but the timed region's frames: --only-timed) --
+and then the same command with a moving camera and the command line of every entry of its `configs` block -- under `rocprofv3 --pmc`, one pass per counter group as MI355X_MICROARCH.md's HBM section prescribes (FETCH_SIZE and
 WRITE_SIZE in separate passes; FETCH_SIZE doubled: on gfx950 it counts 64 B for every 128-byte line fetched), reads each pass's
 counter_collection.csv the way scripts/summarise_profile.py reads the committed passes, and hands bench.py the same record that
 profiles/hbm_traffic.json holds -- measured on this box, on this build, minutes after the timed region.  The committed figure
@@ -103,7 +103,7 @@ def run_group(cmd, cwd, env, timeout):
     return p.returncode, (err or "")[-300:]
 
 
-def live_pmc(workload_args, kernel_source_sha, frames_per_launch=1.0, passes=PASSES, pass_timeout=150.0, total_timeout=330.0,
+def live_pmc(workload_args, kernel_source_sha, frames_per_launch=1.0, passes=PASSES, pass_timeout=90.0, total_timeout=200.0,
              run=run_group, which=shutil.which):
     """Run the passes; -> a record like load_pmc()'s with "live": {...}, or {"dropped": reason}.  `run` / `which`: seams for the
     CPU tests (tests/test_bench_contract.py)."""

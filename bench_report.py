@@ -242,6 +242,15 @@ def configs_summary(out, cfgs):
         if lp.get("used") == "live":
             text += (f" | live pmc (this run, {f(lp.get('seconds'), 0)}s): cfg2 {f((lp.get('hbm_bytes_per_frame') or 0) / 1e6, 1)}MB "
                      f"{f((lp.get('valu_insts_per_frame') or 0) / 1e6, 2)}M valu = {f(lp.get('live_over_committed'), 4)} x committed bytes")
+            # --live-pmc all: the moving-camera pass and the `configs` rows counted in this run too -- live bytes over committed bytes
+            more = []
+            if isinstance(lp.get("orbit"), dict):
+                more.append("orbit " + (f(lp["orbit"].get("live_over_committed"), 4) if lp["orbit"].get("used") == "live" else "dropped"))
+            for k, e in (cfgs.items() if isinstance(cfgs, dict) else ()):
+                if isinstance(e, dict) and isinstance(e.get("live_pmc"), dict):
+                    more.append(f"{names.get(k, k[:10])} " + (f(e["live_pmc"].get("live_over_committed"), 4) if e["live_pmc"].get("used") == "live" else "dropped"))
+            if more:
+                text += "; " + "; ".join(more)
         else:
             text += " | live pmc dropped: " + str(lp.get("dropped"))[:80]
     return text[:1500]

@@ -238,6 +238,10 @@ def test_sustained_block_reaches_the_summary_and_prices_the_observed_clock():
     live = {"used": "live", "seconds": 7.7, "hbm_bytes_per_frame": 216319390, "valu_insts_per_frame": 55339941, "live_over_committed": 1.0002}
     text = bench.configs_summary({"ms_per_step": 0.0896, "value": 23135.0, "roofline": {"hbm_frac": 0.33, "live_pmc": live}}, {})
     assert text.endswith("| live pmc (this run, 8s): cfg2 216.3MB 55.34M valu = 1.0002 x committed bytes")
+    text = bench.configs_summary({"ms_per_step": 0.0896, "value": 23135.0, "roofline": {"live_pmc": dict(live, orbit={"used": "live", "live_over_committed": 0.9991})}},
+                                 {"cfg3_4k": {"ms_per_step": 0.3, "value": 1.0, "live_pmc": {"used": "live", "live_over_committed": 1.0011}},
+                                  "cfg2_depth10": {"ms_per_step": 0.1, "value": 1.0, "live_pmc": {"used": "committed", "dropped": "x"}}})
+    assert text.endswith("x committed bytes; orbit 0.9991; cfg3 1.0011; d10 dropped")
     text = bench.configs_summary({"ms_per_step": 0.0896, "value": 23135.0, "roofline": {"live_pmc": {"used": "committed", "dropped": "rocprofv3 is not on PATH"}}}, {})
     assert text.endswith("| live pmc dropped: rocprofv3 is not on PATH")
     assert bs.sustained_seconds("auto", True) == (5.0, 3.0, 2.0) and bs.sustained_seconds("auto", False) == (0.0, 0.0, 0.0)
@@ -445,4 +449,5 @@ def test_headline_counts_its_own_bytes_through_child_passes():
     assert [p["counters"] for p in lp["passes"]][:2] == [["FETCH_SIZE"], ["WRITE_SIZE"]] and all(p["exit"] == 0 and p["frames_counted"] >= 5 for p in lp["passes"])
     assert 0.97 < lp["live_over_committed"] < 1.03, lp
     assert lp["valu_insts_per_frame"] == lp["committed"]["valu_insts_per_frame"]          # the instruction count of a frame is deterministic
-    assert j["configs_summary"].endswith("x committed bytes")
+    assert lp["orbit"]["used"] == "live" and 0.97 < lp["orbit"]["live_over_committed"] < 1.03 and r["orbit"]["traffic"] == lp["orbit"]["hbm_bytes_per_frame"]
+    assert "x committed bytes; orbit " in j["configs_summary"]
