@@ -111,7 +111,11 @@ def live_pmc(workload_args, kernel_source_sha, frames_per_launch=1.0, passes=PAS
         return {"dropped": "rocprofv3 is not on PATH"}
     t_all = time.time()
     per_frame, log = {}, []
-    env = dict(os.environ, TMPDIR="/tmp")
+    # the children are single processes of their own: nothing of a launcher's rendezvous (torch.distributed.run) reaches them
+    launcher = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                "TORCHELASTIC_RUN_ID", "SDFHIP_BENCH_LINK_FAULT")
+    env = {k: v for k, v in os.environ.items() if k not in launcher}
+    env["TMPDIR"] = "/tmp"
     env.setdefault("GPU_MAX_HW_QUEUES", "8")
     tmp = tempfile.mkdtemp(prefix="sdfhip_live_pmc_", dir="/tmp")
     try:
