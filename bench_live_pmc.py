@@ -83,6 +83,12 @@ def child_command(workload_args, counters, out_dir, steps=5, warmup=1):
             "--sustained", "off", "--only-timed", "--live-pmc", "off"] + list(workload_args))
 
 
+def under_profiler(environ):
+    """rocprofv3 starts its program with librocprofiler-sdk-tool.so preloaded and ROCPROFILER_LIBRARY_CTOR / ROCP_TOOL_LIBRARIES set: a
+    bench.py that somebody profiles (scripts/profile.sh, or the driver's own trace of the default command) starts no profiler of its own"""
+    return ("rocprofiler" in environ.get("LD_PRELOAD", "") or "ROCPROFILER_LIBRARY_CTOR" in environ or "ROCP_TOOL_LIBRARIES" in environ)
+
+
 def run_group(cmd, cwd, env, timeout):
     """One pass as a child in a process group of its own; at the timeout the whole GROUP is ended (rocprofv3 and the program it
     started -- by the group id this call created, never by a pattern).  -> (exit code, tail of stderr)"""
@@ -109,6 +115,8 @@ def live_pmc(workload_args, kernel_source_sha, frames_per_launch=1.0, passes=PAS
     CPU tests (tests/test_bench_contract.py)."""
     if which("rocprofv3") is None:
         return {"dropped": "rocprofv3 is not on PATH"}
+    if under_profiler(os.environ):
+        return {"dropped": "this process is itself running under a profiler (its environment preloads rocprofiler): no nested passes"}
     t_all = time.time()
     per_frame, log = {}, []
     # the children are single processes of their own: nothing of a launcher's rendezvous (torch.distributed.run) reaches them

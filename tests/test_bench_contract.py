@@ -406,6 +406,9 @@ def test_live_pmc_passes_are_parsed_like_the_committed_ones_and_fall_back_loudly
         raise sp.TimeoutExpired(cmd, timeout)
     assert "did not end within" in L.live_pmc([], "abc", run=run_hangs, which=lambda _: "x")["dropped"]
     assert "not on PATH" in L.live_pmc([], "abc", run=run, which=lambda _: None)["dropped"]
+    # a bench.py that is itself being profiled starts no profiler of its own
+    assert L.under_profiler({"LD_PRELOAD": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so:/opt/rocm/lib/librocprofiler-sdk.so"})
+    assert L.under_profiler({"ROCPROFILER_LIBRARY_CTOR": "1"}) and not L.under_profiler({"LD_PRELOAD": "libfoo.so", "PATH": "/opt/rocm/bin"})
     # a pass that ends without a row of the renderer's kernels is no measurement
     def run_empty(cmd, cwd, env, timeout):
         _fake_counter_csv(os.path.join(cmd[cmd.index("-d") + 1], "h", "1_counter_collection.csv"), {})
