@@ -14,7 +14,10 @@
  * host's word stands) or SDFHIP_KEEP_ENV is set, it exports GPU_MAX_HW_QUEUES=8 -- the HIP runtime reads that variable when the
  * process makes its first HIP call, and a host that keeps four frames in flight on four streams renders 20 % slower on the
  * runtime's default of four hardware queues (0.1014 against 0.0841 ms per 1080p frame: INTEGRATION.md section 3).  A process
- * that has initialised HIP before it loads the library keeps what it had.
+ * that has initialised HIP before it loads the library keeps what it had.  (The export is a setenv() in the library's
+ * constructor: like every setenv it is not ordered against a getenv() that another thread of the host makes at that very moment.
+ * A host that loads the library while other threads of it run either exports the variable itself at start-up -- the export then
+ * never happens -- or sets SDFHIP_KEEP_ENV.)
  */
 #ifndef SDFHIP_H
 #define SDFHIP_H
