@@ -772,7 +772,10 @@ def main():
             """one workload's passes; once a pass has HUNG (not merely failed) no further child is started in this run"""
             if live_state["broken"]:
                 return {"dropped": "not run: " + live_state["broken"]}
-            r = live_pmc(workload_args, kernel_source_hash(), fpl)
+            try:
+                r = live_pmc(workload_args, kernel_source_hash(), fpl)
+            except Exception as e:         # (a counter file of another shape, a full /tmp: the committed figure stands, the line is printed)
+                r = {"dropped": f"{type(e).__name__}: {str(e)[:200]}"}
             if "did not end within" in str(r.get("dropped", "")):
                 live_state["broken"] = "an earlier pass of this run hung (" + r["dropped"] + ")"
             return r

@@ -106,7 +106,11 @@ def run_configs(sb, torch, scene, scene_name, copy_gbs, scale=1, depth=9, shared
         live_note = None
         if live is not None and live_args is not None and scale == 1:
             torch.cuda.synchronize()
-            pmc, live_note = merge_pmc(live(live_args() if callable(live_args) else live_args), pmc)
+            try:
+                got = live(live_args() if callable(live_args) else live_args)
+            except Exception as ex:        # (the mesh scene's file could not be written, ...: the committed pass stands, the timing is kept)
+                got = {"dropped": f"{type(ex).__name__}: {str(ex)[:200]}"}
+            pmc, live_note = merge_pmc(got, pmc)
             live_note = {k: v for k, v in live_note.items() if k != "passes"}           # (the headline's entry keeps the per-pass log)
         stale = "dropped" in pmc
         e = {"workload": f"{W}x{H}, {sname}, " + (f"path trace {spp} spp, 3 diffuse bounces" if pt is not None else
